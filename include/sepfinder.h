@@ -1,0 +1,242 @@
+/*
+ * sepfinder.h -- C-ABI boundary of the MI355X-native inter-robot separator finder.
+ *
+ * This is the drop-in surface for ONE hot path of bramtoula/multi_robot_SLAM_separators
+ * (SURVEY.md section 8): NetVLAD nearest-neighbour candidate search + binary local-descriptor
+ * matching + RANSAC 3D-3D relative pose.  Everything is `extern "C"`, plain pointers and sizes,
+ * no torch / ROS / OpenCV types.  All citations are relative to the reference tree, with
+ * PKG = ros_ws/src/multi_robot_separators.
+ *
+ * Reference interface each group of entry points replaces:
+ *   sf_nn_*            PKG/scripts/data_handler.py:166-209   DataHandler.find_matches
+ *                      PKG/scripts/data_handler.py:297-301   find_matches_service (descriptor append)
+ *                      PKG/scripts/data_handler.py:402-408,437-438  mask bookkeeping
+ *                      wire: PKG/srv/FindMatches.srv:1 (float64[] new_netvlad_descriptors)
+ *   sf_store_*         PKG/scripts/data_handler.py:268,421-422  geometric_feats cache of one keyframe's
+ *                      (descriptors, kpts3D, kpts); layouts PKG/msg/Descriptors.msg:1-3,
+ *                      KeyPoint3DVec.msg:1-2, KeyPointVec.msg:1-2, PKG/src/MsgConversion.cpp:8-42,113-116
+ *   sf_estimate_*      PKG/src/stereoCamGeometricTools.cpp:122-178  estimateTransformation service
+ *                      (PKG/srv/EstTransform.srv:1-9), which drives
+ *                      PKG/src/myRegistration.cpp:225-303 and PKG/src/myRegistrationVis.cpp:441-1410
+ *   sf_result          geometry_msgs/PoseWithCovariance + bool success (EstTransform.srv:8-9),
+ *                      packed as PKG/src/MsgConversion.cpp:61-64,71-81 do
+ *   sf_separator       one row of PKG/srv/ReceiveSeparators.srv:1-10 (what the back-end consumes,
+ *                      PKG/src/factorGraph.cpp:98-118)
+ *
+ * Ownership: every input pointer is BORROWED for the duration of the call; every output is
+ * written into CALLER-allocated memory; the handle owns all device memory.  No allocation
+ * crosses the ABI.  A handle is single-caller (not thread-safe), like the reference's
+ * single-threaded geometry node (stereoCamGeometricTools.cpp:212).
+ *
+ * Errors: every function returns an int status.  A failed pose estimation is NOT an error
+ * (success=0, zero pose, covariance as the reference leaves it).  Size mismatches on which the
+ * reference UASSERT-aborts (myRegistrationVis.cpp:482-483,859-860,878-880) return SF_EINVAL.
+ */
+#ifndef SEPFINDER_H
+#define SEPFINDER_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+  SF_OK = 0,
+  SF_EINVAL = 1,   /* bad argument / size mismatch (reference: UASSERT abort)            */
+  SF_EHIP = 2,     /* HIP runtime error; text via sf_last_error                          */
+  SF_ENOMEM = 3,   /* host or device allocation failed                                   */
+  SF_ERANGE = 4,   /* index out of range / capacity exceeded / IDL limit exceeded         */
+  SF_ENODEV = 5    /* no GPU visible: the product path has NO CPU fallback                */
+};
+
+/* ---- limits inherited from the reference IDL --------------------------------------------- */
+#define SF_MAX_FEATURES   32767  /* KeyPoint3DVec.msg:1 / KeyPointVec.msg:1  `int16 size`   */
+#define SF_MAX_DESC_BYTES 64     /* 512-bit binary descriptors (BASELINE.json configs[4])   */
+
+/* ---- parameters -------------------------------------------------------------------------- */
+typedef struct sf_params {
+  /* NetVLAD NN stage: data_handler.py:96-100, defaults multi_robot_separators.launch:19-22 */
+  double  netvlad_distance;        /* 0.13 ; accept iff dist <  this (data_handler.py:202)  */
+  int32_t netvlad_dimensions;      /* 128                                                   */
+  int32_t netvlad_max_matches_nb;  /* 20                                                    */
+  int32_t nn_precision;            /* 0 = fp32 MFMA (+ f64 re-evaluation of row minima),
+                                      1 = fp16 inputs on MFMA (BASELINE configs[4])         */
+  /* Registration: myRegistrationVis.cpp:52-71 reads rtabmap's compiled-in defaults [upstream];
+     stereoCamGeometricTools.cpp:87 overrides only Vis/MinInliers                           */
+  int32_t min_inliers;             /* 5    separators_min_inliers -> Vis/MinInliers          */
+  float   inlier_distance;         /* 0.1  Vis/InlierDistance (m)                            */
+  int32_t iterations;              /* 300  Vis/Iterations                                    */
+  int32_t refine_iterations;       /* 5    Vis/RefineIterations                              */
+  double  refine_sigma;            /* 3.0  refineModelSigma (rtabmap util3d_registration)    */
+  int32_t estimation_type;         /* 0 = 3D->3D (implemented; north_star). 1 = PnP and
+                                      2 = epipolar are NOT implemented: sf_create -> SF_EINVAL */
+  float   nndr;                    /* 0.6  Vis/CorNNDR                                       */
+  int32_t guess_win_size;          /* 20   Vis/CorGuessWinSize (px); 0 disables guided pass  */
+  int32_t ransac_adaptive_stop;    /* 1 = PCL RandomSampleConsensus adaptive k (p=0.99);
+                                      0 = evaluate exactly iterations+1 hypotheses           */
+  int32_t max_sample_checks;       /* 1000 PCL SampleConsensusModel::max_sample_checks_      */
+  uint64_t seed;                   /* sampler key (PCL uses a fixed mt19937 seed 12345)      */
+  /* Camera model `cam_` used for BOTH frames (stereoCamGeometricTools.cpp:76,142-143)       */
+  double  fx, fy, cx, cy;          /* left().K()                                             */
+  int32_t image_width, image_height; /* left().imageSize(); 0 => uncalibrated => no guided pass */
+  float   local_transform[12];     /* left().localTransform(): base->optical, row-major 3x4  */
+  /* Capacity hints (device memory is grown on demand; these avoid regrowth)                 */
+  int32_t store_capacity;          /* keyframes                                              */
+  int32_t max_features;            /* per keyframe (rounded up to a multiple of 64)          */
+  int32_t desc_bytes;              /* descriptor bytes per feature, 1..64 (32 = ORB/BRIEF)   */
+  int32_t reserved[8];
+} sf_params;
+
+/* ---- wire layouts ------------------------------------------------------------------------ */
+/* rtabmap_ros/KeyPoint as carried by KeyPointVec.msg (fields per MsgConversion.cpp:50-56)   */
+typedef struct sf_keypoint {
+  float   x, y;        /* pt.x, pt.y (pixels) */
+  float   size;
+  float   angle;
+  float   response;
+  int32_t octave;
+  int32_t class_id;
+} sf_keypoint;         /* 28 bytes */
+
+/* One keyframe's geometric features = (Descriptors, KeyPoint3DVec, KeyPointVec)            */
+typedef struct sf_features {
+  const uint8_t*     desc;      /* rows x cols, row-major (Descriptors.msg, zero-copy view
+                                   exactly as MsgConversion.cpp:113-116)                     */
+  uint16_t           rows;      /* Descriptors.rows */
+  uint16_t           cols;      /* Descriptors.cols (bytes per descriptor) */
+  const float*       xyz;       /* n3d x 3 float32, base frame (KeyPoint3DVec.kpts3DVec)     */
+  int32_t            n3d;       /* KeyPoint3DVec.size ; must be 0 or rows                    */
+  const sf_keypoint* kpts;      /* nkp entries (KeyPointVec.kptsVec)                         */
+  int32_t            nkp;       /* KeyPointVec.size ; must equal rows (or 0 when rows==0)    */
+} sf_features;
+
+/* EstTransform.srv response + the RegistrationInfo fields the node keeps (info_)           */
+typedef struct sf_result {
+  double  position[3];     /* geometry_msgs/Pose.position                                   */
+  double  orientation[4];  /* quaternion x,y,z,w (w >= 0, tf::poseEigenToMsg)               */
+  double  covariance[36];  /* row-major 6x6, as memcpy'd by MsgConversion.cpp:61-64         */
+  int32_t inliers;         /* RegistrationInfo.inliers of pass 2                            */
+  int32_t matches;         /* RegistrationInfo.matches of pass 2                            */
+  int32_t inliers_pass1;
+  int32_t matches_pass1;
+  uint8_t success;         /* !result2.isNull()  (stereoCamGeometricTools.cpp:168-175)      */
+  uint8_t pass1_success;
+  uint8_t pass2_guided;    /* 1 if pass 2 took the guess-guided branch                      */
+  uint8_t pad[5];
+} sf_result;               /* 392 bytes */
+
+/* One row of ReceiveSeparators.srv, the record all-gathered across GPUs                    */
+typedef struct sf_separator {
+  int8_t  robot_from_id, robot_to_id;
+  int16_t kf_id_from, kf_id_to;
+  int16_t frame_id_from, frame_id_to;      /* frames_kepts_ids_* */
+  uint8_t transform_est_success;
+  uint8_t pad[5];
+  double  position[3];
+  double  orientation[4];
+  double  covariance[36];
+} sf_separator;            /* 360 bytes */
+
+typedef struct sf_match {  /* one element of DataHandler.find_matches' return value         */
+  int32_t idx_local;
+  int32_t idx_other;
+  double  distance;        /* Euclidean distance of the pair (float64)                      */
+} sf_match;
+
+typedef struct sf_context* sf_handle;
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+int  sf_abi_version(void);
+void sf_default_params(sf_params* p);
+/* device: HIP device ordinal.  Fails with SF_ENODEV when no GPU is visible (no CPU fallback). */
+int  sf_create(const sf_params* p, int device, sf_handle* out);
+void sf_destroy(sf_handle h);
+const char* sf_last_error(sf_handle h);   /* h may be NULL: last create() error              */
+int  sf_get_params(sf_handle h, sf_params* out);
+/* Make the handle issue all work on a caller-owned hipStream_t (e.g. torch's current stream). */
+int  sf_set_stream(sf_handle h, void* hip_stream);
+int  sf_synchronize(sf_handle h);
+
+/* ---- NetVLAD nearest-neighbour stage (data_handler.py:166-209, 297-301, 402-408, 437-438) --- */
+/* Append n descriptors of `dim` float64 values (FindMatches.srv:1 wire type) to the local
+   (self.local_descriptors) or received (self.received_descriptors) database.                */
+int  sf_nn_append_local(sf_handle h, const double* desc, int32_t n, int32_t dim);
+int  sf_nn_append_received(sf_handle h, const double* desc, int32_t n, int32_t dim);
+/* Same, from float32 rows already resident in device memory (bulk ingest; MI355X-native).   */
+int  sf_nn_append_local_f32_device(sf_handle h, const float* d_desc, int32_t n, int32_t dim);
+int  sf_nn_append_received_f32_device(sf_handle h, const float* d_desc, int32_t n, int32_t dim);
+int  sf_nn_sizes(sf_handle h, int32_t* n_local, int32_t* n_received);
+/* local_kf_already_used.append / other_kf_already_used.append / add_frames_kept_pairs_to_ignore */
+int  sf_nn_mark_local_used(sf_handle h, int32_t idx_local);
+int  sf_nn_mark_other_used(sf_handle h, int32_t idx_other);
+int  sf_nn_ignore_pair(sf_handle h, int32_t idx_local, int32_t idx_other);
+int  sf_nn_reset(sf_handle h);
+/* DataHandler.find_matches(): writes up to `cap` matches, *n_out = number found.
+   Returns SF_EINVAL when either database is empty (the reference guards this at
+   data_handler.py:308).                                                                     */
+int  sf_nn_find_matches(sf_handle h, sf_match* out, int32_t cap, int32_t* n_out);
+/* Per-row minima of the last find_matches call (diagnostics / tests): n_local entries.      */
+int  sf_nn_last_row_minima(sf_handle h, double* dist, int32_t* idx, int32_t cap);
+
+/* ---- device-resident keyframe feature store (data_handler.py:268 geometric_feats) ----------- */
+int  sf_store_add_keyframe(sf_handle h, const sf_features* f, int32_t* out_slot);
+/* Bulk ingest from device memory: n keyframes, each with exactly `rows` features of `cols`
+   bytes; d_desc [n][rows][cols] u8, d_xyz [n][rows][3] f32, d_kp [n][rows] sf_keypoint.     */
+int  sf_store_add_keyframes_device(sf_handle h, int32_t n, int32_t rows, int32_t cols,
+                                   const uint8_t* d_desc, const float* d_xyz,
+                                   const sf_keypoint* d_kp, int32_t* out_first_slot);
+int  sf_store_size(sf_handle h, int32_t* n_slots);
+int  sf_store_clear(sf_handle h);
+
+/* ---- geometric verification (stereoCamGeometricTools.cpp:122-178) ---------------------------- */
+/* One estimate_transformation service call on host buffers.                                  */
+int  sf_estimate_transform(sf_handle h, const sf_features* from, const sf_features* to,
+                           sf_result* out);
+/* n service calls in one launch sequence, host buffers (features are staged into scratch
+   store slots).                                                                              */
+int  sf_estimate_transform_batch(sf_handle h, const sf_features* from, const sf_features* to,
+                                 int32_t n, sf_result* out);
+/* n candidate pairs given as store slots (from_slot[i] -> to_slot[i]); results to host.      */
+int  sf_verify_pairs(sf_handle h, const int32_t* from_slot, const int32_t* to_slot, int32_t n,
+                     sf_result* out);
+/* Fully device-resident variant: slot arrays and results live in device memory (e.g. a torch
+   tensor's data_ptr()); asynchronous on the handle's stream.                                 */
+int  sf_verify_pairs_device(sf_handle h, const int32_t* d_from_slot, const int32_t* d_to_slot,
+                            int32_t n, sf_result* d_out);
+/* Correspondences found by the two matching passes of the LAST verify call for pair `i`
+   (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.           */
+int  sf_debug_correspondences(sf_handle h, int32_t pair, int32_t pass, uint16_t* from_idx,
+                              uint16_t* to_idx, int32_t cap, int32_t* n_out);
+
+/* ---- separator records ------------------------------------------------------------------------ */
+/* Pack accepted/failed results into ReceiveSeparators rows (host side, no GPU work).          */
+int  sf_pack_separators(const sf_result* res, int32_t n, int8_t robot_from, int8_t robot_to,
+                        const int16_t* kf_from, const int16_t* kf_to, const int16_t* frame_from,
+                        const int16_t* frame_to, sf_separator* out);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Kernel ids for sf_prof_get */
+enum {
+  SF_K_MATCH = 0,      /* global Hamming kNN-2 + NNDR + uniqueness (pass 1)                   */
+  SF_K_RANSAC1 = 1,    /* RANSAC 3D-3D + refine, pass 1                                       */
+  SF_K_GUIDED = 2,     /* guess-guided window matching (pass 2)                               */
+  SF_K_RANSAC2 = 3,    /* RANSAC 3D-3D + refine, pass 2                                       */
+  SF_K_NN = 4,         /* NetVLAD distance matrix + fused row arg-min                         */
+  SF_K_NN_SELECT = 5,  /* f64 re-evaluation + sort + top-K walk                               */
+  SF_K_COUNT = 6
+};
+/* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
+int  sf_prof_enable(sf_handle h, int on);
+int  sf_prof_reset(sf_handle h);
+int  sf_prof_get(sf_handle h, int kernel, int64_t* launches, double* total_ms);
+const char* sf_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEPFINDER_H */

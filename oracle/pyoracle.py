@@ -1,0 +1,217 @@
+"""ctypes loader for the CPU ORACLE (oracle/libsf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from multi_robot_slam_separators_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsf_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile oracle/libsf_oracle.so with gcc (Makefile in this directory)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "sf_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.POINTER
+        L.sfo_find_matches.restype = C.c_int
+        L.sfo_find_matches.argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+            C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+            C.c_double, C.c_int, C.c_void_p, C.c_int, P(C.c_int), C.c_void_p, C.c_void_p]
+        L.sfo_match_global.restype = C.c_int
+        L.sfo_match_global.argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+        L.sfo_match_guided.restype = C.c_int
+        L.sfo_match_guided.argtypes = [
+            P(_abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+        L.sfo_estimate_motion_3d3d.restype = C.c_int
+        L.sfo_estimate_motion_3d3d.argtypes = [
+            P(_abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+            P(Motion), C.c_void_p]
+        L.sfo_estimate_transform.restype = C.c_int
+        L.sfo_estimate_transform.argtypes = [P(_abi.Params), P(_abi.Features), P(_abi.Features),
+                                             P(_abi.Result)]
+        L.sfo_estimate_transform_dbg.restype = C.c_int
+        L.sfo_estimate_transform_dbg.argtypes = [
+            P(_abi.Params), P(_abi.Features), P(_abi.Features), P(_abi.Result),
+            C.c_void_p, C.c_void_p, P(C.c_int), C.c_void_p, C.c_void_p, P(C.c_int)]
+        L.sfo_estimate_transform_batch.restype = C.c_int
+        L.sfo_estimate_transform_batch.argtypes = [
+            P(_abi.Params), P(_abi.Features), P(_abi.Features), C.c_int, C.c_void_p, C.c_int]
+        L.sfo_fit_rigid.restype = None
+        L.sfo_fit_rigid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sfo_canon_log.restype = C.c_double
+        L.sfo_canon_log.argtypes = [C.c_double]
+        L.sfo_sample_triplet.restype = None
+        L.sfo_sample_triplet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.sfo_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class Motion(C.Structure):
+    _fields_ = [
+        ("transform", C.c_float * 12),
+        ("is_null", C.c_int),
+        ("variance", C.c_double),
+        ("matches", C.c_int),
+        ("inliers", C.c_int),
+        ("ransac_best_iteration", C.c_int),
+        ("ransac_iterations_run", C.c_int),
+        ("ransac_best_count", C.c_int),
+        ("refine_rounds", C.c_int),
+    ]
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+def find_matches(local, received, local_used=(), other_used=(), ignored_pairs=(),
+                 netvlad_distance=0.13, max_matches_nb=20):
+    """DataHandler.find_matches (data_handler.py:166-209).  Returns (matches, row_min, row_arg)
+    with matches a structured array (idx_local, idx_other, distance)."""
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    received = np.ascontiguousarray(received, dtype=np.float64)
+    n_l, dim = local.shape
+    n_r = received.shape[0]
+    lu = np.ascontiguousarray(local_used, dtype=np.int32)
+    ou = np.ascontiguousarray(other_used, dtype=np.int32)
+    ig = np.ascontiguousarray(ignored_pairs, dtype=np.int32).reshape(-1, 2)
+    cap = max(1, min(n_l, max_matches_nb))
+    out = np.zeros(cap, dtype=_abi.MATCH_DTYPE)
+    n = C.c_int(0)
+    row_min = np.zeros(n_l, dtype=np.float64)
+    row_arg = np.zeros(n_l, dtype=np.int32)
+    rc = lib().sfo_find_matches(_ptr(local), n_l, _ptr(received), n_r, dim, _ptr(lu), lu.size,
+                                _ptr(ou), ou.size, _ptr(ig), ig.shape[0], netvlad_distance,
+                                max_matches_nb, out.ctypes.data, cap, C.byref(n),
+                                row_min.ctypes.data, row_arg.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("sfo_find_matches -> %s" % _abi.STATUS_NAMES.get(rc, rc))
+    return out[: n.value], row_min, row_arg
+
+
+def match_global(desc_from, desc_to, nndr=0.6, has3d_from=True, has3d_to=True):
+    df = np.ascontiguousarray(desc_from, dtype=np.uint8)
+    dt = np.ascontiguousarray(desc_to, dtype=np.uint8)
+    cap = max(1, df.shape[0], dt.shape[0])
+    cf = np.zeros(cap, dtype=np.uint16)
+    ct = np.zeros(cap, dtype=np.uint16)
+    n, wf, wt, wt2 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    cols = df.shape[1] if df.ndim == 2 and df.shape[0] else (dt.shape[1] if dt.ndim == 2 else 0)
+    rc = lib().sfo_match_global(_ptr(df), df.shape[0], _ptr(dt), dt.shape[0], cols,
+                                C.c_float(nndr), int(has3d_from), int(has3d_to), cf.ctypes.data,
+                                ct.ctypes.data, C.byref(n), C.byref(wf), C.byref(wt), C.byref(wt2))
+    if rc != 0:
+        raise RuntimeError("sfo_match_global -> %d" % rc)
+    return cf[: n.value].copy(), ct[: n.value].copy(), wf.value, wt.value, wt2.value
+
+
+def match_guided(params, guess, f_from, f_to):
+    guess = np.ascontiguousarray(guess, dtype=np.float32).reshape(12)
+    cap = max(1, f_from.desc.shape[0], f_to.desc.shape[0])
+    cf = np.zeros(cap, dtype=np.uint16)
+    ct = np.zeros(cap, dtype=np.uint16)
+    n, wf, wt, wt2, ao = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = lib().sfo_match_guided(C.byref(params), guess.ctypes.data, _ptr(f_from.desc),
+                                _ptr(f_from.xyz), _ptr(f_from.kpts), f_from.desc.shape[0],
+                                _ptr(f_to.desc), _ptr(f_to.kpts), f_to.desc.shape[0],
+                                int(f_to.xyz.shape[0] > 0), f_from.desc.shape[1], cf.ctypes.data,
+                                ct.ctypes.data, C.byref(n), C.byref(wf), C.byref(wt), C.byref(wt2),
+                                C.byref(ao))
+    if rc != 0:
+        raise RuntimeError("sfo_match_guided -> %d" % rc)
+    return cf[: n.value].copy(), ct[: n.value].copy(), wf.value, wt.value, wt2.value, ao.value
+
+
+def estimate_motion_3d3d(params, xyz_from, xyz_to, corr_from, corr_to):
+    xf = np.ascontiguousarray(xyz_from, dtype=np.float32)
+    xt = np.ascontiguousarray(xyz_to, dtype=np.float32)
+    cf = np.ascontiguousarray(corr_from, dtype=np.uint16)
+    ct = np.ascontiguousarray(corr_to, dtype=np.uint16)
+    mo = Motion()
+    mask = np.zeros(max(1, cf.size), dtype=np.uint8)
+    rc = lib().sfo_estimate_motion_3d3d(C.byref(params), _ptr(xf), _ptr(xt), _ptr(cf), _ptr(ct),
+                                        cf.size, C.byref(mo), mask.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("sfo_estimate_motion_3d3d -> %d" % rc)
+    return mo, mask[: cf.size]
+
+
+def estimate_transform(params, f_from, f_to, debug=False):
+    """estimateTransformation (stereoCamGeometricTools.cpp:122-178).  Returns a numpy record of
+    RESULT_DTYPE (and the two correspondence lists when debug=True)."""
+    res = np.zeros(1, dtype=_abi.RESULT_DTYPE)
+    a, b = f_from.c_struct(), f_to.c_struct()
+    if not debug:
+        rc = lib().sfo_estimate_transform(C.byref(params), C.byref(a), C.byref(b),
+                                          C.cast(res.ctypes.data, C.POINTER(_abi.Result)))
+        if rc != 0:
+            raise RuntimeError("sfo_estimate_transform -> %s" % _abi.STATUS_NAMES.get(rc, rc))
+        return res[0]
+    cap = max(1, f_from.desc.shape[0], f_to.desc.shape[0])
+    bufs = [np.zeros(cap, dtype=np.uint16) for _ in range(4)]
+    n1, n2 = C.c_int(), C.c_int()
+    rc = lib().sfo_estimate_transform_dbg(C.byref(params), C.byref(a), C.byref(b),
+                                          C.cast(res.ctypes.data, C.POINTER(_abi.Result)),
+                                          bufs[0].ctypes.data, bufs[1].ctypes.data, C.byref(n1),
+                                          bufs[2].ctypes.data, bufs[3].ctypes.data, C.byref(n2))
+    if rc != 0:
+        raise RuntimeError("sfo_estimate_transform_dbg -> %s" % _abi.STATUS_NAMES.get(rc, rc))
+    return res[0], (bufs[0][: n1.value], bufs[1][: n1.value]), (bufs[2][: n2.value], bufs[3][: n2.value])
+
+
+def estimate_transform_batch(params, feats_from, feats_to, threads=1):
+    n = len(feats_from)
+    fa = _abi.features_array(feats_from)
+    ta = _abi.features_array(feats_to)
+    res = np.zeros(n, dtype=_abi.RESULT_DTYPE)
+    rc = lib().sfo_estimate_transform_batch(C.byref(params), fa, ta, n, res.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("sfo_estimate_transform_batch -> %s" % _abi.STATUS_NAMES.get(rc, rc))
+    return res
+
+
+def fit_rigid(src, dst):
+    src = np.ascontiguousarray(src, dtype=np.float64)
+    dst = np.ascontiguousarray(dst, dtype=np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    lib().sfo_fit_rigid(src.ctypes.data, dst.ctypes.data, src.shape[0], R.ctypes.data, t.ctypes.data)
+    return R.reshape(3, 3), t
+
+
+def canon_log(x):
+    return lib().sfo_canon_log(float(x))
+
+
+def sample_triplet(seed, it, attempt, m):
+    out = np.zeros(3, dtype=np.uint32)
+    lib().sfo_sample_triplet(seed, it, attempt, m, out.ctypes.data)
+    return out
+
+
+def num_threads():
+    return lib().sfo_num_threads()

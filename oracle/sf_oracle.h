@@ -1,0 +1,110 @@
+/*
+ * sf_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's separator-finder hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (multi_robot_slam_separators_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - NN stage (sfo_find_matches): PINNED against scipy.spatial.distance.cdist + numpy.argsort
+ *     driven through the statement sequence of data_handler.py:170-205 (tests/golden/nn_*.npz,
+ *     generator oracle/gen_golden.py).
+ *   - Matching / RANSAC stage: PARITY UNPINNED.  The reference delegates that arithmetic to
+ *     rtabmap (unpinned master), PCL >= 1.7, OpenCV and FLANN, none of which are vendored under
+ *     /root/reference or installed here, and the reference ships no tests or golden vectors.
+ *     The restatement follows the reference's call sites line by line and the published
+ *     algorithms of those libraries (cited per function); it is validated against planted
+ *     ground truth and an independent numpy restatement (tests/), not against reference output.
+ *
+ * Citations: PKG = /root/reference/ros_ws/src/multi_robot_separators.
+ */
+#ifndef SF_ORACLE_H
+#define SF_ORACLE_H
+
+#include <stdint.h>
+#include "../include/sepfinder.h"   /* POD wire structs + sf_params only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DataHandler.find_matches -- PKG/scripts/data_handler.py:166-209.
+ * local [n_l][dim], received [n_r][dim] float64.  Masks: rows local_used[], columns
+ * other_used[], pairs ignored[2*i]=(local,other).  Writes up to cap matches in walk order.
+ * row_min / row_arg (optional, n_l entries) receive the masked per-row minimum and arg-min. */
+int sfo_find_matches(const double* local, int n_l, const double* received, int n_r, int dim,
+                     const int32_t* local_used, int n_local_used,
+                     const int32_t* other_used, int n_other_used,
+                     const int32_t* ignored_pairs, int n_ignored,
+                     double netvlad_distance, int max_matches_nb,
+                     sf_match* out, int cap, int* n_out,
+                     double* row_min, int32_t* row_arg);
+
+/* Global matching branch -- PKG/src/myRegistrationVis.cpp:826-895 with VWDictionary in
+ * brute-force mode [upstream rtabmap VWDictionary::addNewWords].  Outputs the id-aligned
+ * correspondences (ascending "from" index) and the word counts the 3D-3D gate uses. */
+int sfo_match_global(const uint8_t* desc_from, int k_from, const uint8_t* desc_to, int k_to,
+                     int cols, float nndr, int has3d_from, int has3d_to,
+                     uint16_t* corr_from, uint16_t* corr_to, int* n_corr,
+                     int* n_words_from, int* n_words_to, int* n_words_to_2d);
+
+/* Guess-guided matching branch -- PKG/src/myRegistrationVis.cpp:476-825 (default sub-branch
+ * :667-818, _guessMatchToProjection=false), exact radius search instead of FLANN's
+ * approximate kd-tree.  guess = row-major 3x4 float (p_from = guess * p_to).
+ * Returns *all_outside = 1 when no projected point falls in the image (:820-823). */
+int sfo_match_guided(const sf_params* p, const float* guess,
+                     const uint8_t* desc_from, const float* xyz_from, const sf_keypoint* kp_from,
+                     int k_from,
+                     const uint8_t* desc_to, const sf_keypoint* kp_to, int k_to, int has3d_to,
+                     int cols,
+                     uint16_t* corr_from, uint16_t* corr_to, int* n_corr,
+                     int* n_words_from, int* n_words_to, int* n_words_to_2d, int* all_outside);
+
+/* util3d::estimateMotion3DTo3D as called at PKG/src/myRegistrationVis.cpp:1122-1131
+ * [upstream rtabmap util3d_motion_estimation.cpp / util3d_registration.cpp
+ *  transformFromXYZCorrespondences; PCL RandomSampleConsensus +
+ *  SampleConsensusModelRegistration].
+ * Inputs are the id-aligned correspondences.  transform (row-major 3x4 float, p_from = T p_to)
+ * is all-zero when null.  variance_out multiplies I6 (1.0 when untouched). */
+typedef struct sfo_motion {
+  float  transform[12];
+  int    is_null;
+  double variance;      /* covariance = variance * I6 */
+  int    matches;
+  int    inliers;
+  int    ransac_best_iteration;   /* diagnostics */
+  int    ransac_iterations_run;
+  int    ransac_best_count;
+  int    refine_rounds;
+} sfo_motion;
+
+int sfo_estimate_motion_3d3d(const sf_params* p,
+                             const float* xyz_from, const float* xyz_to,
+                             const uint16_t* corr_from, const uint16_t* corr_to, int n_corr,
+                             sfo_motion* out, uint8_t* inlier_mask /* optional, n_corr */);
+
+/* estimateTransformation service -- PKG/src/stereoCamGeometricTools.cpp:122-178 driving
+ * PKG/src/myRegistration.cpp:225-303 and PKG/src/myRegistrationVis.cpp:441-1410 twice. */
+int sfo_estimate_transform(const sf_params* p, const sf_features* from, const sf_features* to,
+                           sf_result* out);
+/* Same with the intermediate correspondences exposed (tests). pass = 1 or 2. */
+int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, const sf_features* to,
+                               sf_result* out,
+                               uint16_t* c1_from, uint16_t* c1_to, int* n_c1,
+                               uint16_t* c2_from, uint16_t* c2_to, int* n_c2);
+
+/* Batch helper for the timed CPU baseline: n independent calls, optional OpenMP over pairs. */
+int sfo_estimate_transform_batch(const sf_params* p, const sf_features* from,
+                                 const sf_features* to, int n, sf_result* out, int threads);
+
+/* Building blocks exposed for unit tests */
+void   sfo_fit_rigid(const double* src, const double* dst, int n, double R[9], double t[3]);
+double sfo_canon_log(double x);
+void   sfo_sample_triplet(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m,
+                          uint32_t out[3]);
+int    sfo_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""Pins the oracle's NN stage against the golden vectors produced by scipy.cdist + numpy.argsort
+driven through data_handler.py:168-205 (oracle/gen_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nn_*.npz")))
+
+
+def test_golden_present():
+    assert len(CASES) >= 9
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_oracle_matches_scipy_numpy_golden(oracle, path):
+    g = np.load(path)
+    m, row_min, row_arg = oracle.find_matches(
+        g["local"].astype(np.float64), g["received"].astype(np.float64), g["local_used"],
+        g["other_used"], g["ignored"], float(g["netvlad_distance"]), int(g["max_matches_nb"]))
+    got = np.stack([m["idx_local"], m["idx_other"]], axis=1).reshape(-1, 2)
+    assert np.array_equal(got, g["matches"])            # index work: bit-exact
+    fin = np.isfinite(g["row_min"])
+    assert np.array_equal(np.isfinite(row_min), fin)
+    assert np.array_equal(row_arg[fin], g["row_arg"][fin])
+    # float64 distances: cdist and the restatement use the same direct formula
+    assert np.allclose(row_min[fin], g["row_min"][fin], rtol=1e-12, atol=1e-15)
+    if len(m):
+        d = np.linalg.norm(g["local"][m["idx_local"]].astype(np.float64)
+                           - g["received"][m["idx_other"]].astype(np.float64), axis=1)
+        assert np.allclose(m["distance"], d, rtol=1e-12)
+
+
+def test_empty_database_is_einval(oracle):
+    a = np.zeros((0, 8))
+    b = np.ones((3, 8))
+    with pytest.raises(RuntimeError):
+        oracle.find_matches(a.reshape(0, 8), b)
+
+
+def test_taken_other_index_consumes_slot(oracle):
+    # rows 0 and 1 both nearest to column 0; row 1 is skipped but still uses a slot (:199-200)
+    b = np.eye(4)[:2]
+    a = np.array([[1, 0.01, 0, 0], [1, 0.02, 0, 0], [0, 1, 0.05, 0]], dtype=np.float64)
+    m, _, _ = oracle.find_matches(a, b, netvlad_distance=0.5, max_matches_nb=2)
+    assert [(r["idx_local"], r["idx_other"]) for r in m] == [(0, 0)]
+    m, _, _ = oracle.find_matches(a, b, netvlad_distance=0.5, max_matches_nb=3)
+    assert [(r["idx_local"], r["idx_other"]) for r in m] == [(0, 0), (2, 1)]
+
+
+def test_break_at_first_row_over_threshold(oracle):
+    b = np.eye(3)
+    a = np.array([[1, 0.01, 0], [0, 1, 0.5], [0, 0.02, 1]], dtype=np.float64)
+    m, _, _ = oracle.find_matches(a, b, netvlad_distance=0.1, max_matches_nb=20)
+    assert [(r["idx_local"], r["idx_other"]) for r in m] == [(0, 0), (2, 2)]
