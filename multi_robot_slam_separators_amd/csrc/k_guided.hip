@@ -1,0 +1,333 @@
+// k_guided.hip -- pass-2 GUESS-GUIDED window matching, one candidate pair per 256-thread workgroup.
+//
+// Replaces myRegistrationVis.cpp:476-825 of the reference (default sub-branch :667-818,
+// _guessMatchToProjection = false): project the "from" 3D points into the "to" image with the
+// pass-1 pose, search the "to" keypoints inside a guess_win_size-pixel radius around every
+// projection, keep candidates of the same octave, brute-force Hamming k=2 + NNDR among them (a
+// single candidate is accepted without descriptor test), every "to" keypoint claimed once by the
+// lowest "from" index.  FLANN's approximate kd-tree radius search [upstream] is replaced by an
+// EXACT scan of the K_to keypoints.
+//
+// CDNA4 mapping: one lane per "from" point (projection in fp64 as cv::projectPoints does); the
+// "to" keypoints {x, y, octave} are wave-uniform float4 records fetched with scalar loads; the
+// Hamming distance is only evaluated for the few (from, to) combinations that pass the window
+// and octave tests; claims use LDS atomicMin; the id-ordered compaction uses wavefront ballots.
+// Also the stage that decides what pass 2 is for every pair (stereoCamGeometricTools.cpp:153-164):
+// a failed pass 1 or an unusable guess re-runs the global branch, whose deterministic result is
+// the pass-1 state, so those pairs are finished here without re-computation.
+// Compiled with -ffp-contract=off (canonical arithmetic).
+#include "sf_device_math.hpp"
+#include "sf_internal.hpp"
+
+namespace {
+
+template <int W>
+__global__ void __launch_bounds__(SF_BLOCK)
+k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+         const PassState* __restrict__ pass1, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
+         uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr, int32_t* __restrict__ list,
+         int32_t* __restrict__ counter, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  const int4 mF = st.meta[sF], mT = st.meta[sT];
+  const int Kf = mF.x, Kt = mT.x;
+  const PassState p1 = pass1[pair];
+
+  bool ident = true;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ident = ident && (p1.T[i] == ((i == 0 || i == 5 || i == 10) ? 1.f : 0.f));
+  // myRegistrationVis.cpp:477-479
+  const bool eligible = !p1.is_null && !ident && P.guess_win > 0 && mF.y > 0 && P.calibrated && Kf > 0 && Kt > 0;
+  if (!eligible) {
+    if (tid == 0) {
+      pass2[pair] = p1;
+      guided_flag[pair] = 0;
+      CorrHeader h = {0, 0, 0, 0};
+      hdr[pair] = h;
+    }
+    return;
+  }
+
+  int* claim = smem;               // [kcap] lowest "from" index that matched each "to" row
+  int* matched = smem + kcap;      // [kcap] "to" row matched by each "from" point, or -1
+  int* misc = smem + 2 * kcap;     // [16]
+  for (int i = tid; i < Kt; i += SF_BLOCK) claim[i] = 0x7FFFFFFF;
+  for (int i = tid; i < Kf; i += SF_BLOCK) matched[i] = -1;
+  if (tid < 16) misc[tid] = 0;
+
+  // :486-487 guessCameraRef = (guess * localTransform).inverse()
+  float Rc[9], tc[3];
+  {
+    const float* g = p1.T;
+    const float* Lt = P.L;
+    float GR[9], Gt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        GR[3 * i + j] = (g[4 * i] * Lt[j] + g[4 * i + 1] * Lt[4 + j]) + g[4 * i + 2] * Lt[8 + j];
+      Gt[i] = ((g[4 * i] * Lt[3] + g[4 * i + 1] * Lt[7]) + g[4 * i + 2] * Lt[11]) + g[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rc[3 * i + j] = GR[3 * j + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tc[i] = -((Rc[3 * i] * Gt[0] + Rc[3 * i + 1] * Gt[1]) + Rc[3 * i + 2] * Gt[2]);
+  }
+  __syncthreads();
+
+  const uint32_t* dF = st.desc + (size_t)sF * kcap * W;
+  const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float4* kF = st.kp + (size_t)sF * kcap;
+  const float4* kT = st.kp + (size_t)sT * kcap;
+  const float r2lim = (float)P.guess_win * (float)P.guess_win;
+
+  int n_finite = 0, n_proj = 0;
+  for (int base = 0; base < Kf; base += SF_BLOCK) {
+    const int i = base + tid;
+    bool inimg = false;
+    float u = 0.f, v = 0.f;
+    if (i < Kf) {
+      const float x = xF[3 * i], y = xF[3 * i + 1], z = xF[3 * i + 2];
+      if (sfd::finite3(x, y, z)) {
+        ++n_finite;
+        const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
+        const double X = (((double)Rc[0] * (double)x + (double)Rc[1] * (double)y) + (double)Rc[2] * (double)z) + (double)tc[0];
+        const double Y = (((double)Rc[3] * (double)x + (double)Rc[4] * (double)y) + (double)Rc[5] * (double)z) + (double)tc[1];
+        const double Z = (((double)Rc[6] * (double)x + (double)Rc[7] * (double)y) + (double)Rc[8] * (double)z) + (double)tc[2];
+        const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;
+        u = (float)((X * iz) * P.fx + P.cx);
+        v = (float)((Y * iz) * P.fy + P.cy);
+        inimg = isfinite(u) && isfinite(v) && !(u < 0.f) && !(u >= P.wlim) && !(v < 0.f) && !(v >= P.hlim) &&
+                (zf > 0.f);
+      }
+    }
+    if (inimg) {
+      ++n_proj;
+      const int octf = __float_as_int(kF[i].z);
+      uint32_t q[W];
+      {
+        const uint4* p = reinterpret_cast<const uint4*>(dF + (size_t)i * W);
+#pragma unroll
+        for (int c = 0; c < W / 4; ++c) {
+          uint4 t4 = p[c];
+          q[4 * c] = t4.x; q[4 * c + 1] = t4.y; q[4 * c + 2] = t4.z; q[4 * c + 3] = t4.w;
+        }
+      }
+      int oi = 0, last = -1;
+      uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;  // (dist << 16 | to_idx) keys
+      for (int t = 0; t < Kt; ++t) {
+        const float4 k = kT[t];
+        const float dx = u - k.x, dy = v - k.y;
+        const float d2 = dx * dx + dy * dy;
+        if (d2 < r2lim && __float_as_int(k.z) == octf) {
+          const uint32_t* r = dT + (size_t)t * W;
+          uint32_t d = 0;
+#pragma unroll
+          for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
+          const uint32_t key = (d << 16) | (uint32_t)t;
+          b1 = min(max(key, b0), b1);
+          b0 = min(b0, key);
+          ++oi;
+          last = t;
+        }
+      }
+      int m = -1;
+      if (oi >= 2) {
+        if ((float)(b0 >> 16) < P.nndr * (float)(b1 >> 16)) m = (int)(b0 & 0xFFFFu);  // :744
+      } else if (oi == 1) {
+        m = last;                                                                    // :751-764
+      }
+      if (m >= 0) {
+        matched[i] = m;
+        atomicMin(&claim[m], i);                                                      // :776-787
+      }
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    n_finite += __shfl_xor(n_finite, off);
+    n_proj += __shfl_xor(n_proj, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&misc[0], n_finite);
+    atomicAdd(&misc[1], n_proj);
+  }
+  __syncthreads();
+  n_finite = misc[0];
+  n_proj = misc[1];
+
+  // id-ordered compaction
+  uint32_t* out = corr + (size_t)pair * kcap;
+  int running = 0;
+  for (int base = 0; base < Kf; base += SF_BLOCK) {
+    const int i = base + tid;
+    int m = (i < Kf) ? matched[i] : -1;
+    const bool flag = (m >= 0) && (claim[m] == i);
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+      int c = misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (flag) out[running + woff + before] = (uint32_t)i | ((uint32_t)m << 16);
+    running += total;
+    __syncthreads();
+  }
+  const int n_corr = running;
+
+  const bool outside = (n_proj == 0);                                   // :820-823
+  const int words_from = outside ? 0 : n_finite;
+  const int words_to_2d = outside ? 0 : Kt;
+  const int words_to = (outside || mT.y <= 0) ? 0 : Kt;
+  const bool motion = words_to_2d > 0 && words_from >= P.min_inliers && words_to >= P.min_inliers;
+  const bool survivor = motion && n_corr >= P.min_inliers && n_corr >= 3;
+  if (motion && !survivor) {
+    const float* xT = st.xyz + (size_t)sT * kcap * 3;
+    for (int i = tid; i < n_corr; i += SF_BLOCK) {
+      uint32_t c = out[i];
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      const float* b = xT + 3 * (c >> 16);
+      bool ok = sfd::finite3(a[0], a[1], a[2]) && sfd::finite3(b[0], b[1], b[2]) &&
+                (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) && (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      if (ok) atomicAdd(&misc[2], 1);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    CorrHeader h;
+    h.n_corr = n_corr;
+    h.words_from = words_from;
+    h.words_to = words_to;
+    h.words_to_2d = words_to_2d;
+    hdr[pair] = h;
+    guided_flag[pair] = 1;
+    PassState ps;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+    ps.var = 1.0;
+    ps.is_null = 1;
+    ps.inliers = 0;
+    ps.matches = (motion && !survivor) ? misc[2] : 0;
+    ps.pad = 0;
+    pass2[pair] = ps;
+    if (survivor) {
+      int pos = atomicAdd(counter, 1);
+      list[pos] = pair;
+    }
+  }
+}
+
+// ---- result assembly: myRegistration.cpp:279-295 covariance clamp + MsgConversion.cpp:61-81 ------
+__global__ void __launch_bounds__(SF_BLOCK)
+k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restrict__ pass2,
+           const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
+  const int i = blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const PassState a = pass1[i], b = pass2[i];
+  sf_result r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.position[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.orientation[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 36; ++k) r.covariance[k] = 0.0;
+  double cd = b.var;
+  if (cd <= 1e-9) cd = 1e-9;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.covariance[7 * k] = cd;
+  r.inliers = b.inliers;
+  r.matches = b.matches;
+  r.inliers_pass1 = a.inliers;
+  r.matches_pass1 = a.matches;
+  r.success = b.is_null ? 0 : 1;
+  r.pass1_success = a.is_null ? 0 : 1;
+  r.pass2_guided = guided_flag[i];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) r.pad[k] = 0;
+  if (!b.is_null) {
+    // Eigen rotation-matrix -> quaternion, then tf::poseEigenToMsg's w >= 0 convention
+    double m[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) m[p][q] = (double)b.T[4 * p + q];
+      r.position[p] = (double)b.T[4 * p + 3];
+    }
+    double x, y, z, w;
+    const double tr = (m[0][0] + m[1][1]) + m[2][2];
+    if (tr > 0.0) {
+      double t = sqrt(tr + 1.0);
+      w = 0.5 * t;
+      t = 0.5 / t;
+      x = (m[2][1] - m[1][2]) * t;
+      y = (m[0][2] - m[2][0]) * t;
+      z = (m[1][0] - m[0][1]) * t;
+    } else if (m[0][0] >= m[1][1] && m[0][0] >= m[2][2]) {   // i = 0
+      double t = sqrt(((m[0][0] - m[1][1]) - m[2][2]) + 1.0);
+      x = 0.5 * t;
+      t = 0.5 / t;
+      w = (m[2][1] - m[1][2]) * t;
+      y = (m[1][0] + m[0][1]) * t;
+      z = (m[2][0] + m[0][2]) * t;
+    } else if (m[1][1] > m[0][0] && m[1][1] >= m[2][2]) {    // i = 1
+      double t = sqrt(((m[1][1] - m[2][2]) - m[0][0]) + 1.0);
+      y = 0.5 * t;
+      t = 0.5 / t;
+      w = (m[0][2] - m[2][0]) * t;
+      z = (m[2][1] + m[1][2]) * t;
+      x = (m[0][1] + m[1][0]) * t;
+    } else {                                                  // i = 2
+      double t = sqrt(((m[2][2] - m[0][0]) - m[1][1]) + 1.0);
+      z = 0.5 * t;
+      t = 0.5 / t;
+      w = (m[1][0] - m[0][1]) * t;
+      x = (m[0][2] + m[2][0]) * t;
+      y = (m[1][2] + m[2][1]) * t;
+    }
+    if (w < 0.0) { x = -x; y = -y; z = -z; w = -w; }
+    r.orientation[0] = x; r.orientation[1] = y; r.orientation[2] = z; r.orientation[3] = w;
+  }
+  out[i] = r;
+}
+
+}  // namespace
+
+int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  sf_prof_begin(c, SF_K_GUIDED);
+  if (st.w == 8) {
+    hipLaunchKernelGGL(k_guided<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                       (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
+                       c->dparams);
+  } else {
+    hipLaunchKernelGGL(k_guided<16>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                       (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
+                       c->dparams);
+  }
+  sf_prof_end(c, SF_K_GUIDED);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
+int sf_launch_finalize(sf_context* c, int n, sf_result* d_out) {
+  if (n <= 0) return SF_OK;
+  hipLaunchKernelGGL(k_finalize, dim3((n + SF_BLOCK - 1) / SF_BLOCK), dim3(SF_BLOCK), 0, c->stream, n,
+                     (const PassState*)c->pass1.p, (const PassState*)c->pass2.p, (const uint8_t*)c->flags.p, d_out);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

@@ -1,0 +1,210 @@
+// k_match.hip -- pass-1 GLOBAL matching: brute-force Hamming kNN (k=2) + NNDR + uniqueness.
+//
+// Replaces the dictionary round trip at myRegistrationVis.cpp:826-895 of the reference
+// (VWDictionary::addNewWords in brute-force mode [upstream rtabmap] = cv::BFMatcher NORM_HAMMING
+// knnMatch k=2, accept nearest id unless d1 > nndr*d2, keep ids occurring exactly once per side).
+//
+// CDNA4 mapping (one 256-thread workgroup per candidate pair):
+//   * every lane keeps TWO "to" descriptors resident in VGPRs (8 or 16 dwords each);
+//   * the "from" descriptors are wave-uniform, so they are fetched with SCALAR loads
+//     (s_load_dwordx8/x16 through the scalar cache) and fed to v_xor_b32 as SGPR operands --
+//     no LDS traffic and no per-lane address math in the K_from x K_to inner product;
+//   * v_bcnt_u32_b32 accumulates the popcount; distance and index are packed into one 32-bit
+//     key (dist << 16 | from_idx) so best/second-best tracking is 3 integer min/max ops and ties
+//     resolve to the lowest index (BFMatcher order);
+//   * uniqueness uses LDS counters; the id-ordered compaction uses wavefront ballots.
+// The kernel is VALU-bound (~19 lane-ops per descriptor pair); HBM traffic is the two descriptor
+// blocks, read once (the "to" block coalesced 16 B/lane, the "from" block via the scalar cache).
+#include "sf_internal.hpp"
+
+namespace {
+
+template <int W, int NQ>
+__device__ __forceinline__ void knn2_scan(const uint32_t* __restrict__ dF, int Kf, const uint32_t (&qa)[W],
+                                          const uint32_t (&qb)[W], uint32_t& a1, uint32_t& a2, uint32_t& b1,
+                                          uint32_t& b2) {
+#pragma unroll 4
+  for (int f = 0; f < Kf; ++f) {
+    const uint32_t* r = dF + (size_t)f * W;  // wave-uniform -> scalar loads
+    uint32_t da = 0, db = 0;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      uint32_t x = r[c];
+      da += __popc(x ^ qa[c]);
+      if (NQ == 2) db += __popc(x ^ qb[c]);
+    }
+    uint32_t ka = (da << 16) | (uint32_t)f;
+    a2 = min(max(ka, a1), a2);
+    a1 = min(a1, ka);
+    if (NQ == 2) {
+      uint32_t kb = (db << 16) | (uint32_t)f;
+      b2 = min(max(kb, b1), b2);
+      b1 = min(b1, kb);
+    }
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int row, bool valid, uint32_t (&q)[W]) {
+  const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)(valid ? row : 0) * W);
+#pragma unroll
+  for (int c = 0; c < W / 4; ++c) {
+    uint4 v = p[c];
+    q[4 * c + 0] = v.x; q[4 * c + 1] = v.y; q[4 * c + 2] = v.z; q[4 * c + 3] = v.w;
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(SF_BLOCK)
+k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+               float nndr, int min_inliers, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+               PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  const int4 mF = st.meta[sF], mT = st.meta[sT];
+  const int Kf = mF.x, Kt = mT.x;
+  const uint32_t* dF = st.desc + (size_t)sF * kcap * W;
+  const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
+
+  int* cnt = smem;               // [kcap] "to" rows that matched each "from" word
+  int* owner = smem + kcap;      // [kcap] the matching "to" row (meaningful when cnt == 1)
+  int* misc = smem + 2 * kcap;   // [16]   0: rejected "to" rows, 1: unique "from", 2: finite corr, 4..7 wave totals
+
+  for (int i = tid; i < Kf; i += SF_BLOCK) cnt[i] = 0;
+  if (tid < 16) misc[tid] = 0;
+  __syncthreads();
+
+  int rejected = 0;
+  if (Kf > 0) {
+    for (int base = 0; base < Kt; base += 2 * SF_BLOCK) {
+      const int ta = base + tid, tb = base + SF_BLOCK + tid;
+      const bool va = ta < Kt, vb = tb < Kt;
+      uint32_t qa[W], qb[W];
+      uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+      load_desc<W>(dT, ta, va, qa);
+      // wave-uniform: does any lane of this wave own a second row?
+      const bool wave_has_b = (base + SF_BLOCK + (tid & ~63)) < Kt;
+      if (wave_has_b) {
+        load_desc<W>(dT, tb, vb, qb);
+        knn2_scan<W, 2>(dF, Kf, qa, qb, a1, a2, b1, b2);
+      } else {
+        knn2_scan<W, 1>(dF, Kf, qa, qa, a1, a2, b1, b2);
+      }
+      if (va) {
+        bool acc = (Kf >= 2) && !((float)(a1 >> 16) > nndr * (float)(a2 >> 16));
+        if (acc) {
+          int f = (int)(a1 & 0xFFFFu);
+          atomicAdd(&cnt[f], 1);
+          owner[f] = ta;
+        } else {
+          ++rejected;
+        }
+      }
+      if (vb) {
+        bool acc = (Kf >= 2) && !((float)(b1 >> 16) > nndr * (float)(b2 >> 16));
+        if (acc) {
+          int f = (int)(b1 & 0xFFFFu);
+          atomicAdd(&cnt[f], 1);
+          owner[f] = tb;
+        } else {
+          ++rejected;
+        }
+      }
+    }
+  }
+  // wave-reduce the rejected count, one LDS atomic per wave
+  for (int off = 32; off >= 1; off >>= 1) rejected += __shfl_xor(rejected, off);
+  if (lane == 0 && rejected) atomicAdd(&misc[0], rejected);
+  __syncthreads();
+
+  // id-ordered compaction of the "from" words matched by exactly one "to" row
+  uint32_t* out = corr + (size_t)pair * kcap;
+  int running = 0;
+  for (int base = 0; base < Kf; base += SF_BLOCK) {
+    const int f = base + tid;
+    const bool flag = (f < Kf) && (cnt[f] == 1);
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+      int c = misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (flag) out[running + woff + before] = (uint32_t)f | ((uint32_t)owner[f] << 16);
+    running += total;
+    __syncthreads();
+  }
+  const int n_corr = running;
+
+  // Gate of the 3D->3D estimation (myRegistrationVis.cpp:928,1117-1118) and, when RANSAC will not
+  // run, the `matches` count util3d::findCorrespondences would still report.
+  const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
+  const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;
+  const int words_to = (mT.y > 0) ? unique_to : 0;
+  const bool motion = unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers;
+  const bool survivor = motion && n_corr >= min_inliers && n_corr >= 3;
+  if (motion && !survivor) {
+    const float* xF = st.xyz + (size_t)sF * kcap * 3;
+    const float* xT = st.xyz + (size_t)sT * kcap * 3;
+    for (int i = tid; i < n_corr; i += SF_BLOCK) {
+      uint32_t c = out[i];
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      const float* b = xT + 3 * (c >> 16);
+      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(b[0]) && isfinite(b[1]) &&
+                isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
+                (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      if (ok) atomicAdd(&misc[2], 1);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    CorrHeader h;
+    h.n_corr = n_corr;
+    h.words_from = words_from;
+    h.words_to = words_to;
+    h.words_to_2d = unique_to;
+    hdr[pair] = h;
+    PassState ps;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+    ps.var = 1.0;
+    ps.is_null = 1;
+    ps.inliers = 0;
+    ps.matches = (motion && !survivor) ? misc[2] : 0;
+    ps.pad = 0;
+    pass[pair] = ps;
+    if (survivor) {
+      int pos = atomicAdd(counter, 1);
+      list[pos] = pair;
+    }
+  }
+}
+
+}  // namespace
+
+int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  sf_prof_begin(c, SF_K_MATCH);
+  if (st.w == 8) {
+    hipLaunchKernelGGL(k_match_global<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                       (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+  } else {
+    hipLaunchKernelGGL(k_match_global<16>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                       (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+  }
+  sf_prof_end(c, SF_K_MATCH);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

@@ -1,0 +1,330 @@
+// k_nn.hip -- NetVLAD nearest-neighbour stage: DataHandler.find_matches
+// (data_handler.py:166-209 of the reference), MI355X-native.
+//
+// The reference materialises the full N_l x N_r float64 distance matrix with scipy cdist, masks
+// it, arg-sorts every row to take column 0, sorts the row minima and walks the first
+// max_matches_nb rows.  Here:
+//   k_nn_argmin   dense ||a||^2 + ||b||^2 - 2 a.b on the fp32 matrix cores
+//                 (v_mfma_f32_32x32x2_f32: exact f32 fma chains), 128x128 tile per 256-thread
+//                 workgroup, operands staged through LDS with a 36-float row pitch (conflict-free
+//                 ds_read_b128), column masks folded into the column norms (+inf), ignored pairs
+//                 checked against a per-row CSR list, and the row arg-min FUSED into the epilogue
+//                 as a packed (dist bits << 32 | column) 64-bit minimum -- the N_l x N_r matrix
+//                 never exists in HBM; only one partial minimum per (row, 64-column strip) does.
+//   k_nn_select   reduces the partial minima per row, re-evaluates the winner's distance in
+//                 float64 with the direct sqrt(sum (a-b)^2) form cdist uses, applies row masks.
+//   host          sorts the N_l row minima (ties: lowest index) and performs the sequential walk
+//                 of data_handler.py:193-205 (skip taken idx_other, accept under threshold, break
+//                 at the first row over it).
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sf_internal.hpp"
+
+namespace {
+
+constexpr int NN_BM = 128, NN_BN = 128, NN_BK = 32, NN_PITCH = 36;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256)
+k_nn_cast_rows(const double* __restrict__ src, float* __restrict__ dst, float* __restrict__ norms, int n, int dim,
+               int ld) {
+  // one wavefront per row: f64 -> f32 rows (zero padded to ld) + squared norms of the f32 values
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < ld; k += 64) {
+    float v = (k < dim) ? (float)src[(size_t)row * dim + k] : 0.f;
+    dst[(size_t)row * ld + k] = v;
+    s = fmaf(v, v, s);
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) norms[row] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_nn_copy_rows(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ norms, int n, int dim,
+               int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < ld; k += 64) {
+    float v = (k < dim) ? src[(size_t)row * dim + k] : 0.f;
+    dst[(size_t)row * ld + k] = v;
+    s = fmaf(v, v, s);
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) norms[row] = s;
+}
+
+// A: local rows [n_l_pad][ld], B: received rows [n_r_pad][ld] (both zero padded).
+// nb_eff[j] = ||b_j||^2, or +inf for masked / padding columns.
+// part[(strip) * n_l_pad + row] = packed min over the 64 columns of strip = blockIdx.x*2 + wave_col.
+__global__ void __launch_bounds__(256)
+k_nn_argmin(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ na,
+            const float* __restrict__ nb_eff, const int* __restrict__ ign_ptr, const int* __restrict__ ign_col,
+            unsigned long long* __restrict__ part, int n_l_pad, int ld) {
+  __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];
+  __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;           // wave tile origin: (64*wr, 64*wc)
+  const int row0 = blockIdx.y * NN_BM, col0 = blockIdx.x * NN_BN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;   // staging: 32 rows x 8 float4 per pass
+  for (int k0 = 0; k0 < ld; k0 += NN_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      const float4 va = *reinterpret_cast<const float4*>(A + (size_t)(row0 + r) * ld + k0 + sk4);
+      const float4 vb = *reinterpret_cast<const float4*>(B + (size_t)(col0 + r) * ld + k0 + sk4);
+      *reinterpret_cast<float4*>(&sA[r * NN_PITCH + sk4]) = va;
+      *reinterpret_cast<float4*>(&sB[r * NN_PITCH + sk4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const float4*>(&sA[(64 * wr + 32 * i + l31) * NN_PITCH + 8 * q + 4 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&sB[(64 * wc + 32 * j + l31) * NN_PITCH + 8 * q + 4 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int strip = blockIdx.x * 2 + wc;
+  float nbj[2];
+  int colj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    colj[j] = col0 + 64 * wc + 32 * j + l31;
+    nbj[j] = nb_eff[colj[j]];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float nai = na[row];
+      const int ip0 = ign_ptr[row], ip1 = ign_ptr[row + 1];
+      unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float d2 = (nai + nbj[j]) - 2.f * acc[i][j][r];
+        d2 = d2 > 0.f ? d2 : 0.f;   // also maps -0 and tiny negative cancellation to +0
+        for (int e = ip0; e < ip1; ++e)
+          if (ign_col[e] == colj[j]) d2 = __int_as_float(0x7F800000);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)colj[j];
+        best = key < best ? key : best;
+      }
+      // min across the 32 lanes that hold this row (same lane>>5)
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+      }
+      if (l31 == 0) part[(size_t)strip * n_l_pad + row] = best;
+    }
+  }
+}
+
+// one wavefront per local row: reduce strips, re-evaluate in float64, apply row mask
+__global__ void __launch_bounds__(256)
+k_nn_select(const unsigned long long* __restrict__ part, int n_strips, int n_l, int n_l_pad,
+            const float* __restrict__ A, const float* __restrict__ B, int dim, int ld,
+            const uint8_t* __restrict__ mask_local, double* __restrict__ out_dist, int* __restrict__ out_idx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_l) return;
+  unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+  for (int s = lane; s < n_strips; s += 64) {
+    const unsigned long long k = part[(size_t)s * n_l_pad + row];
+    best = k < best ? k : best;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off);
+    best = o < best ? o : best;
+  }
+  const int j = (int)(best & 0xFFFFFFFFu);
+  const bool finite = ((unsigned)(best >> 32) < 0x7F800000u) && !mask_local[row];
+  double s = 0.0;
+  if (finite) {
+    const float* a = A + (size_t)row * ld;
+    const float* b = B + (size_t)j * ld;
+    for (int k = lane; k < dim; k += 64) {
+      const double d = (double)a[k] - (double)b[k];
+      s += d * d;
+    }
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  }
+  if (lane == 0) {
+    out_dist[row] = finite ? sqrt(s) : (double)INFINITY;
+    // an all-inf row has no meaningful arg-min (numpy returns an unspecified index there)
+    out_idx[row] = ((unsigned)(best >> 32) < 0x7F800000u) ? j : 0;
+  }
+}
+
+__global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_r_pad) return;
+  nb_eff[j] = (j < n_r && !mask_other[j]) ? nb[j] : __int_as_float(0x7F800000);
+}
+
+}  // namespace
+
+static int nn_reserve(sf_context* c, NNDb& db, int n_total, int ld) {
+  const int cap = std::max(128, (n_total + 127) & ~127);
+  if (cap <= db.cap) return SF_OK;
+  int newcap = std::max(cap, ((db.cap * 2) + 127) & ~127);
+  const size_t old_rows = (size_t)db.cap * ld * 4, old_norms = (size_t)db.cap * 4;
+  int rc;
+  if ((rc = sf_buf_reserve(c, db.rows, (size_t)newcap * ld * 4, true)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, db.norms, (size_t)newcap * 4, true)) != SF_OK) return rc;
+  // zero the new tail so tile loads of padding rows read zeros
+  SF_HIP(c, hipMemsetAsync((char*)db.rows.p + old_rows, 0, (size_t)newcap * ld * 4 - old_rows, c->stream));
+  SF_HIP(c, hipMemsetAsync((char*)db.norms.p + old_norms, 0, (size_t)newcap * 4 - old_norms, c->stream));
+  db.cap = newcap;
+  return SF_OK;
+}
+
+// src_kind 0: host float64 rows ; 1: device float32 rows
+int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int src_kind) {
+  if (n < 0 || dim <= 0) return sf_fail(c, SF_EINVAL, "bad descriptor block %d x %d", n, dim);
+  if (n == 0) return SF_OK;
+  if (!src) return sf_fail(c, SF_EINVAL, "null descriptor pointer");
+  if (c->nn_dim == 0) c->nn_dim = dim;
+  if (dim != c->nn_dim)
+    return sf_fail(c, SF_EINVAL, "descriptor dimension %d differs from the database's %d (data_handler.py:300-301 reshape)", dim, c->nn_dim);
+  SF_HIP(c, hipSetDevice(c->device));
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  int rc = nn_reserve(c, db, db.n + n, ld);
+  if (rc != SF_OK) return rc;
+  float* dst = (float*)db.rows.p + (size_t)db.n * ld;
+  float* nrm = (float*)db.norms.p + db.n;
+  if (src_kind == 0) {
+    Buf tmp;
+    if ((rc = sf_buf_reserve(c, tmp, (size_t)n * dim * 8)) != SF_OK) return rc;
+    hipError_t e = hipMemcpyAsync(tmp.p, src, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_nn_cast_rows, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const double*)tmp.p, dst, nrm, n, dim, ld);
+      e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp.p);
+    if (e != hipSuccess) return sf_fail(c, SF_EHIP, "NN append -> %s", hipGetErrorString(e));
+  } else {
+    hipLaunchKernelGGL(k_nn_copy_rows, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const float*)src, dst, nrm, n, dim, ld);
+    SF_HIP(c, hipGetLastError());
+  }
+  db.n += n;
+  c->masks_dirty = true;
+  return SF_OK;
+}
+
+int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  if (c->params.nn_precision != 0) return sf_fail(c, SF_EINVAL, "nn_precision %d not implemented yet (0 = fp32)", c->params.nn_precision);
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
+  const int n_strips = n_r_pad / 64;
+  int rc;
+  // masks / ignore CSR (rebuilt only when they changed)
+  c->mask_local.resize(n_l, 0);
+  c->mask_other.resize(n_r, 0);
+  if (c->masks_dirty) {
+    if ((rc = sf_buf_reserve(c, c->d_mask_local, (size_t)n_l_pad)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->d_mask_other, (size_t)n_r_pad)) != SF_OK) return rc;
+    std::vector<int> ptr(n_l_pad + 1, 0), col(std::max<size_t>(1, c->ignored.size() / 2));
+    for (size_t e = 0; e + 1 < c->ignored.size(); e += 2) ptr[c->ignored[e] + 1]++;
+    for (int i = 0; i < n_l_pad; ++i) ptr[i + 1] += ptr[i];
+    {
+      std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+      for (size_t e = 0; e + 1 < c->ignored.size(); e += 2) col[fill[c->ignored[e]]++] = c->ignored[e + 1];
+    }
+    if ((rc = sf_buf_reserve(c, c->d_ign_ptr, ptr.size() * 4)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->d_ign_col, col.size() * 4)) != SF_OK) return rc;
+    SF_HIP(c, hipMemcpyAsync(c->d_mask_local.p, c->mask_local.data(), n_l, hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipMemcpyAsync(c->d_mask_other.p, c->mask_other.data(), n_r, hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipMemcpyAsync(c->d_ign_ptr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipMemcpyAsync(c->d_ign_col.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    c->masks_dirty = false;
+  }
+  // workspace: partial minima, effective column norms, per-row results
+  const size_t part_bytes = (size_t)n_strips * n_l_pad * 8;
+  if ((rc = sf_buf_reserve(c, c->nn_rowmin, part_bytes + (size_t)n_r_pad * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->nn_exact, (size_t)n_l * 12)) != SF_OK) return rc;
+  unsigned long long* part = (unsigned long long*)c->nn_rowmin.p;
+  float* nb_eff = (float*)((char*)c->nn_rowmin.p + part_bytes);
+  double* d_dist = (double*)c->nn_exact.p;
+  int* d_idx = (int*)((char*)c->nn_exact.p + (size_t)n_l * 8);
+
+  hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
+                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
+  sf_prof_begin(c, SF_K_NN);
+  hipLaunchKernelGGL(k_nn_argmin, dim3(n_r_pad / NN_BN, n_l_pad / NN_BM), dim3(256), 0, c->stream,
+                     (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p,
+                     (const float*)c->nn_local.norms.p, nb_eff, (const int*)c->d_ign_ptr.p,
+                     (const int*)c->d_ign_col.p, part, n_l_pad, ld);
+  sf_prof_end(c, SF_K_NN);
+  sf_prof_begin(c, SF_K_NN_SELECT);
+  hipLaunchKernelGGL(k_nn_select, dim3((n_l + 3) / 4), dim3(256), 0, c->stream, part, n_strips, n_l, n_l_pad,
+                     (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld,
+                     (const uint8_t*)c->d_mask_local.p, d_dist, d_idx);
+  sf_prof_end(c, SF_K_NN_SELECT);
+  SF_HIP(c, hipGetLastError());
+
+  c->last_row_min.resize(n_l);
+  c->last_row_arg.resize(n_l);
+  SF_HIP(c, hipMemcpyAsync(c->last_row_min.data(), d_dist, (size_t)n_l * 8, hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipMemcpyAsync(c->last_row_arg.data(), d_idx, (size_t)n_l * 4, hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+
+  // data_handler.py:191-205: argsort of the row minima, then the sequential walk
+  std::vector<int> order(n_l);
+  for (int i = 0; i < n_l; ++i) order[i] = i;
+  const std::vector<double>& rm = c->last_row_min;
+  std::sort(order.begin(), order.end(), [&rm](int a, int b) { return rm[a] < rm[b] || (rm[a] == rm[b] && a < b); });
+  const int lim = std::min(n_l, c->params.netvlad_max_matches_nb);
+  int n = 0;
+  std::vector<uint8_t> taken(n_r, 0);
+  for (int s = 0; s < lim; ++s) {
+    const int il = order[s], io = c->last_row_arg[il];
+    if (taken[io]) continue;                                  // :199-200 (slot still consumed)
+    if (rm[il] < c->params.netvlad_distance) {                // :202-203
+      if (n < cap) { out[n].idx_local = il; out[n].idx_other = io; out[n].distance = rm[il]; }
+      taken[io] = 1;
+      ++n;
+      if (n >= cap) break;
+    } else {
+      break;                                                  // :204-205
+    }
+  }
+  *n_out = std::min(n, cap);
+  return SF_OK;
+}

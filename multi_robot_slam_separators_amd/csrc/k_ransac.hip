@@ -1,0 +1,458 @@
+// k_ransac.hip -- RANSAC 3D->3D rigid registration + model refinement for one candidate pair per
+// 256-thread workgroup.
+//
+// Replaces util3d::estimateMotion3DTo3D as called at myRegistrationVis.cpp:1122-1131 of the
+// reference [upstream rtabmap util3d_motion_estimation.cpp / util3d_registration.cpp
+// transformFromXYZCorrespondences; PCL RandomSampleConsensus + SampleConsensusModelRegistration +
+// the refineModel loop], for the correspondences produced by k_match / k_guided.
+//
+// CDNA4 mapping:
+//   * the finite, non-zero correspondences are gathered once into LDS as float4 pairs;
+//   * one LANE per hypothesis: stateless keyed sampling, PCL's sample-distance test, a closed-form
+//     3-point rigid fit in fp64 (Horn quaternion, Jacobi 4x4 in registers), then the inlier count
+//     over all points with LDS BROADCAST reads (every lane reads the same address -> one LDS
+//     cycle, no bank conflicts) -- 12 fma + compare per point, no cross-lane traffic at all;
+//   * PCL's sequential adaptive-termination rule is applied afterwards to the per-hypothesis
+//     counts, which reproduces the sequential algorithm's choice exactly;
+//   * refinement: block-wide fp64 moment reductions in a FIXED order (strided partials, xor
+//     butterfly inside each wavefront via DPP shuffles, four wave sums folded left to right), so
+//     the result is reproducible bit for bit; inlier sets live in LDS byte masks.
+// Compiled with -ffp-contract=off (canonical arithmetic, see sf_device_math.hpp).
+#include "sf_device_math.hpp"
+#include "sf_internal.hpp"
+
+namespace {
+
+struct RansacLds {
+  float4* src;      // [kcap] "from" points (PCL model input_)
+  float4* dst;      // [kcap] "to" points   (PCL target_)
+  float* d2;        // [kcap] squared residuals of the last selectWithinDistance
+  uint8_t* mask_a;  // [kcap]
+  uint8_t* mask_b;  // [kcap]
+  int* counts;      // [iterations + 2]
+  double* red;      // [4][16]
+  int* misc;        // [16]
+};
+
+template <int N>
+__device__ __forceinline__ void block_sum_vec(double (&v)[N], double* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] + __shfl_xor(v[k], off);
+  }
+  __syncthreads();  // previous users of `red` are done
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[wave * 16 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[16 + k]) + red[32 + k]) + red[48 + k];
+}
+
+__device__ __forceinline__ int block_sum_int(int v, int* misc, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (lane == 0) misc[8 + wave] = v;
+  __syncthreads();
+  return ((misc[8] + misc[9]) + misc[10]) + misc[11];
+}
+
+// PCL isSampleGood on the source cloud + keyed sampler; returns false when max_checks attempts fail
+__device__ __forceinline__ bool draw_sample(const RansacLds& L, uint64_t seed, uint32_t it, int max_checks,
+                                            uint32_t m, double sdt, uint32_t& s0, uint32_t& s1, uint32_t& s2) {
+  for (int a = 0; a < max_checks; ++a) {
+    sfd::sample_triplet(seed, it, (uint32_t)a, m, s0, s1, s2);
+    float4 p0 = L.src[s0], p1 = L.src[s1], p2 = L.src[s2];
+    float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+    float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+    float cx = p2.x - p1.x, cy = p2.y - p1.y, cz = p2.z - p1.z;
+    float da = (ax * ax + ay * ay) + az * az;
+    float db = (bx * bx + by * by) + bz * bz;
+    float dc = (cx * cx + cy * cy) + cz * cz;
+    if ((double)da > sdt && (double)db > sdt && (double)dc > sdt) return true;
+  }
+  return false;
+}
+
+// 3-point rigid fit, sequential summation order
+__device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32_t s2, float (&coef)[12]) {
+  const float4 p[3] = {L.src[s0], L.src[s1], L.src[s2]};
+  const float4 q[3] = {L.dst[s0], L.dst[s1], L.dst[s2]};
+  const double inv_n = 1.0 / 3.0;
+  double mp[3] = {0.0, 0.0, 0.0}, mq[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mp[0] += (double)p[i].x; mp[1] += (double)p[i].y; mp[2] += (double)p[i].z;
+    mq[0] += (double)q[i].x; mq[1] += (double)q[i].y; mq[2] += (double)q[i].z;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { mp[j] *= inv_n; mq[j] *= inv_n; }
+  double S[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a[3] = {(double)p[i].x - mp[0], (double)p[i].y - mp[1], (double)p[i].z - mp[2]};
+    const double b[3] = {(double)q[i].x - mq[0], (double)q[i].y - mq[1], (double)q[i].z - mq[2]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) S[j][k] += a[j] * b[k];
+  }
+  sfd::rigid_from_moments(S, mp, mq, coef);
+}
+
+// optimizeModelCoefficients over the members of `mask` (block-order reductions)
+__device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask, int n_in, float (&coef)[12],
+                                  int tid) {
+  const double inv_n = 1.0 / (double)n_in;
+  double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    if (mask[i]) {
+      float4 p = L.src[i], q = L.dst[i];
+      s6[0] += (double)p.x; s6[1] += (double)p.y; s6[2] += (double)p.z;
+      s6[3] += (double)q.x; s6[4] += (double)q.y; s6[5] += (double)q.z;
+    }
+  }
+  block_sum_vec<6>(s6, L.red, tid);
+  double mp[3] = {s6[0] * inv_n, s6[1] * inv_n, s6[2] * inv_n};
+  double mq[3] = {s6[3] * inv_n, s6[4] * inv_n, s6[5] * inv_n};
+  double s9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    if (mask[i]) {
+      float4 p = L.src[i], q = L.dst[i];
+      const double a[3] = {(double)p.x - mp[0], (double)p.y - mp[1], (double)p.z - mp[2]};
+      const double b[3] = {(double)q.x - mq[0], (double)q.y - mq[1], (double)q.z - mq[2]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s9[3 * j + k] += a[j] * b[k];
+    }
+  }
+  block_sum_vec<9>(s9, L.red, tid);
+  double S[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S[j][k] = s9[3 * j + k];
+  sfd::rigid_from_moments(S, mp, mq, coef);
+}
+
+// selectWithinDistance: residuals of all points, membership mask, member count
+__device__ inline int select_within(const RansacLds& L, int m, const float (&coef)[12], double thr2,
+                                    uint8_t* mask, int tid) {
+  int n = 0;
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    float4 p = L.src[i], q = L.dst[i];
+    float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+    bool in = (double)r2 < thr2;
+    L.d2[i] = r2;
+    mask[i] = in ? 1 : 0;
+    n += in ? 1 : 0;
+  }
+  return block_sum_int(n, L.misc, tid);
+}
+
+// 2.1981 * median (element n>>1 in sorted order) of the members' squared residuals
+// [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting.
+__device__ inline double variance_of(const RansacLds& L, int m, const uint8_t* mask, int n, int tid) {
+  const int med = n >> 1;
+  __syncthreads();
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    if (mask[i]) {
+      const float v = L.d2[i];
+      int lt = 0, eq = 0;
+      for (int j = 0; j < m; ++j) {
+        const float u = L.d2[j];
+        const bool mem = mask[j] != 0;
+        lt += (mem && u < v) ? 1 : 0;
+        eq += (mem && u == v) ? 1 : 0;
+      }
+      if (lt <= med && med < lt + eq) L.red[15] = (double)v;  // every writer holds the same value
+    }
+  }
+  __syncthreads();
+  const double medv = L.red[15];
+  return 2.1981 * medv;
+}
+
+__global__ void __launch_bounds__(SF_BLOCK)
+k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+         const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+         const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+         PassState* __restrict__ pass, DeviceParams P) {
+  if ((int)blockIdx.x >= *counter) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const int pair = list[blockIdx.x];
+  const int sF = pair_from[pair], sT = pair_to[pair];
+
+  RansacLds L;
+  {
+    unsigned char* p = smem_raw;
+    L.src = (float4*)p; p += (size_t)kcap * 16;
+    L.dst = (float4*)p; p += (size_t)kcap * 16;
+    L.red = (double*)p; p += 64 * 8;
+    L.d2 = (float*)p; p += (size_t)kcap * 4;
+    L.counts = (int*)p; p += (size_t)((P.iterations + 2 + 3) & ~3) * 4;
+    L.misc = (int*)p; p += 16 * 4;
+    L.mask_a = p; p += kcap;
+    L.mask_b = p;
+  }
+
+  // ---- util3d::findCorrespondences: finite, non-zero, id-ordered ---------------------------------
+  const int n_corr = hdr[pair].n_corr;
+  const uint32_t* cl = corr + (size_t)pair * kcap;
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  if (tid < 16) L.misc[tid] = 0;
+  __syncthreads();
+  int m = 0;
+  for (int base = 0; base < n_corr; base += SF_BLOCK) {
+    const int i = base + tid;
+    bool ok = false;
+    float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+    if (i < n_corr) {
+      const uint32_t c = cl[i];
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      const float* b = xT + 3 * (c >> 16);
+      ax = a[0]; ay = a[1]; az = a[2];
+      bx = b[0]; by = b[1]; bz = b[2];
+      ok = sfd::finite3(ax, ay, az) && sfd::finite3(bx, by, bz) && (ax != 0.f || ay != 0.f || az != 0.f) &&
+           (bx != 0.f || by != 0.f || bz != 0.f);
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+      int c = L.misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (ok) {
+      L.src[m + woff + before] = make_float4(ax, ay, az, 0.f);
+      L.dst[m + woff + before] = make_float4(bx, by, bz, 0.f);
+    }
+    m += total;
+    __syncthreads();
+  }
+
+  PassState ps;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+  ps.var = 1.0;
+  ps.is_null = 1;
+  ps.inliers = 0;
+  ps.matches = m;
+  ps.pad = 0;
+  if (m < P.min_inliers || m < 3) {
+    if (tid == 0) pass[pair] = ps;
+    return;
+  }
+
+  // ---- computeSampleDistanceThreshold (PCA of the source cloud) ----------------------------------
+  const double inv_m = 1.0 / (double)m;
+  double mean[3];
+  {
+    double s3[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < m; i += SF_BLOCK) {
+      float4 p = L.src[i];
+      s3[0] += (double)p.x; s3[1] += (double)p.y; s3[2] += (double)p.z;
+    }
+    block_sum_vec<3>(s3, L.red, tid);
+    mean[0] = s3[0] * inv_m; mean[1] = s3[1] * inv_m; mean[2] = s3[2] * inv_m;
+  }
+  double sdt;
+  {
+    double c6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // xx xy xz yy yz zz
+    for (int i = tid; i < m; i += SF_BLOCK) {
+      float4 p = L.src[i];
+      const double a0 = (double)p.x - mean[0], a1 = (double)p.y - mean[1], a2 = (double)p.z - mean[2];
+      c6[0] += a0 * a0; c6[1] += a0 * a1; c6[2] += a0 * a2;
+      c6[3] += a1 * a1; c6[4] += a1 * a2; c6[5] += a2 * a2;
+    }
+    block_sum_vec<6>(c6, L.red, tid);
+    double C[3][3], V[3][3];
+    C[0][0] = c6[0] * inv_m; C[0][1] = C[1][0] = c6[1] * inv_m; C[0][2] = C[2][0] = c6[2] * inv_m;
+    C[1][1] = c6[3] * inv_m; C[1][2] = C[2][1] = c6[4] * inv_m; C[2][2] = c6[5] * inv_m;
+    sfd::jacobi<3>(C, V);
+    const double e0 = C[0][0] > 0.0 ? C[0][0] : 0.0, e1 = C[1][1] > 0.0 ? C[1][1] : 0.0,
+                 e2 = C[2][2] > 0.0 ? C[2][2] : 0.0;
+    sdt = ((sqrt(e0) + sqrt(e1)) + sqrt(e2)) / 3.0;
+    sdt = sdt * sdt;
+  }
+
+  // ---- hypotheses: one lane each -----------------------------------------------------------------
+  const double thr = P.inlier_thr;
+  const double thr2 = thr * thr;
+  float thr2f = (float)thr2;                       // largest float strictly below thr2
+  if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
+  const int max_it = P.iterations;
+  for (int it = tid; it <= max_it; it += SF_BLOCK) {
+    uint32_t s0, s1, s2;
+    int cnt = -1;
+    if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
+      float coef[12];
+      fit3(L, s0, s1, s2, coef);
+      cnt = 0;
+      for (int i = 0; i < m; ++i) {
+        const float4 p = L.src[i], q = L.dst[i];  // same address in every lane: LDS broadcast
+        const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+        cnt += (r2 <= thr2f) ? 1 : 0;
+      }
+    }
+    L.counts[it] = cnt;
+  }
+  __syncthreads();
+
+  // ---- PCL's sequential loop with adaptive k, replayed on the counts -------------------------------
+  if (tid == 0) {
+    double k = 1.0;
+    const double log_probability = sfd::canon_log(1.0 - 0.99);
+    int best = -1, best_it = -1, it = 0;
+    while (P.adaptive_stop ? ((double)it < k) : true) {
+      if (it > max_it) break;
+      const int c = L.counts[it];
+      if (c < 0) break;
+      if (c > best) {
+        best = c;
+        best_it = it;
+        const double w = (double)best * inv_m;
+        double pno = 1.0 - (w * w) * w;
+        if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
+        if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
+        k = log_probability / sfd::canon_log(pno);
+      }
+      ++it;
+      if (it > max_it) break;
+    }
+    L.misc[0] = best_it;
+  }
+  __syncthreads();
+  const int best_it = L.misc[0];
+  if (best_it < 0) {
+    if (tid == 0) pass[pair] = ps;
+    return;
+  }
+
+  // ---- winning model (recomputed redundantly in every lane: identical arithmetic, no broadcast) ----
+  float coef[12];
+  {
+    uint32_t s0 = 0, s1 = 1, s2 = 2;
+    draw_sample(L, P.seed, (uint32_t)best_it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2);
+    fit3(L, s0, s1, s2, coef);
+  }
+  uint8_t* inl = L.mask_a;
+  int n_inl = select_within(L, m, coef, thr2, inl, tid);
+  const uint8_t* last_mask = inl;
+  int n_last = n_inl;
+
+  // ---- refine loop (copy of pcl::SampleConsensus::refineModel inside rtabmap) ----------------------
+  if (P.refine_iterations > 0) {
+    double error_threshold = thr;
+    int refine_iterations = 0;
+    bool inlier_changed = false;
+    uint8_t* prev = L.mask_a;
+    uint8_t* neu = L.mask_b;
+    int n_prev = n_inl, n_new = 0;
+    for (int i = tid; i < m; i += SF_BLOCK) neu[i] = 0;
+    int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;  // last four pushed sizes (z1 newest)
+    float newc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) newc[i] = coef[i];
+    do {
+      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, newc, tid);
+      z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
+      ++n_sizes;
+      __syncthreads();
+      n_new = select_within(L, m, newc, error_threshold * error_threshold, neu, tid);
+      last_mask = neu;
+      n_last = n_new;
+      if (n_new == 0) {
+        ++refine_iterations;
+        if (refine_iterations >= P.refine_iterations) break;
+        continue;
+      }
+      const double variance = variance_of(L, m, neu, n_new, tid);
+      const double sthr = P.refine_sigma * sqrt(variance);
+      error_threshold = thr < sthr ? thr : sthr;
+      inlier_changed = false;
+      { uint8_t* t = prev; prev = neu; neu = t; int tn = n_prev; n_prev = n_new; n_new = tn; }
+      if (n_new != n_prev) {
+        if (n_sizes >= 4 && z1 == z3 && z2 == z4) break;  // oscillating
+        inlier_changed = true;
+        continue;
+      }
+      int diff = 0;
+      for (int i = tid; i < m; i += SF_BLOCK) diff |= (prev[i] != neu[i]) ? 1 : 0;
+      inlier_changed = block_sum_int(diff, L.misc, tid) != 0;
+    } while (inlier_changed && ++refine_iterations < P.refine_iterations);
+    inl = neu;
+    n_inl = n_new;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) coef[i] = newc[i];
+  }
+
+  if (n_inl >= 3) {
+    const double variance = variance_of(L, m, last_mask, n_last, tid);
+    ps.var = variance;
+    ps.inliers = n_inl;
+    if (n_inl >= P.min_inliers) {
+      double R[9], t[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = (double)coef[4 * i + j];
+        t[i] = (double)coef[4 * i + 3];
+      }
+      bool allz = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ps.T[4 * i + j] = (float)R[3 * j + i];
+        ps.T[4 * i + 3] = (float)(-((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]));
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) allz = allz && (ps.T[i] == 0.f);
+      ps.is_null = allz ? 1 : 0;
+    }
+  }
+  if (tid == 0) pass[pair] = ps;
+}
+
+}  // namespace
+
+size_t sf_ransac_lds_bytes(int kcap, int iterations) {
+  return (size_t)kcap * 32 + 64 * 8 + (size_t)kcap * 4 + (size_t)((iterations + 2 + 3) & ~3) * 4 + 16 * 4 +
+         (size_t)kcap * 2;
+}
+
+int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int32_t* counters = (int32_t*)c->counters.p;
+  const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
+  sf_prof_begin(c, kid);
+  hipLaunchKernelGGL(k_ransac, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
+                     (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
+                     (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
+                     (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  sf_prof_end(c, kid);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

@@ -1,0 +1,634 @@
+// sf_api.hip -- the C-ABI of include/sepfinder.h: context, device-resident keyframe store,
+// verification pipeline orchestration, measurement hooks.  gfx950 only; there is no CPU path:
+// sf_create fails with SF_ENODEV when no GPU is visible.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "sf_internal.hpp"
+
+static thread_local std::string g_create_error;
+
+int sf_fail(sf_context* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+int sf_buf_reserve(sf_context* c, Buf& b, size_t bytes, bool keep) {
+  if (bytes <= b.bytes) return SF_OK;
+  size_t want = std::max(bytes, b.bytes + b.bytes / 2);
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) return sf_fail(c, SF_ENOMEM, "hipMalloc(%zu) -> %s", want, hipGetErrorString(e));
+  if (b.p) {
+    if (keep && b.bytes) {
+      e = hipMemcpyAsync(p, b.p, b.bytes, hipMemcpyDeviceToDevice, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) { (void)hipFree(p); return sf_fail(c, SF_EHIP, "grow copy -> %s", hipGetErrorString(e)); }
+    } else {
+      (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(b.p);
+  }
+  b.p = p;
+  b.bytes = want;
+  return SF_OK;
+}
+
+static void buf_free(Buf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+StoreView sf_store_view(const Store& s) {
+  StoreView v;
+  v.desc = (const uint32_t*)s.desc.p;
+  v.xyz = (const float*)s.xyz.p;
+  v.kp = (const float4*)s.kp.p;
+  v.meta = (const int4*)s.meta.p;
+  v.kcap = s.kcap;
+  v.w = s.w;
+  return v;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "k_guided",
+                                          "k_ransac(pass2)", "k_nn_argmin", "k_nn_select"};
+const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
+
+void sf_prof_begin(sf_context* c, int kernel) {
+  if (!c->prof) return;
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(a, c->stream);
+  c->pending_events.push_back({kernel, {a, b}});
+}
+
+void sf_prof_end(sf_context* c, int kernel) {
+  if (!c->prof || c->pending_events.empty()) return;
+  auto& pe = c->pending_events.back();
+  if (pe.first != kernel) return;
+  (void)hipEventRecord(pe.second.second, c->stream);
+}
+
+static void prof_resolve(sf_context* c) {
+  if (c->pending_events.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& pe : c->pending_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+      c->prof_slots[pe.first].launches += 1;
+      c->prof_slots[pe.first].total_ms += (double)ms;
+    }
+    (void)hipEventDestroy(pe.second.first);
+    (void)hipEventDestroy(pe.second.second);
+  }
+  c->pending_events.clear();
+}
+
+// ---- ingest kernel: wire layout -> store layout ---------------------------------------------------
+namespace {
+
+// one workgroup per keyframe.  desc rows are zero padded to w dwords; keypoints are reduced to
+// {x, y, sign-extended (octave & 255)} (myRegistrationVis.cpp:709-710 compares only that byte).
+__global__ void __launch_bounds__(SF_BLOCK)
+k_ingest(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __restrict__ kp, int4* __restrict__ meta,
+         int kcap, int w, int first_slot, int rows, int cols, int n3d, const uint8_t* __restrict__ s_desc,
+         const float* __restrict__ s_xyz, const sf_keypoint* __restrict__ s_kp) {
+  const int k = blockIdx.x;
+  const int slot = first_slot + k;
+  const int tid = threadIdx.x;
+  uint8_t* d8 = reinterpret_cast<uint8_t*>(desc + (size_t)slot * kcap * w);
+  const uint8_t* sd = s_desc + (size_t)k * rows * cols;
+  const int rowb = w * 4;
+  for (int i = tid; i < rows * rowb; i += SF_BLOCK) {
+    const int r = i / rowb, b = i - r * rowb;
+    d8[i] = (b < cols) ? sd[(size_t)r * cols + b] : (uint8_t)0;
+  }
+  float* dx = xyz + (size_t)slot * kcap * 3;
+  if (n3d > 0) {
+    const float* sx = s_xyz + (size_t)k * rows * 3;
+    for (int i = tid; i < rows * 3; i += SF_BLOCK) dx[i] = sx[i];
+  }
+  float4* dk = kp + (size_t)slot * kcap;
+  const sf_keypoint* sk = s_kp + (size_t)k * rows;
+  for (int i = tid; i < rows; i += SF_BLOCK) {
+    const sf_keypoint q = sk[i];
+    int o = q.octave & 255;
+    o = o < 128 ? o : (-128 | o);
+    dk[i] = make_float4(q.x, q.y, __int_as_float(o), 0.f);
+  }
+  if (tid == 0) meta[slot] = make_int4(rows, n3d > 0 ? rows : 0, rows, cols);
+}
+
+}  // namespace
+
+static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, int cols) {
+  if (cols < 1 || cols > SF_MAX_DESC_BYTES) return sf_fail(c, SF_ERANGE, "descriptor bytes %d not in 1..%d", cols, SF_MAX_DESC_BYTES);
+  if (rows > SF_MAX_FEATURES) return sf_fail(c, SF_ERANGE, "rows %d > int16 limit of KeyPointVec.size", rows);
+  const int w = cols <= 32 ? 8 : 16;
+  int kcap = s.kcap ? s.kcap : std::max(64, (c->params.max_features + 63) & ~63);
+  while (kcap < rows) kcap *= 2;
+  if (kcap > SF_MAX_KCAP) return sf_fail(c, SF_ERANGE, "%d features per keyframe exceed the kernel capacity %d", rows, SF_MAX_KCAP);
+  if (s.slots > 0 && s.w != w) return sf_fail(c, SF_EINVAL, "descriptor width %d B differs from the store's (%d dwords)", cols, s.w);
+  int cap = s.cap_slots;
+  if (cap < slots_needed) cap = std::max(slots_needed, std::max(cap * 2, &s == &c->store ? c->params.store_capacity : 64));
+  if (kcap == s.kcap && cap == s.cap_slots && s.w == w) return SF_OK;
+  // (re)allocate; keep old contents slot by slot (pitch copy when kcap grew)
+  Store n;
+  n.kcap = kcap; n.w = w; n.cap_slots = cap; n.slots = s.slots;
+  int rc;
+  if ((rc = sf_buf_reserve(c, n.desc, (size_t)cap * kcap * w * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, n.xyz, (size_t)cap * kcap * 12)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, n.kp, (size_t)cap * kcap * 16)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, n.meta, (size_t)cap * 16)) != SF_OK) return rc;
+  if (s.slots > 0) {
+    SF_HIP(c, hipMemcpy2DAsync(n.desc.p, (size_t)kcap * w * 4, s.desc.p, (size_t)s.kcap * w * 4, (size_t)s.kcap * w * 4, s.slots, hipMemcpyDeviceToDevice, c->stream));
+    SF_HIP(c, hipMemcpy2DAsync(n.xyz.p, (size_t)kcap * 12, s.xyz.p, (size_t)s.kcap * 12, (size_t)s.kcap * 12, s.slots, hipMemcpyDeviceToDevice, c->stream));
+    SF_HIP(c, hipMemcpy2DAsync(n.kp.p, (size_t)kcap * 16, s.kp.p, (size_t)s.kcap * 16, (size_t)s.kcap * 16, s.slots, hipMemcpyDeviceToDevice, c->stream));
+    SF_HIP(c, hipMemcpyAsync(n.meta.p, s.meta.p, (size_t)s.slots * 16, hipMemcpyDeviceToDevice, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  buf_free(s.desc); buf_free(s.xyz); buf_free(s.kp); buf_free(s.meta);
+  s = n;
+  return SF_OK;
+}
+
+int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, int cols,
+                     const uint8_t* d_desc, const float* d_xyz, const sf_keypoint* d_kp) {
+  if (n <= 0) return SF_OK;
+  hipLaunchKernelGGL(k_ingest, dim3(n), dim3(SF_BLOCK), 0, c->stream, (uint32_t*)st.desc.p, (float*)st.xyz.p,
+                     (float4*)st.kp.p, (int4*)st.meta.p, st.kcap, st.w, first_slot, rows, cols, d_xyz ? rows : 0,
+                     d_desc, d_xyz, d_kp);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
+static int validate_features(sf_context* c, const sf_features* f) {
+  if (!f) return sf_fail(c, SF_EINVAL, "null sf_features");
+  if (f->rows > SF_MAX_FEATURES) return sf_fail(c, SF_ERANGE, "rows %d exceed int16", (int)f->rows);
+  if (f->rows > 0 && (!f->desc || f->cols == 0)) return sf_fail(c, SF_EINVAL, "descriptors missing");
+  if (f->n3d != 0 && f->n3d != (int32_t)f->rows)
+    return sf_fail(c, SF_EINVAL, "kpts3D size %d != descriptor rows %d (myRegistrationVis.cpp:859)", f->n3d, (int)f->rows);
+  if (f->nkp != (int32_t)f->rows)
+    return sf_fail(c, SF_EINVAL, "kpts size %d != descriptor rows %d (myRegistrationVis.cpp:879)", f->nkp, (int)f->rows);
+  if (f->n3d > 0 && !f->xyz) return sf_fail(c, SF_EINVAL, "kpts3D missing");
+  if (f->nkp > 0 && !f->kpts) return sf_fail(c, SF_EINVAL, "kpts missing");
+  return SF_OK;
+}
+
+// host features -> one store slot (staged through a device bounce buffer on the handle's stream)
+struct Staging {
+  Buf &desc, &xyz, &kp;
+};
+static Staging staging(sf_context* c) { return Staging{c->stage_desc, c->stage_xyz, c->stage_kp}; }
+
+static int store_add_host(sf_context* c, Store& st, const sf_features* f, int* out_slot) {
+  int rc = validate_features(c, f);
+  if (rc != SF_OK) return rc;
+  const int rows = f->rows;
+  int cols = f->cols;
+  if (rows == 0 && cols == 0) cols = st.slots > 0 ? 32 : std::max(1, c->params.desc_bytes);
+  if ((rc = store_reserve(c, st, st.slots + 1, rows, cols)) != SF_OK) return rc;
+  if (st.slots > 0 || rows > 0) {
+    // all keyframes of one store share the descriptor width class
+    if (st.w != (cols <= 32 ? 8 : 16)) return sf_fail(c, SF_EINVAL, "descriptor width mismatch");
+  }
+  Staging sg = staging(c);
+  const uint8_t* dd = nullptr; const float* dx = nullptr; const sf_keypoint* dk = nullptr;
+  if (rows > 0) {
+    if ((rc = sf_buf_reserve(c, sg.desc, (size_t)rows * cols)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, sg.kp, (size_t)rows * sizeof(sf_keypoint))) != SF_OK) return rc;
+    SF_HIP(c, hipMemcpyAsync(sg.desc.p, f->desc, (size_t)rows * cols, hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipMemcpyAsync(sg.kp.p, f->kpts, (size_t)rows * sizeof(sf_keypoint), hipMemcpyHostToDevice, c->stream));
+    dd = (const uint8_t*)sg.desc.p; dk = (const sf_keypoint*)sg.kp.p;
+    if (f->n3d > 0) {
+      if ((rc = sf_buf_reserve(c, sg.xyz, (size_t)rows * 12)) != SF_OK) return rc;
+      SF_HIP(c, hipMemcpyAsync(sg.xyz.p, f->xyz, (size_t)rows * 12, hipMemcpyHostToDevice, c->stream));
+      dx = (const float*)sg.xyz.p;
+    }
+  }
+  if ((rc = sf_launch_ingest(c, st, st.slots, 1, rows, cols, dd, dx, dk)) != SF_OK) return rc;
+  // the bounce buffers are reused by the next call: drain before returning
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (out_slot) *out_slot = st.slots;
+  st.slots += 1;
+  return SF_OK;
+}
+
+// ---- parameters ---------------------------------------------------------------------------------
+extern "C" int sf_abi_version(void) { return SF_ABI_VERSION; }
+
+extern "C" void sf_default_params(sf_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->netvlad_distance = 0.13;        // multi_robot_separators.launch:19
+  p->netvlad_dimensions = 128;       // :20
+  p->netvlad_max_matches_nb = 20;    // :22
+  p->nn_precision = 0;
+  p->min_inliers = 5;                // :23 separators_min_inliers
+  p->inlier_distance = 0.1f;         // rtabmap Vis/InlierDistance [upstream default]
+  p->iterations = 300;               // Vis/Iterations
+  p->refine_iterations = 5;          // Vis/RefineIterations
+  p->refine_sigma = 3.0;
+  p->estimation_type = 0;            // 3D->3D (BASELINE.json north_star)
+  p->nndr = 0.6f;                    // Vis/CorNNDR
+  p->guess_win_size = 20;            // Vis/CorGuessWinSize
+  p->ransac_adaptive_stop = 1;
+  p->max_sample_checks = 1000;
+  p->seed = 12345;
+  const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  memcpy(p->local_transform, I, sizeof(I));
+  p->store_capacity = 1024;
+  p->max_features = 512;
+  p->desc_bytes = 32;
+}
+
+static int fill_device_params(sf_context* c) {
+  const sf_params& p = c->params;
+  if (p.estimation_type != 0) return sf_fail(c, SF_EINVAL, "estimation_type %d not implemented (0 = 3D->3D only)", p.estimation_type);
+  if (p.min_inliers < 1) return sf_fail(c, SF_EINVAL, "min_inliers must be >= 1 (myRegistrationVis.cpp:117)");
+  if (!(p.inlier_distance > 0.f)) return sf_fail(c, SF_EINVAL, "inlier_distance must be > 0 (:118)");
+  if (p.iterations < 1) return sf_fail(c, SF_EINVAL, "iterations must be > 0 (:119)");
+  if (p.iterations > 30000) return sf_fail(c, SF_ERANGE, "iterations > 30000");
+  if (p.max_sample_checks < 1) return sf_fail(c, SF_EINVAL, "max_sample_checks must be >= 1");
+  if (p.netvlad_max_matches_nb < 0) return sf_fail(c, SF_EINVAL, "netvlad_max_matches_nb < 0");
+  DeviceParams& d = c->dparams;
+  memset(&d, 0, sizeof(d));
+  d.nndr = p.nndr;
+  d.min_inliers = p.min_inliers;
+  d.iterations = p.iterations;
+  d.refine_iterations = p.refine_iterations;
+  d.refine_sigma = p.refine_sigma;
+  d.inlier_thr = (double)p.inlier_distance;
+  d.adaptive_stop = p.ransac_adaptive_stop;
+  d.max_sample_checks = p.max_sample_checks;
+  d.seed = p.seed;
+  d.guess_win = p.guess_win_size;
+  d.calibrated = (p.image_width > 0 && p.image_height > 0 && p.fx > 0.0 && p.fy > 0.0) ? 1 : 0;
+  d.fx = p.fx; d.fy = p.fy; d.cx = p.cx; d.cy = p.cy;
+  d.wlim = (float)(p.image_width - 1);
+  d.hlim = (float)(p.image_height - 1);
+  memcpy(d.L, p.local_transform, sizeof(d.L));
+  return SF_OK;
+}
+
+// ---- lifecycle ----------------------------------------------------------------------------------
+extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
+  if (!out) return SF_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return sf_fail(nullptr, SF_ENODEV, "no HIP device visible (%s); this library has no CPU fallback",
+                   e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return sf_fail(nullptr, SF_EINVAL, "device %d out of range (%d visible)", device, ndev);
+  sf_context* c = new (std::nothrow) sf_context();
+  if (!c) return SF_ENOMEM;
+  if (p) c->params = *p; else sf_default_params(&c->params);
+  c->device = device;
+  int rc = fill_device_params(c);
+  if (rc != SF_OK) { g_create_error = c->err; delete c; return rc; }
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    sf_fail(nullptr, SF_EHIP, "device init -> %s", hipGetErrorString(e));
+    delete c;
+    return SF_EHIP;
+  }
+  c->own_stream = true;
+  if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
+  *out = c;
+  return SF_OK;
+}
+
+extern "C" void sf_destroy(sf_handle c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  prof_resolve(c);
+  Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
+                 &c->scratch.kp, &c->scratch.meta, &c->pair_from, &c->pair_to, &c->corr1, &c->corr2, &c->hdr1,
+                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list2, &c->list3, &c->counters, &c->results,
+                 &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_recv.rows,
+                 &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+  for (Buf* b : bufs) buf_free(*b);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char* sf_last_error(sf_handle c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int sf_get_params(sf_handle c, sf_params* out) {
+  if (!c || !out) return SF_EINVAL;
+  *out = c->params;
+  return SF_OK;
+}
+
+extern "C" int sf_set_stream(sf_handle c, void* hip_stream) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)hip_stream;
+  c->own_stream = false;
+  return SF_OK;
+}
+
+extern "C" int sf_synchronize(sf_handle c) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  return SF_OK;
+}
+
+// ---- keyframe store -----------------------------------------------------------------------------
+extern "C" int sf_store_add_keyframe(sf_handle c, const sf_features* f, int32_t* out_slot) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return store_add_host(c, c->store, f, out_slot);
+}
+
+extern "C" int sf_store_add_keyframes_device(sf_handle c, int32_t n, int32_t rows, int32_t cols,
+                                             const uint8_t* d_desc, const float* d_xyz,
+                                             const sf_keypoint* d_kp, int32_t* out_first_slot) {
+  if (!c || n < 0 || rows < 0) return SF_EINVAL;
+  if (n == 0) return SF_OK;
+  if (rows > 0 && (!d_desc || !d_kp)) return sf_fail(c, SF_EINVAL, "device descriptor / keypoint pointers missing");
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc = store_reserve(c, c->store, c->store.slots + n, rows, cols);
+  if (rc != SF_OK) return rc;
+  if ((rc = sf_launch_ingest(c, c->store, c->store.slots, n, rows, cols, d_desc, d_xyz, d_kp)) != SF_OK) return rc;
+  if (out_first_slot) *out_first_slot = c->store.slots;
+  c->store.slots += n;
+  return SF_OK;
+}
+
+extern "C" int sf_store_size(sf_handle c, int32_t* n_slots) {
+  if (!c || !n_slots) return SF_EINVAL;
+  *n_slots = c->store.slots;
+  return SF_OK;
+}
+
+extern "C" int sf_store_clear(sf_handle c) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  c->store.slots = 0;
+  return SF_OK;
+}
+
+// ---- verification pipeline ------------------------------------------------------------------------
+static int ws_reserve(sf_context* c, int n, int kcap) {
+  int rc;
+  const size_t np = (size_t)n;
+  if ((rc = sf_buf_reserve(c, c->corr1, np * kcap * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->corr2, np * kcap * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->hdr1, np * sizeof(CorrHeader))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->hdr2, np * sizeof(CorrHeader))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pass1, np * sizeof(PassState))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pass2, np * sizeof(PassState))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->list1, np * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->list3, np * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->flags, np)) != SF_OK) return rc;
+  c->ws_pairs = n;
+  c->ws_kcap = kcap;
+  return SF_OK;
+}
+
+static const int SF_CHUNK = 32768;  // pairs per launch sequence (bounds the workspace: ~4 KiB / pair)
+
+// d_from / d_to / d_out: device pointers. Asynchronous on the handle's stream.
+static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, const int32_t* d_to, int n,
+                         sf_result* d_out) {
+  if (n <= 0) return SF_OK;
+  if (st.slots <= 0) return sf_fail(c, SF_EINVAL, "keyframe store is empty");
+  const StoreView view = sf_store_view(st);
+  int rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap);
+  if (rc != SF_OK) return rc;
+  for (int off = 0; off < n; off += SF_CHUNK) {
+    const int m = std::min(SF_CHUNK, n - off);
+    SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    if ((rc = sf_launch_match_global(c, view, d_from + off, d_to + off, m)) != SF_OK) return rc;
+    if ((rc = sf_launch_ransac(c, view, d_from + off, d_to + off, m, 1)) != SF_OK) return rc;
+    if ((rc = sf_launch_guided(c, view, d_from + off, d_to + off, m)) != SF_OK) return rc;
+    if ((rc = sf_launch_ransac(c, view, d_from + off, d_to + off, m, 2)) != SF_OK) return rc;
+    if ((rc = sf_launch_finalize(c, m, d_out + off)) != SF_OK) return rc;
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_verify_pairs_device(sf_handle c, const int32_t* d_from, const int32_t* d_to, int32_t n,
+                                      sf_result* d_out) {
+  if (!c || n < 0 || (n > 0 && (!d_from || !d_to || !d_out))) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return verify_device(c, c->store, d_from, d_to, n, d_out);
+}
+
+static int verify_host_indices(sf_context* c, const Store& st, const int32_t* from, const int32_t* to, int n,
+                               sf_result* out) {
+  if (n == 0) return SF_OK;
+  for (int i = 0; i < n; ++i)
+    if (from[i] < 0 || from[i] >= st.slots || to[i] < 0 || to[i] >= st.slots)
+      return sf_fail(c, SF_ERANGE, "pair %d: slot (%d,%d) outside the store (%d slots)", i, from[i], to[i], st.slots);
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->pair_from, (size_t)n * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pair_to, (size_t)n * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->results, (size_t)n * sizeof(sf_result))) != SF_OK) return rc;
+  SF_HIP(c, hipMemcpyAsync(c->pair_from.p, from, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  SF_HIP(c, hipMemcpyAsync(c->pair_to.p, to, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = verify_device(c, st, (const int32_t*)c->pair_from.p, (const int32_t*)c->pair_to.p, n,
+                          (sf_result*)c->results.p)) != SF_OK) return rc;
+  SF_HIP(c, hipMemcpyAsync(out, c->results.p, (size_t)n * sizeof(sf_result), hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  return SF_OK;
+}
+
+extern "C" int sf_verify_pairs(sf_handle c, const int32_t* from_slot, const int32_t* to_slot, int32_t n,
+                               sf_result* out) {
+  if (!c || n < 0 || (n > 0 && (!from_slot || !to_slot || !out))) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return verify_host_indices(c, c->store, from_slot, to_slot, n, out);
+}
+
+extern "C" int sf_estimate_transform_batch(sf_handle c, const sf_features* from, const sf_features* to,
+                                           int32_t n, sf_result* out) {
+  if (!c || n < 0 || (n > 0 && (!from || !to || !out))) return SF_EINVAL;
+  if (n == 0) return SF_OK;
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = validate_features(c, from + i)) != SF_OK) return rc;
+    if ((rc = validate_features(c, to + i)) != SF_OK) return rc;
+    if (from[i].rows > 0 && to[i].rows > 0 && from[i].cols != to[i].cols)
+      return sf_fail(c, SF_EINVAL, "pair %d: descriptor widths differ (%d vs %d; myRegistrationVis.cpp:683)", i,
+                     (int)from[i].cols, (int)to[i].cols);
+  }
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  c->scratch.slots = 0;
+  std::vector<int32_t> fi(n), ti(n);
+  for (int i = 0; i < n; ++i) {
+    if ((rc = store_add_host(c, c->scratch, from + i, &fi[i])) != SF_OK) return rc;
+    if ((rc = store_add_host(c, c->scratch, to + i, &ti[i])) != SF_OK) return rc;
+  }
+  return verify_host_indices(c, c->scratch, fi.data(), ti.data(), n, out);
+}
+
+extern "C" int sf_estimate_transform(sf_handle c, const sf_features* from, const sf_features* to, sf_result* out) {
+  return sf_estimate_transform_batch(c, from, to, 1, out);
+}
+
+extern "C" int sf_debug_correspondences(sf_handle c, int32_t pair, int32_t pass, uint16_t* from_idx,
+                                        uint16_t* to_idx, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out || pair < 0 || pair >= c->ws_pairs || (pass != 1 && pass != 2)) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  CorrHeader h;
+  const Buf& hb = pass == 1 ? c->hdr1 : c->hdr2;
+  const Buf& cb = pass == 1 ? c->corr1 : c->corr2;
+  SF_HIP(c, hipMemcpy(&h, (const CorrHeader*)hb.p + pair, sizeof(h), hipMemcpyDeviceToHost));
+  int n = std::min(h.n_corr, cap);
+  std::vector<uint32_t> tmp(std::max(n, 1));
+  if (n > 0) SF_HIP(c, hipMemcpy(tmp.data(), (const uint32_t*)cb.p + (size_t)pair * c->ws_kcap, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) {
+    if (from_idx) from_idx[i] = (uint16_t)(tmp[i] & 0xFFFFu);
+    if (to_idx) to_idx[i] = (uint16_t)(tmp[i] >> 16);
+  }
+  *n_out = h.n_corr;
+  return SF_OK;
+}
+
+// ---- separator records ----------------------------------------------------------------------------
+extern "C" int sf_pack_separators(const sf_result* res, int32_t n, int8_t robot_from, int8_t robot_to,
+                                  const int16_t* kf_from, const int16_t* kf_to, const int16_t* frame_from,
+                                  const int16_t* frame_to, sf_separator* out) {
+  if (n < 0 || (n > 0 && (!res || !out))) return SF_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    sf_separator s;
+    memset(&s, 0, sizeof(s));
+    s.robot_from_id = robot_from;
+    s.robot_to_id = robot_to;
+    s.kf_id_from = kf_from ? kf_from[i] : 0;
+    s.kf_id_to = kf_to ? kf_to[i] : 0;
+    s.frame_id_from = frame_from ? frame_from[i] : 0;
+    s.frame_id_to = frame_to ? frame_to[i] : 0;
+    s.transform_est_success = res[i].success;
+    memcpy(s.position, res[i].position, sizeof(s.position));
+    memcpy(s.orientation, res[i].orientation, sizeof(s.orientation));
+    memcpy(s.covariance, res[i].covariance, sizeof(s.covariance));
+    out[i] = s;
+  }
+  return SF_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------
+extern "C" int sf_prof_enable(sf_handle c, int on) {
+  if (!c) return SF_EINVAL;
+  prof_resolve(c);
+  c->prof = on != 0;
+  return SF_OK;
+}
+
+extern "C" int sf_prof_reset(sf_handle c) {
+  if (!c) return SF_EINVAL;
+  prof_resolve(c);
+  for (auto& s : c->prof_slots) s = ProfSlot();
+  return SF_OK;
+}
+
+extern "C" int sf_prof_get(sf_handle c, int kernel, int64_t* launches, double* total_ms) {
+  if (!c || kernel < 0 || kernel >= SF_K_COUNT) return SF_EINVAL;
+  prof_resolve(c);
+  if (launches) *launches = c->prof_slots[kernel].launches;
+  if (total_ms) *total_ms = c->prof_slots[kernel].total_ms;
+  return SF_OK;
+}
+
+// ---- NN stage entry points (implementation in k_nn.hip) --------------------------------------------
+extern "C" int sf_nn_append_local(sf_handle c, const double* desc, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_local, desc, n, dim, 0);
+}
+extern "C" int sf_nn_append_received(sf_handle c, const double* desc, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_recv, desc, n, dim, 0);
+}
+extern "C" int sf_nn_append_local_f32_device(sf_handle c, const float* d, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_local, d, n, dim, 1);
+}
+extern "C" int sf_nn_append_received_f32_device(sf_handle c, const float* d, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_recv, d, n, dim, 1);
+}
+
+extern "C" int sf_nn_sizes(sf_handle c, int32_t* n_local, int32_t* n_received) {
+  if (!c) return SF_EINVAL;
+  if (n_local) *n_local = c->nn_local.n;
+  if (n_received) *n_received = c->nn_recv.n;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_mark_local_used(sf_handle c, int32_t idx) {
+  if (!c) return SF_EINVAL;
+  if (idx < 0 || idx >= c->nn_local.n) return sf_fail(c, SF_ERANGE, "local index %d outside [0,%d)", idx, c->nn_local.n);
+  if ((int)c->mask_local.size() < c->nn_local.n) c->mask_local.resize(c->nn_local.n, 0);
+  c->mask_local[idx] = 1;
+  c->masks_dirty = true;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_mark_other_used(sf_handle c, int32_t idx) {
+  if (!c) return SF_EINVAL;
+  if (idx < 0 || idx >= c->nn_recv.n) return sf_fail(c, SF_ERANGE, "other index %d outside [0,%d)", idx, c->nn_recv.n);
+  if ((int)c->mask_other.size() < c->nn_recv.n) c->mask_other.resize(c->nn_recv.n, 0);
+  c->mask_other[idx] = 1;
+  c->masks_dirty = true;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_ignore_pair(sf_handle c, int32_t il, int32_t io) {
+  if (!c) return SF_EINVAL;
+  if (il < 0 || il >= c->nn_local.n || io < 0 || io >= c->nn_recv.n)
+    return sf_fail(c, SF_ERANGE, "pair (%d,%d) outside the %d x %d distance matrix", il, io, c->nn_local.n, c->nn_recv.n);
+  c->ignored.push_back(il);
+  c->ignored.push_back(io);
+  c->masks_dirty = true;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_reset(sf_handle c) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  c->nn_local.n = 0;
+  c->nn_recv.n = 0;
+  c->nn_dim = 0;
+  c->mask_local.clear();
+  c->mask_other.clear();
+  c->ignored.clear();
+  c->masks_dirty = true;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_find_matches(sf_handle c, sf_match* out, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out || cap < 0 || (cap > 0 && !out)) return SF_EINVAL;
+  *n_out = 0;
+  if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
+    return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_nn_run(c, out, cap, n_out);
+}
+
+extern "C" int sf_nn_last_row_minima(sf_handle c, double* dist, int32_t* idx, int32_t cap) {
+  if (!c) return SF_EINVAL;
+  const int n = std::min<int>(cap, (int)c->last_row_min.size());
+  for (int i = 0; i < n; ++i) {
+    if (dist) dist[i] = c->last_row_min[i];
+    if (idx) idx[i] = c->last_row_arg[i];
+  }
+  return SF_OK;
+}

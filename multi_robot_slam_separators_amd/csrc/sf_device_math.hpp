@@ -1,0 +1,178 @@
+// sf_device_math.hpp -- device-side numerics of the RANSAC / guided-matching kernels.
+//
+// DESIGN.md "Canonical arithmetic" fixes the ORDER of every floating-point operation so that the
+// GPU and the CPU restatement can be compared bit for bit.  This file is the GPU statement of
+// that order; translation units including it are compiled with -ffp-contract=off and use
+// explicit fma where the canonical form has one.
+//
+// Upstream algorithms restated (none of this code exists in the reference repository; it calls
+// un-vendored rtabmap / PCL):
+//   rigid fit        pcl::SampleConsensusModelRegistration::estimateRigidTransformationSVD
+//                    (pcl::umeyama, double) -- solved here with Horn's unit quaternion
+//   sample test      pcl::SampleConsensusModelRegistration::isSampleGood
+//   adaptive k       pcl::RandomSampleConsensus::computeModel
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sfd {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// Three distinct indices in [0,m): stateless stand-in for PCL's drawIndexSample.
+__device__ __forceinline__ void sample_triplet(uint64_t seed, uint32_t it, uint32_t attempt, uint32_t m,
+                                               uint32_t& i0, uint32_t& i1, uint32_t& i2) {
+  uint64_t ha = mix64(seed ^ mix64(((uint64_t)it << 32) | (uint64_t)attempt));
+  uint64_t hb = mix64(ha);
+  uint32_t r0 = (uint32_t)(ha >> 32), r1 = (uint32_t)ha, r2 = (uint32_t)(hb >> 32);
+  i0 = __umulhi(r0, m);
+  i1 = __umulhi(r1, m - 1);
+  if (i1 >= i0) ++i1;
+  i2 = __umulhi(r2, m - 2);
+  uint32_t lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+  if (i2 >= lo) ++i2;
+  if (i2 >= hi) ++i2;
+}
+
+// ln(x) from IEEE + - * / only (bit-identical to the CPU restatement's series).
+__device__ inline double canon_log(double x) {
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.70710678118654752440) { m = m * 2.0; e -= 1; }
+  double z = (m - 1.0) / (m + 1.0);
+  double z2 = z * z;
+  double s = 1.0 / 27.0;
+#pragma unroll
+  for (int k = 12; k >= 0; --k) s = s * z2 + 1.0 / (double)(2 * k + 1);
+  return 2.0 * z * s + (double)e * 0.69314718055994530942;
+}
+
+// Cyclic Jacobi on a symmetric N x N matrix held in registers (all indices compile-time).
+template <int N>
+__device__ inline void jacobi(double (&a)[N][N], double (&v)[N][N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    double sm = 0.0;
+#pragma unroll
+    for (int p = 0; p < N - 1; ++p)
+#pragma unroll
+      for (int q = p + 1; q < N; ++q) sm += fabs(a[p][q]);
+    if (sm == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+      for (int q = p + 1; q < N; ++q) {
+        double apq = a[p][q];
+        double g = 100.0 * fabs(apq);
+        double app = fabs(a[p][p]), aqq = fabs(a[q][q]);
+        if (sweep > 3 && app + g == app && aqq + g == aqq) {
+          a[p][q] = 0.0;
+          a[q][p] = 0.0;
+        } else if (apq != 0.0) {
+          double h = a[q][q] - a[p][p];
+          double t;
+          if (fabs(h) + g == fabs(h)) {
+            t = apq / h;
+          } else {
+            double theta = 0.5 * h / apq;
+            t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+            if (theta < 0.0) t = -t;
+          }
+          double c = 1.0 / sqrt(1.0 + t * t);
+          double s = t * c;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            double akp = a[k][p], akq = a[k][q];
+            a[k][p] = c * akp - s * akq;
+            a[k][q] = s * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            double apk = a[p][k], aqk = a[q][k];
+            a[p][k] = c * apk - s * aqk;
+            a[q][k] = s * apk + c * aqk;
+          }
+          a[p][q] = 0.0;
+          a[q][p] = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            double vkp = v[k][p], vkq = v[k][q];
+            v[k][p] = c * vkp - s * vkq;
+            v[k][q] = s * vkp + c * vkq;
+          }
+        }
+      }
+    }
+  }
+}
+
+// Rotation (row-major R[9]) and translation from the cross-covariance S[j][k] = sum a_j b_k of
+// the demeaned source/target and their means.  Output as the float coefficients PCL stores.
+__device__ inline void rigid_from_moments(const double (&S)[3][3], const double (&mp)[3],
+                                          const double (&mq)[3], float (&coef)[12]) {
+  double Nm[4][4], V[4][4];
+  Nm[0][0] = (S[0][0] + S[1][1]) + S[2][2];
+  Nm[1][1] = (S[0][0] - S[1][1]) - S[2][2];
+  Nm[2][2] = (S[1][1] - S[0][0]) - S[2][2];
+  Nm[3][3] = (S[2][2] - S[0][0]) - S[1][1];
+  Nm[0][1] = Nm[1][0] = S[1][2] - S[2][1];
+  Nm[0][2] = Nm[2][0] = S[2][0] - S[0][2];
+  Nm[0][3] = Nm[3][0] = S[0][1] - S[1][0];
+  Nm[1][2] = Nm[2][1] = S[0][1] + S[1][0];
+  Nm[1][3] = Nm[3][1] = S[2][0] + S[0][2];
+  Nm[2][3] = Nm[3][2] = S[1][2] + S[2][1];
+  jacobi<4>(Nm, V);
+  // eigenvector of the largest eigenvalue (first maximum), selected without dynamic indexing
+  double bv = Nm[0][0];
+  double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    bool gt = Nm[i][i] > bv;
+    bv = gt ? Nm[i][i] : bv;
+    w = gt ? V[0][i] : w;
+    x = gt ? V[1][i] : x;
+    y = gt ? V[2][i] : y;
+    z = gt ? V[3][i] : z;
+  }
+  double nrm = sqrt(((w * w + x * x) + y * y) + z * z);
+  double inv = 1.0 / nrm;
+  w = w * inv; x = x * inv; y = y * inv; z = z * inv;
+  double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+  double wx = w * x, wy = w * y, wz = w * z;
+  double R[9];
+  R[0] = 1.0 - 2.0 * (yy + zz); R[1] = 2.0 * (xy - wz);       R[2] = 2.0 * (xz + wy);
+  R[3] = 2.0 * (xy + wz);       R[4] = 1.0 - 2.0 * (xx + zz); R[5] = 2.0 * (yz - wx);
+  R[6] = 2.0 * (xz - wy);       R[7] = 2.0 * (yz + wx);       R[8] = 1.0 - 2.0 * (xx + yy);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    double t = mq[j] - ((R[3 * j] * mp[0] + R[3 * j + 1] * mp[1]) + R[3 * j + 2] * mp[2]);
+    coef[4 * j + 0] = (float)R[3 * j + 0];
+    coef[4 * j + 1] = (float)R[3 * j + 1];
+    coef[4 * j + 2] = (float)R[3 * j + 2];
+    coef[4 * j + 3] = (float)t;
+  }
+}
+
+// Squared residual of one correspondence under float coefficients (canonical fma chain).
+__device__ __forceinline__ float residual2(const float (&c)[12], float px, float py, float pz,
+                                           float qx, float qy, float qz) {
+  float tx = __fmaf_rn(c[2], pz, __fmaf_rn(c[1], py, __fmaf_rn(c[0], px, c[3])));
+  float ty = __fmaf_rn(c[6], pz, __fmaf_rn(c[5], py, __fmaf_rn(c[4], px, c[7])));
+  float tz = __fmaf_rn(c[10], pz, __fmaf_rn(c[9], py, __fmaf_rn(c[8], px, c[11])));
+  float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+}  // namespace sfd

@@ -1,0 +1,154 @@
+// sf_internal.hpp -- host-side context and device views shared by the kernel translation units.
+// Product code (gfx950 only). No CPU fallback exists anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sepfinder.h"
+
+#define SF_BLOCK 256            // every verification kernel runs 256-thread workgroups (4 waves)
+#define SF_MAX_KCAP 4096        // per-keyframe feature capacity ceiling of the GPU kernels
+
+// ---- device-resident keyframe store (one arena per field, fixed per-slot stride) ---------------
+// desc : [slots][kcap][W] uint32   W = 8 (<=256-bit descriptors) or 16 (<=512-bit), zero padded
+// xyz  : [slots][kcap][3] float    wire layout of KeyPoint3DVec (base frame)
+// kp   : [slots][kcap]    float4   {pt.x, pt.y, bit-cast sign-extended (octave & 255), 0}
+// meta : [slots]          int4     {rows, n3d, nkp, cols}
+struct StoreView {
+  const uint32_t* desc;
+  const float* xyz;
+  const float4* kp;
+  const int4* meta;
+  int kcap;   // features per slot (multiple of 64)
+  int w;      // dwords per descriptor
+};
+
+// Outcome of one registration pass for one pair (RegistrationVis result + RegistrationInfo)
+struct PassState {
+  float T[12];      // row-major 3x4, p_from = T p_to ; all zero when null
+  double var;       // covariance = var * I6 (before the 1e-9 clamp)
+  int32_t is_null;
+  int32_t inliers;
+  int32_t matches;
+  int32_t pad;
+};
+
+// Header written by the matching kernels in front of each pair's correspondence list
+struct CorrHeader {
+  int32_t n_corr;        // id-aligned correspondences (ascending "from" index)
+  int32_t words_from;    // words3From.size()
+  int32_t words_to;      // words3To.size()
+  int32_t words_to_2d;   // wordsTo.size()
+};
+
+struct DeviceParams {
+  float nndr;
+  int32_t min_inliers;
+  int32_t iterations;
+  int32_t refine_iterations;
+  double refine_sigma;
+  double inlier_thr;       // (double)inlier_distance
+  int32_t adaptive_stop;
+  int32_t max_sample_checks;
+  uint64_t seed;
+  int32_t guess_win;
+  int32_t calibrated;
+  double fx, fy, cx, cy;
+  float wlim, hlim;        // image_width-1, image_height-1
+  float L[12];             // local transform
+};
+
+struct Buf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Store {
+  Buf desc, xyz, kp, meta;
+  int kcap = 0, w = 0, slots = 0, cap_slots = 0;
+};
+
+struct NNDb {
+  Buf rows;        // float32 [cap][dim]
+  Buf norms;       // float32 [cap]
+  Buf rows_h;      // fp16 [cap][dim] (nn_precision == 1)
+  int n = 0, cap = 0;
+};
+
+struct ProfSlot {
+  int64_t launches = 0;
+  double total_ms = 0.0;
+};
+
+struct sf_context {
+  sf_params params;
+  DeviceParams dparams;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  Store store;        // persistent keyframes
+  Store scratch;      // staging slots for host-buffer calls
+  Buf stage_desc, stage_xyz, stage_kp;   // H2D bounce buffers of the host-buffer ingest path
+
+  // verification workspace (sized for `ws_pairs` pairs)
+  int ws_pairs = 0, ws_kcap = 0;
+  Buf pair_from, pair_to;       // int32[n]
+  Buf corr1, corr2;             // uint32[n][kcap]
+  Buf hdr1, hdr2;               // CorrHeader[n]
+  Buf pass1, pass2;             // PassState[n]
+  Buf list1, list2, list3;      // int32[n] work lists (ransac1, guided, ransac2)
+  Buf counters;                 // int32[8]
+  Buf results;                  // sf_result[n]
+  Buf flags;                    // uint8[n] pass2_guided
+
+  // NN stage
+  NNDb nn_local, nn_recv;
+  int nn_dim = 0;
+  std::vector<uint8_t> mask_local, mask_other;         // host mirrors
+  std::vector<int32_t> ignored;                        // pairs (local, other)
+  Buf d_mask_local, d_mask_other, d_ign_ptr, d_ign_col;
+  bool masks_dirty = true;
+  Buf nn_rowmin;     // per-row packed (dist bits, idx) uint64 [n_local]
+  Buf nn_exact;      // double [n_local]
+  std::vector<double> last_row_min;
+  std::vector<int32_t> last_row_arg;
+
+  // profiling
+  bool prof = false;
+  ProfSlot prof_slots[SF_K_COUNT];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+};
+
+// ---- helpers implemented in sf_api.hip ---------------------------------------------------------
+int sf_fail(sf_context* c, int code, const char* fmt, ...);
+int sf_buf_reserve(sf_context* c, Buf& b, size_t bytes, bool keep = false);
+StoreView sf_store_view(const Store& s);
+void sf_prof_begin(sf_context* c, int kernel);
+void sf_prof_end(sf_context* c, int kernel);
+
+#define SF_HIP(c, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return sf_fail((c), SF_EHIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- kernel launchers (one per translation unit) -----------------------------------------------
+// Pass-1 global matching for n pairs; also writes PassState defaults and the RANSAC work list.
+int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
+// RANSAC for the pairs in work list `list` (count in counters[ctr]); pass = 1 or 2.
+int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass);
+// Guided matching for pairs whose pass 1 succeeded; builds the pass-2 RANSAC work list.
+int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
+// Assemble sf_result records.
+int sf_launch_finalize(sf_context* c, int n, sf_result* d_out);
+// Ingest kernels
+int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, int cols,
+                     const uint8_t* d_desc, const float* d_xyz, const sf_keypoint* d_kp);
+// NN stage
+int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out);
+int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int src_kind);

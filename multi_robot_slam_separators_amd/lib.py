@@ -1,0 +1,299 @@
+"""ctypes binding of the product library libsepfinder.so (C-ABI: include/sepfinder.h).
+
+There is NO CPU fallback: if the shared library is missing, or no GPU is visible, every entry
+point raises.  PyTorch is imported first (when installed) only so that this process ends up with
+ONE HIP runtime: torch bundles libamdhip64.so (SONAME libamdhip64.so.7) and the library's
+NEEDED entry resolves to the copy that is already loaded.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsepfinder.so")
+_lib = None
+
+
+class SepfinderError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (_abi.STATUS_NAMES.get(code, code), msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (csrc/Makefile, hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the separator-finder path)" % LIB_PATH)
+    try:  # one HIP runtime per process (see module docstring)
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing, not a requirement of the C-ABI itself
+        for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                break
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    sig = {
+        "sf_abi_version": (C.c_int, []),
+        "sf_default_params": (None, [P(_abi.Params)]),
+        "sf_create": (C.c_int, [P(_abi.Params), C.c_int, P(vp)]),
+        "sf_destroy": (None, [vp]),
+        "sf_last_error": (C.c_char_p, [vp]),
+        "sf_get_params": (C.c_int, [vp, P(_abi.Params)]),
+        "sf_set_stream": (C.c_int, [vp, vp]),
+        "sf_synchronize": (C.c_int, [vp]),
+        "sf_nn_append_local": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_append_received": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_append_local_f32_device": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_append_received_f32_device": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_sizes": (C.c_int, [vp, P(i32), P(i32)]),
+        "sf_nn_mark_local_used": (C.c_int, [vp, i32]),
+        "sf_nn_mark_other_used": (C.c_int, [vp, i32]),
+        "sf_nn_ignore_pair": (C.c_int, [vp, i32, i32]),
+        "sf_nn_reset": (C.c_int, [vp]),
+        "sf_nn_find_matches": (C.c_int, [vp, vp, i32, P(i32)]),
+        "sf_nn_last_row_minima": (C.c_int, [vp, vp, vp, i32]),
+        "sf_store_add_keyframe": (C.c_int, [vp, P(_abi.Features), P(i32)]),
+        "sf_store_add_keyframes_device": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, P(i32)]),
+        "sf_store_size": (C.c_int, [vp, P(i32)]),
+        "sf_store_clear": (C.c_int, [vp]),
+        "sf_estimate_transform": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), vp]),
+        "sf_estimate_transform_batch": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), i32, vp]),
+        "sf_verify_pairs": (C.c_int, [vp, vp, vp, i32, vp]),
+        "sf_verify_pairs_device": (C.c_int, [vp, vp, vp, i32, vp]),
+        "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
+        "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
+        "sf_prof_enable": (C.c_int, [vp, C.c_int]),
+        "sf_prof_reset": (C.c_int, [vp]),
+        "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
+        "sf_kernel_name": (C.c_char_p, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    if L.sf_abi_version() != 1:
+        raise ImportError("libsepfinder.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+EXPORTED = [
+    "sf_abi_version", "sf_default_params", "sf_create", "sf_destroy", "sf_last_error", "sf_get_params",
+    "sf_set_stream", "sf_synchronize", "sf_nn_append_local", "sf_nn_append_received",
+    "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_sizes",
+    "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
+    "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_store_add_keyframe",
+    "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
+    "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device",
+    "sf_debug_correspondences", "sf_pack_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
+    "sf_kernel_name",
+]
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class SeparatorFinder:
+    """One handle = one robot's separator-finder state on one GPU (single caller, like the
+    reference's single-threaded geometry node)."""
+
+    def __init__(self, params=None, device=0):
+        self._L = load()
+        self.params = _abi.copy_params(params) if params is not None else _abi.default_params()
+        h = C.c_void_p()
+        rc = self._L.sf_create(C.byref(self.params), device, C.byref(h))
+        if rc != 0:
+            raise SepfinderError(rc, (self._L.sf_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise SepfinderError(rc, (self._L.sf_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.sf_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        self._check(self._L.sf_synchronize(self._h))
+
+    # -- NN stage (data_handler.py:166-209) ---------------------------------------------------
+    def nn_append_local(self, desc):
+        d = np.ascontiguousarray(desc, dtype=np.float64)
+        d = d.reshape(-1, d.shape[-1]) if d.ndim > 1 else d.reshape(-1, self.params.netvlad_dimensions)
+        self._check(self._L.sf_nn_append_local(self._h, _ptr(d), d.shape[0], d.shape[1]))
+
+    def nn_append_received(self, desc):
+        d = np.ascontiguousarray(desc, dtype=np.float64)
+        d = d.reshape(-1, d.shape[-1]) if d.ndim > 1 else d.reshape(-1, self.params.netvlad_dimensions)
+        self._check(self._L.sf_nn_append_received(self._h, _ptr(d), d.shape[0], d.shape[1]))
+
+    def nn_append_local_device(self, dptr, n, dim):
+        self._check(self._L.sf_nn_append_local_f32_device(self._h, C.c_void_p(dptr), n, dim))
+
+    def nn_append_received_device(self, dptr, n, dim):
+        self._check(self._L.sf_nn_append_received_f32_device(self._h, C.c_void_p(dptr), n, dim))
+
+    def nn_sizes(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self._L.sf_nn_sizes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def nn_mark_local_used(self, idx):
+        self._check(self._L.sf_nn_mark_local_used(self._h, int(idx)))
+
+    def nn_mark_other_used(self, idx):
+        self._check(self._L.sf_nn_mark_other_used(self._h, int(idx)))
+
+    def nn_ignore_pair(self, idx_local, idx_other):
+        self._check(self._L.sf_nn_ignore_pair(self._h, int(idx_local), int(idx_other)))
+
+    def nn_reset(self):
+        self._check(self._L.sf_nn_reset(self._h))
+
+    def nn_find_matches(self, cap=None):
+        n_l, _ = self.nn_sizes()
+        if cap is None:
+            cap = max(1, min(max(n_l, 1), self.params.netvlad_max_matches_nb))
+        out = np.zeros(max(cap, 1), dtype=_abi.MATCH_DTYPE)
+        n = C.c_int32()
+        self._check(self._L.sf_nn_find_matches(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value]
+
+    def nn_last_row_minima(self):
+        n_l, _ = self.nn_sizes()
+        d = np.zeros(n_l, dtype=np.float64)
+        i = np.zeros(n_l, dtype=np.int32)
+        self._check(self._L.sf_nn_last_row_minima(self._h, _ptr(d), _ptr(i), n_l))
+        return d, i
+
+    # -- keyframe store ---------------------------------------------------------------------------
+    def store_add_keyframe(self, feats):
+        f = feats.c_struct()
+        slot = C.c_int32()
+        self._check(self._L.sf_store_add_keyframe(self._h, C.byref(f), C.byref(slot)))
+        return slot.value
+
+    def store_add_keyframes_device(self, n, rows, cols, d_desc, d_xyz, d_kp):
+        first = C.c_int32()
+        self._check(self._L.sf_store_add_keyframes_device(self._h, n, rows, cols, C.c_void_p(d_desc),
+                                                          C.c_void_p(d_xyz), C.c_void_p(d_kp),
+                                                          C.byref(first)))
+        return first.value
+
+    def store_size(self):
+        n = C.c_int32()
+        self._check(self._L.sf_store_size(self._h, C.byref(n)))
+        return n.value
+
+    def store_clear(self):
+        self._check(self._L.sf_store_clear(self._h))
+
+    # -- verification -----------------------------------------------------------------------------
+    def estimate_transform(self, f_from, f_to):
+        res = np.zeros(1, dtype=_abi.RESULT_DTYPE)
+        a, b = f_from.c_struct(), f_to.c_struct()
+        self._check(self._L.sf_estimate_transform(self._h, C.byref(a), C.byref(b), res.ctypes.data))
+        return res[0]
+
+    def estimate_transform_batch(self, feats_from, feats_to):
+        n = len(feats_from)
+        res = np.zeros(n, dtype=_abi.RESULT_DTYPE)
+        if n == 0:
+            return res
+        fa, ta = _abi.features_array(feats_from), _abi.features_array(feats_to)
+        self._check(self._L.sf_estimate_transform_batch(self._h, fa, ta, n, res.ctypes.data))
+        return res
+
+    def verify_pairs(self, from_slots, to_slots):
+        f = np.ascontiguousarray(from_slots, dtype=np.int32)
+        t = np.ascontiguousarray(to_slots, dtype=np.int32)
+        res = np.zeros(f.size, dtype=_abi.RESULT_DTYPE)
+        self._check(self._L.sf_verify_pairs(self._h, _ptr(f), _ptr(t), f.size, _ptr(res)))
+        return res
+
+    def verify_pairs_device(self, d_from, d_to, n, d_out):
+        self._check(self._L.sf_verify_pairs_device(self._h, C.c_void_p(d_from), C.c_void_p(d_to), n,
+                                                   C.c_void_p(d_out)))
+
+    def debug_correspondences(self, pair, which_pass, cap=4096):
+        cf = np.zeros(cap, dtype=np.uint16)
+        ct = np.zeros(cap, dtype=np.uint16)
+        n = C.c_int32()
+        self._check(self._L.sf_debug_correspondences(self._h, pair, which_pass, cf.ctypes.data,
+                                                     ct.ctypes.data, cap, C.byref(n)))
+        return cf[: n.value].copy(), ct[: n.value].copy()
+
+    # -- measurement ------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self._L.sf_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        self._check(self._L.sf_prof_reset(self._h))
+
+    def prof_get(self):
+        """{kernel name: (launches, total_ms)} measured with hipEvents on the handle's stream."""
+        out = {}
+        for k in range(_abi.SF_K_COUNT):
+            n, ms = C.c_int64(), C.c_double()
+            self._check(self._L.sf_prof_get(self._h, k, C.byref(n), C.byref(ms)))
+            out[self._L.sf_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+
+def pack_separators(results, robot_from, robot_to, kf_from, kf_to, frame_from, frame_to):
+    """ReceiveSeparators.srv rows (one per result) as a structured array of SEPARATOR_DTYPE."""
+    L = load()
+    res = np.ascontiguousarray(results, dtype=_abi.RESULT_DTYPE)
+    n = res.size
+    arrs = [np.ascontiguousarray(a, dtype=np.int16) for a in (kf_from, kf_to, frame_from, frame_to)]
+    for a in arrs:
+        if a.size != n:
+            raise ValueError("id arrays must have one entry per result")
+    for v in (robot_from, robot_to):
+        if not -128 <= int(v) <= 127:
+            raise ValueError("robot ids are int8 on the wire (ReceiveSeparators.srv:1-2)")
+    out = np.zeros(n, dtype=_abi.SEPARATOR_DTYPE)
+    rc = L.sf_pack_separators(_ptr(res), n, int(robot_from), int(robot_to), _ptr(arrs[0]), _ptr(arrs[1]),
+                              _ptr(arrs[2]), _ptr(arrs[3]), _ptr(out))
+    if rc != 0:
+        raise SepfinderError(rc, "sf_pack_separators")
+    return out

@@ -1,0 +1,228 @@
+"""GPU parity tests of the verification path (matching + RANSAC + two-pass driver), through the
+C-ABI, against the CPU oracle on identical seeded inputs.
+
+Bars: correspondences, match / inlier counts and success flags are integer work -> bit-exact;
+poses within BASELINE.json's 1e-4 m / 1e-3 rad; covariance within 1e-9 relative."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi, synth
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL = 1e-4   # metres   (BASELINE.json north_star)
+ROT_TOL = 1e-3   # radians
+
+
+@pytest.fixture(scope="module")
+def finder():
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = 500
+    f = lib.SeparatorFinder(p)
+    yield f
+    f.close()
+
+
+def quat_angle(q1, q2):
+    d = abs(float(np.dot(q1, q2))) / max(np.linalg.norm(q1) * np.linalg.norm(q2), 1e-300)
+    return 2.0 * np.arccos(np.clip(d, -1.0, 1.0))
+
+
+def assert_result_parity(g, o, ctx=""):
+    for k in ("success", "pass1_success", "pass2_guided", "inliers", "matches", "inliers_pass1",
+              "matches_pass1"):
+        assert g[k] == o[k], "%s %s: gpu %s oracle %s" % (ctx, k, g[k], o[k])
+    if o["success"]:
+        assert np.linalg.norm(g["position"] - o["position"]) <= POS_TOL, ctx
+        assert quat_angle(g["orientation"], o["orientation"]) <= ROT_TOL, ctx
+    else:
+        assert np.all(g["position"] == 0) and np.all(g["orientation"] == 0)
+    assert np.allclose(g["covariance"], o["covariance"], rtol=1e-9, atol=0), ctx
+
+
+def test_batch_parity_mixed_pairs(finder, oracle):
+    A, B, is_true, Ts = synth.make_pairs(2024, 48, k=500, cols=32, true_frac=0.4)
+    got = finder.estimate_transform_batch(A, B)
+    n_exact = 0
+    for i in range(len(A)):
+        o, c1, c2 = oracle.estimate_transform(finder.params, A[i], B[i], debug=True)
+        g1 = finder.debug_correspondences(i, 1)
+        assert np.array_equal(g1[0], c1[0]) and np.array_equal(g1[1], c1[1]), "pass-1 correspondences %d" % i
+        if o["pass2_guided"]:
+            g2 = finder.debug_correspondences(i, 2)
+            assert np.array_equal(g2[0], c2[0]) and np.array_equal(g2[1], c2[1]), "pass-2 correspondences %d" % i
+        assert_result_parity(got[i], o, "pair %d" % i)
+        if is_true[i]:
+            assert got[i]["success"] == 1
+            dt, dr = synth.pose_error(got[i], Ts[i])
+            assert dt < 0.05 and dr < 0.01
+        n_exact += int(np.array_equal(got[i]["position"], o["position"])
+                       and np.array_equal(got[i]["orientation"], o["orientation"])
+                       and np.array_equal(got[i]["covariance"], o["covariance"]))
+    # canonical arithmetic: the GPU and the oracle are expected to agree bit for bit
+    print("bit-identical results: %d / %d" % (n_exact, len(A)))
+    assert n_exact >= len(A) - 2
+
+
+def test_single_call_equals_batch_entry(finder, oracle):
+    A, B, _, _ = synth.make_pairs(7, 3, k=300, true_frac=1.0)
+    batch = finder.estimate_transform_batch(A, B)
+    for i in range(3):
+        single = finder.estimate_transform(A[i], B[i])
+        assert single.tobytes() == batch[i].tobytes()    # n = 1 reproduces one service call
+
+
+@pytest.mark.parametrize("k,cols,iters", [(1000, 32, 2000), (500, 64, 500), (200, 16, 300), (77, 32, 100)])
+def test_other_configs(oracle, k, cols, iters):
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = iters
+    p.max_features = k
+    A, B, is_true, _ = synth.make_pairs(100 + k, 10, k=k, cols=cols, true_frac=0.5)
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    for i in range(len(A)):
+        assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "k=%d pair %d" % (k, i))
+    assert got["success"][is_true].all()
+
+
+def test_store_resident_pairs(finder, oracle):
+    rng = np.random.default_rng(5)
+    A, B, is_true, _ = synth.make_pairs(55, 12, k=400, true_frac=0.5)
+    finder.store_clear()
+    slots_a = [finder.store_add_keyframe(a) for a in A]
+    slots_b = [finder.store_add_keyframe(b) for b in B]
+    assert finder.store_size() == 24
+    # arbitrary pairing, including cross pairs and a keyframe against itself
+    fs = slots_a + [slots_a[0], slots_b[3], slots_a[2]]
+    ts = slots_b + [slots_a[0], slots_a[3], slots_b[5]]
+    feats = {s: f for s, f in zip(slots_a + slots_b, A + B)}
+    got = finder.verify_pairs(fs, ts)
+    for i, (s, t) in enumerate(zip(fs, ts)):
+        assert_result_parity(got[i], oracle.estimate_transform(finder.params, feats[s], feats[t]), "slot pair %d" % i)
+    with pytest.raises(Exception):
+        finder.verify_pairs([0], [999])
+    finder.store_clear()
+    _ = rng
+
+
+def test_edge_cases(finder, oracle):
+    rng = np.random.default_rng(3)
+    p = finder.params
+    a = synth.make_keyframe(rng, 60)
+    empty = _abi.FeatureArrays(np.zeros((0, 32), np.uint8), np.zeros((0, 3), np.float32),
+                               np.zeros(0, _abi.KEYPOINT_DTYPE))
+    one = synth.make_keyframe(rng, 1)
+    no3d = _abi.FeatureArrays(a.desc, np.zeros((0, 3), np.float32), a.kpts)
+    nan3d = _abi.FeatureArrays(a.desc, a.xyz.copy(), a.kpts)
+    nan3d.xyz[::2] = np.nan
+    nan3d.xyz[1] = 0.0
+    cases = [(a, empty), (empty, a), (empty, empty), (a, a), (one, a), (a, one), (a, no3d), (no3d, a),
+             (nan3d, a), (a, nan3d), (nan3d, nan3d)]
+    got = finder.estimate_transform_batch([c[0] for c in cases], [c[1] for c in cases])
+    for i, (f, t) in enumerate(cases):
+        assert_result_parity(got[i], oracle.estimate_transform(p, f, t), "edge %d" % i)
+    assert got[3]["success"] == 1 and got[3]["covariance"][0] == 1e-9
+    # size mismatches the reference UASSERTs on -> SF_EINVAL, never a crash
+    bad = _abi.FeatureArrays(a.desc, a.xyz[:10], a.kpts)
+    with pytest.raises(Exception):
+        finder.estimate_transform(bad, a)
+    bad2 = _abi.FeatureArrays(a.desc, a.xyz, a.kpts[:5])
+    with pytest.raises(Exception):
+        finder.estimate_transform(a, bad2)
+    wide = synth.make_keyframe(rng, 60, cols=64)
+    with pytest.raises(Exception):
+        finder.estimate_transform(a, wide)
+
+
+def test_duplicate_descriptors_and_ties(finder, oracle):
+    # many identical descriptors: NNDR ties (d1 == d2) must reject, d1 = d2 = 0 accepts lowest index
+    rng = np.random.default_rng(9)
+    a = synth.make_keyframe(rng, 128)
+    a.desc[10:20] = a.desc[10]
+    b, _ = synth.make_true_partner(rng, a, synth.random_transform(rng), overlap=0.7, noise=0.01, flip=0.0)
+    b.desc[:5] = a.desc[10]
+    got = finder.estimate_transform(a, b)
+    assert_result_parity(got, oracle.estimate_transform(finder.params, a, b), "ties")
+    g = finder.debug_correspondences(0, 1)
+    o = oracle.match_global(a.desc, b.desc, finder.params.nndr)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+
+
+def test_parameter_variants(oracle):
+    from multi_robot_slam_separators_amd import lib
+    A, B, _, _ = synth.make_pairs(31, 8, k=300, true_frac=0.75)
+    variants = []
+    for kw in [dict(ransac_adaptive_stop=0), dict(refine_iterations=0), dict(guess_win_size=0),
+               dict(min_inliers=50), dict(nndr=0.9), dict(image_width=0), dict(seed=999),
+               dict(inlier_distance=0.02), dict(guess_win_size=5), dict(refine_sigma=1.0)]:
+        p = synth.camera_params()
+        p.iterations = 200
+        for k, v in kw.items():
+            setattr(p, k, v)
+        variants.append((kw, p))
+    for kw, p in variants:
+        with lib.SeparatorFinder(p) as f:
+            got = f.estimate_transform_batch(A, B)
+        for i in range(len(A)):
+            assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "%s pair %d" % (kw, i))
+
+
+def test_unsupported_estimators_are_rejected():
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.estimation_type = 1
+    with pytest.raises(lib.SepfinderError):
+        lib.SeparatorFinder(p)
+
+
+def test_octave_and_window_semantics(finder, oracle):
+    rng = np.random.default_rng(77)
+    a = synth.make_keyframe(rng, 200)
+    T = synth.random_transform(rng, 8.0, 0.5)
+    b, _ = synth.make_true_partner(rng, a, T, overlap=0.6, noise=0.01, flip=0.03)
+    a.kpts["octave"] = rng.integers(0, 3, size=200)
+    b.kpts["octave"] = rng.integers(0, 3, size=200) | 0x100   # only the low byte is compared
+    got = finder.estimate_transform(a, b)
+    o, c1, c2 = oracle.estimate_transform(finder.params, a, b, debug=True)
+    assert_result_parity(got, o, "octaves")
+    g2 = finder.debug_correspondences(0, 2)
+    assert np.array_equal(g2[0], c2[0]) and np.array_equal(g2[1], c2[1])
+
+
+def test_size_independent_properties_full_config(finder):
+    """BASELINE configs[1] sizes (K=500, 256-bit, 500 iterations) on a larger batch: properties that
+    need no oracle -- planted transforms recovered, false pairs rejected, batch order irrelevant."""
+    d = synth.make_store_batch(4242, 256, k=500, cols=32, true_frac=0.25)
+    import torch
+    finder.store_clear()
+    dev = torch.device("cuda:0")
+    tens = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.uint8) if v.dtype.fields else v).to(dev)
+            for k, v in d.items() if k not in ("is_true", "T_gt")}
+    torch.cuda.synchronize()
+    n = 256
+    first_a = finder.store_add_keyframes_device(n, 500, 32, tens["desc_a"].data_ptr(), tens["xyz_a"].data_ptr(),
+                                                tens["kp_a"].data_ptr())
+    first_b = finder.store_add_keyframes_device(n, 500, 32, tens["desc_b"].data_ptr(), tens["xyz_b"].data_ptr(),
+                                                tens["kp_b"].data_ptr())
+    fs = np.arange(n, dtype=np.int32) + first_a
+    ts = np.arange(n, dtype=np.int32) + first_b
+    res = finder.verify_pairs(fs, ts)
+    assert np.array_equal(res["success"].astype(bool), d["is_true"])
+    for i in np.nonzero(d["is_true"])[0]:
+        dt, dr = synth.pose_error(res[i], d["T_gt"][i])
+        assert dt < 0.03 and dr < 5e-3
+        assert res[i]["inliers"] >= 50
+    perm = np.random.default_rng(1).permutation(n)
+    res2 = finder.verify_pairs(fs[perm], ts[perm])
+    assert res2.tobytes() == res[perm].tobytes()            # results do not depend on batch position
+    # symmetry: swapping from/to inverts the pose (up to the RANSAC tolerance)
+    j = int(np.nonzero(d["is_true"])[0][0])
+    r_ab = finder.verify_pairs([fs[j]], [ts[j]])[0]
+    r_ba = finder.verify_pairs([ts[j]], [fs[j]])[0]
+    assert r_ba["success"] == 1
+    Tinv = np.linalg.inv(d["T_gt"][j])
+    dt, dr = synth.pose_error(r_ba, Tinv)
+    assert dt < 0.03 and dr < 5e-3 and r_ab["success"] == 1
+    finder.store_clear()
