@@ -33,9 +33,11 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
-  const int4 mF = st.meta[sF], mT = st.meta[sT];
-  const int Kf = mF.x, Kt = mT.x;
   const PassState p1 = pass1[pair];
+  const bool bad_slot = (unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots;
+  const int4 mF = bad_slot ? make_int4(0, 0, 0, 0) : st.meta[sF];
+  const int4 mT = bad_slot ? make_int4(0, 0, 0, 0) : st.meta[sT];
+  const int Kf = mF.x, Kt = mT.x;
 
   bool ident = true;
 #pragma unroll

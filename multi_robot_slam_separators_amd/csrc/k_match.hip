@@ -65,6 +65,19 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
+  if ((unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots) {
+    // caller-provided slot outside the store: report a failed estimation, touch nothing else
+    if (tid == 0) {
+      CorrHeader h = {0, 0, 0, 0};
+      hdr[pair] = h;
+      PassState ps;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+      ps.var = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
+      pass[pair] = ps;
+    }
+    return;
+  }
   const int4 mF = st.meta[sF], mT = st.meta[sT];
   const int Kf = mF.x, Kt = mT.x;
   const uint32_t* dF = st.desc + (size_t)sF * kcap * W;

@@ -57,6 +57,7 @@ StoreView sf_store_view(const Store& s) {
   v.meta = (const int4*)s.meta.p;
   v.kcap = s.kcap;
   v.w = s.w;
+  v.n_slots = s.slots;
   return v;
 }
 

@@ -23,6 +23,7 @@ struct StoreView {
   const int4* meta;
   int kcap;   // features per slot (multiple of 64)
   int w;      // dwords per descriptor
+  int n_slots;  // valid slots (device-side guard for caller-provided slot indices)
 };
 
 // Outcome of one registration pass for one pair (RegistrationVis result + RegistrationInfo)
