@@ -213,7 +213,7 @@ def test_size_independent_properties_full_config(finder):
     for i in np.nonzero(d["is_true"])[0]:
         dt, dr = synth.pose_error(res[i], d["T_gt"][i])
         assert dt < 0.03 and dr < 5e-3
-        assert res[i]["inliers"] >= 50
+        assert res[i]["inliers"] >= 20 and res[i]["inliers_pass1"] >= 150
     perm = np.random.default_rng(1).permutation(n)
     res2 = finder.verify_pairs(fs[perm], ts[perm])
     assert res2.tobytes() == res[perm].tobytes()            # results do not depend on batch position
