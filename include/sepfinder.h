@@ -128,7 +128,7 @@ typedef struct sf_result {
   uint8_t pass1_success;
   uint8_t pass2_guided;    /* 1 if pass 2 took the guess-guided branch                      */
   uint8_t pad[5];
-} sf_result;               /* 392 bytes */
+} sf_result;               /* 368 bytes */
 
 /* One row of ReceiveSeparators.srv, the record all-gathered across GPUs                    */
 typedef struct sf_separator {

@@ -1,0 +1,93 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm;
+"gloo" in the CPU tests).
+
+The path shards naturally: candidate pairs are independent
+(stereoCamGeometricTools.cpp:122-178 is stateless per call) and NN rows are independent until
+the final sequential walk (data_handler.py:191-205).  So there is exactly ONE data-path exchange:
+an all-gather of fixed-size separator records (one row of ReceiveSeparators.srv each), plus, for
+the row-sharded NN stage, an all-gather of per-row (distance, index) minima followed by the walk
+replicated on every rank.
+"""
+import numpy as np
+
+
+def shard_pairs(n_pairs, rank, world):
+    """Round-robin partition: pair p belongs to rank p mod world."""
+    return np.arange(rank, n_pairs, world, dtype=np.int64)
+
+
+def _dist():
+    import torch.distributed as td
+    return td
+
+
+def allgather_records(local, group=None):
+    """All-gather a ragged set of fixed-size records.
+
+    local: torch.uint8 tensor [n_local, record_bytes] on the device of the process group's backend.
+    Returns (records [sum n, record_bytes], counts list).  Two-phase: counts first, then one
+    all_gather_into_tensor of the payload padded to the largest shard (a single direct exchange
+    over xGMI for the few-MB shards this path produces)."""
+    import torch
+    td = _dist()
+    world = td.get_world_size(group)
+    n_local, rec = int(local.shape[0]), int(local.shape[1])
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=local.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
+    td.all_gather_into_tensor(counts, cnt, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    cap = max(max(counts), 1)
+    send = torch.zeros((cap, rec), dtype=torch.uint8, device=local.device)
+    if n_local:
+        send[:n_local] = local
+    recv = torch.empty((world * cap, rec), dtype=torch.uint8, device=local.device)
+    td.all_gather_into_tensor(recv, send, group=group)
+    parts = [recv[r * cap: r * cap + counts[r]] for r in range(world)]
+    return torch.cat(parts, dim=0), counts
+
+
+def interleave_round_robin(records, counts):
+    """Undo shard_pairs: records gathered rank-major -> global pair order (p = i*world + rank)."""
+    import torch
+    world = len(counts)
+    total = sum(counts)
+    out = torch.empty_like(records)
+    off = 0
+    for r in range(world):
+        idx = torch.arange(r, total, world, device=records.device)[: counts[r]]
+        out[idx] = records[off: off + counts[r]]
+        off += counts[r]
+    return out
+
+
+def walk_matches(row_min, row_arg, netvlad_distance, max_matches_nb):
+    """The sequential tail of DataHandler.find_matches (data_handler.py:191-205) on gathered row
+    minima; ties in the sort resolve to the lowest index.  Returns [(idx_local, idx_other)]."""
+    row_min = np.asarray(row_min, dtype=np.float64)
+    order = np.lexsort((np.arange(row_min.size), row_min))
+    matches, taken = [], set()
+    for s in range(min(row_min.size, int(max_matches_nb))):
+        il = int(order[s])
+        io = int(row_arg[il])
+        if io in taken:
+            continue
+        if row_min[il] < netvlad_distance:
+            matches.append((il, io))
+            taken.add(io)
+        else:
+            break
+    return matches
+
+
+def allgather_row_minima(row_min, row_arg, group=None):
+    """NN stage sharded over LOCAL rows: every rank searched a contiguous block of local rows
+    against the replicated received database; gather the (float64 distance, int32 index) pairs so
+    that every rank can run the identical walk.  Inputs: torch tensors on the backend's device."""
+    import torch
+    rec = torch.empty((row_min.shape[0], 12), dtype=torch.uint8, device=row_min.device)
+    rec[:, :8] = row_min.contiguous().view(torch.uint8).reshape(-1, 8)
+    rec[:, 8:] = row_arg.contiguous().view(torch.uint8).reshape(-1, 4)
+    allrec, counts = allgather_records(rec, group)
+    d = allrec[:, :8].contiguous().view(torch.float64).reshape(-1)
+    i = allrec[:, 8:].contiguous().view(torch.int32).reshape(-1)
+    return d, i, counts

@@ -51,7 +51,11 @@ int sfo_find_matches(const double* local, int n_l, const double* received, int n
   int32_t* arg = (int32_t*)malloc((size_t)n_l * sizeof(int32_t));
   if (!dist || !rows || !arg) { free(dist); free(rows); free(arg); return SF_ENOMEM; }
 
-  /* :170 distances = cdist(local_descs, received_descs)  -- Euclidean, float64, direct form */
+  /* :170 distances = cdist(local_descs, received_descs)  -- Euclidean, float64, direct form.
+   * (rows are independent; OpenMP only changes who computes a row, never the arithmetic) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int i = 0; i < n_l; ++i) {
     const double* a = local + (size_t)i * dim;
     for (int j = 0; j < n_r; ++j) {

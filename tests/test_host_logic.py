@@ -1,0 +1,182 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/sepfinder.h declares,
+struct layouts agree between the header (gcc) and the ctypes mirror, host-only entry points work,
+the product fails loudly without a GPU, and the N > 1 exchange path is correct under gloo."""
+import ctypes as C
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi, dist, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu_visible():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    from multi_robot_slam_separators_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
+    declared = sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), "libsepfinder.so does not export %s" % name
+    assert sorted(lib.EXPORTED) == declared
+    assert L.sf_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "sepfinder.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(sf_params), sizeof(sf_keypoint),"
+        " sizeof(sf_features), sizeof(sf_result), sizeof(sf_separator), sizeof(sf_match),"
+        " offsetof(sf_params, seed), offsetof(sf_params, local_transform), offsetof(sf_result, inliers),"
+        " offsetof(sf_separator, position)); return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(_abi.Params), C.sizeof(_abi.Keypoint), C.sizeof(_abi.Features), C.sizeof(_abi.Result),
+            C.sizeof(_abi.Separator), C.sizeof(_abi.Match), _abi.Params.seed.offset,
+            _abi.Params.local_transform.offset, _abi.Result.inliers.offset, _abi.Separator.position.offset]
+    assert got == want
+    assert _abi.RESULT_DTYPE.itemsize == got[3] and _abi.SEPARATOR_DTYPE.itemsize == got[4]
+
+
+def test_default_params_match_reference_launch_file():
+    from multi_robot_slam_separators_amd import lib
+    L = lib.load()
+    p = _abi.Params()
+    L.sf_default_params(C.byref(p))
+    assert bytes(p) == bytes(_abi.default_params())
+    # multi_robot_separators.launch:19-23
+    assert (p.netvlad_distance, p.netvlad_dimensions, p.netvlad_max_matches_nb, p.min_inliers) == (0.13, 128, 20, 5)
+
+
+@pytest.mark.skipif(_gpu_visible(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu():
+    from multi_robot_slam_separators_amd import lib
+    with pytest.raises(lib.SepfinderError) as e:
+        lib.SeparatorFinder()
+    assert e.value.code == _abi.SF_ENODEV and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multi_robot_slam_separators_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "pyoracle" not in txt and "sf_oracle" not in txt and "libsf_oracle" not in txt, fn
+    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
+    assert "oracle" not in hdr.lower()
+
+
+def test_pack_separators_rows():
+    from multi_robot_slam_separators_amd import lib
+    res = np.zeros(3, dtype=_abi.RESULT_DTYPE)
+    res["success"] = [1, 0, 1]
+    res["position"][0] = [1, 2, 3]
+    res["orientation"][0] = [0, 0, 0, 1]
+    res["covariance"][:, ::7] = 0.5
+    sep = lib.pack_separators(res, 0, 1, [10, 11, 12], [20, 21, 22], [1, 2, 3], [4, 5, 6])
+    assert sep["robot_from_id"].tolist() == [0, 0, 0] and sep["robot_to_id"].tolist() == [1, 1, 1]
+    assert sep["kf_id_from"].tolist() == [10, 11, 12] and sep["frame_id_to"].tolist() == [4, 5, 6]
+    assert sep["transform_est_success"].tolist() == [1, 0, 1]
+    assert np.array_equal(sep["position"], res["position"]) and np.array_equal(sep["covariance"], res["covariance"])
+    with pytest.raises(ValueError):
+        lib.pack_separators(res, 200, 1, [1, 2, 3], [1, 2, 3], [1, 2, 3], [1, 2, 3])   # int8 on the wire
+    with pytest.raises(ValueError):
+        lib.pack_separators(res, 0, 1, [1], [1], [1], [1])
+
+
+def test_walk_matches_equals_oracle(oracle):
+    for seed in range(5):
+        local, other, _ = synth.make_netvlad(seed, 120, 90, 64, planted_frac=0.3)
+        m, rmin, rarg = oracle.find_matches(local.astype(np.float64), other.astype(np.float64),
+                                            netvlad_distance=0.13, max_matches_nb=17)
+        got = dist.walk_matches(rmin, rarg, 0.13, 17)
+        assert got == [(int(r["idx_local"]), int(r["idx_other"])) for r in m]
+
+
+def test_shard_pairs_round_robin():
+    parts = [dist.shard_pairs(23, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(23))
+    assert parts[1].tolist() == [1, 5, 9, 13, 17, 21]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as td
+sys.path.insert(0, %(root)r)
+from multi_robot_slam_separators_amd import dist, _abi
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+td.init_process_group("gloo", rank=rank, world_size=world)
+# --- separator records: 11 pairs sharded round-robin, ragged shards ---------------------------------
+n_pairs, B = 11, _abi.RESULT_DTYPE.itemsize
+mine = dist.shard_pairs(n_pairs, rank, world)
+rec = np.zeros(len(mine), dtype=_abi.RESULT_DTYPE)
+rec["inliers"] = mine * 7 + 1
+rec["success"] = (mine %% 2).astype(np.uint8)
+rec["position"][:, 0] = mine + 0.25
+local = torch.from_numpy(rec.view(np.uint8).reshape(len(mine), B).copy())
+allrec, counts = dist.allgather_records(local)
+ordered = dist.interleave_round_robin(allrec, counts)
+out = np.frombuffer(ordered.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+assert counts == [len(dist.shard_pairs(n_pairs, r, world)) for r in range(world)]
+assert out["inliers"].tolist() == [p * 7 + 1 for p in range(n_pairs)], out["inliers"]
+assert out["success"].tolist() == [p %% 2 for p in range(n_pairs)]
+assert np.allclose(out["position"][:, 0], np.arange(n_pairs) + 0.25)
+# --- empty shard on one rank ---------------------------------------------------------------------------
+few = torch.zeros((1 if rank == 0 else 0, 8), dtype=torch.uint8)
+g, c = dist.allgather_records(few)
+assert c == [1] + [0] * (world - 1) and g.shape == (1, 8)
+# --- NN stage sharded over local rows: gather the row minima, replicate the walk ----------------------
+rng = np.random.default_rng(3)
+rmin = rng.random(40); rarg = rng.integers(0, 25, 40).astype(np.int32)
+lo, hi = rank * 40 // world, (rank + 1) * 40 // world
+d, i, cnt = dist.allgather_row_minima(torch.from_numpy(rmin[lo:hi].copy()), torch.from_numpy(rarg[lo:hi].copy()))
+assert np.array_equal(d.numpy(), rmin) and np.array_equal(i.numpy(), rarg)
+assert dist.walk_matches(d.numpy(), i.numpy(), 0.5, 10) == dist.walk_matches(rmin, rarg, 0.5, 10)
+td.barrier(); td.destroy_process_group()
+print("rank %%d ok" %% rank)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_exchange_gloo(tmp_path, world):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o.decode())
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o[-3000:]

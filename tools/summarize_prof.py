@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output directories (kernel stats + PMC passes) into profiles/<tag>_*.{csv,json}.
+Usage: python tools/summarize_prof.py <tag> <stats_dir> [<fetch_dir> <write_dir>]"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+(?:<\d+>)?)", name)
+    return m.group(1) if m else name[:40]
+
+def pmc(dirname):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+tag, stats = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+out = {"kernels": []}
+for f in glob.glob(os.path.join(stats, "**", "*_kernel_stats.csv"), recursive=True):
+    shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
+    for r in csv.DictReader(open(f)):
+        out["kernels"].append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
+                               "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])})
+if len(sys.argv) >= 5:
+    fe, wr = pmc(sys.argv[3]), pmc(sys.argv[4])
+    out["pmc_per_launch"] = {}
+    for (k, c), (v, n) in sorted(list(fe.items()) + list(wr.items())):
+        # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section)
+        out["pmc_per_launch"].setdefault(k, {})[c + "_KiB"] = v
+        out["pmc_per_launch"][k]["launches"] = n
+json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
+for k in out["kernels"]:
+    print("%-22s calls %3d avg %10.1f us  %5.1f %%" % (k["kernel"], k["calls"], k["avg_us"], k["pct"]))
+for k, v in out.get("pmc_per_launch", {}).items():
+    print(k, v)
