@@ -19,27 +19,33 @@
 
 namespace {
 
+// popcount(x) + acc in ONE VALU op; written as asm because LLVM's reassociation otherwise turns the
+// accumulate chain into `v_bcnt x, 0` + `v_add3` trees (+3 VALU ops per 256-bit descriptor pair).
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+// Scan all "from" descriptors (wave-uniform -> scalar loads, SGPR operands) against the NQ "to"
+// descriptors this lane keeps in VGPRs; track best / second-best keys (dist << 16 | from_idx).
 template <int W, int NQ>
-__device__ __forceinline__ void knn2_scan(const uint32_t* __restrict__ dF, int Kf, const uint32_t (&qa)[W],
-                                          const uint32_t (&qb)[W], uint32_t& a1, uint32_t& a2, uint32_t& b1,
-                                          uint32_t& b2) {
+__device__ __forceinline__ void knn2_scan(const uint32_t* __restrict__ dF, int Kf, const uint32_t (&q)[NQ][W],
+                                          uint32_t (&k1)[NQ], uint32_t (&k2)[NQ]) {
 #pragma unroll 4
   for (int f = 0; f < Kf; ++f) {
-    const uint32_t* r = dF + (size_t)f * W;  // wave-uniform -> scalar loads
-    uint32_t da = 0, db = 0;
+    const uint32_t* r = dF + (size_t)f * W;
+    uint32_t x[W];
 #pragma unroll
-    for (int c = 0; c < W; ++c) {
-      uint32_t x = r[c];
-      da += __popc(x ^ qa[c]);
-      if (NQ == 2) db += __popc(x ^ qb[c]);
-    }
-    uint32_t ka = (da << 16) | (uint32_t)f;
-    a2 = min(max(ka, a1), a2);
-    a1 = min(a1, ka);
-    if (NQ == 2) {
-      uint32_t kb = (db << 16) | (uint32_t)f;
-      b2 = min(max(kb, b1), b2);
-      b1 = min(b1, kb);
+    for (int c = 0; c < W; ++c) x[c] = r[c];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int c = 0; c < W; ++c) d = bcnt_acc(x[c] ^ q[j][c], d);
+      const uint32_t key = (d << 16) | (uint32_t)f;
+      k2[j] = min(max(key, k1[j]), k2[j]);
+      k1[j] = min(k1[j], key);
     }
   }
 }
@@ -54,12 +60,16 @@ __device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int
   }
 }
 
-template <int W>
-__global__ void __launch_bounds__(SF_BLOCK)
+// W  : dwords per descriptor (8 / 16)
+// NQ : "to" descriptors resident per lane
+// NT : threads per workgroup (one workgroup per candidate pair)
+template <int W, int NQ, int NT>
+__global__ void __launch_bounds__(NT)
 k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                float nndr, int min_inliers, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
+  constexpr int NW = NT / 64;
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -85,46 +95,54 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 
   int* cnt = smem;               // [kcap] "to" rows that matched each "from" word
   int* owner = smem + kcap;      // [kcap] the matching "to" row (meaningful when cnt == 1)
-  int* misc = smem + 2 * kcap;   // [16]   0: rejected "to" rows, 1: unique "from", 2: finite corr, 4..7 wave totals
+  int* misc = smem + 2 * kcap;   // [16]   0: rejected "to" rows, 2: finite corr, 4..7 wave totals
 
-  for (int i = tid; i < Kf; i += SF_BLOCK) cnt[i] = 0;
+  for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
   if (tid < 16) misc[tid] = 0;
   __syncthreads();
 
   int rejected = 0;
   if (Kf > 0) {
-    for (int base = 0; base < Kt; base += 2 * SF_BLOCK) {
-      const int ta = base + tid, tb = base + SF_BLOCK + tid;
-      const bool va = ta < Kt, vb = tb < Kt;
-      uint32_t qa[W], qb[W];
-      uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
-      load_desc<W>(dT, ta, va, qa);
-      // wave-uniform: does any lane of this wave own a second row?
-      const bool wave_has_b = (base + SF_BLOCK + (tid & ~63)) < Kt;
-      if (wave_has_b) {
-        load_desc<W>(dT, tb, vb, qb);
-        knn2_scan<W, 2>(dF, Kf, qa, qb, a1, a2, b1, b2);
-      } else {
-        knn2_scan<W, 1>(dF, Kf, qa, qa, a1, a2, b1, b2);
+    for (int base = 0; base < Kt; base += NQ * NT) {
+      uint32_t q[NQ][W], k1[NQ], k2[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int t = base + j * NT + tid;
+        load_desc<W>(dT, t, t < Kt, q[j]);
+        k1[j] = 0xFFFFFFFFu;
+        k2[j] = 0xFFFFFFFFu;
       }
-      if (va) {
-        bool acc = (Kf >= 2) && !((float)(a1 >> 16) > nndr * (float)(a2 >> 16));
-        if (acc) {
-          int f = (int)(a1 & 0xFFFFu);
-          atomicAdd(&cnt[f], 1);
-          owner[f] = ta;
-        } else {
-          ++rejected;
+      // wave-uniform: how many of this wave's NQ row groups hold at least one valid row?
+      const int wave_rows = Kt - base - (tid & ~63);
+      const int groups = wave_rows <= 0 ? 0 : min(NQ, (wave_rows + NT - 1) / NT);
+      if (groups == NQ) {
+        knn2_scan<W, NQ>(dF, Kf, q, k1, k2);
+      } else if (groups > 0) {
+        // ragged tail: scan only the populated groups (compile-time indices keep q[] in registers)
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j < groups) {
+            uint32_t qq[1][W], a1[1] = {0xFFFFFFFFu}, a2[1] = {0xFFFFFFFFu};
+#pragma unroll
+            for (int c = 0; c < W; ++c) qq[0][c] = q[j][c];
+            knn2_scan<W, 1>(dF, Kf, qq, a1, a2);
+            k1[j] = a1[0];
+            k2[j] = a2[0];
+          }
         }
       }
-      if (vb) {
-        bool acc = (Kf >= 2) && !((float)(b1 >> 16) > nndr * (float)(b2 >> 16));
-        if (acc) {
-          int f = (int)(b1 & 0xFFFFu);
-          atomicAdd(&cnt[f], 1);
-          owner[f] = tb;
-        } else {
-          ++rejected;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int t = base + j * NT + tid;
+        if (t < Kt) {
+          const bool acc = (Kf >= 2) && !((float)(k1[j] >> 16) > nndr * (float)(k2[j] >> 16));
+          if (acc) {
+            const int f = (int)(k1[j] & 0xFFFFu);
+            atomicAdd(&cnt[f], 1);
+            owner[f] = t;
+          } else {
+            ++rejected;
+          }
         }
       }
     }
@@ -137,7 +155,7 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   // id-ordered compaction of the "from" words matched by exactly one "to" row
   uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
-  for (int base = 0; base < Kf; base += SF_BLOCK) {
+  for (int base = 0; base < Kf; base += NT) {
     const int f = base + tid;
     const bool flag = (f < Kf) && (cnt[f] == 1);
     const unsigned long long bal = __ballot(flag);
@@ -146,7 +164,7 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
       int c = misc[4 + w];
       if (w < wave) woff += c;
       total += c;
@@ -167,7 +185,7 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   if (motion && !survivor) {
     const float* xF = st.xyz + (size_t)sF * kcap * 3;
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
-    for (int i = tid; i < n_corr; i += SF_BLOCK) {
+    for (int i = tid; i < n_corr; i += NT) {
       uint32_t c = out[i];
       const float* a = xF + 3 * (c & 0xFFFFu);
       const float* b = xT + 3 * (c >> 16);
@@ -201,22 +219,41 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   }
 }
 
+template <int W, int NQ, int NT>
+void launch_match(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
+  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  hipLaunchKernelGGL((k_match_global<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
+                     c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                     (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+}
+
 }  // namespace
 
 int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
-  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
-  int32_t* counters = (int32_t*)c->counters.p;
+  // geometry: variant = NQ * 1000 + NT (tunable through SF_MATCH_VARIANT for A/B runs)
+  int variant = c->match_variant;
+  if (variant == 0) variant = st.w == 8 ? 2256 : 2256;
   sf_prof_begin(c, SF_K_MATCH);
-  if (st.w == 8) {
-    hipLaunchKernelGGL(k_match_global<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                       c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
-                       (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
-  } else {
-    hipLaunchKernelGGL(k_match_global<16>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                       c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
-                       (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+#define SF_CASE(NQ_, NT_)                                                        \
+  case NQ_ * 1000 + NT_:                                                         \
+    if (st.w == 8) launch_match<8, NQ_, NT_>(c, st, d_from, d_to, n);            \
+    else launch_match<16, NQ_, NT_>(c, st, d_from, d_to, n);                     \
+    break;
+  switch (variant) {
+    SF_CASE(1, 256)
+    SF_CASE(2, 256)
+    SF_CASE(4, 128)
+    SF_CASE(2, 128)
+    SF_CASE(4, 256)
+    SF_CASE(8, 64)
+    SF_CASE(4, 64)
+    default:
+      sf_prof_end(c, SF_K_MATCH);
+      return sf_fail(c, SF_EINVAL, "unknown match kernel variant %d", variant);
   }
+#undef SF_CASE
   sf_prof_end(c, SF_K_MATCH);
   SF_HIP(c, hipGetLastError());
   return SF_OK;

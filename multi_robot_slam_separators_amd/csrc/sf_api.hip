@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -305,6 +306,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
     return SF_EHIP;
   }
   c->own_stream = true;
+  if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
   *out = c;
   return SF_OK;

@@ -118,6 +118,8 @@ struct sf_context {
   std::vector<double> last_row_min;
   std::vector<int32_t> last_row_arg;
 
+  int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
+
   // profiling
   bool prof = false;
   ProfSlot prof_slots[SF_K_COUNT];
