@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 METRIC = "candidate keyframe-pair verifications/sec (NetVLAD NN + ORB match + RANSAC) @1/2/4/8 GPU"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_F16_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: bf16/fp16 dense matrix peak
 
 
 def bytes_per_pair(k, cols):
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--dim", type=int, default=4096)
     ap.add_argument("--iterations", type=int, default=500)
     ap.add_argument("--true-frac", type=float, default=0.2)
+    ap.add_argument("--nn-precision", type=int, default=1,
+                    help="1 = fp16 MFMA filter with rigorous error band + exact f64 refinement (identical "
+                         "matches); 0 = fp32 MFMA ranking of every column")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2048)
     ap.add_argument("--cpu-sample-rows", type=int, default=64)
@@ -116,6 +120,7 @@ def main():
     p.iterations = args.iterations
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf            # batch operation: walk every row
+    p.nn_precision = args.nn_precision
     p.max_features = k
     p.desc_bytes = cols
     p.store_capacity = 2 * n_kf
@@ -202,6 +207,22 @@ def main():
     elapsed = float(t.item())
     total_pairs = float(npairs.item())
 
+    # ---- the same step with the fp32-ranking NN stage, for reference (untimed by the driver) -------
+    alt = None
+    if args.nn_precision == 1:
+        f.nn_set_precision(0)
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_alt = 0
+        for _ in range(3):
+            n_alt += step()
+        torch.cuda.synchronize()
+        alt = n_alt / (time.perf_counter() - t1)
+        alt_m = state["last"][0]
+        f.nn_set_precision(1)
+        step()
+
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
     res = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)[:n]
@@ -217,7 +238,9 @@ def main():
         nm, tm = prof["k_match_global"]
         match_ms = tm / max(nm, 1)
         ach = pairs_per_step * bpp / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
-        nn_n, nn_t = prof["k_nn_argmin"]
+        nn_kernel, nn_peak = (("k_nn_filter_f16", MFMA_F16_PEAK_TF) if args.nn_precision == 1
+                              else ("k_nn_argmin", MFMA_F32_PEAK_TF))
+        nn_n, nn_t = prof[nn_kernel]
         nn_ms = nn_t / max(nn_n, 1)
         nn_tf = 2.0 * n_kf * n_kf * dim / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
         out = {
@@ -231,7 +254,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8+f32",
+            "dtype": "u8+f32" if args.nn_precision == 0 else "u8+f32 (NN candidates filtered in f16, refined in f64)",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: 1xMI355X per rank, 2 robots x %d keyframes, %d-D fp32 NetVLAD, "
@@ -246,13 +269,18 @@ def main():
                 "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_step, "avg_launch_ms": match_ms,
             },
             "roofline_nn": {
-                "kernel": "k_nn_argmin", "bound": "mfma", "achieved": nn_tf, "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": nn_tf / MFMA_F32_PEAK_TF, "avg_launch_ms": nn_ms,
+                "kernel": nn_kernel, "bound": "mfma", "achieved": nn_tf, "peak": nn_peak,
+                "unit": "TFLOP/s", "frac": nn_tf / nn_peak, "avg_launch_ms": nn_ms,
             },
             "kernel_ms_per_step": {kname: (ms / args.steps) for kname, (cnt, ms) in prof.items()},
             "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n)},
             "input_generation_s": t_gen,
         }
+        if alt is not None:
+            out["value_with_fp32_nn_ranking"] = alt * world
+            out["check"]["nn_matches_identical_fp32_vs_f16filter"] = bool(
+                np.array_equal(alt_m["idx_local"], m["idx_local"]) and np.array_equal(alt_m["idx_other"], m["idx_other"])
+                and np.array_equal(alt_m["distance"], m["distance"]))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, feats, nv_a, nv_b, n_kf, args.cpu_sample_pairs,
                                                args.cpu_sample_rows)

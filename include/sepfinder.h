@@ -64,8 +64,13 @@ typedef struct sf_params {
   double  netvlad_distance;        /* 0.13 ; accept iff dist <  this (data_handler.py:202)  */
   int32_t netvlad_dimensions;      /* 128                                                   */
   int32_t netvlad_max_matches_nb;  /* 20                                                    */
-  int32_t nn_precision;            /* 0 = fp32 MFMA (+ f64 re-evaluation of row minima),
-                                      1 = fp16 inputs on MFMA (BASELINE configs[4])         */
+  int32_t nn_precision;            /* 0 = fp32 MFMA ranks every column, f64 re-evaluation of the
+                                          row minima (all rows exact);
+                                      1 = fp16 MFMA FILTER with a rigorous error band + f64
+                                          evaluation of every surviving (row, column): identical
+                                          matches; rows whose minimum is >= netvlad_distance
+                                          report +inf in sf_nn_last_row_minima
+                                          (BASELINE configs[4]: fp16 NetVLAD on MFMA)           */
   /* Registration: myRegistrationVis.cpp:52-71 reads rtabmap's compiled-in defaults [upstream];
      stereoCamGeometricTools.cpp:87 overrides only Vis/MinInliers                           */
   int32_t min_inliers;             /* 5    separators_min_inliers -> Vis/MinInliers          */
@@ -176,6 +181,8 @@ int  sf_nn_mark_local_used(sf_handle h, int32_t idx_local);
 int  sf_nn_mark_other_used(sf_handle h, int32_t idx_other);
 int  sf_nn_ignore_pair(sf_handle h, int32_t idx_local, int32_t idx_other);
 int  sf_nn_reset(sf_handle h);
+/* Switch sf_params.nn_precision (0 / 1, see above) on a live handle; databases are kept.        */
+int  sf_nn_set_precision(sf_handle h, int32_t nn_precision);
 /* DataHandler.find_matches(): writes up to `cap` matches, *n_out = number found.
    Returns SF_EINVAL when either database is empty (the reference guards this at
    data_handler.py:308).                                                                     */
@@ -227,8 +234,10 @@ enum {
   SF_K_GUIDED = 2,     /* guess-guided window matching (pass 2)                               */
   SF_K_RANSAC2 = 3,    /* RANSAC 3D-3D + refine, pass 2                                       */
   SF_K_NN = 4,         /* NetVLAD distance matrix + fused row arg-min                         */
-  SF_K_NN_SELECT = 5,  /* f64 re-evaluation + sort + top-K walk                               */
-  SF_K_COUNT = 6
+  SF_K_NN_SELECT = 5,  /* f64 re-evaluation of the row minima                                 */
+  SF_K_NN_FILTER = 6,  /* fp16 MFMA candidate filter (nn_precision = 1)                       */
+  SF_K_NN_REFINE = 7,  /* exact f64 distance of every filter survivor                         */
+  SF_K_COUNT = 8
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);

@@ -17,6 +17,8 @@
 //                 of data_handler.py:193-205 (skip taken idx_other, accept under threshold, break
 //                 at the first row over it).
 #include <math.h>
+#include <string.h>
+#include <cmath>
 
 #include <algorithm>
 #include <vector>
@@ -35,14 +37,14 @@ k_nn_cast_rows(const double* __restrict__ src, float* __restrict__ dst, float* _
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  float s = 0.f;
+  double s = 0.0;   // squared norm of the float32 row, accumulated in float64 (error 2^-24 relative)
   for (int k = lane; k < ld; k += 64) {
     float v = (k < dim) ? (float)src[(size_t)row * dim + k] : 0.f;
     dst[(size_t)row * ld + k] = v;
-    s = fmaf(v, v, s);
+    s += (double)v * (double)v;
   }
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) norms[row] = s;
+  if (lane == 0) norms[row] = (float)s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -51,14 +53,14 @@ k_nn_copy_rows(const float* __restrict__ src, float* __restrict__ dst, float* __
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  float s = 0.f;
+  double s = 0.0;
   for (int k = lane; k < ld; k += 64) {
     float v = (k < dim) ? src[(size_t)row * dim + k] : 0.f;
     dst[(size_t)row * ld + k] = v;
-    s = fmaf(v, v, s);
+    s += (double)v * (double)v;
   }
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) norms[row] = s;
+  if (lane == 0) norms[row] = (float)s;
 }
 
 // A: local rows [n_l_pad][ld], B: received rows [n_r_pad][ld] (both zero padded).
@@ -190,6 +192,139 @@ k_nn_select(const unsigned long long* __restrict__ part, int n_strips, int n_l, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp16 FILTER path (nn_precision = 1): the matrix cores only have to decide which (row, column)
+// pairs CAN lie under netvlad_distance; every survivor is then re-evaluated exactly in float64.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) k_nn_maxabs(const float* __restrict__ rows, size_t n_elems, unsigned* out) {
+  unsigned m = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(fabsf(rows[i])));
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// rows * scale -> fp16 (scale is a power of two: exact).  One wavefront per row; the fp16 row pitch
+// ld16 (multiple of 64) may exceed the float pitch ld: the tail is zero filled.
+__global__ void __launch_bounds__(256) k_nn_to_f16(const float* __restrict__ rows, _Float16* __restrict__ out,
+                                                    int n, int ld, int ld16, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  for (int k = lane; k < ld16; k += 64)
+    out[(size_t)row * ld16 + k] = (k < ld) ? (_Float16)(rows[(size_t)row * ld + k] * scale) : (_Float16)0.f;
+}
+
+// effective row norms: +inf for masked / padding rows (a masked row can never be a candidate)
+__global__ void k_nn_fill_row_norms(float* na_eff, const float* na, const uint8_t* mask_local, int n_l, int n_l_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_l_pad) return;
+  na_eff[i] = (i < n_l && !mask_local[i]) ? na[i] : __int_as_float(0x7F800000);
+}
+
+// A16: local rows [n_l_pad][ld] fp16 (x scale_a), B16: received rows [n_r_pad][ld] fp16 (x scale_b).
+// A (row, col) pair is emitted when its fp16 distance estimate can be below thr2 given the
+// rigorous error bound  |dot16 - dot32| <= eps_rel * sqrt(na * nb).
+__global__ void __launch_bounds__(256)
+k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float* __restrict__ na_eff,
+                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld,
+                uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
+  __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];   // 128 rows x 64 halfs (+ pad)
+  __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int row0 = blockIdx.y * NN_BM, col0 = blockIdx.x * NN_BN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int ldw = ld / 2;                      // row pitch in dwords (ld halfs)
+  const float* Aw = reinterpret_cast<const float*>(A);
+  const float* Bw = reinterpret_cast<const float*>(B);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;   // staging: 32 rows x 8 x 16 B per pass
+  for (int k0 = 0; k0 < ldw; k0 += 32) {            // 32 dwords = 64 halfs per step
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      const float4 va = *reinterpret_cast<const float4*>(Aw + (size_t)(row0 + r) * ldw + k0 + sk4);
+      const float4 vb = *reinterpret_cast<const float4*>(Bw + (size_t)(col0 + r) * ldw + k0 + sk4);
+      *reinterpret_cast<float4*>(&sA[r * NN_PITCH + sk4]) = va;
+      *reinterpret_cast<float4*>(&sB[r * NN_PITCH + sk4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // 16 halfs of K per MFMA: lane holds k = 16 q + 8 h + 0..7
+      half8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const half8*>(&sA[(64 * wr + 32 * i + l31) * NN_PITCH + 8 * q + 4 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const half8*>(&sB[(64 * wc + 32 * j + l31) * NN_PITCH + 8 * q + 4 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float nbj[2];
+  int colj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    colj[j] = col0 + 64 * wc + 32 * j + l31;
+    nbj[j] = nb_eff[colj[j]];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float nai = na_eff[row];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float dot = acc[i][j][r] * inv_scale;
+        const float d2 = (nai + nbj[j]) - 2.f * dot;
+        const float slack = 2.f * eps_rel * sqrtf(nai * nbj[j]) + 1e-6f * (nai + nbj[j]);
+        if (d2 < thr2 + slack) {            // false for inf / NaN (masked or padding rows / columns)
+          const unsigned pos = atomicAdd(cand_count, 1u);
+          if (pos < cand_cap) cand[pos] = make_uint2((unsigned)row, (unsigned)colj[j]);
+        }
+      }
+    }
+  }
+}
+
+// one wavefront per candidate: exact float64 distance in cdist's direct form
+__global__ void __launch_bounds__(256)
+k_nn_refine(const uint2* __restrict__ cand, unsigned n_cand, const float* __restrict__ A,
+            const float* __restrict__ B, int dim, int ld, double* __restrict__ out) {
+  const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= n_cand) return;
+  const uint2 rc = cand[c];
+  const float* a = A + (size_t)rc.x * ld;
+  const float* b = B + (size_t)rc.y * ld;
+  double s = 0.0;
+  for (int k = lane; k < dim; k += 64) {
+    const double d = (double)a[k] - (double)b[k];
+    s += d * d;
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[c] = sqrt(s);
+}
+
 __global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_r_pad) return;
@@ -246,9 +381,120 @@ int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int s
   return SF_OK;
 }
 
+
+// ---- fp16 filter path -----------------------------------------------------------------------------
+static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16) {
+  if (db.h_n == db.n && db.h_ld == ld16) return SF_OK;
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->nn_scalar, 64)) != SF_OK) return rc;
+  SF_HIP(c, hipMemsetAsync(c->nn_scalar.p, 0, 64, c->stream));
+  hipLaunchKernelGGL(k_nn_maxabs, dim3(1024), dim3(256), 0, c->stream, (const float*)db.rows.p, (size_t)db.n * ld,
+                     (unsigned*)c->nn_scalar.p);
+  unsigned bits = 0;
+  SF_HIP(c, hipMemcpyAsync(&bits, c->nn_scalar.p, 4, hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  float maxabs;
+  memcpy(&maxabs, &bits, 4);
+  float scale = 1.f;
+  if (maxabs > 0.f && std::isfinite(maxabs)) {
+    int e;
+    frexpf(32768.f / maxabs, &e);          // 32768/maxabs = m * 2^e, m in [0.5, 1)
+    e = std::max(-60, std::min(60, e - 1));
+    scale = ldexpf(1.f, e);                // largest power of two with maxabs * scale <= 32768
+  }
+  const int n_pad = (db.n + 127) & ~127;
+  const size_t bytes = (size_t)n_pad * ld16 * 2;
+  if ((rc = sf_buf_reserve(c, db.rows_h, bytes)) != SF_OK) return rc;
+  SF_HIP(c, hipMemsetAsync(db.rows_h.p, 0, bytes, c->stream));
+  hipLaunchKernelGGL(k_nn_to_f16, dim3((db.n + 3) / 4), dim3(256), 0, c->stream, (const float*)db.rows.p,
+                     (_Float16*)db.rows_h.p, db.n, ld, ld16, scale);
+  SF_HIP(c, hipGetLastError());
+  db.h_n = db.n;
+  db.h_ld = ld16;
+  db.h_scale = scale;
+  return SF_OK;
+}
+
+// Returns SF_OK with *done = 1 when the filter path produced the row minima; *done = 0 means the
+// candidate buffer overflowed (threshold too loose for a sparse filter) -> caller runs the exact path.
+static int nn_run_filter(sf_context* c, int* done) {
+  *done = 0;
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int ld16 = (dim + 63) / 64 * 64;
+  const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
+  int rc;
+  if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16)) != SF_OK) return rc;
+  if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16)) != SF_OK) return rc;
+  const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
+  if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 64)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 4)) != SF_OK) return rc;
+  float* na_eff = (float*)c->nn_rowmin.p;
+  float* nb_eff = na_eff + n_l_pad;
+  unsigned* count = (unsigned*)c->nn_cand.p;
+  uint2* cand = (uint2*)((char*)c->nn_cand.p + 64);
+  double* cdist = (double*)((char*)c->nn_cand.p + 64 + (size_t)cap * 8);
+
+  const double thr = c->params.netvlad_distance;
+  float thr2 = (float)(thr * thr);
+  thr2 = nextafterf(thr2, INFINITY);
+  // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + dim 2^-24) * ||a|| ||b||   (operand rounding + fp32 accumulation)
+  const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)dim * ldexp(1.0, -24));
+  const float inv_scale = 1.f / (c->nn_local.h_scale * c->nn_recv.h_scale);
+
+  SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
+  hipLaunchKernelGGL(k_nn_fill_row_norms, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, na_eff,
+                     (const float*)c->nn_local.norms.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad);
+  hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
+                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
+  sf_prof_begin(c, SF_K_NN_FILTER);
+  hipLaunchKernelGGL(k_nn_filter_f16, dim3(n_r_pad / NN_BN, n_l_pad / NN_BM), dim3(256), 0, c->stream,
+                     (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, na_eff, nb_eff,
+                     inv_scale, thr2, eps_rel, ld16, cand, count, cap);
+  sf_prof_end(c, SF_K_NN_FILTER);
+  SF_HIP(c, hipGetLastError());
+  unsigned n_cand = 0;
+  SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (n_cand > cap) return SF_OK;   // too dense for the filter: exact path
+  std::vector<uint2> h_cand(n_cand);
+  std::vector<double> h_dist(n_cand);
+  if (n_cand) {
+    sf_prof_begin(c, SF_K_NN_REFINE);
+    hipLaunchKernelGGL(k_nn_refine, dim3((n_cand + 3) / 4), dim3(256), 0, c->stream, cand, n_cand,
+                       (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
+    sf_prof_end(c, SF_K_NN_REFINE);
+    SF_HIP(c, hipMemcpyAsync(h_cand.data(), cand, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipMemcpyAsync(h_dist.data(), cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  // per-row minimum over the exact candidate distances (ties: lowest column), ignored pairs skipped.
+  // Rows without a candidate have their true minimum >= netvlad_distance: reported as +inf.
+  c->last_row_min.assign(n_l, (double)INFINITY);
+  c->last_row_arg.assign(n_l, 0);
+  std::vector<std::pair<int, int>> ign;
+  for (size_t e = 0; e + 1 < c->ignored.size(); e += 2) ign.push_back({c->ignored[e], c->ignored[e + 1]});
+  std::sort(ign.begin(), ign.end());
+  for (unsigned i = 0; i < n_cand; ++i) {
+    const int r = (int)h_cand[i].x, col = (int)h_cand[i].y;
+    if (r >= n_l || col >= n_r) continue;
+    if (!ign.empty() && std::binary_search(ign.begin(), ign.end(), std::make_pair(r, col))) continue;
+    const double d = h_dist[i];
+    if (d < c->last_row_min[r] || (d == c->last_row_min[r] && col < c->last_row_arg[r])) {
+      c->last_row_min[r] = d;
+      c->last_row_arg[r] = col;
+    }
+  }
+  // a candidate admitted only by the error band may still be >= the threshold: that is fine, the
+  // walk compares the exact float64 value
+  *done = 1;
+  return SF_OK;
+}
+
 int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
-  if (c->params.nn_precision != 0) return sf_fail(c, SF_EINVAL, "nn_precision %d not implemented yet (0 = fp32)", c->params.nn_precision);
+  if (c->params.nn_precision != 0 && c->params.nn_precision != 1)
+    return sf_fail(c, SF_EINVAL, "nn_precision %d unknown (0 = fp32 exact ranking, 1 = fp16 filter + exact refine)", c->params.nn_precision);
   const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
   const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
   const int n_strips = n_r_pad / 64;
@@ -275,6 +521,11 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     SF_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
     c->masks_dirty = false;
   }
+  int filtered = 0;
+  if (c->params.nn_precision == 1) {
+    if ((rc = nn_run_filter(c, &filtered)) != SF_OK) return rc;
+  }
+  if (!filtered) {
   // workspace: partial minima, effective column norms, per-row results
   const size_t part_bytes = (size_t)n_strips * n_l_pad * 8;
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, part_bytes + (size_t)n_r_pad * 4)) != SF_OK) return rc;
@@ -304,6 +555,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   SF_HIP(c, hipMemcpyAsync(c->last_row_min.data(), d_dist, (size_t)n_l * 8, hipMemcpyDeviceToHost, c->stream));
   SF_HIP(c, hipMemcpyAsync(c->last_row_arg.data(), d_idx, (size_t)n_l * 4, hipMemcpyDeviceToHost, c->stream));
   SF_HIP(c, hipStreamSynchronize(c->stream));
+  }
 
   // data_handler.py:191-205: argsort of the row minima, then the sequential walk
   std::vector<int> order(n_l);

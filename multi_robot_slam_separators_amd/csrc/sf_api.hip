@@ -64,7 +64,8 @@ StoreView sf_store_view(const Store& s) {
 
 // ---- profiling ------------------------------------------------------------------------------
 static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "k_guided",
-                                          "k_ransac(pass2)", "k_nn_argmin", "k_nn_select"};
+                                          "k_ransac(pass2)", "k_nn_argmin", "k_nn_select",
+                                          "k_nn_filter_f16", "k_nn_refine"};
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
 void sf_prof_begin(sf_context* c, int kernel) {
@@ -322,7 +323,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list2, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
-                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
   for (Buf* b : bufs) buf_free(*b);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -609,11 +610,20 @@ extern "C" int sf_nn_reset(sf_handle c) {
   SF_HIP(c, hipStreamSynchronize(c->stream));
   c->nn_local.n = 0;
   c->nn_recv.n = 0;
+  c->nn_local.h_n = -1;
+  c->nn_recv.h_n = -1;
   c->nn_dim = 0;
   c->mask_local.clear();
   c->mask_other.clear();
   c->ignored.clear();
   c->masks_dirty = true;
+  return SF_OK;
+}
+
+extern "C" int sf_nn_set_precision(sf_handle c, int32_t nn_precision) {
+  if (!c) return SF_EINVAL;
+  if (nn_precision != 0 && nn_precision != 1) return sf_fail(c, SF_EINVAL, "nn_precision must be 0 or 1");
+  c->params.nn_precision = nn_precision;
   return SF_OK;
 }
 

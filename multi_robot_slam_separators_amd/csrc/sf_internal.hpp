@@ -76,6 +76,8 @@ struct NNDb {
   Buf norms;       // float32 [cap]
   Buf rows_h;      // fp16 [cap][dim] (nn_precision == 1)
   int n = 0, cap = 0;
+  int h_n = -1, h_ld = 0;   // rows / pitch covered by the fp16 copy
+  float h_scale = 1.f;      // power-of-two scale applied before the fp16 conversion
 };
 
 struct ProfSlot {
@@ -115,6 +117,8 @@ struct sf_context {
   bool masks_dirty = true;
   Buf nn_rowmin;     // per-row packed (dist bits, idx) uint64 [n_local]
   Buf nn_exact;      // double [n_local]
+  Buf nn_cand;       // filter path: counter + candidate (row, col) pairs + exact distances
+  Buf nn_scalar;     // small reduction scratch
   std::vector<double> last_row_min;
   std::vector<int32_t> last_row_arg;
 

@@ -69,6 +69,7 @@ def load():
         "sf_nn_mark_other_used": (C.c_int, [vp, i32]),
         "sf_nn_ignore_pair": (C.c_int, [vp, i32, i32]),
         "sf_nn_reset": (C.c_int, [vp]),
+        "sf_nn_set_precision": (C.c_int, [vp, i32]),
         "sf_nn_find_matches": (C.c_int, [vp, vp, i32, P(i32)]),
         "sf_nn_last_row_minima": (C.c_int, [vp, vp, vp, i32]),
         "sf_store_add_keyframe": (C.c_int, [vp, P(_abi.Features), P(i32)]),
@@ -101,6 +102,7 @@ EXPORTED = [
     "sf_set_stream", "sf_synchronize", "sf_nn_append_local", "sf_nn_append_received",
     "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_sizes",
     "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
+    "sf_nn_set_precision",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device",
@@ -188,6 +190,10 @@ class SeparatorFinder:
 
     def nn_reset(self):
         self._check(self._L.sf_nn_reset(self._h))
+
+    def nn_set_precision(self, nn_precision):
+        self._check(self._L.sf_nn_set_precision(self._h, int(nn_precision)))
+        self.params.nn_precision = int(nn_precision)
 
     def nn_find_matches(self, cap=None):
         n_l, _ = self.nn_sizes()
