@@ -93,6 +93,7 @@ __device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32
 #pragma unroll
   for (int j = 0; j < 3; ++j) { mp[j] *= inv_n; mq[j] *= inv_n; }
   double S[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  double ga = 0.0, gb = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double a[3] = {(double)p[i].x - mp[0], (double)p[i].y - mp[1], (double)p[i].z - mp[2]};
@@ -101,8 +102,10 @@ __device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int k = 0; k < 3; ++k) S[j][k] += a[j] * b[k];
+    ga += (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    gb += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
   }
-  sfd::rigid_from_moments(S, mp, mq, coef);
+  sfd::rigid_from_moments(S, mp, mq, ga, gb, coef);
 }
 
 // optimizeModelCoefficients over the members of `mask` (block-order reductions)
@@ -120,7 +123,7 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
   block_sum_vec<6>(s6, L.red, tid);
   double mp[3] = {s6[0] * inv_n, s6[1] * inv_n, s6[2] * inv_n};
   double mq[3] = {s6[3] * inv_n, s6[4] * inv_n, s6[5] * inv_n};
-  double s9[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double s9[11] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // S (9), ga, gb
   for (int i = tid; i < m; i += SF_BLOCK) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
@@ -130,15 +133,17 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) s9[3 * j + k] += a[j] * b[k];
+      s9[9] += (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+      s9[10] += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
     }
   }
-  block_sum_vec<9>(s9, L.red, tid);
+  block_sum_vec<11>(s9, L.red, tid);
   double S[3][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int k = 0; k < 3; ++k) S[j][k] = s9[3 * j + k];
-  sfd::rigid_from_moments(S, mp, mq, coef);
+  sfd::rigid_from_moments(S, mp, mq, s9[9], s9[10], coef);
 }
 
 // selectWithinDistance: residuals of all points, membership mask, member count

@@ -114,11 +114,21 @@ __device__ inline void jacobi(double (&a)[N][N], double (&v)[N][N]) {
   }
 }
 
-// Rotation (row-major R[9]) and translation from the cross-covariance S[j][k] = sum a_j b_k of
-// the demeaned source/target and their means.  Output as the float coefficients PCL stores.
+__device__ __forceinline__ double det3(double a, double b, double c, double d, double e, double f, double g,
+                                       double h, double i) {
+  return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+
+// Rotation and translation from the cross-covariance S[j][k] = sum a_j b_k of the demeaned
+// source/target, their means and spreads ga = sum |a|^2, gb = sum |b|^2 (Horn's quaternion
+// method).  The dominant eigenpair of the 4x4 matrix N comes from Newton's iteration on the
+// characteristic quartic, started at the upper bound (ga+gb)/2 (monotone convergence to the largest
+// root), and the best-conditioned column of adj(N - lambda I): ~0.5 kflop and a dozen divisions
+// instead of a full Jacobi eigen-decomposition (3 div + 2 sqrt per rotation).  Jacobi remains the
+// fallback for a vanishing adjugate.  Output as the float coefficients PCL stores.
 __device__ inline void rigid_from_moments(const double (&S)[3][3], const double (&mp)[3],
-                                          const double (&mq)[3], float (&coef)[12]) {
-  double Nm[4][4], V[4][4];
+                                          const double (&mq)[3], double ga, double gb, float (&coef)[12]) {
+  double Nm[4][4];
   Nm[0][0] = (S[0][0] + S[1][1]) + S[2][2];
   Nm[1][1] = (S[0][0] - S[1][1]) - S[2][2];
   Nm[2][2] = (S[1][1] - S[0][0]) - S[2][2];
@@ -129,24 +139,74 @@ __device__ inline void rigid_from_moments(const double (&S)[3][3], const double 
   Nm[1][2] = Nm[2][1] = S[0][1] + S[1][0];
   Nm[1][3] = Nm[3][1] = S[2][0] + S[0][2];
   Nm[2][3] = Nm[3][2] = S[1][2] + S[2][1];
-  jacobi<4>(Nm, V);
-  // eigenvector of the largest eigenvalue (first maximum), selected without dynamic indexing
-  double bv = Nm[0][0];
-  double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
+
+  double ss = 0.0;
 #pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    bool gt = Nm[i][i] > bv;
-    bv = gt ? Nm[i][i] : bv;
-    w = gt ? V[0][i] : w;
-    x = gt ? V[1][i] : x;
-    y = gt ? V[2][i] : y;
-    z = gt ? V[3][i] : z;
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ss += S[j][k] * S[j][k];
+  const double c2 = -2.0 * ss;
+  const double c1 = -8.0 * det3(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], S[2][0], S[2][1], S[2][2]);
+  const double m0 = det3(Nm[1][1], Nm[1][2], Nm[1][3], Nm[2][1], Nm[2][2], Nm[2][3], Nm[3][1], Nm[3][2], Nm[3][3]);
+  const double m1 = det3(Nm[1][0], Nm[1][2], Nm[1][3], Nm[2][0], Nm[2][2], Nm[2][3], Nm[3][0], Nm[3][2], Nm[3][3]);
+  const double m2 = det3(Nm[1][0], Nm[1][1], Nm[1][3], Nm[2][0], Nm[2][1], Nm[2][3], Nm[3][0], Nm[3][1], Nm[3][3]);
+  const double m3 = det3(Nm[1][0], Nm[1][1], Nm[1][2], Nm[2][0], Nm[2][1], Nm[2][2], Nm[3][0], Nm[3][1], Nm[3][2]);
+  const double c0 = ((Nm[0][0] * m0 - Nm[0][1] * m1) + Nm[0][2] * m2) - Nm[0][3] * m3;
+
+  double x = 0.5 * (ga + gb);
+  for (int it = 0; it < 50; ++it) {
+    const double x2 = x * x;
+    const double b = (x2 + c2) * x;
+    const double a = b + c1;
+    const double pv = a * x + c0;
+    const double dp = (2.0 * x2 * x + b) + a;
+    if (dp == 0.0) break;
+    const double xn = x - pv / dp;
+    if (!(xn < x)) break;
+    const double step = x - xn;
+    x = xn;
+    if (step <= 1e-14 * fabs(xn)) break;
   }
-  double nrm = sqrt(((w * w + x * x) + y * y) + z * z);
-  double inv = 1.0 / nrm;
-  w = w * inv; x = x * inv; y = y * inv; z = z * inv;
-  double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
-  double wx = w * x, wy = w * y, wz = w * z;
+
+  const double b00 = Nm[0][0] - x, b11 = Nm[1][1] - x, b22 = Nm[2][2] - x, b33 = Nm[3][3] - x;
+  const double b01 = Nm[0][1], b02 = Nm[0][2], b03 = Nm[0][3], b12 = Nm[1][2], b13 = Nm[1][3], b23 = Nm[2][3];
+  const double a00 = det3(b11, b12, b13, b12, b22, b23, b13, b23, b33);
+  const double a11 = det3(b00, b02, b03, b02, b22, b23, b03, b23, b33);
+  const double a22 = det3(b00, b01, b03, b01, b11, b13, b03, b13, b33);
+  const double a33 = det3(b00, b01, b02, b01, b11, b12, b02, b12, b22);
+  const double a01 = -det3(b01, b12, b13, b02, b22, b23, b03, b23, b33);
+  const double a02 = det3(b01, b11, b13, b02, b12, b23, b03, b13, b33);
+  const double a03 = -det3(b01, b11, b12, b02, b12, b22, b03, b13, b23);
+  const double a12 = -det3(b00, b01, b03, b02, b12, b23, b03, b13, b33);
+  const double a13 = det3(b00, b01, b02, b02, b12, b22, b03, b13, b23);
+  const double a23 = -det3(b00, b01, b02, b01, b11, b12, b03, b13, b23);
+  double best = fabs(a00);
+  double w = a00, qx = a01, qy = a02, qz = a03;
+  if (fabs(a11) > best) { best = fabs(a11); w = a01; qx = a11; qy = a12; qz = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); w = a02; qx = a12; qy = a22; qz = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); w = a03; qx = a13; qy = a23; qz = a33; }
+  double nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
+  if (!(best > 0.0) || !(nrm2 > 0.0) || !isfinite(nrm2)) {
+    double V[4][4];
+    jacobi<4>(Nm, V);
+    double bv = Nm[0][0];
+    w = V[0][0]; qx = V[1][0]; qy = V[2][0]; qz = V[3][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      const bool gt = Nm[i][i] > bv;
+      bv = gt ? Nm[i][i] : bv;
+      w = gt ? V[0][i] : w;
+      qx = gt ? V[1][i] : qx;
+      qy = gt ? V[2][i] : qy;
+      qz = gt ? V[3][i] : qz;
+    }
+    nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
+  }
+  const double inv = 1.0 / sqrt(nrm2);
+  w = w * inv;
+  const double x_ = qx * inv, y = qy * inv, z = qz * inv;
+  const double xx = x_ * x_, yy = y * y, zz = z * z, xy = x_ * y, xz = x_ * z, yz = y * z;
+  const double wx = w * x_, wy = w * y, wz = w * z;
   double R[9];
   R[0] = 1.0 - 2.0 * (yy + zz); R[1] = 2.0 * (xy - wz);       R[2] = 2.0 * (xz + wy);
   R[3] = 2.0 * (xy + wz);       R[4] = 1.0 - 2.0 * (xx + zz); R[5] = 2.0 * (yz - wx);

@@ -214,13 +214,23 @@ static void sfo_jacobi(int n, double a[4][4], double v[4][4]) {
   }
 }
 
+static double sfo_det3(double a, double b, double c, double d, double e, double f, double g, double h,
+                       double i) {
+  return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
+}
+
 /* Rotation + translation from the 3x3 cross-covariance S[j][k] = sum a_j b_k (a = demeaned
- * source, b = demeaned target) and the two means: Horn's unit-quaternion solution of the
- * absolute-orientation problem.  Same optimum as the SVD form PCL uses
- * [upstream pcl::SampleConsensusModelRegistration::estimateRigidTransformationSVD ->
- *  pcl::umeyama(src, tgt, false), computed in double]. */
+ * source, b = demeaned target), the two means and the spreads ga = sum |a|^2, gb = sum |b|^2:
+ * Horn's unit-quaternion solution of the absolute-orientation problem.  Same optimum as the SVD
+ * form PCL uses [upstream pcl::SampleConsensusModelRegistration::estimateRigidTransformationSVD ->
+ * pcl::umeyama(src, tgt, false), computed in double].
+ * The dominant eigenpair of Horn's 4x4 matrix N is found without an eigen-decomposition:
+ * Newton's iteration on the characteristic quartic from the upper bound (ga+gb)/2 (monotone
+ * convergence to the largest root), then the eigenvector as the best-conditioned column of
+ * adj(N - lambda I).  Only + - * / sqrt: the HIP kernel restates it bit for bit.  A vanishing
+ * adjugate (repeated top eigenvalue / no spread) falls back to the cyclic Jacobi solver. */
 static void sfo_rigid_from_moments(const double S[3][3], const double mp[3], const double mq[3],
-                                   double R[9], double t[3]) {
+                                   double ga, double gb, double R[9], double t[3]) {
   double N[4][4], V[4][4];
   N[0][0] = (S[0][0] + S[1][1]) + S[2][2];
   N[1][1] = (S[0][0] - S[1][1]) - S[2][2];
@@ -232,15 +242,65 @@ static void sfo_rigid_from_moments(const double S[3][3], const double mp[3], con
   N[1][2] = N[2][1] = S[0][1] + S[1][0];
   N[1][3] = N[3][1] = S[2][0] + S[0][2];
   N[2][3] = N[3][2] = S[1][2] + S[2][1];
-  sfo_jacobi(4, N, V);
-  int best = 0;
-  for (int i = 1; i < 4; ++i) if (N[i][i] > N[best][best]) best = i;
-  double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
-  double nrm = sqrt(((w * w + x * x) + y * y) + z * z);
-  double inv = 1.0 / nrm;
-  w = w * inv; x = x * inv; y = y * inv; z = z * inv;
-  double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
-  double wx = w * x, wy = w * y, wz = w * z;
+
+  /* p(x) = x^4 + c2 x^2 + c1 x + c0  (N is traceless) */
+  double ss = 0.0;
+  for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) ss += S[j][k] * S[j][k];
+  const double c2 = -2.0 * ss;
+  const double c1 = -8.0 * sfo_det3(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], S[2][0], S[2][1], S[2][2]);
+  const double m0 = sfo_det3(N[1][1], N[1][2], N[1][3], N[2][1], N[2][2], N[2][3], N[3][1], N[3][2], N[3][3]);
+  const double m1 = sfo_det3(N[1][0], N[1][2], N[1][3], N[2][0], N[2][2], N[2][3], N[3][0], N[3][2], N[3][3]);
+  const double m2 = sfo_det3(N[1][0], N[1][1], N[1][3], N[2][0], N[2][1], N[2][3], N[3][0], N[3][1], N[3][3]);
+  const double m3 = sfo_det3(N[1][0], N[1][1], N[1][2], N[2][0], N[2][1], N[2][2], N[3][0], N[3][1], N[3][2]);
+  const double c0 = ((N[0][0] * m0 - N[0][1] * m1) + N[0][2] * m2) - N[0][3] * m3;
+
+  double x = 0.5 * (ga + gb);
+  for (int it = 0; it < 50; ++it) {
+    const double x2 = x * x;
+    const double b = (x2 + c2) * x;
+    const double a = b + c1;
+    const double pv = a * x + c0;
+    const double dp = (2.0 * x2 * x + b) + a;
+    if (dp == 0.0) break;
+    const double xn = x - pv / dp;
+    if (!(xn < x)) break;
+    const double step = x - xn;
+    x = xn;
+    if (step <= 1e-14 * fabs(xn)) break;
+  }
+
+  /* B = N - x I ; adj(B) is symmetric: 10 cofactors */
+  const double b00 = N[0][0] - x, b11 = N[1][1] - x, b22 = N[2][2] - x, b33 = N[3][3] - x;
+  const double b01 = N[0][1], b02 = N[0][2], b03 = N[0][3], b12 = N[1][2], b13 = N[1][3], b23 = N[2][3];
+  const double a00 = sfo_det3(b11, b12, b13, b12, b22, b23, b13, b23, b33);
+  const double a11 = sfo_det3(b00, b02, b03, b02, b22, b23, b03, b23, b33);
+  const double a22 = sfo_det3(b00, b01, b03, b01, b11, b13, b03, b13, b33);
+  const double a33 = sfo_det3(b00, b01, b02, b01, b11, b12, b02, b12, b22);
+  const double a01 = -sfo_det3(b01, b12, b13, b02, b22, b23, b03, b23, b33);
+  const double a02 = sfo_det3(b01, b11, b13, b02, b12, b23, b03, b13, b33);
+  const double a03 = -sfo_det3(b01, b11, b12, b02, b12, b22, b03, b13, b23);
+  const double a12 = -sfo_det3(b00, b01, b03, b02, b12, b23, b03, b13, b33);
+  const double a13 = sfo_det3(b00, b01, b02, b02, b12, b22, b03, b13, b23);
+  const double a23 = -sfo_det3(b00, b01, b02, b01, b11, b12, b03, b13, b23);
+  double best = fabs(a00);
+  double w = a00, qx = a01, qy = a02, qz = a03;
+  if (fabs(a11) > best) { best = fabs(a11); w = a01; qx = a11; qy = a12; qz = a13; }
+  if (fabs(a22) > best) { best = fabs(a22); w = a02; qx = a12; qy = a22; qz = a23; }
+  if (fabs(a33) > best) { best = fabs(a33); w = a03; qx = a13; qy = a23; qz = a33; }
+  double nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
+  if (!(best > 0.0) || !(nrm2 > 0.0) || !isfinite(nrm2)) {
+    /* degenerate: full symmetric eigen-decomposition */
+    sfo_jacobi(4, N, V);
+    int bi = 0;
+    for (int i = 1; i < 4; ++i) if (N[i][i] > N[bi][bi]) bi = i;
+    w = V[0][bi]; qx = V[1][bi]; qy = V[2][bi]; qz = V[3][bi];
+    nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
+  }
+  const double inv = 1.0 / sqrt(nrm2);
+  w = w * inv;
+  const double x_ = qx * inv, y = qy * inv, z = qz * inv;
+  const double xx = x_ * x_, yy = y * y, zz = z * z, xy = x_ * y, xz = x_ * z, yz = y * z;
+  const double wx = w * x_, wy = w * y, wz = w * z;
   R[0] = 1.0 - 2.0 * (yy + zz); R[1] = 2.0 * (xy - wz);       R[2] = 2.0 * (xz + wy);
   R[3] = 2.0 * (xy + wz);       R[4] = 1.0 - 2.0 * (xx + zz); R[5] = 2.0 * (yz - wx);
   R[6] = 2.0 * (xz - wy);       R[7] = 2.0 * (yz + wx);       R[8] = 1.0 - 2.0 * (xx + yy);
@@ -256,11 +316,16 @@ void sfo_fit_rigid(const double* src, const double* dst, int n, double R[9], dou
     for (int j = 0; j < 3; ++j) { mp[j] += src[3 * i + j]; mq[j] += dst[3 * i + j]; }
   for (int j = 0; j < 3; ++j) { mp[j] *= inv_n; mq[j] *= inv_n; }
   double S[3][3] = {{0}};
-  for (int i = 0; i < n; ++i)
+  double ga = 0.0, gb = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double a[3], b[3];
+    for (int j = 0; j < 3; ++j) { a[j] = src[3 * i + j] - mp[j]; b[j] = dst[3 * i + j] - mq[j]; }
     for (int j = 0; j < 3; ++j)
-      for (int k = 0; k < 3; ++k)
-        S[j][k] += (src[3 * i + j] - mp[j]) * (dst[3 * i + k] - mq[k]);
-  sfo_rigid_from_moments(S, mp, mq, R, t);
+      for (int k = 0; k < 3; ++k) S[j][k] += a[j] * b[k];
+    ga += (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    gb += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+  }
+  sfo_rigid_from_moments(S, mp, mq, ga, gb, R, t);
 }
 
 /* Canonical block sum: SFO_LANES strided partials, xor-butterfly inside each group of 64,
@@ -298,7 +363,22 @@ static void sfo_fit_rigid_masked(const float* src, const float* dst, int m, cons
         scratch[i] = mask[i] ? ((double)src[3 * i + j] - mp[j]) * ((double)dst[3 * i + k] - mq[k]) : 0.0;
       S[j][k] = sfo_block_sum(scratch, m);
     }
-  sfo_rigid_from_moments(S, mp, mq, R, t);
+  double g[2];
+  for (int w = 0; w < 2; ++w) {
+    const float* pts = w == 0 ? src : dst;
+    const double* mean = w == 0 ? mp : mq;
+    for (int i = 0; i < m; ++i) {
+      if (mask[i]) {
+        double d0 = (double)pts[3 * i] - mean[0], d1 = (double)pts[3 * i + 1] - mean[1],
+               d2 = (double)pts[3 * i + 2] - mean[2];
+        scratch[i] = (d0 * d0 + d1 * d1) + d2 * d2;
+      } else {
+        scratch[i] = 0.0;
+      }
+    }
+    g[w] = sfo_block_sum(scratch, m);
+  }
+  sfo_rigid_from_moments(S, mp, mq, g[0], g[1], R, t);
 }
 
 /* squared residual of one correspondence under float coefficients c[12] (row-major 3x4):
