@@ -158,6 +158,7 @@ def main():
     d_from = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_to = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    h_res = torch.empty((n_kf * world, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
     h_from = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     h_to = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     state = {"pairs": 0, "accepted": 0, "last": None}
@@ -176,7 +177,9 @@ def main():
             rec, counts = dist.allgather_records(d_res[:n])
         else:
             rec = d_res[:n]
-        host = rec.cpu()                                     # results delivered to the host
+        host = h_res[: rec.shape[0]]
+        host.copy_(rec, non_blocking=True)                   # results delivered to the host (pinned)
+        torch.cuda.synchronize()
         state["pairs"] += n
         state["last"] = (m, host, n)
         return n

@@ -557,25 +557,60 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   SF_HIP(c, hipStreamSynchronize(c->stream));
   }
 
-  // data_handler.py:191-205: argsort of the row minima, then the sequential walk
-  std::vector<int> order(n_l);
-  for (int i = 0; i < n_l; ++i) order[i] = i;
+  // data_handler.py:191-205: argsort of the row minima, then the sequential walk.
+  // Only rows whose minimum is under the threshold can be accepted, and they sort in front of all
+  // others; once they are exhausted the reference's loop can only `continue` or `break`.  So the
+  // sort is restricted to those rows: LSD radix sort on the float64 bit patterns (non-negative
+  // doubles order like unsigned integers; the sort is stable, so ties keep the lowest row first).
   const std::vector<double>& rm = c->last_row_min;
-  std::sort(order.begin(), order.end(), [&rm](int a, int b) { return rm[a] < rm[b] || (rm[a] == rm[b] && a < b); });
+  const double thr_d = c->params.netvlad_distance;
+  std::vector<uint64_t>& keys = c->nn_sort_keys;
+  std::vector<int32_t>& rows = c->nn_sort_rows;
+  keys.clear();
+  rows.clear();
+  for (int i = 0; i < n_l; ++i) {
+    if (rm[i] < thr_d) {
+      uint64_t b;
+      const double v = rm[i] == 0.0 ? 0.0 : rm[i];   // -0.0 -> +0.0
+      memcpy(&b, &v, 8);
+      keys.push_back(b);
+      rows.push_back(i);
+    }
+  }
+  const size_t nu = keys.size();
+  if (nu > 1) {
+    std::vector<uint64_t>& k2 = c->nn_sort_keys2;
+    std::vector<int32_t>& r2 = c->nn_sort_rows2;
+    k2.resize(nu);
+    r2.resize(nu);
+    uint64_t diff = 0;
+    for (size_t i = 1; i < nu; ++i) diff |= keys[i] ^ keys[0];
+    for (int shift = 0; shift < 64; shift += 8) {
+      if (((diff >> shift) & 0xFF) == 0) continue;   // this byte is identical in every key
+      size_t hist[257] = {0};
+      for (size_t i = 0; i < nu; ++i) hist[((keys[i] >> shift) & 0xFF) + 1]++;
+      for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+      for (size_t i = 0; i < nu; ++i) {
+        const size_t pos = hist[(keys[i] >> shift) & 0xFF]++;
+        k2[pos] = keys[i];
+        r2[pos] = rows[i];
+      }
+      keys.swap(k2);
+      rows.swap(r2);
+    }
+  }
   const int lim = std::min(n_l, c->params.netvlad_max_matches_nb);
   int n = 0;
-  std::vector<uint8_t> taken(n_r, 0);
-  for (int s = 0; s < lim; ++s) {
-    const int il = order[s], io = c->last_row_arg[il];
+  std::vector<uint8_t>& taken = c->nn_taken;
+  taken.assign(n_r, 0);
+  for (int s = 0; s < lim && s < (int)nu; ++s) {
+    const int il = rows[s], io = c->last_row_arg[il];
     if (taken[io]) continue;                                  // :199-200 (slot still consumed)
-    if (rm[il] < c->params.netvlad_distance) {                // :202-203
-      if (n < cap) { out[n].idx_local = il; out[n].idx_other = io; out[n].distance = rm[il]; }
-      taken[io] = 1;
-      ++n;
-      if (n >= cap) break;
-    } else {
-      break;                                                  // :204-205
-    }
+    // rm[il] < netvlad_distance holds for every row kept above (:202-203)
+    if (n < cap) { out[n].idx_local = il; out[n].idx_other = io; out[n].distance = rm[il]; }
+    taken[io] = 1;
+    ++n;
+    if (n >= cap) break;
   }
   *n_out = std::min(n, cap);
   return SF_OK;

@@ -184,7 +184,7 @@ __device__ inline double variance_of(const RansacLds& L, int m, const uint8_t* m
   return 2.1981 * medv;
 }
 
-__global__ void __launch_bounds__(SF_BLOCK)
+__global__ void __launch_bounds__(SF_BLOCK, 4)
 k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
          const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
          const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
@@ -295,58 +295,73 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     sdt = sdt * sdt;
   }
 
+  if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+
   // ---- hypotheses: one lane each -----------------------------------------------------------------
   const double thr = P.inlier_thr;
   const double thr2 = thr * thr;
   float thr2f = (float)thr2;                       // largest float strictly below thr2
   if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
   const int max_it = P.iterations;
-  for (int it = tid; it <= max_it; it += SF_BLOCK) {
-    uint32_t s0, s1, s2;
-    int cnt = -1;
-    if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
-      float coef[12];
-      fit3(L, s0, s1, s2, coef);
-      cnt = 0;
-      for (int i = 0; i < m; ++i) {
-        const float4 p = L.src[i], q = L.dst[i];  // same address in every lane: LDS broadcast
-        const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
-        cnt += (r2 <= thr2f) ? 1 : 0;
+  // Hypotheses are evaluated in rounds of SF_BLOCK (one lane each); after every round thread 0
+  // advances PCL's sequential loop (adaptive k) over the counts available so far.  Once that loop
+  // has terminated the remaining rounds are skipped: their counts would never be read.
+  double k_adapt = 1.0;                                  // thread 0 only
+  const double log_probability = sfd::canon_log(1.0 - 0.99);
+  int sc_best = -1, sc_best_it = -1, sc_it = 0;          // thread 0 only
+  for (int base = 0; base <= max_it; base += SF_BLOCK) {
+    const int it = base + tid;
+    if (it <= max_it) {
+      uint32_t s0, s1, s2;
+      int cnt = -1;
+      if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
+        float coef[12];
+        fit3(L, s0, s1, s2, coef);
+        cnt = 0;
+        for (int i = 0; i < m; ++i) {
+          const float4 p = L.src[i], q = L.dst[i];  // same address in every lane: LDS broadcast
+          const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+          cnt += (r2 <= thr2f) ? 1 : 0;
+        }
       }
+      L.counts[it] = cnt;
     }
-    L.counts[it] = cnt;
-  }
-  __syncthreads();
-
-  // ---- PCL's sequential loop with adaptive k, replayed on the counts -------------------------------
-  if (tid == 0) {
-    double k = 1.0;
-    const double log_probability = sfd::canon_log(1.0 - 0.99);
-    int best = -1, best_it = -1, it = 0;
-    while (P.adaptive_stop ? ((double)it < k) : true) {
-      if (it > max_it) break;
-      const int c = L.counts[it];
-      if (c < 0) break;
-      if (c > best) {
-        best = c;
-        best_it = it;
-        const double w = (double)best * inv_m;
-        double pno = 1.0 - (w * w) * w;
-        if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
-        if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
-        k = log_probability / sfd::canon_log(pno);
+    __syncthreads();
+    if (tid == 0) {
+      const int lim = min(max_it, base + SF_BLOCK - 1);  // last iteration whose count exists
+      bool stop = false;
+      while (true) {
+        if (P.adaptive_stop && !((double)sc_it < k_adapt)) { stop = true; break; }
+        if (sc_it > max_it) { stop = true; break; }
+        if (sc_it > lim) break;                           // needs the next round
+        const int c = L.counts[sc_it];
+        if (c < 0) { stop = true; break; }                // getSamples failed -> PCL breaks out
+        if (c > sc_best) {
+          sc_best = c;
+          sc_best_it = sc_it;
+          const double w = (double)sc_best * inv_m;
+          double pno = 1.0 - (w * w) * w;
+          if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
+          if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
+          k_adapt = log_probability / sfd::canon_log(pno);
+        }
+        ++sc_it;
+        if (sc_it > max_it) { stop = true; break; }
       }
-      ++it;
-      if (it > max_it) break;
+      L.misc[0] = sc_best_it;
+      L.misc[1] = stop ? 1 : 0;
     }
-    L.misc[0] = best_it;
+    __syncthreads();
+    if (L.misc[1]) break;
   }
-  __syncthreads();
+  if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation
   const int best_it = L.misc[0];
   if (best_it < 0) {
     if (tid == 0) pass[pair] = ps;
     return;
   }
+
+  if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
 
   // ---- winning model (recomputed redundantly in every lane: identical arithmetic, no broadcast) ----
   float coef[12];
@@ -359,6 +374,8 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   int n_inl = select_within(L, m, coef, thr2, inl, tid);
   const uint8_t* last_mask = inl;
   int n_last = n_inl;
+
+  if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
 
   // ---- refine loop (copy of pcl::SampleConsensus::refineModel inside rtabmap) ----------------------
   if (P.refine_iterations > 0) {
@@ -406,6 +423,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     for (int i = 0; i < 12; ++i) coef[i] = newc[i];
   }
 
+  if (P.dbg_stop == 5) { if (tid == 0) pass[pair] = ps; return; }
   if (n_inl >= 3) {
     const double variance = variance_of(L, m, last_mask, n_last, tid);
     ps.var = variance;

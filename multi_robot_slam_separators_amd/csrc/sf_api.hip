@@ -282,6 +282,7 @@ static int fill_device_params(sf_context* c) {
   d.wlim = (float)(p.image_width - 1);
   d.hlim = (float)(p.image_height - 1);
   memcpy(d.L, p.local_transform, sizeof(d.L));
+  if (const char* v = getenv("SF_RANSAC_STOP")) d.dbg_stop = atoi(v);
   return SF_OK;
 }
 

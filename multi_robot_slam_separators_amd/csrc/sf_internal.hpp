@@ -59,6 +59,8 @@ struct DeviceParams {
   double fx, fy, cx, cy;
   float wlim, hlim;        // image_width-1, image_height-1
   float L[12];             // local transform
+  int32_t dbg_stop;        // diagnostics only: truncate k_ransac after phase N (0 = full kernel)
+  int32_t pad_;
 };
 
 struct Buf {
@@ -121,6 +123,9 @@ struct sf_context {
   Buf nn_scalar;     // small reduction scratch
   std::vector<double> last_row_min;
   std::vector<int32_t> last_row_arg;
+  std::vector<uint64_t> nn_sort_keys, nn_sort_keys2;   // host scratch of the walk (kept to avoid reallocation)
+  std::vector<int32_t> nn_sort_rows, nn_sort_rows2;
+  std::vector<uint8_t> nn_taken;
 
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
 
