@@ -30,6 +30,25 @@ namespace {
 constexpr int NN_BM = 128, NN_BN = 128, NN_BK = 32, NN_PITCH = 36;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// XCD-aware tile rasterisation.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2
+// each), so consecutive ids never share an L2.  Give every XCD a CONTIGUOUS chunk of the logical
+// tile order (bijective for any grid size), and walk that order in bands of 8 row panels with the
+// column index fastest inside a band: the ~100 workgroups an XCD runs concurrently then cover a
+// compact 8 x 12 patch of tiles whose A/B panels are re-used out of that XCD's L2 instead of
+// being re-fetched through the fabric (speed only; correctness never depends on placement).
+__device__ __forceinline__ void nn_tile_of_block(int bid, int gx, int gy, int& tx, int& ty) {
+  const int nwg = gx * gy;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int logical = xcd * q + (xcd < r ? xcd : r) + local;
+  const int band = 8 * gx;
+  const int g = logical / band, in = logical - g * band;
+  const int first = g * 8;
+  const int gsz = (gy - first) < 8 ? (gy - first) : 8;
+  ty = first + in % gsz;
+  tx = in / gsz;
+}
+
 __global__ void __launch_bounds__(256)
 k_nn_cast_rows(const double* __restrict__ src, float* __restrict__ dst, float* __restrict__ norms, int n, int dim,
                int ld) {
@@ -69,13 +88,15 @@ k_nn_copy_rows(const float* __restrict__ src, float* __restrict__ dst, float* __
 __global__ void __launch_bounds__(256)
 k_nn_argmin(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ na,
             const float* __restrict__ nb_eff, const int* __restrict__ ign_ptr, const int* __restrict__ ign_col,
-            unsigned long long* __restrict__ part, int n_l_pad, int ld) {
+            unsigned long long* __restrict__ part, int n_l_pad, int ld, int gx, int gy) {
   __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];
   __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;           // wave tile origin: (64*wr, 64*wc)
-  const int row0 = blockIdx.y * NN_BM, col0 = blockIdx.x * NN_BN;
+  int tile_x, tile_y;
+  nn_tile_of_block(blockIdx.x, gx, gy, tile_x, tile_y);
+  const int row0 = tile_y * NN_BM, col0 = tile_x * NN_BN;
   const int l31 = lane & 31, h = lane >> 5;
 
   f32x16 acc[2][2];
@@ -120,7 +141,7 @@ k_nn_argmin(const float* __restrict__ A, const float* __restrict__ B, const floa
   }
 
   // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int strip = blockIdx.x * 2 + wc;
+  const int strip = tile_x * 2 + wc;
   float nbj[2];
   int colj[2];
 #pragma unroll
@@ -230,14 +251,16 @@ __global__ void k_nn_fill_row_norms(float* na_eff, const float* na, const uint8_
 // rigorous error bound  |dot16 - dot32| <= eps_rel * sqrt(na * nb).
 __global__ void __launch_bounds__(256)
 k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float* __restrict__ na_eff,
-                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld,
+                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld, int gx, int gy,
                 uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
   __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];   // 128 rows x 64 halfs (+ pad)
   __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int row0 = blockIdx.y * NN_BM, col0 = blockIdx.x * NN_BN;
+  int tile_x, tile_y;
+  nn_tile_of_block(blockIdx.x, gx, gy, tile_x, tile_y);
+  const int row0 = tile_y * NN_BM, col0 = tile_x * NN_BN;
   const int l31 = lane & 31, h = lane >> 5;
   const int ldw = ld / 2;                      // row pitch in dwords (ld halfs)
   const float* Aw = reinterpret_cast<const float*>(A);
@@ -252,17 +275,34 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int srow = tid >> 3, sk4 = (tid & 7) * 4;   // staging: 32 rows x 8 x 16 B per pass
+  // register-staged software pipeline: the global loads of K-tile t+1 are in flight while the
+  // MFMAs of tile t run; they are written to LDS after the tile's reads are done.
+  // (named registers, not arrays: hipcc demotes a float4[4] carried around the loop to scratch)
+  const float* pa = Aw + (size_t)(row0 + srow) * ldw + sk4;
+  const float* pb = Bw + (size_t)(col0 + srow) * ldw + sk4;
+  const size_t rstep = (size_t)32 * ldw;
+#define SF_LD4(ptr) (*reinterpret_cast<const float4*>(ptr))
+  float4 ra0 = SF_LD4(pa), ra1 = SF_LD4(pa + rstep), ra2 = SF_LD4(pa + 2 * rstep), ra3 = SF_LD4(pa + 3 * rstep);
+  float4 rb0 = SF_LD4(pb), rb1 = SF_LD4(pb + rstep), rb2 = SF_LD4(pb + 2 * rstep), rb3 = SF_LD4(pb + 3 * rstep);
+  float* wa = &sA[srow * NN_PITCH + sk4];
+  float* wb = &sB[srow * NN_PITCH + sk4];
   for (int k0 = 0; k0 < ldw; k0 += 32) {            // 32 dwords = 64 halfs per step
+    __syncthreads();                                // previous tile's LDS reads are complete
+    *reinterpret_cast<float4*>(wa) = ra0;
+    *reinterpret_cast<float4*>(wa + 32 * NN_PITCH) = ra1;
+    *reinterpret_cast<float4*>(wa + 64 * NN_PITCH) = ra2;
+    *reinterpret_cast<float4*>(wa + 96 * NN_PITCH) = ra3;
+    *reinterpret_cast<float4*>(wb) = rb0;
+    *reinterpret_cast<float4*>(wb + 32 * NN_PITCH) = rb1;
+    *reinterpret_cast<float4*>(wb + 64 * NN_PITCH) = rb2;
+    *reinterpret_cast<float4*>(wb + 96 * NN_PITCH) = rb3;
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = srow + 32 * p;
-      const float4 va = *reinterpret_cast<const float4*>(Aw + (size_t)(row0 + r) * ldw + k0 + sk4);
-      const float4 vb = *reinterpret_cast<const float4*>(Bw + (size_t)(col0 + r) * ldw + k0 + sk4);
-      *reinterpret_cast<float4*>(&sA[r * NN_PITCH + sk4]) = va;
-      *reinterpret_cast<float4*>(&sB[r * NN_PITCH + sk4]) = vb;
+    {
+      const int kn = (k0 + 32 < ldw) ? k0 + 32 : k0;   // last iteration re-reads its own tile (unused)
+      ra0 = SF_LD4(pa + kn); ra1 = SF_LD4(pa + rstep + kn); ra2 = SF_LD4(pa + 2 * rstep + kn); ra3 = SF_LD4(pa + 3 * rstep + kn);
+      rb0 = SF_LD4(pb + kn); rb1 = SF_LD4(pb + rstep + kn); rb2 = SF_LD4(pb + 2 * rstep + kn); rb3 = SF_LD4(pb + 3 * rstep + kn);
     }
-    __syncthreads();
+#undef SF_LD4
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // 16 halfs of K per MFMA: lane holds k = 16 q + 8 h + 0..7
       half8 a[2], b[2];
@@ -448,9 +488,9 @@ static int nn_run_filter(sf_context* c, int* done) {
   hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
                      (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
   sf_prof_begin(c, SF_K_NN_FILTER);
-  hipLaunchKernelGGL(k_nn_filter_f16, dim3(n_r_pad / NN_BN, n_l_pad / NN_BM), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                      (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, na_eff, nb_eff,
-                     inv_scale, thr2, eps_rel, ld16, cand, count, cap);
+                     inv_scale, thr2, eps_rel, ld16, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
   sf_prof_end(c, SF_K_NN_FILTER);
   SF_HIP(c, hipGetLastError());
   unsigned n_cand = 0;
@@ -538,10 +578,10 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
                      (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
   sf_prof_begin(c, SF_K_NN);
-  hipLaunchKernelGGL(k_nn_argmin, dim3(n_r_pad / NN_BN, n_l_pad / NN_BM), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_nn_argmin, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                      (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p,
                      (const float*)c->nn_local.norms.p, nb_eff, (const int*)c->d_ign_ptr.p,
-                     (const int*)c->d_ign_col.p, part, n_l_pad, ld);
+                     (const int*)c->d_ign_col.p, part, n_l_pad, ld, n_r_pad / NN_BN, n_l_pad / NN_BM);
   sf_prof_end(c, SF_K_NN);
   sf_prof_begin(c, SF_K_NN_SELECT);
   hipLaunchKernelGGL(k_nn_select, dim3((n_l + 3) / 4), dim3(256), 0, c->stream, part, n_strips, n_l, n_l_pad,
