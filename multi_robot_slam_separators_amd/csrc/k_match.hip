@@ -219,6 +219,234 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 2 ("LDS + u16"), shaped by the measured gfx950 VALU issue rates (tools/ubench/valu_rate.hip:
+// v_xor_b32 VGPR,VGPR / v_min_u16 / v_max_u16 issue at full rate; v_bcnt_u32_b32, every 32-bit
+// min/max, v_lshl_or_b32 and any VALU op with an SGPR operand at HALF rate):
+//   * the "from" block is staged once into LDS and broadcast-read into VGPRs (uniform address: one
+//     LDS cycle group, no conflicts), so the xor is VGPR x VGPR;
+//   * best and second-best are tracked as 16-bit DISTANCES only (3 full-rate ops, no key packing);
+//   * which "from" row holds the minimum is recovered afterwards, for accepted lanes only, by
+//     re-scanning the 16-row chunk in which the running minimum last decreased (first row whose
+//     distance equals the minimum = lowest index, the tie rule of the packed-key variant).
+__device__ __forceinline__ uint32_t min_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+constexpr int MATCH_CH = 16;   // rows per index-recovery chunk
+
+template <int W, int NQ>
+__device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, const uint32_t (&q)[NQ][W],
+                                              uint32_t (&d1)[NQ], uint32_t (&d2)[NQ], uint32_t (&chunk)[NQ]) {
+  for (int c0 = 0; c0 < Kf; c0 += MATCH_CH) {
+    uint32_t prev[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) prev[j] = d1[j];
+    const int cend = min(c0 + MATCH_CH, Kf);
+#pragma unroll 4
+    for (int f = c0; f < cend; ++f) {
+      const uint4* r = reinterpret_cast<const uint4*>(fromD + (size_t)f * W);   // same address in every lane
+      uint32_t x[W];
+#pragma unroll
+      for (int c = 0; c < W / 4; ++c) {
+        const uint4 v = r[c];
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int c = 0; c < W; ++c) d = bcnt_acc(x[c] ^ q[j][c], d);
+        d2[j] = min_u16(d2[j], max_u16(d, d1[j]));
+        d1[j] = min_u16(d1[j], d);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) chunk[j] = ((d1[j] & 0xFFFFu) != (prev[j] & 0xFFFFu)) ? (uint32_t)c0 : chunk[j];
+  }
+}
+
+template <int W, int NQ, int NT>
+__global__ void __launch_bounds__(NT)
+k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                  float nndr, int min_inliers, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                  PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  constexpr int NW = NT / 64;
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  if ((unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots) {
+    if (tid == 0) {
+      CorrHeader h = {0, 0, 0, 0};
+      hdr[pair] = h;
+      PassState ps;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+      ps.var = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
+      pass[pair] = ps;
+    }
+    return;
+  }
+  const int4 mF = st.meta[sF], mT = st.meta[sT];
+  const int Kf = mF.x, Kt = mT.x;
+  const uint32_t* dF = st.desc + (size_t)sF * kcap * W;
+  const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
+
+  uint32_t* fromD = reinterpret_cast<uint32_t*>(smem);   // [kcap * W] staged "from" descriptors
+  int* cnt = smem + kcap * W;                              // [kcap]
+  int* owner = cnt + kcap;                                 // [kcap]
+  int* misc = owner + kcap;                                // [16]
+
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(dF);
+    uint4* dst = reinterpret_cast<uint4*>(fromD);
+    for (int i = tid; i < Kf * (W / 4); i += NT) dst[i] = src[i];
+  }
+  for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
+  if (tid < 16) misc[tid] = 0;
+  __syncthreads();
+
+  int rejected = 0;
+  if (Kf > 0) {
+    for (int base = 0; base < Kt; base += NQ * NT) {
+      uint32_t q[NQ][W], d1[NQ], d2[NQ], chunk[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int t = base + j * NT + tid;
+        load_desc<W>(dT, t, t < Kt, q[j]);
+        d1[j] = 0xFFFFu;
+        d2[j] = 0xFFFFu;
+        chunk[j] = 0;
+      }
+      const int wave_rows = Kt - base - (tid & ~63);
+      const int groups = wave_rows <= 0 ? 0 : min(NQ, (wave_rows + NT - 1) / NT);
+      if (groups == NQ) {
+        knn2_scan_lds<W, NQ>(fromD, Kf, q, d1, d2, chunk);
+      } else if (groups > 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j < groups) {
+            uint32_t qq[1][W], a1[1] = {0xFFFFu}, a2[1] = {0xFFFFu}, ch[1] = {0};
+#pragma unroll
+            for (int c = 0; c < W; ++c) qq[0][c] = q[j][c];
+            knn2_scan_lds<W, 1>(fromD, Kf, qq, a1, a2, ch);
+            d1[j] = a1[0]; d2[j] = a2[0]; chunk[j] = ch[0];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int t = base + j * NT + tid;
+        if (t < Kt) {
+          const uint32_t b1 = d1[j] & 0xFFFFu, b2 = d2[j] & 0xFFFFu;
+          const bool acc = (Kf >= 2) && !((float)b1 > nndr * (float)b2);
+          if (acc) {
+            // index recovery inside the chunk where the minimum was reached
+            int f = (int)chunk[j];
+            const int fend = min(f + MATCH_CH, Kf);
+            for (; f < fend; ++f) {
+              const uint32_t* r = fromD + (size_t)f * W;
+              uint32_t d = 0;
+#pragma unroll
+              for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[j][c]);
+              if (d == b1) break;
+            }
+            atomicAdd(&cnt[f], 1);
+            owner[f] = t;
+          } else {
+            ++rejected;
+          }
+        }
+      }
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) rejected += __shfl_xor(rejected, off);
+  if (lane == 0 && rejected) atomicAdd(&misc[0], rejected);
+  __syncthreads();
+
+  uint32_t* out = corr + (size_t)pair * kcap;
+  int running = 0;
+  for (int base = 0; base < Kf; base += NT) {
+    const int f = base + tid;
+    const bool flag = (f < Kf) && (cnt[f] == 1);
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int c = misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (flag) out[running + woff + before] = (uint32_t)f | ((uint32_t)owner[f] << 16);
+    running += total;
+    __syncthreads();
+  }
+  const int n_corr = running;
+
+  const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
+  const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;
+  const int words_to = (mT.y > 0) ? unique_to : 0;
+  const bool motion = unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers;
+  const bool survivor = motion && n_corr >= min_inliers && n_corr >= 3;
+  if (motion && !survivor) {
+    const float* xF = st.xyz + (size_t)sF * kcap * 3;
+    const float* xT = st.xyz + (size_t)sT * kcap * 3;
+    for (int i = tid; i < n_corr; i += NT) {
+      uint32_t c = out[i];
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      const float* b = xT + 3 * (c >> 16);
+      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(b[0]) && isfinite(b[1]) &&
+                isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
+                (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      if (ok) atomicAdd(&misc[2], 1);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    CorrHeader h;
+    h.n_corr = n_corr;
+    h.words_from = words_from;
+    h.words_to = words_to;
+    h.words_to_2d = unique_to;
+    hdr[pair] = h;
+    PassState ps;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+    ps.var = 1.0;
+    ps.is_null = 1;
+    ps.inliers = 0;
+    ps.matches = (motion && !survivor) ? misc[2] : 0;
+    ps.pad = 0;
+    pass[pair] = ps;
+    if (survivor) {
+      int pos = atomicAdd(counter, 1);
+      list[pos] = pair;
+    }
+  }
+}
+
+template <int W, int NQ, int NT>
+void launch_match_v2(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
+  const size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  hipLaunchKernelGGL((k_match_global_v2<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
+                     c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                     (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+}
+
 template <int W, int NQ, int NT>
 void launch_match(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
@@ -234,7 +462,11 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
   if (n <= 0) return SF_OK;
   // geometry: variant = NQ * 1000 + NT (tunable through SF_MATCH_VARIANT for A/B runs)
   int variant = c->match_variant;
-  if (variant == 0) variant = st.w == 8 ? 2256 : 2256;
+  if (variant == 0) {
+    // default: LDS + u16 variant while the staged "from" block keeps >= 2 workgroups per CU
+    const size_t lds_v2 = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+    variant = lds_v2 <= 64 * 1024 ? 12256 : 2256;
+  }
   sf_prof_begin(c, SF_K_MATCH);
 #define SF_CASE(NQ_, NT_)                                                        \
   case NQ_ * 1000 + NT_:                                                         \
@@ -249,6 +481,16 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
     SF_CASE(4, 256)
     SF_CASE(8, 64)
     SF_CASE(4, 64)
+#define SF_CASE2(NQ_, NT_)                                                          \
+  case 10000 + NQ_ * 1000 + NT_:                                                    \
+    if (st.w == 8) launch_match_v2<8, NQ_, NT_>(c, st, d_from, d_to, n);            \
+    else launch_match_v2<16, NQ_, NT_>(c, st, d_from, d_to, n);                     \
+    break;
+    SF_CASE2(2, 256)
+    SF_CASE2(1, 256)
+    SF_CASE2(4, 128)
+    SF_CASE2(2, 128)
+#undef SF_CASE2
     default:
       sf_prof_end(c, SF_K_MATCH);
       return sf_fail(c, SF_EINVAL, "unknown match kernel variant %d", variant);
