@@ -37,6 +37,26 @@ def bytes_per_pair(k, cols):
     return 2 * k * (cols + 12) + 352
 
 
+def pmc_traffic(kernel_prefix, pairs_per_launch):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_summary.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).
+    gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts half of a coalesced stream
+    (calibrated here on k_nn_copy_rows / k_ingest, see profiles/README.md)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
+    for path in reversed(files):
+        try:
+            pm = json.load(open(path)).get("pmc_per_launch", {})
+        except Exception:
+            continue
+        for name, v in pm.items():
+            if name.startswith(kernel_prefix) and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+                return {"bytes": (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0,
+                        "source": os.path.basename(path), "kernel": name,
+                        "note": "measured at 10000 pairs per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB"}
+    return None
+
+
 def generate_inputs(seed, n_kf, k, cols, dim, true_frac):
     from multi_robot_slam_separators_amd import synth
     t0 = time.time()
@@ -238,6 +258,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_step = total_pairs / args.steps / world
         bpp = bytes_per_pair(k, cols)
+        pmc = pmc_traffic("k_match_global", pairs_per_step)
         nm, tm = prof["k_match_global"]
         match_ms = tm / max(nm, 1)
         ach = pairs_per_step * bpp / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
@@ -268,7 +289,13 @@ def main():
             },
             "roofline": {
                 "kernel": "k_match_global", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": (pmc or {}).get("bytes") if abs(pairs_per_step - 10000) < 1 else None,
+                "traffic_source": pmc,
+                "valu": {"note": "the kernel is VALU-bound, not HBM-bound: per 256-bit descriptor pair 8 v_xor (full "
+                                 "rate) + 8 v_bcnt_u32_b32 (HALF rate on gfx950, tools/ubench/valu_rate.hip) + 6 "
+                                 "16-bit min/max",
+                         "descriptor_pairs_per_s": pairs_per_step * k * k / (match_ms * 1e-3) if match_ms > 0 else 0.0},
                 "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_step, "avg_launch_ms": match_ms,
             },
             "roofline_nn": {
