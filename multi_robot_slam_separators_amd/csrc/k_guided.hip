@@ -57,8 +57,14 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   int* claim = smem;               // [kcap] lowest "from" index that matched each "to" row
   int* matched = smem + kcap;      // [kcap] "to" row matched by each "from" point, or -1
   int* misc = smem + 2 * kcap;     // [16]
+  const int NC = P.grid_gx * P.grid_gy;
+  int* cell_start = misc + 16;     // [NC + 1] CSR of "to" keypoints bucketed on a uniform grid
+  int* cell_fill = cell_start + NC + 1;   // [NC]
+  int* items = cell_fill + NC;     // [kcap] "to" indices grouped by cell
   for (int i = tid; i < Kt; i += SF_BLOCK) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += SF_BLOCK) matched[i] = -1;
+  for (int i = tid; i <= NC; i += SF_BLOCK) cell_start[i] = 0;
+  for (int i = tid; i < NC; i += SF_BLOCK) cell_fill[i] = 0;
   if (tid < 16) misc[tid] = 0;
 
   // :486-487 guessCameraRef = (guess * localTransform).inverse()
@@ -89,6 +95,59 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   const float4* kF = st.kp + (size_t)sF * kcap;
   const float4* kT = st.kp + (size_t)sT * kcap;
   const float r2lim = (float)P.guess_win * (float)P.guess_win;
+
+  // ---- bucket the "to" keypoints: the reference searches a kd-tree (myRegistrationVis.cpp:670-680);
+  // a uniform grid with cell >= window radius makes the exact radius search a 3x3-cell visit.
+  // Keypoints outside the image are clamped into border cells (any point within the radius of an
+  // in-image projection still lands in that projection's 3x3 neighbourhood); non-finite ones can
+  // never pass the window test and are left out.
+  const float inv_cell = P.grid_inv_cell;
+  const int gxm = P.grid_gx - 1, gym = P.grid_gy - 1;
+  for (int t = tid; t < Kt; t += SF_BLOCK) {
+    const float4 k = kT[t];
+    if (isfinite(k.x) && isfinite(k.y)) {
+      const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
+      const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
+      atomicAdd(&cell_start[cy * P.grid_gx + cx + 1], 1);
+    }
+  }
+  __syncthreads();
+  {
+    // exclusive scan of the per-cell counts (each thread owns a run of consecutive cells)
+    const int per = (NC + SF_BLOCK - 1) / SF_BLOCK;
+    const int c0 = tid * per, c1 = min(c0 + per, NC);
+    int local = 0;
+    for (int cidx = c0; cidx < c1; ++cidx) local += cell_start[cidx + 1];
+    int incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) misc[8 + wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += misc[8 + w];
+    int run = woff + incl - local;
+    __syncthreads();   // all counts read before they are overwritten with offsets
+    for (int cidx = c0; cidx < c1; ++cidx) {
+      const int cnt_c = cell_start[cidx + 1];
+      cell_start[cidx + 1] = run + cnt_c;     // becomes the END offset of cell cidx = start of cidx + 1
+      run += cnt_c;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < Kt; t += SF_BLOCK) {
+    const float4 k = kT[t];
+    if (isfinite(k.x) && isfinite(k.y)) {
+      const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
+      const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
+      const int cidx = cy * P.grid_gx + cx;
+      const int pos = atomicAdd(&cell_fill[cidx], 1);
+      items[cell_start[cidx] + pos] = t;
+    }
+  }
+  __syncthreads();
+  const float reach = (float)P.guess_win * 1.0001f + 1e-3f;   // window radius with a rounding margin
 
   int n_finite = 0, n_proj = 0;
   for (int base = 0; base < Kf; base += SF_BLOCK) {
@@ -124,20 +183,29 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
       }
       int oi = 0, last = -1;
       uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;  // (dist << 16 | to_idx) keys
-      for (int t = 0; t < Kt; ++t) {
-        const float4 k = kT[t];
-        const float dx = u - k.x, dy = v - k.y;
-        const float d2 = dx * dx + dy * dy;
-        if (d2 < r2lim && __float_as_int(k.z) == octf) {
-          const uint32_t* r = dT + (size_t)t * W;
-          uint32_t d = 0;
+      const int cx0 = min(max((int)floorf((u - reach) * inv_cell), 0), gxm);
+      const int cx1 = min(max((int)floorf((u + reach) * inv_cell), 0), gxm);
+      const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
+      const int cy1 = min(max((int)floorf((v + reach) * inv_cell), 0), gym);
+      for (int cy = cy0; cy <= cy1; ++cy) {
+        // cells cx0..cx1 of one grid row are contiguous in the CSR
+        const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
+        for (int e = e0; e < e1; ++e) {
+          const int t = items[e];
+          const float4 k = kT[t];
+          const float dx = u - k.x, dy = v - k.y;
+          const float d2 = dx * dx + dy * dy;
+          if (d2 < r2lim && __float_as_int(k.z) == octf) {
+            const uint32_t* r = dT + (size_t)t * W;
+            uint32_t d = 0;
 #pragma unroll
-          for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
-          const uint32_t key = (d << 16) | (uint32_t)t;
-          b1 = min(max(key, b0), b1);
-          b0 = min(b0, key);
-          ++oi;
-          last = t;
+            for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
+            const uint32_t key = (d << 16) | (uint32_t)t;
+            b1 = min(max(key, b0), b1);
+            b0 = min(b0, key);
+            ++oi;
+            if (last < 0 || t > last) last = t;
+          }
         }
       }
       int m = -1;
@@ -307,7 +375,8 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
-  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
+  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  const size_t lds = (size_t)(3 * st.kcap + 16 + 2 * nc + 1) * sizeof(int);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_GUIDED);
   if (st.w == 8) {

@@ -283,6 +283,15 @@ static int fill_device_params(sf_context* c) {
   d.hlim = (float)(p.image_height - 1);
   memcpy(d.L, p.local_transform, sizeof(d.L));
   if (const char* v = getenv("SF_RANSAC_STOP")) d.dbg_stop = atoi(v);
+  {
+    // grid for the guided pass: cell >= window radius, at most 48 x 48 cells
+    const float w = (float)std::max(p.image_width, 1), h = (float)std::max(p.image_height, 1);
+    float cell = std::max((float)std::max(p.guess_win_size, 1), std::max(ceilf(w / 48.f), ceilf(h / 48.f)));
+    cell *= 1.001f;   // strictly larger than the padded reach used by the kernel
+    d.grid_gx = std::max(1, std::min(48, (int)ceilf(w / cell)));
+    d.grid_gy = std::max(1, std::min(48, (int)ceilf(h / cell)));
+    d.grid_inv_cell = 1.f / cell;
+  }
   return SF_OK;
 }
 

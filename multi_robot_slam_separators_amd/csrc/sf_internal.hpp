@@ -60,7 +60,8 @@ struct DeviceParams {
   float wlim, hlim;        // image_width-1, image_height-1
   float L[12];             // local transform
   int32_t dbg_stop;        // diagnostics only: truncate k_ransac after phase N (0 = full kernel)
-  int32_t pad_;
+  int32_t grid_gx, grid_gy;   // guided matching: uniform grid over the image (cell >= window radius)
+  float grid_inv_cell;
 };
 
 struct Buf {
