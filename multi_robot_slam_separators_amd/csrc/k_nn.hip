@@ -229,14 +229,22 @@ __global__ void __launch_bounds__(256) k_nn_maxabs(const float* __restrict__ row
 }
 
 // rows * scale -> fp16 (scale is a power of two: exact).  One wavefront per row; the fp16 row pitch
-// ld16 (multiple of 64) may exceed the float pitch ld: the tail is zero filled.
+// ld16 (multiple of 64) may exceed the float pitch ld: the tail is zero filled.  Also emits the
+// squared norm of the first `kprefix` elements of the float32 row (float64 accumulation).
 __global__ void __launch_bounds__(256) k_nn_to_f16(const float* __restrict__ rows, _Float16* __restrict__ out,
-                                                    int n, int ld, int ld16, float scale) {
+                                                    float* __restrict__ prefix_norm, int n, int ld, int ld16,
+                                                    int kprefix, float scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  for (int k = lane; k < ld16; k += 64)
-    out[(size_t)row * ld16 + k] = (k < ld) ? (_Float16)(rows[(size_t)row * ld + k] * scale) : (_Float16)0.f;
+  double s = 0.0;
+  for (int k = lane; k < ld16; k += 64) {
+    const float v = (k < ld) ? rows[(size_t)row * ld + k] : 0.f;
+    out[(size_t)row * ld16 + k] = (_Float16)(v * scale);
+    if (k < kprefix) s += (double)v * (double)v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) prefix_norm[row] = (float)s;
 }
 
 // effective row norms: +inf for masked / padding rows (a masked row can never be a candidate)
@@ -251,7 +259,7 @@ __global__ void k_nn_fill_row_norms(float* na_eff, const float* na, const uint8_
 // rigorous error bound  |dot16 - dot32| <= eps_rel * sqrt(na * nb).
 __global__ void __launch_bounds__(256)
 k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float* __restrict__ na_eff,
-                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld, int gx, int gy,
+                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld, int kdims, int gx, int gy,
                 uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
   __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];   // 128 rows x 64 halfs (+ pad)
   __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
@@ -286,7 +294,8 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
   float4 rb0 = SF_LD4(pb), rb1 = SF_LD4(pb + rstep), rb2 = SF_LD4(pb + 2 * rstep), rb3 = SF_LD4(pb + 3 * rstep);
   float* wa = &sA[srow * NN_PITCH + sk4];
   float* wb = &sB[srow * NN_PITCH + sk4];
-  for (int k0 = 0; k0 < ldw; k0 += 32) {            // 32 dwords = 64 halfs per step
+  const int kdw = kdims / 2;                       // dwords of the (prefix of the) row to contract
+  for (int k0 = 0; k0 < kdw; k0 += 32) {            // 32 dwords = 64 halfs per step
     __syncthreads();                                // previous tile's LDS reads are complete
     *reinterpret_cast<float4*>(wa) = ra0;
     *reinterpret_cast<float4*>(wa + 32 * NN_PITCH) = ra1;
@@ -298,7 +307,7 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
     *reinterpret_cast<float4*>(wb + 96 * NN_PITCH) = rb3;
     __syncthreads();
     {
-      const int kn = (k0 + 32 < ldw) ? k0 + 32 : k0;   // last iteration re-reads its own tile (unused)
+      const int kn = (k0 + 32 < kdw) ? k0 + 32 : k0;   // last iteration re-reads its own tile (unused)
       ra0 = SF_LD4(pa + kn); ra1 = SF_LD4(pa + rstep + kn); ra2 = SF_LD4(pa + 2 * rstep + kn); ra3 = SF_LD4(pa + 3 * rstep + kn);
       rb0 = SF_LD4(pb + kn); rb1 = SF_LD4(pb + rstep + kn); rb2 = SF_LD4(pb + 2 * rstep + kn); rb3 = SF_LD4(pb + 3 * rstep + kn);
     }
@@ -423,8 +432,8 @@ int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int s
 
 
 // ---- fp16 filter path -----------------------------------------------------------------------------
-static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16) {
-  if (db.h_n == db.n && db.h_ld == ld16) return SF_OK;
+static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16, int kprefix) {
+  if (db.h_n == db.n && db.h_ld == ld16 && db.h_kprefix == kprefix) return SF_OK;
   int rc;
   if ((rc = sf_buf_reserve(c, c->nn_scalar, 64)) != SF_OK) return rc;
   SF_HIP(c, hipMemsetAsync(c->nn_scalar.p, 0, 64, c->stream));
@@ -445,12 +454,15 @@ static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16) {
   const int n_pad = (db.n + 127) & ~127;
   const size_t bytes = (size_t)n_pad * ld16 * 2;
   if ((rc = sf_buf_reserve(c, db.rows_h, bytes)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, db.norms_k, (size_t)n_pad * 4)) != SF_OK) return rc;
   SF_HIP(c, hipMemsetAsync(db.rows_h.p, 0, bytes, c->stream));
+  SF_HIP(c, hipMemsetAsync(db.norms_k.p, 0, (size_t)n_pad * 4, c->stream));
   hipLaunchKernelGGL(k_nn_to_f16, dim3((db.n + 3) / 4), dim3(256), 0, c->stream, (const float*)db.rows.p,
-                     (_Float16*)db.rows_h.p, db.n, ld, ld16, scale);
+                     (_Float16*)db.rows_h.p, (float*)db.norms_k.p, db.n, ld, ld16, kprefix, scale);
   SF_HIP(c, hipGetLastError());
   db.h_n = db.n;
   db.h_ld = ld16;
+  db.h_kprefix = kprefix;
   db.h_scale = scale;
   return SF_OK;
 }
@@ -464,8 +476,14 @@ static int nn_run_filter(sf_context* c, int* done) {
   const int ld16 = (dim + 63) / 64 * 64;
   const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
   int rc;
-  if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16)) != SF_OK) return rc;
-  if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16)) != SF_OK) return rc;
+  // Stage 1 contracts only a PREFIX of the descriptor: the squared distance over the first k
+  // dimensions is a lower bound of the full squared distance, so "prefix distance (within the fp16
+  // error band) under the threshold" is a necessary condition.  PCA-whitened NetVLAD spreads its
+  // energy evenly (the reference itself ranks on a 128-dim prefix, data_handler.py:157-158), so an
+  // eighth of the dimensions already rejects everything but real neighbours.  If the candidate
+  // buffer overflows the full length is tried, and after that the exact fp32-ranking path.
+  const int kfull = ld16;
+  const int kpre = dim <= 1024 ? kfull : std::max(512, ((dim / 8) + 63) / 64 * 64);
   const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
   if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 64)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 4)) != SF_OK) return rc;
@@ -478,25 +496,34 @@ static int nn_run_filter(sf_context* c, int* done) {
   const double thr = c->params.netvlad_distance;
   float thr2 = (float)(thr * thr);
   thr2 = nextafterf(thr2, INFINITY);
-  // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + dim 2^-24) * ||a|| ||b||   (operand rounding + fp32 accumulation)
-  const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)dim * ldexp(1.0, -24));
-  const float inv_scale = 1.f / (c->nn_local.h_scale * c->nn_recv.h_scale);
-
-  SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
-  hipLaunchKernelGGL(k_nn_fill_row_norms, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, na_eff,
-                     (const float*)c->nn_local.norms.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad);
-  hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
-                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
-  sf_prof_begin(c, SF_K_NN_FILTER);
-  hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
-                     (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, na_eff, nb_eff,
-                     inv_scale, thr2, eps_rel, ld16, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
-  sf_prof_end(c, SF_K_NN_FILTER);
-  SF_HIP(c, hipGetLastError());
   unsigned n_cand = 0;
-  SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
-  SF_HIP(c, hipStreamSynchronize(c->stream));
-  if (n_cand > cap) return SF_OK;   // too dense for the filter: exact path
+  bool ok = false;
+  for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+    const int kdims = attempt == 0 ? kpre : kfull;
+    if (attempt == 1 && kpre == kfull) break;
+    if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16, kdims)) != SF_OK) return rc;
+    if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16, kdims)) != SF_OK) return rc;
+    // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
+    const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
+    const float inv_scale = 1.f / (c->nn_local.h_scale * c->nn_recv.h_scale);
+    SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_nn_fill_row_norms, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, na_eff,
+                       (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad);
+    hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
+                       (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
+    sf_prof_begin(c, SF_K_NN_FILTER);
+    hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
+                       (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, na_eff, nb_eff,
+                       inv_scale, thr2, eps_rel, ld16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
+    sf_prof_end(c, SF_K_NN_FILTER);
+    SF_HIP(c, hipGetLastError());
+    SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+    // a dense prefix result would make the exact refinement the expensive part: insist on a sparse
+    // candidate set from the prefix stage, accept anything that fits from the full-length stage
+    ok = attempt == 0 && kpre != kfull ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
+  }
+  if (!ok) return SF_OK;   // too dense for the filter: exact path
   std::vector<uint2> h_cand(n_cand);
   std::vector<double> h_dist(n_cand);
   if (n_cand) {

@@ -79,7 +79,8 @@ struct NNDb {
   Buf norms;       // float32 [cap]
   Buf rows_h;      // fp16 [cap][dim] (nn_precision == 1)
   int n = 0, cap = 0;
-  int h_n = -1, h_ld = 0;   // rows / pitch covered by the fp16 copy
+  Buf norms_k;     // float32 [cap] squared norm of the first h_kprefix elements (filter stage)
+  int h_n = -1, h_ld = 0, h_kprefix = 0;   // rows / pitch / prefix covered by the fp16 copy
   float h_scale = 1.f;      // power-of-two scale applied before the fp16 conversion
 };
 
