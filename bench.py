@@ -127,11 +127,17 @@ def main():
     import torch.distributed as td
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the separator-finder path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from multi_robot_slam_separators_amd import _abi, dist, lib, synth
 
@@ -146,7 +152,7 @@ def main():
     p.store_capacity = 2 * n_kf
     feats, nv_a, nv_b, t_gen = generate_inputs(12345 + rank, n_kf, k, cols, dim, args.true_frac)
 
-    f = lib.SeparatorFinder(p, device=local_rank)
+    f = lib.SeparatorFinder(p, device=dev_index)
     f.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # ---- make everything resident in HBM (untimed) -------------------------------------------------
@@ -194,14 +200,15 @@ def main():
         d_to[:n].copy_(h_to[:n], non_blocking=True)
         f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
         if world > 1:
-            rec, counts = dist.allgather_records(d_res[:n])
+            rec, counts = dist.allgather_records(d_res[:n].to(coll_dev))
         else:
             rec = d_res[:n]
         host = h_res[: rec.shape[0]]
         host.copy_(rec, non_blocking=True)                   # results delivered to the host (pinned)
         torch.cuda.synchronize()
         state["pairs"] += n
-        state["last"] = (m, host, n)
+        state["last"] = (m, host.clone() if world > 1 else host, n)
+        state["gathered"] = int(rec.shape[0])
         return n
 
     for _ in range(args.warmup):
@@ -222,8 +229,8 @@ def main():
     prof = f.prof_get()
     f.prof_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    npairs = torch.tensor([state["pairs"]], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    npairs = torch.tensor([state["pairs"]], dtype=torch.float64, device=coll_dev)
     if world > 1:
         td.all_reduce(t, op=td.ReduceOp.MAX)
         td.all_reduce(npairs, op=td.ReduceOp.SUM)
@@ -248,7 +255,8 @@ def main():
 
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
-    res = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)[:n]
+    all_res = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+    res = all_res[rank * n: rank * n + n] if world > 1 else all_res[:n]   # shards are equal-sized here
     truth = feats["is_true"][m["idx_local"]]
     same = m["idx_local"] == m["idx_other"]
     accepted = int(res["success"].sum())
@@ -303,7 +311,8 @@ def main():
                 "unit": "TFLOP/s", "frac": nn_tf / nn_peak, "avg_launch_ms": nn_ms,
             },
             "kernel_ms_per_step": {kname: (ms / args.steps) for kname, (cnt, ms) in prof.items()},
-            "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n)},
+            "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n),
+                      "records_gathered_per_step": state.get("gathered", int(n))},
             "input_generation_s": t_gen,
         }
         if alt is not None:
