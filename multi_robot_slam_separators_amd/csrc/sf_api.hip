@@ -133,6 +133,44 @@ k_ingest(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __restric
   if (tid == 0) meta[slot] = make_int4(rows, n3d > 0 ? rows : 0, rows, cols);
 }
 
+// ragged variant for host-buffer batches: per-keyframe table {rows, cols, n3d, desc_off, xyz_off, kp_off}
+struct IngestEntry {
+  int32_t rows, cols, n3d, pad;
+  uint64_t desc_off, xyz_off, kp_off;   // byte offsets into the packed staging buffers
+};
+
+__global__ void __launch_bounds__(SF_BLOCK)
+k_ingest_ragged(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __restrict__ kp, int4* __restrict__ meta,
+                int kcap, int w, int first_slot, const IngestEntry* __restrict__ table,
+                const uint8_t* __restrict__ s_desc, const uint8_t* __restrict__ s_xyz,
+                const uint8_t* __restrict__ s_kp) {
+  const int k = blockIdx.x;
+  const int slot = first_slot + k;
+  const int tid = threadIdx.x;
+  const IngestEntry e = table[k];
+  uint8_t* d8 = reinterpret_cast<uint8_t*>(desc + (size_t)slot * kcap * w);
+  const uint8_t* sd = s_desc + e.desc_off;
+  const int rowb = w * 4;
+  for (int i = tid; i < e.rows * rowb; i += SF_BLOCK) {
+    const int r = i / rowb, b = i - r * rowb;
+    d8[i] = (b < e.cols) ? sd[(size_t)r * e.cols + b] : (uint8_t)0;
+  }
+  if (e.n3d > 0) {
+    float* dx = xyz + (size_t)slot * kcap * 3;
+    const float* sx = reinterpret_cast<const float*>(s_xyz + e.xyz_off);
+    for (int i = tid; i < e.rows * 3; i += SF_BLOCK) dx[i] = sx[i];
+  }
+  float4* dk = kp + (size_t)slot * kcap;
+  const sf_keypoint* sk = reinterpret_cast<const sf_keypoint*>(s_kp + e.kp_off);
+  for (int i = tid; i < e.rows; i += SF_BLOCK) {
+    const sf_keypoint q = sk[i];
+    int o = q.octave & 255;
+    o = o < 128 ? o : (-128 | o);
+    dk[i] = make_float4(q.x, q.y, __int_as_float(o), 0.f);
+  }
+  if (tid == 0) meta[slot] = make_int4(e.rows, e.n3d > 0 ? e.rows : 0, e.rows, e.cols);
+}
+
 }  // namespace
 
 static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, int cols) {
@@ -225,6 +263,82 @@ static int store_add_host(sf_context* c, Store& st, const sf_features* f, int* o
   SF_HIP(c, hipStreamSynchronize(c->stream));
   if (out_slot) *out_slot = st.slots;
   st.slots += 1;
+  return SF_OK;
+}
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+static int pinned_reserve(sf_context* c, PinnedBuf& b, size_t bytes) {
+  if (bytes <= b.bytes) return SF_OK;
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  size_t want = bytes + bytes / 2;
+  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+  if (e != hipSuccess) return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) -> %s", want, hipGetErrorString(e));
+  b.bytes = want;
+  return SF_OK;
+}
+
+// n host keyframes -> consecutive slots: features are packed into pinned staging, copied with one
+// H2D per field and converted by ONE ragged ingest launch (no per-keyframe synchronisation).
+static int store_add_host_batch(sf_context* c, Store& st, const sf_features* const* feats, int n, int* first_slot) {
+  if (n <= 0) return SF_OK;
+  int rc;
+  int max_rows = 0, cols = 0;
+  size_t bd = 0, bx = 0, bk = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((rc = validate_features(c, feats[i])) != SF_OK) return rc;
+    max_rows = std::max<int>(max_rows, feats[i]->rows);
+    if (feats[i]->rows > 0) {
+      if (cols == 0) cols = feats[i]->cols;
+      if ((feats[i]->cols <= 32) != (cols <= 32)) return sf_fail(c, SF_EINVAL, "descriptor width classes differ inside one batch");
+      if (feats[i]->cols > SF_MAX_DESC_BYTES) return sf_fail(c, SF_ERANGE, "descriptor bytes %d > %d", (int)feats[i]->cols, SF_MAX_DESC_BYTES);
+    }
+    bd += ((size_t)feats[i]->rows * feats[i]->cols + 15) & ~(size_t)15;
+    bx += feats[i]->n3d > 0 ? (size_t)feats[i]->rows * 12 + 4 : 0;
+    bk += (size_t)feats[i]->rows * sizeof(sf_keypoint) + 4;
+  }
+  if (cols == 0) cols = st.slots > 0 ? (st.w == 8 ? 32 : 64) : std::max(1, c->params.desc_bytes);
+  if ((rc = store_reserve(c, st, st.slots + n, max_rows, cols)) != SF_OK) return rc;
+  static thread_local PinnedBuf pin;   // host staging (process lifetime)
+  const size_t tb = (size_t)n * sizeof(IngestEntry);
+  const size_t off_d = (tb + 255) & ~(size_t)255, off_x = (off_d + bd + 255) & ~(size_t)255,
+               off_k = (off_x + bx + 255) & ~(size_t)255, total = off_k + bk + 256;
+  if ((rc = pinned_reserve(c, pin, total)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->stage_desc, total)) != SF_OK) return rc;
+  uint8_t* hp = (uint8_t*)pin.p;
+  IngestEntry* tab = (IngestEntry*)hp;
+  size_t pd = 0, px = 0, pk = 0;
+  for (int i = 0; i < n; ++i) {
+    const sf_features* f = feats[i];
+    IngestEntry e;
+    e.rows = f->rows; e.cols = f->rows > 0 ? f->cols : cols; e.n3d = f->n3d; e.pad = 0;
+    e.desc_off = pd; e.xyz_off = px; e.kp_off = pk;
+    if (f->rows > 0) {
+      memcpy(hp + off_d + pd, f->desc, (size_t)f->rows * f->cols);
+      memcpy(hp + off_k + pk, f->kpts, (size_t)f->rows * sizeof(sf_keypoint));
+      if (f->n3d > 0) memcpy(hp + off_x + px, f->xyz, (size_t)f->rows * 12);
+    }
+    pd += ((size_t)f->rows * f->cols + 15) & ~(size_t)15;
+    px += f->n3d > 0 ? (size_t)f->rows * 12 + 4 : 0;
+    px = (px + 3) & ~(size_t)3;
+    pk += (size_t)f->rows * sizeof(sf_keypoint) + 4;
+    pk = (pk + 3) & ~(size_t)3;
+    tab[i] = e;
+  }
+  uint8_t* dp = (uint8_t*)c->stage_desc.p;
+  SF_HIP(c, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_ingest_ragged, dim3(n), dim3(SF_BLOCK), 0, c->stream, (uint32_t*)st.desc.p, (float*)st.xyz.p,
+                     (float4*)st.kp.p, (int4*)st.meta.p, st.kcap, st.w, st.slots, (const IngestEntry*)dp, dp + off_d,
+                     dp + off_x, dp + off_k);
+  SF_HIP(c, hipGetLastError());
+  // the pinned staging is reused by the next call: the copy must have left host memory
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (first_slot) *first_slot = st.slots;
+  st.slots += n;
   return SF_OK;
 }
 
@@ -486,10 +600,11 @@ extern "C" int sf_estimate_transform_batch(sf_handle c, const sf_features* from,
   SF_HIP(c, hipStreamSynchronize(c->stream));
   c->scratch.slots = 0;
   std::vector<int32_t> fi(n), ti(n);
-  for (int i = 0; i < n; ++i) {
-    if ((rc = store_add_host(c, c->scratch, from + i, &fi[i])) != SF_OK) return rc;
-    if ((rc = store_add_host(c, c->scratch, to + i, &ti[i])) != SF_OK) return rc;
-  }
+  std::vector<const sf_features*> all(2 * (size_t)n);
+  for (int i = 0; i < n; ++i) { all[2 * i] = from + i; all[2 * i + 1] = to + i; }
+  int first = 0;
+  if ((rc = store_add_host_batch(c, c->scratch, all.data(), 2 * n, &first)) != SF_OK) return rc;
+  for (int i = 0; i < n; ++i) { fi[i] = first + 2 * i; ti[i] = first + 2 * i + 1; }
   return verify_host_indices(c, c->scratch, fi.data(), ti.data(), n, out);
 }
 

@@ -120,3 +120,23 @@ def test_nn_large_database(oracle):
         assert all((int(planted[r]), int(r)) in found for r in rows), precision
         assert len(m) == len(rows)
         assert np.all(np.diff(m["distance"]) >= 0)
+
+
+def test_chunked_batches_beyond_workspace_chunk():
+    """BASELINE configs[3] shape: far more pairs than one launch sequence holds (the library chunks at
+    32 768 pairs): results are those of the same pairs verified alone, whatever their batch position."""
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = 100
+    p.max_features = 128
+    A, B, is_true, _ = synth.make_pairs(99, 24, k=128, true_frac=0.5)
+    with lib.SeparatorFinder(p) as f:
+        sa = [f.store_add_keyframe(a) for a in A]
+        sb = [f.store_add_keyframe(b) for b in B]
+        base = f.verify_pairs(sa, sb)
+        n = 70000
+        rng = np.random.default_rng(0)
+        pick = rng.integers(0, len(A), size=n)
+        big = f.verify_pairs(np.array(sa)[pick], np.array(sb)[pick])
+    assert big.tobytes() == base[pick].tobytes()
+    assert np.array_equal(base["success"].astype(bool), is_true)
