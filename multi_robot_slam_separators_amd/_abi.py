@@ -145,7 +145,7 @@ def default_params() -> Params:
     p.netvlad_distance = 0.13
     p.netvlad_dimensions = 128
     p.netvlad_max_matches_nb = 20
-    p.nn_precision = 0
+    p.nn_precision = 1
     p.min_inliers = 5
     p.inlier_distance = 0.1
     p.iterations = 300

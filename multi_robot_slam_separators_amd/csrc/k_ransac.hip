@@ -285,13 +285,9 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
       c6[3] += a1 * a1; c6[4] += a1 * a2; c6[5] += a2 * a2;
     }
     block_sum_vec<6>(c6, L.red, tid);
-    double C[3][3], V[3][3];
-    C[0][0] = c6[0] * inv_m; C[0][1] = C[1][0] = c6[1] * inv_m; C[0][2] = C[2][0] = c6[2] * inv_m;
-    C[1][1] = c6[3] * inv_m; C[1][2] = C[2][1] = c6[4] * inv_m; C[2][2] = c6[5] * inv_m;
-    sfd::jacobi<3>(C, V);
-    const double e0 = C[0][0] > 0.0 ? C[0][0] : 0.0, e1 = C[1][1] > 0.0 ? C[1][1] : 0.0,
-                 e2 = C[2][2] > 0.0 ? C[2][2] : 0.0;
-    sdt = ((sqrt(e0) + sqrt(e1)) + sqrt(e2)) / 3.0;
+    double ev[3];
+    sfd::sym3_eigenvalues(c6[0] * inv_m, c6[1] * inv_m, c6[2] * inv_m, c6[3] * inv_m, c6[4] * inv_m, c6[5] * inv_m, ev);
+    sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
     sdt = sdt * sdt;
   }
 

@@ -351,7 +351,7 @@ extern "C" void sf_default_params(sf_params* p) {
   p->netvlad_distance = 0.13;        // multi_robot_separators.launch:19
   p->netvlad_dimensions = 128;       // :20
   p->netvlad_max_matches_nb = 20;    // :22
-  p->nn_precision = 0;
+  p->nn_precision = 1;               // fp16 filter + exact f64 refinement (identical matches)
   p->min_inliers = 5;                // :23 separators_min_inliers
   p->inlier_distance = 0.1f;         // rtabmap Vis/InlierDistance [upstream default]
   p->iterations = 300;               // Vis/Iterations

@@ -119,6 +119,36 @@ __device__ __forceinline__ double det3(double a, double b, double c, double d, d
   return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
 }
 
+// Eigenvalues (descending, clamped at 0) of a symmetric PSD 3x3 matrix given by its upper triangle:
+// Newton on the characteristic cubic from trace(C), then the deflated quadratic.
+__device__ inline void sym3_eigenvalues(double c00, double c01, double c02, double c11, double c12, double c22,
+                                        double (&ev)[3]) {
+  const double c2 = (c00 + c11) + c22;
+  const double c1 = ((c00 * c11 - c01 * c01) + (c00 * c22 - c02 * c02)) + (c11 * c22 - c12 * c12);
+  const double c0 = det3(c00, c01, c02, c01, c11, c12, c02, c12, c22);
+  double x = c2;
+  for (int it = 0; it < 50; ++it) {
+    const double pv = ((x - c2) * x + c1) * x - c0;
+    const double dp = (3.0 * x - 2.0 * c2) * x + c1;
+    if (dp == 0.0) break;
+    const double xn = x - pv / dp;
+    if (!(xn < x)) break;
+    const double step = x - xn;
+    x = xn;
+    if (step <= 1e-14 * fabs(xn)) break;
+  }
+  const double l1 = x > 0.0 ? x : 0.0;
+  const double s = c2 - l1;
+  const double q = c1 - l1 * s;
+  double disc = s * s - 4.0 * q;
+  if (!(disc > 0.0)) disc = 0.0;
+  const double r = sqrt(disc);
+  double l2 = 0.5 * (s + r), l3 = 0.5 * (s - r);
+  if (!(l2 > 0.0)) l2 = 0.0;
+  if (!(l3 > 0.0)) l3 = 0.0;
+  ev[0] = l1; ev[1] = l2; ev[2] = l3;
+}
+
 // Rotation and translation from the cross-covariance S[j][k] = sum a_j b_k of the demeaned
 // source/target, their means and spreads ga = sum |a|^2, gb = sum |b|^2 (Horn's quaternion
 // method).  The dominant eigenpair of the 4x4 matrix N comes from Newton's iteration on the

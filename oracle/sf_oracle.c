@@ -219,6 +219,37 @@ static double sfo_det3(double a, double b, double c, double d, double e, double 
   return (a * (e * i - f * h) - b * (d * i - f * g)) + c * (d * h - e * g);
 }
 
+/* Eigenvalues (descending, clamped at 0) of a symmetric positive semi-definite 3x3 matrix:
+ * Newton on the characteristic cubic from the upper bound trace(C) (monotone convergence to the
+ * largest root), then the deflated quadratic.  Only + - * / sqrt. */
+static void sfo_sym3_eigenvalues(double C[4][4], double ev[3]) {
+  const double c2 = (C[0][0] + C[1][1]) + C[2][2];
+  const double c1 = ((C[0][0] * C[1][1] - C[0][1] * C[0][1]) + (C[0][0] * C[2][2] - C[0][2] * C[0][2])) +
+                    (C[1][1] * C[2][2] - C[1][2] * C[1][2]);
+  const double c0 = sfo_det3(C[0][0], C[0][1], C[0][2], C[0][1], C[1][1], C[1][2], C[0][2], C[1][2], C[2][2]);
+  double x = c2;
+  for (int it = 0; it < 50; ++it) {
+    const double pv = ((x - c2) * x + c1) * x - c0;
+    const double dp = (3.0 * x - 2.0 * c2) * x + c1;
+    if (dp == 0.0) break;
+    const double xn = x - pv / dp;
+    if (!(xn < x)) break;
+    const double step = x - xn;
+    x = xn;
+    if (step <= 1e-14 * fabs(xn)) break;
+  }
+  const double l1 = x > 0.0 ? x : 0.0;
+  const double s = c2 - l1;
+  const double q = c1 - l1 * s;
+  double disc = s * s - 4.0 * q;
+  if (!(disc > 0.0)) disc = 0.0;
+  const double r = sqrt(disc);
+  double l2 = 0.5 * (s + r), l3 = 0.5 * (s - r);
+  if (!(l2 > 0.0)) l2 = 0.0;
+  if (!(l3 > 0.0)) l3 = 0.0;
+  ev[0] = l1; ev[1] = l2; ev[2] = l3;
+}
+
 /* Rotation + translation from the 3x3 cross-covariance S[j][k] = sum a_j b_k (a = demeaned
  * source, b = demeaned target), the two means and the spreads ga = sum |a|^2, gb = sum |b|^2:
  * Horn's unit-quaternion solution of the absolute-orientation problem.  Same optimum as the SVD
@@ -640,17 +671,16 @@ int sfo_estimate_motion_3d3d(const sf_params* p,
       for (int i = 0; i < m; ++i) scratch[i] = (double)src[3 * i + j];
       mean[j] = sfo_block_sum(scratch, m) * inv_m;
     }
-    double C[4][4], V[4][4];
+    double C[4][4];
     for (int j = 0; j < 3; ++j)
       for (int k = j; k < 3; ++k) {
         for (int i = 0; i < m; ++i)
           scratch[i] = ((double)src[3 * i + j] - mean[j]) * ((double)src[3 * i + k] - mean[k]);
         C[j][k] = C[k][j] = sfo_block_sum(scratch, m) * inv_m;
       }
-    sfo_jacobi(3, C, V);
-    double e0 = C[0][0] > 0.0 ? C[0][0] : 0.0, e1 = C[1][1] > 0.0 ? C[1][1] : 0.0,
-           e2 = C[2][2] > 0.0 ? C[2][2] : 0.0;
-    double sdt = ((sqrt(e0) + sqrt(e1)) + sqrt(e2)) / 3.0;
+    double ev[3];
+    sfo_sym3_eigenvalues(C, ev);
+    double sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
     sdt = sdt * sdt;
 
     /* ---- [upstream pcl::RandomSampleConsensus::computeModel] -------------------------------- */
