@@ -146,35 +146,45 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
   sfd::rigid_from_moments(S, mp, mq, s9[9], s9[10], coef);
 }
 
-// selectWithinDistance: residuals of all points, membership mask, member count
+// selectWithinDistance: membership mask, member count, and the members' squared residuals in
+// L.d2 (non-members and the padding up to a multiple of 4 hold +inf, so order statistics over the
+// selected set can scan the array without consulting the mask).
 __device__ inline int select_within(const RansacLds& L, int m, const float (&coef)[12], double thr2,
                                     uint8_t* mask, int tid) {
   int n = 0;
-  for (int i = tid; i < m; i += SF_BLOCK) {
-    float4 p = L.src[i], q = L.dst[i];
-    float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
-    bool in = (double)r2 < thr2;
+  const int m4 = (m + 3) & ~3;
+  for (int i = tid; i < m4; i += SF_BLOCK) {
+    bool in = false;
+    float r2 = __int_as_float(0x7F800000);
+    if (i < m) {
+      float4 p = L.src[i], q = L.dst[i];
+      const float v = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+      in = (double)v < thr2;
+      r2 = in ? v : r2;
+      mask[i] = in ? 1 : 0;
+    }
     L.d2[i] = r2;
-    mask[i] = in ? 1 : 0;
     n += in ? 1 : 0;
   }
   return block_sum_int(n, L.misc, tid);
 }
 
 // 2.1981 * median (element n>>1 in sorted order) of the members' squared residuals
-// [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting.
-__device__ inline double variance_of(const RansacLds& L, int m, const uint8_t* mask, int n, int tid) {
+// [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting
+// over the +inf-padded residual array (4 values per LDS read, broadcast).
+__device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) {
   const int med = n >> 1;
+  const int m4 = (m + 3) & ~3;
   __syncthreads();
   for (int i = tid; i < m; i += SF_BLOCK) {
-    if (mask[i]) {
-      const float v = L.d2[i];
+    const float v = L.d2[i];
+    if (v < __int_as_float(0x7F800000)) {   // member
       int lt = 0, eq = 0;
-      for (int j = 0; j < m; ++j) {
-        const float u = L.d2[j];
-        const bool mem = mask[j] != 0;
-        lt += (mem && u < v) ? 1 : 0;
-        eq += (mem && u == v) ? 1 : 0;
+      const float4* d4 = reinterpret_cast<const float4*>(L.d2);
+      for (int j = 0; j < m4 / 4; ++j) {
+        const float4 u = d4[j];
+        lt += (u.x < v ? 1 : 0) + (u.y < v ? 1 : 0) + (u.z < v ? 1 : 0) + (u.w < v ? 1 : 0);
+        eq += (u.x == v ? 1 : 0) + (u.y == v ? 1 : 0) + (u.z == v ? 1 : 0) + (u.w == v ? 1 : 0);
       }
       if (lt <= med && med < lt + eq) L.red[15] = (double)v;  // every writer holds the same value
     }
@@ -368,7 +378,6 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   }
   uint8_t* inl = L.mask_a;
   int n_inl = select_within(L, m, coef, thr2, inl, tid);
-  const uint8_t* last_mask = inl;
   int n_last = n_inl;
 
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
@@ -392,14 +401,13 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
       ++n_sizes;
       __syncthreads();
       n_new = select_within(L, m, newc, error_threshold * error_threshold, neu, tid);
-      last_mask = neu;
       n_last = n_new;
       if (n_new == 0) {
         ++refine_iterations;
         if (refine_iterations >= P.refine_iterations) break;
         continue;
       }
-      const double variance = variance_of(L, m, neu, n_new, tid);
+      const double variance = variance_of(L, m, n_new, tid);
       const double sthr = P.refine_sigma * sqrt(variance);
       error_threshold = thr < sthr ? thr : sthr;
       inlier_changed = false;
@@ -421,7 +429,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
 
   if (P.dbg_stop == 5) { if (tid == 0) pass[pair] = ps; return; }
   if (n_inl >= 3) {
-    const double variance = variance_of(L, m, last_mask, n_last, tid);
+    const double variance = variance_of(L, m, n_last, tid);
     ps.var = variance;
     ps.inliers = n_inl;
     if (n_inl >= P.min_inliers) {
