@@ -243,31 +243,44 @@ __device__ __forceinline__ uint32_t max_u16(uint32_t a, uint32_t b) {
 constexpr int MATCH_CH = 16;   // rows per index-recovery chunk
 
 template <int W, int NQ>
+__device__ __forceinline__ void knn2_step_lds(const uint32_t* fromD, int f, const uint32_t (&q)[NQ][W],
+                                              uint32_t (&d1)[NQ], uint32_t (&d2)[NQ]) {
+  const uint4* r = reinterpret_cast<const uint4*>(fromD + (size_t)f * W);   // same address in every lane
+  uint32_t x[W];
+#pragma unroll
+  for (int c = 0; c < W / 4; ++c) {
+    const uint4 v = r[c];
+    x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int c = 0; c < W; ++c) d = bcnt_acc(x[c] ^ q[j][c], d);
+    d2[j] = min_u16(d2[j], max_u16(d, d1[j]));
+    d1[j] = min_u16(d1[j], d);
+  }
+}
+
+template <int W, int NQ>
 __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, const uint32_t (&q)[NQ][W],
                                               uint32_t (&d1)[NQ], uint32_t (&d2)[NQ], uint32_t (&chunk)[NQ]) {
-  for (int c0 = 0; c0 < Kf; c0 += MATCH_CH) {
+  int c0 = 0;
+  // full chunks: compile-time trip count, so the LDS reads of several rows are issued ahead
+  for (; c0 + MATCH_CH <= Kf; c0 += MATCH_CH) {
     uint32_t prev[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) prev[j] = d1[j];
-    const int cend = min(c0 + MATCH_CH, Kf);
 #pragma unroll 4
-    for (int f = c0; f < cend; ++f) {
-      const uint4* r = reinterpret_cast<const uint4*>(fromD + (size_t)f * W);   // same address in every lane
-      uint32_t x[W];
+    for (int u = 0; u < MATCH_CH; ++u) knn2_step_lds<W, NQ>(fromD, c0 + u, q, d1, d2);
 #pragma unroll
-      for (int c = 0; c < W / 4; ++c) {
-        const uint4 v = r[c];
-        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-      }
+    for (int j = 0; j < NQ; ++j) chunk[j] = ((d1[j] & 0xFFFFu) != (prev[j] & 0xFFFFu)) ? (uint32_t)c0 : chunk[j];
+  }
+  if (c0 < Kf) {   // ragged last chunk
+    uint32_t prev[NQ];
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        uint32_t d = 0;
-#pragma unroll
-        for (int c = 0; c < W; ++c) d = bcnt_acc(x[c] ^ q[j][c], d);
-        d2[j] = min_u16(d2[j], max_u16(d, d1[j]));
-        d1[j] = min_u16(d1[j], d);
-      }
-    }
+    for (int j = 0; j < NQ; ++j) prev[j] = d1[j];
+    for (int f = c0; f < Kf; ++f) knn2_step_lds<W, NQ>(fromD, f, q, d1, d2);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) chunk[j] = ((d1[j] & 0xFFFFu) != (prev[j] & 0xFFFFu)) ? (uint32_t)c0 : chunk[j];
   }
