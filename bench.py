@@ -8,7 +8,8 @@ One STEP = one full inter-robot matching pass at BASELINE.json configs[1]:
   2. geometric verification of EVERY candidate the NN stage returns (both registration passes of
      stereoCamGeometricTools.cpp:122-178: Hamming kNN-2 + NNDR, RANSAC 3D-3D with 500
      iterations + refinement, guess-guided re-matching, RANSAC again);
-  3. (N > 1 ranks) one RCCL all-gather of the fixed-size result records; results to the host.
+  3. every candidate's success flag and the ACCEPTED separator records go to (pinned) host memory;
+     with N > 1 ranks the accepted records are first all-gathered over RCCL (ragged, two-phase).
 `value` = candidate pairs verified per second over the whole step, all ranks.  Inputs (both
 robots' NetVLAD databases and keyframe feature stores) are resident in HBM before the timed
 region.  Weak scaling: every rank owns an independent robot pair of the same size.
@@ -185,6 +186,8 @@ def main():
     d_to = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     h_res = torch.empty((n_kf * world, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
+    OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     h_from = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     h_to = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     state = {"pairs": 0, "accepted": 0, "last": None}
@@ -199,15 +202,22 @@ def main():
         d_from[:n].copy_(h_from[:n], non_blocking=True)
         d_to[:n].copy_(h_to[:n], non_blocking=True)
         f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+        # every candidate's success flag goes back to the two robots involved (failures feed the ignore
+        # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
+        # the back-end (data_handler.py:352-368).
+        res2d = d_res[:n]
+        succ = res2d[:, OFF_SUCCESS] != 0
+        acc = res2d[succ]                                     # device-side compaction
         if world > 1:
-            rec, counts = dist.allgather_records(d_res[:n].to(coll_dev))
+            rec, counts = dist.allgather_records(acc.to(coll_dev))
         else:
-            rec = d_res[:n]
+            rec = acc
+        h_flags[:n].copy_(succ, non_blocking=True)
         host = h_res[: rec.shape[0]]
-        host.copy_(rec, non_blocking=True)                   # results delivered to the host (pinned)
+        host.copy_(rec, non_blocking=True)                    # accepted separators delivered to the host (pinned)
         torch.cuda.synchronize()
         state["pairs"] += n
-        state["last"] = (m, host.clone() if world > 1 else host, n)
+        state["last"] = (m, host, n)
         state["gathered"] = int(rec.shape[0])
         return n
 
@@ -255,12 +265,13 @@ def main():
 
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
-    all_res = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
-    res = all_res[rank * n: rank * n + n] if world > 1 else all_res[:n]   # shards are equal-sized here
+    flags = h_flags[:n].numpy().copy()
     truth = feats["is_true"][m["idx_local"]]
     same = m["idx_local"] == m["idx_other"]
-    accepted = int(res["success"].sum())
-    correct = int((res["success"].astype(bool) == (truth & same)).sum())
+    accepted = int(flags.sum())
+    correct = int((flags == (truth & same)).sum())
+    sep = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+    all_ok = bool(sep["success"].all()) and len(sep) == state["gathered"]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -312,7 +323,8 @@ def main():
             },
             "kernel_ms_per_step": {kname: (ms / args.steps) for kname, (cnt, ms) in prof.items()},
             "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n),
-                      "records_gathered_per_step": state.get("gathered", int(n))},
+                      "accepted_separators_gathered_per_step": state.get("gathered", 0),
+                      "gathered_records_all_accepted": all_ok},
             "input_generation_s": t_gen,
         }
         if alt is not None:
