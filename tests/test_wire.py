@@ -1,0 +1,121 @@
+"""ROS1 wire format of the hot path's service payloads (wire.py): round trips, exact byte counts from
+the .msg/.srv definitions, and the size constants the reference's own tools/evaluate_communication.py
+uses (8 B per NetVLAD value :96, 344 B per PoseWithCovariance :113, 2 + (8 + 344*3) per separator :88)."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi, synth, wire
+from multi_robot_slam_separators_amd.messages import (EstTransformRequest, EstTransformResponse,
+                                                      FindMatchesRequest, FindMatchesResponse, Pose,
+                                                      PoseWithCovariance, ReceiveSeparatorsRequest)
+
+
+def pwc(rng):
+    return PoseWithCovariance(Pose(rng.normal(size=3), rng.normal(size=4)), rng.normal(size=36))
+
+
+def test_pose_with_covariance_is_344_bytes():
+    rng = np.random.default_rng(0)
+    p = pwc(rng)
+    b = wire.pack_pose_with_cov(p)
+    assert len(b) == wire.POSE_WITH_COV_BYTES == 344          # evaluate_communication.py:88,113
+    q = wire.read_pose_with_cov(wire.Reader(b))
+    assert np.array_equal(q.pose.position, p.pose.position) and np.array_equal(q.covariance, p.covariance)
+
+
+def test_find_matches_request_8_bytes_per_value():
+    v = np.random.default_rng(1).normal(size=3 * 128)
+    b = wire.serialize_find_matches_request(FindMatchesRequest(v))
+    assert len(b) == 4 + 8 * v.size                            # evaluate_communication.py:96 (8 B / value)
+    assert np.array_equal(wire.deserialize_find_matches_request(b).new_netvlad_descriptors, v)
+
+
+def test_receive_separators_size_model():
+    rng = np.random.default_rng(2)
+    n = 5
+    req = ReceiveSeparatorsRequest(1, 0, [3, 4, 5, 6, 7], [9, 8, 7, 6, 5], [0, 1, 2, 3, 4], [4, 3, 2, 1, 0],
+                                   [pwc(rng) for _ in range(n)], [pwc(rng) for _ in range(n)],
+                                   [True, False, True, True, False], [pwc(rng) for _ in range(n)])
+    b = wire.serialize_receive_separators_request(req)
+    headers = 4 * 8            # eight variable-length arrays, uint32 count each
+    bools = n                  # bool[] transform_est_success
+    assert len(b) - headers - bools == 2 + (8 + 344 * 3) * n   # the reference's model, :88
+    back = wire.deserialize_receive_separators_request(b)
+    assert back.kf_ids_from == req.kf_ids_from and back.transform_est_success == req.transform_est_success
+    assert np.array_equal(back.separators[3].covariance, req.separators[3].covariance)
+    assert (back.robot_from_id, back.robot_to_id) == (1, 0)
+    with pytest.raises(OverflowError):
+        wire.serialize_receive_separators_request(ReceiveSeparatorsRequest(300, 0))
+
+
+def test_est_transform_round_trip_and_sizes():
+    rng = np.random.default_rng(3)
+    a, b = synth.make_keyframe(rng, 37), synth.make_keyframe(rng, 52, cols=64)
+    req = EstTransformRequest(a.desc, b.desc, a.xyz, b.xyz, a.kpts, b.kpts)
+    buf = wire.serialize_est_transform_request(req)
+    # Descriptors = 2+2+4+K*C ; KeyPoint3DVec = 2+4+12K ; KeyPointVec = 2+4+28K
+    expect = sum(8 + k * c for k, c in ((37, 32), (52, 64))) + sum(6 + 12 * k for k in (37, 52)) + \
+        sum(6 + 28 * k for k in (37, 52))
+    assert len(buf) == expect
+    back = wire.deserialize_est_transform_request(buf)
+    assert np.array_equal(back.descriptorsTo, b.desc) and np.array_equal(back.kptsFrom3D, a.xyz)
+    assert back.kptsTo.tobytes() == b.kpts.tobytes()
+    res = EstTransformResponse(pwc(rng), True)
+    rb = wire.serialize_est_transform_response(res)
+    assert len(rb) == 345 and wire.deserialize_est_transform_response(rb).success is True
+    with pytest.raises(ValueError):
+        wire.deserialize_est_transform_request(buf[:-3])         # truncated
+    with pytest.raises(ValueError):
+        wire.deserialize_est_transform_request(buf + b"\0")      # trailing bytes
+
+
+def test_find_matches_response_round_trip():
+    rng = np.random.default_rng(4)
+    frames = [synth.make_keyframe(rng, k) for k in (5, 0, 17)]
+    res = FindMatchesResponse([10, 11, 12], [0, 1, 2], [7, 8, 9], [f.desc for f in frames],
+                              [f.xyz for f in frames], [f.kpts for f in frames], [])
+    b = wire.serialize_find_matches_response(res)
+    per_kf = sum(6 + (8 + f.desc.size) + (6 + 12 * len(f.xyz)) + (6 + 28 * len(f.kpts)) for f in frames)
+    assert len(b) == 4 * 7 + per_kf                              # 7 arrays; 40 B per keypoint + descriptor bytes
+    back = wire.deserialize_find_matches_response(b)
+    assert back.kf_ids_computing_robot == [10, 11, 12]
+    assert all(np.array_equal(x, f.desc) for x, f in zip(back.descriptors_vec, frames))
+    assert back.descriptors_vec[1].shape == (0, 0) or back.descriptors_vec[1].size == 0
+
+
+def test_dump_file_round_trip(tmp_path):
+    rng = np.random.default_rng(5)
+    reqs = []
+    for k in (12, 30):
+        a, b = synth.make_keyframe(rng, k), synth.make_keyframe(rng, k + 3)
+        reqs.append(wire.serialize_est_transform_request(EstTransformRequest(a.desc, b.desc, a.xyz, b.xyz, a.kpts, b.kpts)))
+    path = tmp_path / "est.dump"
+    wire.write_dump(str(path), "multi_robot_separators/EstTransformRequest", reqs)
+    kind, back = wire.read_dump(str(path))
+    assert kind.endswith("EstTransformRequest") and back == reqs
+
+
+@pytest.mark.gpu
+def test_replay_dump_through_the_library(tmp_path, oracle):
+    """A recorded estimate_transformation request dump replayed byte for byte: wire -> C-ABI -> wire."""
+    from multi_robot_slam_separators_amd import lib
+    from multi_robot_slam_separators_amd.data_handler import FinderBackend
+    from multi_robot_slam_separators_amd.geometric_tools import StereoCamGeometricTools
+    p = synth.camera_params()
+    p.iterations = 200
+    A, B, is_true, _ = synth.make_pairs(17, 8, k=200, true_frac=0.5)
+    payloads = [wire.serialize_est_transform_request(EstTransformRequest(a.desc, b.desc, a.xyz, b.xyz, a.kpts, b.kpts))
+                for a, b in zip(A, B)]
+    path = tmp_path / "requests.dump"
+    wire.write_dump(str(path), "multi_robot_separators/EstTransformRequest", payloads)
+    _, recorded = wire.read_dump(str(path))
+    with lib.SeparatorFinder(p) as f:
+        node = StereoCamGeometricTools(FinderBackend(f))
+        answers = [wire.serialize_est_transform_response(node.estimateTransformation(
+            wire.deserialize_est_transform_request(buf))) for buf in recorded]
+    for i, ans in enumerate(answers):
+        res = wire.deserialize_est_transform_response(ans)
+        o = oracle.estimate_transform(p, A[i], B[i])
+        assert res.success == bool(o["success"]) == bool(is_true[i])
+        assert np.allclose(res.poseWithCov.pose.position, o["position"], atol=1e-4)
+        assert np.allclose(res.poseWithCov.covariance, o["covariance"], rtol=1e-9)
