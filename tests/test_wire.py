@@ -119,3 +119,47 @@ def test_replay_dump_through_the_library(tmp_path, oracle):
         assert res.success == bool(o["success"]) == bool(is_true[i])
         assert np.allclose(res.poseWithCov.pose.position, o["position"], atol=1e-4)
         assert np.allclose(res.poseWithCov.covariance, o["covariance"], rtol=1e-9)
+
+
+def test_header_is_plain_c_and_cpp_example_builds(tmp_path):
+    """include/sepfinder.h compiles as strict C99 (it is the FFI surface) and the C++ host example links
+    against libsepfinder.so with nothing but the C-ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "sepfinder.h"\nint main(void){ sf_params p; sf_default_params(&p); return sf_abi_version() != SF_ABI_VERSION; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "abi.o")])
+    subprocess.check_call(["make", "-C", os.path.join(root, "multi_robot_slam_separators_amd", "csrc"), "-s", "example"])
+    assert os.path.exists(os.path.join(root, "examples", "replay_cli"))
+
+
+@pytest.mark.gpu
+def test_cpp_replay_cli_matches_python_binding(tmp_path):
+    import os
+    import subprocess
+    from multi_robot_slam_separators_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "multi_robot_slam_separators_amd", "csrc"), "-s", "example"])
+    A, B, is_true, _ = synth.make_pairs(23, 10, k=300, true_frac=0.5)
+    payloads = [wire.serialize_est_transform_request(EstTransformRequest(a.desc, b.desc, a.xyz, b.xyz, a.kpts, b.kpts))
+                for a, b in zip(A, B)]
+    req, out = tmp_path / "req.dump", tmp_path / "res.dump"
+    wire.write_dump(str(req), "multi_robot_separators/EstTransformRequest", payloads)
+    msg = subprocess.check_output([os.path.join(root, "examples", "replay_cli"), str(req), str(out), "250",
+                                   str(synth.FX), str(synth.FY), str(synth.CX), str(synth.CY),
+                                   str(synth.WIDTH), str(synth.HEIGHT)]).decode()
+    assert "%d separators accepted" % int(is_true.sum()) in msg
+    kind, answers = wire.read_dump(str(out))
+    assert kind.endswith("EstTransformResponse") and len(answers) == len(A)
+    p = synth.camera_params()
+    p.iterations = 250
+    with lib.SeparatorFinder(p) as f:
+        ref = f.estimate_transform_batch(A, B)
+    for ans, r in zip(answers, ref):
+        res = wire.deserialize_est_transform_response(ans)
+        assert res.success == bool(r["success"])
+        assert np.array_equal(res.poseWithCov.pose.position, r["position"])      # same library: bit-identical
+        assert np.array_equal(res.poseWithCov.pose.orientation, r["orientation"])
+        assert np.array_equal(res.poseWithCov.covariance, r["covariance"])
