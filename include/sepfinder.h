@@ -51,7 +51,8 @@ enum {
   SF_EHIP = 2,     /* HIP runtime error; text via sf_last_error                          */
   SF_ENOMEM = 3,   /* host or device allocation failed                                   */
   SF_ERANGE = 4,   /* index out of range / capacity exceeded / IDL limit exceeded         */
-  SF_ENODEV = 5    /* no GPU visible: the product path has NO CPU fallback                */
+  SF_ENODEV = 5,   /* no GPU visible: the product path has NO CPU fallback                */
+  SF_ERCCL = 6     /* RCCL error (or librccl.so not loadable); text via sf_last_error        */
 };
 
 /* ---- limits inherited from the reference IDL --------------------------------------------- */
@@ -225,6 +226,19 @@ int  sf_debug_correspondences(sf_handle h, int32_t pair, int32_t pass, uint16_t*
 int  sf_pack_separators(const sf_result* res, int32_t n, int8_t robot_from, int8_t robot_to,
                         const int16_t* kf_from, const int16_t* kf_to, const int16_t* frame_from,
                         const int16_t* frame_to, sf_separator* out);
+
+/* ---- multi-GPU exchange (RCCL over xGMI) ------------------------------------------------------- */
+/* The path shards with no collective in the compute (pairs are independent); the one exchange is an
+   all-gather of accepted separator records, what the reference moves between robots as
+   ReceiveSeparators requests (communication.cpp:15-52).  One handle (one GPU) per rank.          */
+#define SF_COMM_ID_BYTES 128
+int  sf_comm_unique_id(uint8_t* out, int32_t cap);          /* rank 0 creates, the host distributes */
+int  sf_comm_init(sf_handle h, const uint8_t* unique_id, int32_t rank, int32_t world);
+int  sf_comm_destroy(sf_handle h);
+/* d_local: n_local records in device memory.  d_all: world * cap_per_rank records in device memory,
+   rank r's records at d_all + r * cap_per_rank; counts (host): world entries.  Synchronous.          */
+int  sf_allgather_separators(sf_handle h, const sf_separator* d_local, int32_t n_local,
+                             sf_separator* d_all, int32_t cap_per_rank, int32_t* counts);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */

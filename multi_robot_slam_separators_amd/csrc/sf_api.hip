@@ -440,6 +440,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
 extern "C" void sf_destroy(sf_handle c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)sf_comm_destroy(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   prof_resolve(c);
   Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
@@ -447,7 +448,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list2, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
-                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
   for (Buf* b : bufs) buf_free(*b);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -131,6 +131,11 @@ struct sf_context {
 
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
 
+  // multi-GPU exchange (sf_comm.hip)
+  void* comm = nullptr;    // ncclComm_t
+  int comm_rank = 0, comm_world = 1;
+  Buf comm_scratch;
+
   // profiling
   bool prof = false;
   ProfSlot prof_slots[SF_K_COUNT];

@@ -82,6 +82,10 @@ def load():
         "sf_verify_pairs_device": (C.c_int, [vp, vp, vp, i32, vp]),
         "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
+        "sf_comm_unique_id": (C.c_int, [vp, i32]),
+        "sf_comm_init": (C.c_int, [vp, vp, i32, i32]),
+        "sf_comm_destroy": (C.c_int, [vp]),
+        "sf_allgather_separators": (C.c_int, [vp, vp, i32, vp, i32, vp]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_reset": (C.c_int, [vp]),
         "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
@@ -106,7 +110,8 @@ EXPORTED = [
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device",
-    "sf_debug_correspondences", "sf_pack_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
+    "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
+    "sf_allgather_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
 
@@ -268,6 +273,20 @@ class SeparatorFinder:
                                                      ct.ctypes.data, cap, C.byref(n)))
         return cf[: n.value].copy(), ct[: n.value].copy()
 
+    # -- multi-GPU exchange (RCCL through the C-ABI) --------------------------------------------------
+    def comm_init(self, unique_id, rank, world):
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        self._check(self._L.sf_comm_init(self._h, uid.ctypes.data, rank, world))
+
+    def comm_destroy(self):
+        self._check(self._L.sf_comm_destroy(self._h))
+
+    def allgather_separators(self, d_local, n_local, d_all, cap_per_rank, world):
+        counts = np.zeros(world, dtype=np.int32)
+        self._check(self._L.sf_allgather_separators(self._h, C.c_void_p(d_local), n_local, C.c_void_p(d_all),
+                                                    cap_per_rank, counts.ctypes.data))
+        return counts
+
     # -- measurement ------------------------------------------------------------------------------
     def prof_enable(self, on=True):
         self._check(self._L.sf_prof_enable(self._h, int(on)))
@@ -283,6 +302,16 @@ class SeparatorFinder:
             self._check(self._L.sf_prof_get(self._h, k, C.byref(n), C.byref(ms)))
             out[self._L.sf_kernel_name(k).decode()] = (n.value, ms.value)
         return out
+
+
+def comm_unique_id():
+    """ncclUniqueId bytes (created by one rank, distributed by the host side)."""
+    L = load()
+    out = np.zeros(128, dtype=np.uint8)
+    rc = L.sf_comm_unique_id(out.ctypes.data, 128)
+    if rc != 0:
+        raise SepfinderError(rc, "sf_comm_unique_id (is librccl.so loadable?)")
+    return out.tobytes()
 
 
 def pack_separators(results, robot_from, robot_to, kf_from, kf_to, frame_from, frame_to):

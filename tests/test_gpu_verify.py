@@ -226,3 +226,29 @@ def test_size_independent_properties_full_config(finder):
     dt, dr = synth.pose_error(r_ba, Tinv)
     assert dt < 0.03 and dr < 5e-3 and r_ab["success"] == 1
     finder.store_clear()
+
+
+def test_rccl_allgather_separators_single_rank(finder):
+    """The C-ABI's own RCCL exchange (sf_comm_*, sf_allgather_separators) with a 1-rank communicator:
+    counts + records come back unchanged.  (Multi-rank runs need one GPU per rank; the N > 1 logic is
+    covered by the gloo tests and by the driver's multi-GPU bench.)"""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    A, B, _, _ = synth.make_pairs(41, 6, k=200, true_frac=0.5)
+    res = finder.estimate_transform_batch(A, B)
+    sep = lib.pack_separators(res, 0, 1, np.arange(6), np.arange(6) + 10, np.arange(6), np.arange(6))
+    acc = sep[sep["transform_est_success"] == 1]
+    d_local = torch.from_numpy(acc.view(np.uint8).reshape(len(acc), -1).copy()).cuda()
+    cap = 8
+    d_all = torch.zeros((cap, _abi.SEPARATOR_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    finder.comm_init(lib.comm_unique_id(), 0, 1)
+    try:
+        counts = finder.allgather_separators(d_local.data_ptr(), len(acc), d_all.data_ptr(), cap, 1)
+        assert counts.tolist() == [len(acc)]
+        back = np.frombuffer(d_all.cpu().numpy().tobytes(), dtype=_abi.SEPARATOR_DTYPE)[: len(acc)]
+        assert back.tobytes() == acc.tobytes()
+        with pytest.raises(lib.SepfinderError):
+            finder.allgather_separators(d_local.data_ptr(), cap + 1, d_all.data_ptr(), cap, 1)
+    finally:
+        finder.comm_destroy()
