@@ -524,15 +524,28 @@ static int nn_run_filter(sf_context* c, int* done) {
     ok = attempt == 0 && kpre != kfull ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
   }
   if (!ok) return SF_OK;   // too dense for the filter: exact path
-  std::vector<uint2> h_cand(n_cand);
-  std::vector<double> h_dist(n_cand);
+  // pinned staging for the candidate list (pageable D2H copies are staged and slow)
+  {
+    const size_t need = (size_t)n_cand * 16 + 64;
+    if (need > c->nn_pinned_bytes) {
+      if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
+      c->nn_pinned = nullptr;
+      c->nn_pinned_bytes = 0;
+      const size_t want = need + need / 2;
+      if (hipHostMalloc(&c->nn_pinned, want, hipHostMallocDefault) != hipSuccess)
+        return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", want);
+      c->nn_pinned_bytes = want;
+    }
+  }
+  uint2* h_cand = (uint2*)c->nn_pinned;
+  double* h_dist = (double*)((char*)c->nn_pinned + (size_t)n_cand * 8);
   if (n_cand) {
     sf_prof_begin(c, SF_K_NN_REFINE);
     hipLaunchKernelGGL(k_nn_refine, dim3((n_cand + 3) / 4), dim3(256), 0, c->stream, cand, n_cand,
                        (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
     sf_prof_end(c, SF_K_NN_REFINE);
-    SF_HIP(c, hipMemcpyAsync(h_cand.data(), cand, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
-    SF_HIP(c, hipMemcpyAsync(h_dist.data(), cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));
   }
   // per-row minimum over the exact candidate distances (ties: lowest column), ignored pairs skipped.

@@ -466,10 +466,9 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
   if (n <= 0) return SF_OK;
   const size_t lds = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!c->ransac_attr_set) {   // per handle = per device
     SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    c->ransac_attr_set = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;

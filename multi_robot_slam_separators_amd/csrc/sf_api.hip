@@ -450,6 +450,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
   for (Buf* b : bufs) buf_free(*b);
+  if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -130,6 +130,9 @@ struct sf_context {
   std::vector<uint8_t> nn_taken;
 
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
+  bool ransac_attr_set = false;
+  void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
+  size_t nn_pinned_bytes = 0;
 
   // multi-GPU exchange (sf_comm.hip)
   void* comm = nullptr;    // ncclComm_t
