@@ -445,7 +445,7 @@ extern "C" void sf_destroy(sf_handle c) {
   prof_resolve(c);
   Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
                  &c->scratch.kp, &c->scratch.meta, &c->pair_from, &c->pair_to, &c->corr1, &c->corr2, &c->hdr1,
-                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list2, &c->list3, &c->counters, &c->results,
+                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};

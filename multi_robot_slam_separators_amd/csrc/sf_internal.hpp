@@ -107,7 +107,7 @@ struct sf_context {
   Buf corr1, corr2;             // uint32[n][kcap]
   Buf hdr1, hdr2;               // CorrHeader[n]
   Buf pass1, pass2;             // PassState[n]
-  Buf list1, list2, list3;      // int32[n] work lists (ransac1, guided, ransac2)
+  Buf list1, list3;             // int32[n] work lists (RANSAC pass 1, RANSAC pass 2)
   Buf counters;                 // int32[8]
   Buf results;                  // sf_result[n]
   Buf flags;                    // uint8[n] pass2_guided
@@ -142,7 +142,6 @@ struct sf_context {
   // profiling
   bool prof = false;
   ProfSlot prof_slots[SF_K_COUNT];
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 };
 
