@@ -247,19 +247,36 @@ __global__ void __launch_bounds__(256) k_nn_to_f16(const float* __restrict__ row
   if (lane == 0) prefix_norm[row] = (float)s;
 }
 
-// effective row norms: +inf for masked / padding rows (a masked row can never be a candidate)
-__global__ void k_nn_fill_row_norms(float* na_eff, const float* na, const uint8_t* mask_local, int n_l, int n_l_pad) {
+// Filter inequality, rearranged so the epilogue costs one add, one fma and one compare per element:
+//   na + nb - 2 acc/s < thr2 + 2 eps sqrt(na nb) + delta (na + nb)
+//   <=>  acc > (A_i + B_j) - C_i * D_j
+// with A_i = (na_i (1-delta) - thr2) s/2,  B_j = nb_j (1-delta) s/2,  C_i = eps s sqrt(na_i),  D_j = sqrt(nb_j)
+// (delta = 2e-6 also covers the rounding of this rearrangement).  Masked / padding rows and columns get
+// A = +inf (resp. B = +inf) and C = D = 0, so they can never be candidates.
+__global__ void k_nn_filter_row_coef(float2* rowc, const float* na, const uint8_t* mask_local, int n_l, int n_l_pad,
+                                     float half_s, float thr2, float eps_s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_l_pad) return;
-  na_eff[i] = (i < n_l && !mask_local[i]) ? na[i] : __int_as_float(0x7F800000);
+  const bool ok = i < n_l && !mask_local[i];
+  const float n = ok ? na[i] : 0.f;
+  rowc[i] = ok ? make_float2((n * (1.f - 2e-6f) - thr2) * half_s, eps_s * sqrtf(n))
+               : make_float2(__int_as_float(0x7F800000), 0.f);
+}
+__global__ void k_nn_filter_col_coef(float2* colc, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad,
+                                     float half_s) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_r_pad) return;
+  const bool ok = j < n_r && !mask_other[j];
+  const float n = ok ? nb[j] : 0.f;
+  colc[j] = ok ? make_float2(n * (1.f - 2e-6f) * half_s, sqrtf(n)) : make_float2(__int_as_float(0x7F800000), 0.f);
 }
 
 // A16: local rows [n_l_pad][ld] fp16 (x scale_a), B16: received rows [n_r_pad][ld] fp16 (x scale_b).
 // A (row, col) pair is emitted when its fp16 distance estimate can be below thr2 given the
 // rigorous error bound  |dot16 - dot32| <= eps_rel * sqrt(na * nb).
 __global__ void __launch_bounds__(256)
-k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float* __restrict__ na_eff,
-                const float* __restrict__ nb_eff, float inv_scale, float thr2, float eps_rel, int ld, int kdims, int gx, int gy,
+k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float2* __restrict__ rowc,
+                const float2* __restrict__ colc, int ld, int kdims, int gx, int gy,
                 uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
   __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];   // 128 rows x 64 halfs (+ pad)
   __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
@@ -328,25 +345,23 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
     }
   }
 
-  float nbj[2];
+  float2 cj[2];
   int colj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     colj[j] = col0 + 64 * wc + 32 * j + l31;
-    nbj[j] = nb_eff[colj[j]];
+    cj[j] = colc[colj[j]];
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float nai = na_eff[row];
+      const float2 ci = rowc[row];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float dot = acc[i][j][r] * inv_scale;
-        const float d2 = (nai + nbj[j]) - 2.f * dot;
-        const float slack = 2.f * eps_rel * sqrtf(nai * nbj[j]) + 1e-6f * (nai + nbj[j]);
-        if (d2 < thr2 + slack) {            // false for inf / NaN (masked or padding rows / columns)
+        const float rhs = fmaf(-ci.y, cj[j].y, ci.x + cj[j].x);
+        if (acc[i][j][r] > rhs) {           // false for +inf / NaN (masked or padding rows / columns)
           const unsigned pos = atomicAdd(cand_count, 1u);
           if (pos < cand_cap) cand[pos] = make_uint2((unsigned)row, (unsigned)colj[j]);
         }
@@ -486,9 +501,9 @@ static int nn_run_filter(sf_context* c, int* done) {
   const int kpre = dim <= 1024 ? kfull : std::max(512, ((dim / 8) + 63) / 64 * 64);
   const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
   if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 64)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 4)) != SF_OK) return rc;
-  float* na_eff = (float*)c->nn_rowmin.p;
-  float* nb_eff = na_eff + n_l_pad;
+  if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 8)) != SF_OK) return rc;
+  float2* rowc = (float2*)c->nn_rowmin.p;
+  float2* colc = rowc + n_l_pad;
   unsigned* count = (unsigned*)c->nn_cand.p;
   uint2* cand = (uint2*)((char*)c->nn_cand.p + 64);
   double* cdist = (double*)((char*)c->nn_cand.p + 64 + (size_t)cap * 8);
@@ -505,16 +520,18 @@ static int nn_run_filter(sf_context* c, int* done) {
     if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16, kdims)) != SF_OK) return rc;
     // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
     const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
-    const float inv_scale = 1.f / (c->nn_local.h_scale * c->nn_recv.h_scale);
+    const float scale = c->nn_local.h_scale * c->nn_recv.h_scale;   // product of two powers of two: exact
     SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
-    hipLaunchKernelGGL(k_nn_fill_row_norms, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, na_eff,
-                       (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad);
-    hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
-                       (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
+    hipLaunchKernelGGL(k_nn_filter_row_coef, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, rowc,
+                       (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad,
+                       0.5f * scale, thr2, eps_rel * scale);
+    hipLaunchKernelGGL(k_nn_filter_col_coef, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, colc,
+                       (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad,
+                       0.5f * scale);
     sf_prof_begin(c, SF_K_NN_FILTER);
     hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
-                       (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, na_eff, nb_eff,
-                       inv_scale, thr2, eps_rel, ld16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
+                       (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
+                       ld16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
     sf_prof_end(c, SF_K_NN_FILTER);
     SF_HIP(c, hipGetLastError());
     SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
