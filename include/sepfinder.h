@@ -217,7 +217,8 @@ int  sf_verify_pairs(sf_handle h, const int32_t* from_slot, const int32_t* to_sl
 int  sf_verify_pairs_device(sf_handle h, const int32_t* d_from_slot, const int32_t* d_to_slot,
                             int32_t n, sf_result* d_out);
 /* Correspondences found by the two matching passes of the LAST verify call for pair `i`
-   (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.           */
+   (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.  Calls with more
+   than 32768 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */
 int  sf_debug_correspondences(sf_handle h, int32_t pair, int32_t pass, uint16_t* from_idx,
                               uint16_t* to_idx, int32_t cap, int32_t* n_out);
 

@@ -188,10 +188,13 @@ static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, in
   Store n;
   n.kcap = kcap; n.w = w; n.cap_slots = cap; n.slots = s.slots;
   int rc;
-  if ((rc = sf_buf_reserve(c, n.desc, (size_t)cap * kcap * w * 4)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, n.xyz, (size_t)cap * kcap * 12)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, n.kp, (size_t)cap * kcap * 16)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, n.meta, (size_t)cap * 16)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, n.desc, (size_t)cap * kcap * w * 4)) != SF_OK ||
+      (rc = sf_buf_reserve(c, n.xyz, (size_t)cap * kcap * 12)) != SF_OK ||
+      (rc = sf_buf_reserve(c, n.kp, (size_t)cap * kcap * 16)) != SF_OK ||
+      (rc = sf_buf_reserve(c, n.meta, (size_t)cap * 16)) != SF_OK) {
+    buf_free(n.desc); buf_free(n.xyz); buf_free(n.kp); buf_free(n.meta);   // the old store stays valid
+    return rc;
+  }
   if (s.slots > 0) {
     SF_HIP(c, hipMemcpy2DAsync(n.desc.p, (size_t)kcap * w * 4, s.desc.p, (size_t)s.kcap * w * 4, (size_t)s.kcap * w * 4, s.slots, hipMemcpyDeviceToDevice, c->stream));
     SF_HIP(c, hipMemcpy2DAsync(n.xyz.p, (size_t)kcap * 12, s.xyz.p, (size_t)s.kcap * 12, (size_t)s.kcap * 12, s.slots, hipMemcpyDeviceToDevice, c->stream));
