@@ -244,6 +244,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = f.prof_get()
     f.prof_enable(False)
+    filter_dims = f.nn_last_filter_dims()      # prefix length the fp16 filter contracted (0: exact path)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     npairs = torch.tensor([state["pairs"]], dtype=torch.float64, device=coll_dev)
@@ -292,8 +293,8 @@ def main():
         nn_n, nn_t = prof[nn_kernel]
         nn_ms = nn_t / max(nn_n, 1)
         # flops the launched kernel really performs: the fp16 filter contracts a PREFIX of the descriptor
-        # (k_nn.hip, nn_run_filter: 512 dims for D > 1024), the fp32 ranking kernel all D dimensions
-        k_eff = dim if (args.nn_precision == 0 or dim <= 1024) else max(512, ((dim // 8) + 63) // 64 * 64)
+        # (k_nn.hip, nn_run_filter: adaptive 128 / 512 / full), the fp32 ranking kernel all D dimensions
+        k_eff = dim if args.nn_precision == 0 else (filter_dims or dim)
         nn_tf = 2.0 * n_kf * n_kf * k_eff / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
         out = {
             "metric": METRIC,

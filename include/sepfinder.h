@@ -190,6 +190,8 @@ int  sf_nn_set_precision(sf_handle h, int32_t nn_precision);
 int  sf_nn_find_matches(sf_handle h, sf_match* out, int32_t cap, int32_t* n_out);
 /* Per-row minima of the last find_matches call (diagnostics / tests): n_local entries.      */
 int  sf_nn_last_row_minima(sf_handle h, double* dist, int32_t* idx, int32_t cap);
+/* Descriptor dimensions the fp16 filter contracted in the last find_matches call (0: exact path). */
+int  sf_nn_last_filter_dims(sf_handle h, int32_t* dims);
 
 /* ---- device-resident keyframe feature store (data_handler.py:268 geometric_feats) ----------- */
 int  sf_store_add_keyframe(sf_handle h, const sf_features* f, int32_t* out_slot);

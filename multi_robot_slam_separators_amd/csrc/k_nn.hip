@@ -498,7 +498,19 @@ static int nn_run_filter(sf_context* c, int* done) {
   // eighth of the dimensions already rejects everything but real neighbours.  If the candidate
   // buffer overflows the full length is tried, and after that the exact fp32-ranking path.
   const int kfull = ld16;
-  const int kpre = dim <= 1024 ? kfull : std::max(512, ((dim / 8) + 63) / 64 * 64);
+  // prefix ladder: 128 and 512 dimensions when they are at most a quarter of the descriptor, then the
+  // full length.  The handle remembers the level that last produced a sparse candidate set.
+  int levels[3], n_levels = 0;
+  if (128 * 4 <= dim) levels[n_levels++] = 128;
+  if (512 * 4 <= dim) levels[n_levels++] = 512;
+  levels[n_levels++] = kfull;
+  int level = std::min(std::max(c->nn_level, 0), n_levels - 1);
+  if (level > 0 && c->nn_level_cooldown == 0) {   // now and then re-try the cheaper level
+    --level;
+    c->nn_level_cooldown = 32;
+  } else if (c->nn_level_cooldown > 0) {
+    --c->nn_level_cooldown;
+  }
   const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
   if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 64)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 8)) != SF_OK) return rc;
@@ -513,9 +525,8 @@ static int nn_run_filter(sf_context* c, int* done) {
   thr2 = nextafterf(thr2, INFINITY);
   unsigned n_cand = 0;
   bool ok = false;
-  for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
-    const int kdims = attempt == 0 ? kpre : kfull;
-    if (attempt == 1 && kpre == kfull) break;
+  for (; level < n_levels && !ok; ++level) {
+    const int kdims = levels[level];
     if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16, kdims)) != SF_OK) return rc;
     if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16, kdims)) != SF_OK) return rc;
     // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
@@ -537,10 +548,17 @@ static int nn_run_filter(sf_context* c, int* done) {
     SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));
     // a dense prefix result would make the exact refinement the expensive part: insist on a sparse
-    // candidate set from the prefix stage, accept anything that fits from the full-length stage
-    ok = attempt == 0 && kpre != kfull ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
+    // candidate set from a prefix level, accept anything that fits the buffer from the full-length level
+    ok = (level < n_levels - 1) ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
+    if (ok) {
+      c->nn_level = level;
+      c->nn_last_kdims = kdims;
+    }
   }
-  if (!ok) return SF_OK;   // too dense for the filter: exact path
+  if (!ok) {   // too dense for the filter: exact path
+    c->nn_last_kdims = 0;
+    return SF_OK;
+  }
   // pinned staging for the candidate list (pageable D2H copies are staged and slow)
   {
     const size_t need = (size_t)n_cand * 16 + 64;
@@ -619,6 +637,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     c->masks_dirty = false;
   }
   int filtered = 0;
+  c->nn_last_kdims = 0;
   if (c->params.nn_precision == 1) {
     if ((rc = nn_run_filter(c, &filtered)) != SF_OK) return rc;
   }

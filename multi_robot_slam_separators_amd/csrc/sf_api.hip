@@ -766,6 +766,12 @@ extern "C" int sf_nn_find_matches(sf_handle c, sf_match* out, int32_t cap, int32
   return sf_nn_run(c, out, cap, n_out);
 }
 
+extern "C" int sf_nn_last_filter_dims(sf_handle c, int32_t* dims) {
+  if (!c || !dims) return SF_EINVAL;
+  *dims = c->nn_last_kdims;
+  return SF_OK;
+}
+
 extern "C" int sf_nn_last_row_minima(sf_handle c, double* dist, int32_t* idx, int32_t cap) {
   if (!c) return SF_EINVAL;
   const int n = std::min<int>(cap, (int)c->last_row_min.size());

@@ -123,6 +123,7 @@ struct sf_context {
   Buf nn_exact;      // double [n_local]
   Buf nn_cand;       // filter path: counter + candidate (row, col) pairs + exact distances
   Buf nn_scalar;     // small reduction scratch
+  int nn_level = 0, nn_level_cooldown = 32, nn_last_kdims = 0;   // adaptive prefix ladder of the filter
   std::vector<double> last_row_min;
   std::vector<int32_t> last_row_arg;
   std::vector<uint64_t> nn_sort_keys, nn_sort_keys2;   // host scratch of the walk (kept to avoid reallocation)

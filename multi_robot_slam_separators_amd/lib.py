@@ -72,6 +72,7 @@ def load():
         "sf_nn_set_precision": (C.c_int, [vp, i32]),
         "sf_nn_find_matches": (C.c_int, [vp, vp, i32, P(i32)]),
         "sf_nn_last_row_minima": (C.c_int, [vp, vp, vp, i32]),
+        "sf_nn_last_filter_dims": (C.c_int, [vp, P(i32)]),
         "sf_store_add_keyframe": (C.c_int, [vp, P(_abi.Features), P(i32)]),
         "sf_store_add_keyframes_device": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, P(i32)]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
@@ -107,7 +108,7 @@ EXPORTED = [
     "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_sizes",
     "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
     "sf_nn_set_precision",
-    "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_store_add_keyframe",
+    "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -208,6 +209,11 @@ class SeparatorFinder:
         n = C.c_int32()
         self._check(self._L.sf_nn_find_matches(self._h, out.ctypes.data, cap, C.byref(n)))
         return out[: n.value]
+
+    def nn_last_filter_dims(self):
+        d = C.c_int32()
+        self._check(self._L.sf_nn_last_filter_dims(self._h, C.byref(d)))
+        return d.value
 
     def nn_last_row_minima(self):
         n_l, _ = self.nn_sizes()
