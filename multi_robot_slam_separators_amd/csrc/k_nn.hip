@@ -18,6 +18,7 @@
 //                 at the first row over it).
 #include <math.h>
 #include <string.h>
+#include <chrono>
 #include <cmath>
 
 #include <algorithm>
@@ -484,8 +485,24 @@ static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16, int kprefix
 
 // Returns SF_OK with *done = 1 when the filter path produced the row minima; *done = 0 means the
 // candidate buffer overflowed (threshold too loose for a sparse filter) -> caller runs the exact path.
+// SF_NN_TRACE=1: host-side stage times of one query on stderr (diagnostic)
+struct NnTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  NnTrace() : on(getenv("SF_NN_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what, long long n = -1) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sf nn] %-22s %8.3f ms", what, std::chrono::duration<double, std::milli>(now - t).count());
+    if (n >= 0) fprintf(stderr, "  (%lld)", n);
+    fputc('\n', stderr);
+    t = now;
+  }
+};
+
 static int nn_run_filter(sf_context* c, int* done) {
   *done = 0;
+  NnTrace tr;
   const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
   const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
   const int ld16 = (dim + 63) / 64 * 64;
@@ -529,6 +546,7 @@ static int nn_run_filter(sf_context* c, int* done) {
     const int kdims = levels[level];
     if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16, kdims)) != SF_OK) return rc;
     if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16, kdims)) != SF_OK) return rc;
+    if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.mark("prepare f16", kdims); }
     // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
     const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
     const float scale = c->nn_local.h_scale * c->nn_recv.h_scale;   // product of two powers of two: exact
@@ -549,6 +567,7 @@ static int nn_run_filter(sf_context* c, int* done) {
     SF_HIP(c, hipStreamSynchronize(c->stream));
     // a dense prefix result would make the exact refinement the expensive part: insist on a sparse
     // candidate set from a prefix level, accept anything that fits the buffer from the full-length level
+    tr.mark("filter + count", n_cand);
     ok = (level < n_levels - 1) ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
     if (ok) {
       c->nn_level = level;
@@ -572,6 +591,7 @@ static int nn_run_filter(sf_context* c, int* done) {
       c->nn_pinned_bytes = want;
     }
   }
+  tr.mark("pinned staging");
   uint2* h_cand = (uint2*)c->nn_pinned;
   double* h_dist = (double*)((char*)c->nn_pinned + (size_t)n_cand * 8);
   if (n_cand) {
@@ -583,6 +603,7 @@ static int nn_run_filter(sf_context* c, int* done) {
     SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));
   }
+  tr.mark("refine + D2H");
   // per-row minimum over the exact candidate distances (ties: lowest column), ignored pairs skipped.
   // Rows without a candidate have their true minimum >= netvlad_distance: reported as +inf.
   c->last_row_min.assign(n_l, (double)INFINITY);
@@ -600,6 +621,7 @@ static int nn_run_filter(sf_context* c, int* done) {
       c->last_row_arg[r] = col;
     }
   }
+  tr.mark("host row minima");
   // a candidate admitted only by the error band may still be >= the threshold: that is fine, the
   // walk compares the exact float64 value
   *done = 1;

@@ -7,7 +7,7 @@ import torch
 import bench
 from multi_robot_slam_separators_amd import _abi, lib, synth
 
-n_kf, k, cols, dim = 10000, 500, 32, 4096
+n_kf, k, cols, dim = (int(sys.argv[1]) if len(sys.argv) > 1 else 10000), 500, 32, 4096
 p = synth.camera_params(); p.iterations = 500; p.netvlad_dimensions = dim; p.netvlad_max_matches_nb = n_kf
 p.nn_precision = 1; p.max_features = k; p.store_capacity = 2 * n_kf
 feats, nv_a, nv_b, _ = bench.generate_inputs(12345, n_kf, k, cols, dim, 0.2)
@@ -31,7 +31,7 @@ d_from = torch.empty(n_kf, dtype=torch.int32, device=dev); d_to = torch.empty_li
 d_res = torch.empty((n_kf, 368), dtype=torch.uint8, device=dev)
 h_res = torch.empty((n_kf, 368), dtype=torch.uint8).pin_memory()
 T = {"nn": [], "idx": [], "verify_launch": [], "verify_wait": [], "d2h_pageable": [], "d2h_pinned": []}
-for it in range(8):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     t0 = time.perf_counter(); m = f.nn_find_matches(cap=n_kf); t1 = time.perf_counter()
     n = len(m)
     hf = torch.from_numpy(m["idx_other"].astype(np.int32) + slots["a"]); ht = torch.from_numpy(m["idx_local"].astype(np.int32) + slots["b"])
