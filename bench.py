@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--nn-precision", type=int, default=1,
                     help="1 = fp16 MFMA filter with rigorous error band + exact f64 refinement (identical "
                          "matches); 0 = fp32 MFMA ranking of every column")
+    ap.add_argument("--estimator", choices=("3d3d", "pnp"), default="3d3d",
+                    help="motion estimator of both registration passes: 3d3d = RANSAC 3D->3D (north_star, "
+                         "myRegistrationVis.cpp:1113-1152), pnp = RANSAC 3D->2D (:1055-1112, rtabmap's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2048)
     ap.add_argument("--cpu-sample-rows", type=int, default=64)
@@ -151,6 +154,7 @@ def main():
     n_kf, k, cols, dim = args.keyframes, args.features, args.desc_bytes, args.dim
     p = synth.camera_params()
     p.iterations = args.iterations
+    p.estimation_type = 1 if args.estimator == "pnp" else 0
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf            # batch operation: walk every row
     p.nn_precision = args.nn_precision
@@ -311,8 +315,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: 1xMI355X per rank, 2 robots x %d keyframes, %d-D fp32 NetVLAD, "
-                            "%d x %d-bit ORB per keyframe, %d RANSAC iterations, both registration passes, "
-                            "%.0f %% true revisits" % (n_kf, dim, k, cols * 8, args.iterations, 100 * args.true_frac),
+                            "%d x %d-bit ORB per keyframe, %d RANSAC iterations (%s), both registration passes, "
+                            "%.0f %% true revisits" % (n_kf, dim, k, cols * 8, args.iterations,
+                                                       "3D-3D" if args.estimator == "3d3d" else "PnP",
+                                                       100 * args.true_frac),
                 "pairs_per_step_per_gpu": pairs_per_step,
                 "parallelism": "pairs sharded by robot pair, 1 rank per GPU" if world > 1 else "single GPU",
             },
@@ -331,7 +337,8 @@ def main():
                 "kernel": nn_kernel, "bound": "mfma", "achieved": nn_tf, "peak": nn_peak,
                 "unit": "TFLOP/s", "frac": nn_tf / nn_peak, "avg_launch_ms": nn_ms, "contracted_dims": k_eff,
             },
-            "kernel_ms_per_step": {kname: (ms / args.steps) for kname, (cnt, ms) in prof.items()},
+            "kernel_ms_per_step": {(kname.replace("k_ransac", "k_pnp") if args.estimator == "pnp" else kname):
+                                   (ms / args.steps) for kname, (cnt, ms) in prof.items()},
             "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n),
                       "accepted_separators_gathered_per_step": state.get("gathered", 0),
                       "gathered_records_all_accepted": all_ok},

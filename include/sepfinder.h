@@ -79,8 +79,9 @@ typedef struct sf_params {
   int32_t iterations;              /* 300  Vis/Iterations                                    */
   int32_t refine_iterations;       /* 5    Vis/RefineIterations                              */
   double  refine_sigma;            /* 3.0  refineModelSigma (rtabmap util3d_registration)    */
-  int32_t estimation_type;         /* 0 = 3D->3D (implemented; north_star). 1 = PnP and
-                                      2 = epipolar are NOT implemented: sf_create -> SF_EINVAL */
+  int32_t estimation_type;         /* 0 = 3D->3D (north_star; myRegistrationVis.cpp:1113-1152),
+                                      1 = 3D->2D PnP (:1055-1112; rtabmap's compiled-in default),
+                                      2 = epipolar is NOT implemented: sf_create -> SF_EINVAL   */
   float   nndr;                    /* 0.6  Vis/CorNNDR                                       */
   int32_t guess_win_size;          /* 20   Vis/CorGuessWinSize (px); 0 disables guided pass  */
   int32_t ransac_adaptive_stop;    /* 1 = PCL RandomSampleConsensus adaptive k (p=0.99);
@@ -95,7 +96,11 @@ typedef struct sf_params {
   int32_t store_capacity;          /* keyframes                                              */
   int32_t max_features;            /* per keyframe (rounded up to a multiple of 64)          */
   int32_t desc_bytes;              /* descriptor bytes per feature, 1..64 (32 = ORB/BRIEF)   */
-  int32_t reserved[8];
+  /* PnP branch (estimation_type = 1): myRegistrationVis.cpp:59-61,1083-1085 [upstream defaults]  */
+  float   pnp_reproj_error;        /* 2.0  Vis/PnPReprojError (px); inlier iff error <= this  */
+  int32_t pnp_flags;               /* 0    Vis/PnPFlags: only 0 (cv::SOLVEPNP_ITERATIVE)      */
+  int32_t pnp_refine_iterations;   /* 0    Vis/PnPRefineIterations: only 0                    */
+  int32_t reserved[5];
 } sf_params;
 
 /* ---- wire layouts ------------------------------------------------------------------------ */

@@ -45,7 +45,10 @@ class Params(C.Structure):
         ("store_capacity", C.c_int32),
         ("max_features", C.c_int32),
         ("desc_bytes", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("pnp_reproj_error", C.c_float),
+        ("pnp_flags", C.c_int32),
+        ("pnp_refine_iterations", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -165,6 +168,9 @@ def default_params() -> Params:
     p.store_capacity = 1024
     p.max_features = 512
     p.desc_bytes = 32
+    p.pnp_reproj_error = 2.0
+    p.pnp_flags = 0
+    p.pnp_refine_iterations = 0
     return p
 
 

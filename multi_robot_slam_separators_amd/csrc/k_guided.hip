@@ -260,16 +260,20 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   const int words_from = outside ? 0 : n_finite;
   const int words_to_2d = outside ? 0 : Kt;
   const int words_to = (outside || mT.y <= 0) ? 0 : Kt;
-  const bool motion = words_to_2d > 0 && words_from >= P.min_inliers && words_to >= P.min_inliers;
-  const bool survivor = motion && n_corr >= P.min_inliers && n_corr >= 3;
+  const bool pnp = P.estimation_type == 1;   // guided matching implies a calibrated camera
+  const bool motion = words_to_2d > 0 && words_from >= P.min_inliers &&
+                      (pnp ? words_to_2d : words_to) >= P.min_inliers;      // :1117-1118 / :1070-1071
+  const bool survivor = motion && n_corr >= P.min_inliers && n_corr >= (pnp ? 4 : 3);
   if (motion && !survivor) {
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
     for (int i = tid; i < n_corr; i += SF_BLOCK) {
       uint32_t c = out[i];
       const float* a = xF + 3 * (c & 0xFFFFu);
       const float* b = xT + 3 * (c >> 16);
-      bool ok = sfd::finite3(a[0], a[1], a[2]) && sfd::finite3(b[0], b[1], b[2]) &&
-                (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) && (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      bool ok = sfd::finite3(a[0], a[1], a[2]);
+      if (!pnp)
+        ok = ok && sfd::finite3(b[0], b[1], b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
+             (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
       if (ok) atomicAdd(&misc[2], 1);
     }
     __syncthreads();
@@ -285,7 +289,7 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     PassState ps;
 #pragma unroll
     for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-    ps.var = 1.0;
+    ps.var = 1.0; ps.var_ang = 1.0;
     ps.is_null = 1;
     ps.inliers = 0;
     ps.matches = (motion && !survivor) ? misc[2] : 0;
@@ -312,10 +316,11 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
   for (int k = 0; k < 4; ++k) r.orientation[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 36; ++k) r.covariance[k] = 0.0;
-  double cd = b.var;
+  double cd = b.var, ca = b.var_ang;
   if (cd <= 1e-9) cd = 1e-9;
+  if (ca <= 1e-9) ca = 1e-9;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) r.covariance[7 * k] = cd;
+  for (int k = 0; k < 3; ++k) { r.covariance[7 * k] = cd; r.covariance[7 * (k + 3)] = ca; }
   r.inliers = b.inliers;
   r.matches = b.matches;
   r.inliers_pass1 = a.inliers;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int
 template <int W, int NQ, int NT>
 __global__ void __launch_bounds__(NT)
 k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-               float nndr, int min_inliers, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+               float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   constexpr int NW = NT / 64;
@@ -83,7 +83,7 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
       PassState ps;
 #pragma unroll
       for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-      ps.var = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
+      ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
       pass[pair] = ps;
     }
     return;
@@ -180,8 +180,11 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
   const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;
   const int words_to = (mT.y > 0) ? unique_to : 0;
-  const bool motion = unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers;
-  const bool survivor = motion && n_corr >= min_inliers && n_corr >= 3;
+  // est: 0 = 3D->3D gate (:1117-1118); 1 = PnP gate (:1070-1071, 2D words of the "to" frame);
+  //      2 = PnP without a calibrated camera (:1059-1065): the estimation never runs
+  const bool motion = est == 0 ? (unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers)
+                               : (est == 1 && unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers);
+  const bool survivor = motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4);
   if (motion && !survivor) {
     const float* xF = st.xyz + (size_t)sF * kcap * 3;
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
@@ -189,9 +192,10 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
       uint32_t c = out[i];
       const float* a = xF + 3 * (c & 0xFFFFu);
       const float* b = xT + 3 * (c >> 16);
-      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(b[0]) && isfinite(b[1]) &&
-                isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
-                (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]);
+      if (est == 0)   // findCorrespondences (3D-3D) also needs the "to" point and drops zero points
+        ok = ok && isfinite(b[0]) && isfinite(b[1]) && isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
+             (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
       if (ok) atomicAdd(&misc[2], 1);
     }
     __syncthreads();
@@ -206,7 +210,7 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     PassState ps;
 #pragma unroll
     for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-    ps.var = 1.0;
+    ps.var = 1.0; ps.var_ang = 1.0;
     ps.is_null = 1;
     ps.inliers = 0;
     ps.matches = (motion && !survivor) ? misc[2] : 0;
@@ -289,7 +293,7 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
 template <int W, int NQ, int NT>
 __global__ void __launch_bounds__(NT)
 k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-                  float nndr, int min_inliers, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                  float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                   PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   constexpr int NW = NT / 64;
@@ -305,7 +309,7 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
       PassState ps;
 #pragma unroll
       for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-      ps.var = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
+      ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
       pass[pair] = ps;
     }
     return;
@@ -412,8 +416,11 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
   const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
   const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;
   const int words_to = (mT.y > 0) ? unique_to : 0;
-  const bool motion = unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers;
-  const bool survivor = motion && n_corr >= min_inliers && n_corr >= 3;
+  // est: 0 = 3D->3D gate (:1117-1118); 1 = PnP gate (:1070-1071, 2D words of the "to" frame);
+  //      2 = PnP without a calibrated camera (:1059-1065): the estimation never runs
+  const bool motion = est == 0 ? (unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers)
+                               : (est == 1 && unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers);
+  const bool survivor = motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4);
   if (motion && !survivor) {
     const float* xF = st.xyz + (size_t)sF * kcap * 3;
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
@@ -421,9 +428,10 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
       uint32_t c = out[i];
       const float* a = xF + 3 * (c & 0xFFFFu);
       const float* b = xT + 3 * (c >> 16);
-      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(b[0]) && isfinite(b[1]) &&
-                isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
-                (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
+      bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]);
+      if (est == 0)   // findCorrespondences (3D-3D) also needs the "to" point and drops zero points
+        ok = ok && isfinite(b[0]) && isfinite(b[1]) && isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
+             (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
       if (ok) atomicAdd(&misc[2], 1);
     }
     __syncthreads();
@@ -438,7 +446,7 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
     PassState ps;
 #pragma unroll
     for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-    ps.var = 1.0;
+    ps.var = 1.0; ps.var_ang = 1.0;
     ps.is_null = 1;
     ps.inliers = 0;
     ps.matches = (motion && !survivor) ? misc[2] : 0;
@@ -456,7 +464,7 @@ void launch_match_v2(sf_context* c, StoreView st, const int32_t* d_from, const i
   const size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
   int32_t* counters = (int32_t*)c->counters.p;
   hipLaunchKernelGGL((k_match_global_v2<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
-                     c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                     c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
                      (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
 }
 
@@ -465,7 +473,7 @@ void launch_match(sf_context* c, StoreView st, const int32_t* d_from, const int3
   const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
   int32_t* counters = (int32_t*)c->counters.p;
   hipLaunchKernelGGL((k_match_global<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
-                     c->dparams.nndr, c->dparams.min_inliers, (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                     c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
                      (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
 }
 

@@ -1,0 +1,484 @@
+// k_pnp.hip -- RANSAC 3D->2D (PnP) motion estimation for one candidate pair per 256-thread workgroup.
+//
+// Replaces util3d::estimateMotion3DTo2D as called at myRegistrationVis.cpp:1077-1091 of the reference
+// (the `_estimationType == 1` branch, :1055-1112) [upstream rtabmap util3d_motion_estimation.cpp ->
+// cv::solvePnPRansac: RANSACPointSetRegistrator, squared reprojection error <= reprojError^2,
+// RANSACUpdateNumIters with confidence 0.99, final iterative solve on the inliers; then rtabmap's
+// frame change (localTransform * pnp).inverse() and its quartile-based covariance], for the
+// correspondences produced by k_match / k_guided.  What is and is not OpenCV's arithmetic is listed in
+// DESIGN.md (P3P minimal solver on 4-point samples, keyed sampler, cheirality, LM parametrisation).
+//
+// CDNA4 mapping (same shape as k_ransac):
+//   * correspondences with a finite "from" point are compacted once into LDS: world point (float4),
+//     pixel offsets from the principal point (float2), and the packed index pair for the late
+//     covariance gather;
+//   * one LANE per hypothesis: keyed 4-sample, P3P in fp64 (Grunert's quartic by Ferrari + bracketed
+//     Newton, frames of the two triangles), the 4th point picks the root, then the inlier count over
+//     all points with LDS BROADCAST reads and a division-free test (A^2 + B^2 <= thr^2 Z^2, Z > 0:
+//     9 + 2 fma, 4 mul, 2 compares per point);
+//   * OpenCV's sequential "best so far / update niters" rule is replayed by thread 0 after every
+//     round of 256 hypotheses, so later rounds are skipped exactly when the sequential loop would
+//     have stopped;
+//   * Levenberg-Marquardt on the inliers: per-lane partial normal equations (21 + 6 + 1 doubles),
+//     block-wide reduction in the FIXED order of DESIGN.md section 4, then every lane solves the same
+//     6x6 system redundantly (identical arithmetic, no broadcast);
+//   * order statistics (first quartile of the 3D errors / angles) by rank counting over +inf padded
+//     LDS arrays.
+// Compiled with -ffp-contract=off.
+#include "sf_device_math.hpp"
+#include "sf_internal.hpp"
+#include "sf_pnp_math.hpp"
+
+namespace {
+
+#define PNP_NSUM 28
+
+struct PnpLds {
+  float4* obj;      // [kcap] world ("from" base frame) point
+  float2* img;      // [kcap] pixel - principal point of the "to" keypoint
+  uint32_t* cidx;   // [kcap] packed (to << 16 | from) feature indices
+  float* e1;        // [kcap] squared 3D error of the members (+inf elsewhere)
+  float* e2;        // [kcap] angular error
+  uint8_t* mask;    // [kcap]
+  int* counts;      // [iterations]
+  double* red;      // [4][32]
+  int* misc;        // [16]
+};
+
+template <int N>
+__device__ __forceinline__ void block_sum_vec32(double (&v)[N], double* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = v[k] + __shfl_xor(v[k], off);
+  }
+  __syncthreads();  // previous users of `red` are done
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[wave * 32 + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[32 + k]) + red[64 + k]) + red[96 + k];
+}
+
+__device__ __forceinline__ int block_sum_i(int v, int* misc, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (lane == 0) misc[8 + wave] = v;
+  __syncthreads();
+  return ((misc[8] + misc[9]) + misc[10]) + misc[11];
+}
+
+struct PnpCam {
+  double fx, fy;
+  float fxf, fyf, thr2f;
+};
+
+// division-free reprojection test of point i under float coefficients (canonical fma chain)
+__device__ __forceinline__ bool pnp_inlier(const PnpLds& L, const PnpCam& cam, const float (&c)[12], int i) {
+  const float4 P = L.obj[i];
+  const float2 o = L.img[i];
+  const float X = __fmaf_rn(c[2], P.z, __fmaf_rn(c[1], P.y, __fmaf_rn(c[0], P.x, c[3])));
+  const float Y = __fmaf_rn(c[6], P.z, __fmaf_rn(c[5], P.y, __fmaf_rn(c[4], P.x, c[7])));
+  const float Z = __fmaf_rn(c[10], P.z, __fmaf_rn(c[9], P.y, __fmaf_rn(c[8], P.x, c[11])));
+  const float A = __fmaf_rn(-o.x, Z, cam.fxf * X);
+  const float B = __fmaf_rn(-o.y, Z, cam.fyf * Y);
+  const float lhs = __fmaf_rn(B, B, A * A);
+  const float rhs = cam.thr2f * (Z * Z);
+  return (Z > 0.0f) && (lhs <= rhs);
+}
+
+// model of RANSAC iteration `it`: keyed 4-sample, P3P on the first three, the 4th picks the root
+__device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
+                                      float (&coef)[12]) {
+  uint32_t s0, s1, s2, s3;
+  sfd::sample_quad(seed, it, 0u, m, s0, s1, s2, s3);
+  double P[3][3], f[3][3];
+  const uint32_t sk[3] = {s0, s1, s2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float4 p = L.obj[sk[k]];
+    const float2 o = L.img[sk[k]];
+    P[k][0] = (double)p.x; P[k][1] = (double)p.y; P[k][2] = (double)p.z;
+    const double un = (double)o.x / cam.fx, vn = (double)o.y / cam.fy;
+    const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
+    f[k][0] = un * inv; f[k][1] = vn * inv; f[k][2] = inv;
+  }
+  const float4 p4 = L.obj[s3];
+  const float2 o4 = L.img[s3];
+  const double P4[3] = {(double)p4.x, (double)p4.y, (double)p4.z};
+  return sfd::p3p_best(P, f, P4, (double)o4.x, (double)o4.y, cam.fx, cam.fy, coef);
+}
+
+// Normal equations of the reprojection error over the members of L.mask at pose (q, t).
+__device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, const double (&q)[4],
+                                     const double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
+  double R[9];
+  sfd::quat_to_R(q, R);
+#pragma unroll
+  for (int k = 0; k < PNP_NSUM; ++k) ne[k] = 0.0;
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    if (!L.mask[i]) continue;
+    const float4 p = L.obj[i];
+    const float2 o = L.img[i];
+    const double Px = (double)p.x, Py = (double)p.y, Pz = (double)p.z;
+    const double Yx = (R[0] * Px + R[1] * Py) + R[2] * Pz;
+    const double Yy = (R[3] * Px + R[4] * Py) + R[5] * Pz;
+    const double Yz = (R[6] * Px + R[7] * Py) + R[8] * Pz;
+    const double X = Yx + t[0], Y = Yy + t[1], Z = Yz + t[2];
+    if (Z > 0.0) {
+      const double iz = 1.0 / Z;
+      const double xn = X * iz, yn = Y * iz;
+      const double ru = cam.fx * xn - (double)o.x;
+      const double rv = cam.fy * yn - (double)o.y;
+      const double a0 = cam.fx * iz, a2 = -(a0 * xn);
+      const double b1 = cam.fy * iz, b2 = -(b1 * yn);
+      double Ju[6], Jv[6];
+      Ju[0] = a2 * Yy;            Ju[1] = a0 * Yz - a2 * Yx; Ju[2] = -(a0 * Yy);
+      Ju[3] = a0;                 Ju[4] = 0.0;               Ju[5] = a2;
+      Jv[0] = b2 * Yy - b1 * Yz;  Jv[1] = -(b2 * Yx);        Jv[2] = b1 * Yx;
+      Jv[3] = 0.0;                Jv[4] = b1;                Jv[5] = b2;
+      {
+        int o_ = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int k = j; k < 6; ++k) { ne[o_] += Ju[j] * Ju[k] + Jv[j] * Jv[k]; ++o_; }
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ne[21 + j] += Ju[j] * ru + Jv[j] * rv;
+      ne[27] += ru * ru + rv * rv;
+    } else {
+      ne[27] += 1e30;   // a member behind the camera makes the pose unacceptable
+    }
+  }
+  block_sum_vec32<PNP_NSUM>(ne, L.red, tid);
+}
+
+// value of rank `rank` among the finite entries of arr[0..m4) (+inf padded): rank counting, 4 per read
+__device__ inline float rank_value(const float* arr, int m, int rank, double* slot, int tid) {
+  const int m4 = (m + 3) & ~3;
+  __syncthreads();
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    const float v = arr[i];
+    if (v < __int_as_float(0x7F800000)) {
+      int lt = 0, eq = 0;
+      const float4* d4 = reinterpret_cast<const float4*>(arr);
+      for (int j = 0; j < m4 / 4; ++j) {
+        const float4 u = d4[j];
+        lt += (u.x < v ? 1 : 0) + (u.y < v ? 1 : 0) + (u.z < v ? 1 : 0) + (u.w < v ? 1 : 0);
+        eq += (u.x == v ? 1 : 0) + (u.y == v ? 1 : 0) + (u.z == v ? 1 : 0) + (u.w == v ? 1 : 0);
+      }
+      if (lt <= rank && rank < lt + eq) *slot = (double)v;  // every writer holds the same value
+    }
+  }
+  __syncthreads();
+  return (float)*slot;
+}
+
+__global__ void __launch_bounds__(SF_BLOCK, 2)
+k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+      const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+      const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+      PassState* __restrict__ pass, DeviceParams P) {
+  if ((int)blockIdx.x >= *counter) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const int pair = list[blockIdx.x];
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  const int max_it = P.iterations > 0 ? P.iterations : 0;
+
+  PnpLds L;
+  {
+    unsigned char* p = smem_raw;
+    L.obj = (float4*)p; p += (size_t)kcap * 16;
+    L.red = (double*)p; p += 128 * 8;
+    L.img = (float2*)p; p += (size_t)kcap * 8;
+    L.e1 = (float*)p; p += (size_t)kcap * 4;
+    L.e2 = (float*)p; p += (size_t)kcap * 4;
+    L.cidx = (uint32_t*)p; p += (size_t)kcap * 4;
+    L.counts = (int*)p; p += (size_t)((max_it + 4) & ~3) * 4;
+    L.misc = (int*)p; p += 16 * 4;
+    L.mask = p;
+  }
+
+  // ---- estimateMotion3DTo2D: ids of words2B found in words3A with a finite 3D point ---------------
+  const int n_corr = hdr[pair].n_corr;
+  const uint32_t* cl = corr + (size_t)pair * kcap;
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const float4* kT = st.kp + (size_t)sT * kcap;
+  const bool to_has_3d = st.meta[sT].y > 0;
+  const float cxf = (float)P.cx, cyf = (float)P.cy;
+  if (tid < 16) L.misc[tid] = 0;
+  __syncthreads();
+  int m = 0;
+  for (int base = 0; base < n_corr; base += SF_BLOCK) {
+    const int i = base + tid;
+    bool ok = false;
+    float ax = 0, ay = 0, az = 0, ox = 0, oy = 0;
+    uint32_t c = 0;
+    if (i < n_corr) {
+      c = cl[i];
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      ax = a[0]; ay = a[1]; az = a[2];
+      const float4 kp = kT[c >> 16];
+      ox = kp.x - cxf; oy = kp.y - cyf;
+      ok = sfd::finite3(ax, ay, az);
+    }
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+      const int cw = L.misc[4 + w];
+      if (w < wave) woff += cw;
+      total += cw;
+    }
+    if (ok) {
+      L.obj[m + woff + before] = make_float4(ax, ay, az, 0.f);
+      L.img[m + woff + before] = make_float2(ox, oy);
+      L.cidx[m + woff + before] = c;
+    }
+    m += total;
+    __syncthreads();
+  }
+
+  PassState ps;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+  ps.var = 1.0;
+  ps.var_ang = 1.0;
+  ps.is_null = 1;
+  ps.inliers = 0;
+  ps.matches = m;
+  ps.pad = 0;
+  if (m < P.min_inliers || m < 4) {
+    if (tid == 0) pass[pair] = ps;
+    return;
+  }
+
+  PnpCam cam;
+  cam.fx = P.fx; cam.fy = P.fy;
+  cam.fxf = (float)P.fx; cam.fyf = (float)P.fy;
+  cam.thr2f = P.pnp_thr2f;
+
+  // ---- cv::RANSACPointSetRegistrator::run: one lane per hypothesis, rounds of SF_BLOCK ---------------
+  {
+    int niters = max_it, best = 0, best_it = -1, sc_it = 0;   // thread 0 only
+    if (tid == 0) { L.misc[0] = -1; L.misc[1] = 1; }
+    for (int base = 0; base < max_it; base += SF_BLOCK) {
+      const int it = base + tid;
+      if (it < max_it) {
+        float coef[12];
+        int cnt = 0;
+        if (pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
+          for (int i = 0; i < m; ++i) cnt += pnp_inlier(L, cam, coef, i) ? 1 : 0;   // LDS broadcast reads
+        }
+        L.counts[it] = cnt;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int lim = min(max_it, base + SF_BLOCK);   // counts exist for iterations < lim
+        while (sc_it < niters && sc_it < lim) {
+          const int good = L.counts[sc_it];
+          const int bar = best > 3 ? best : 3;          // max(maxGoodCount, modelPoints - 1)
+          if (good > bar) {
+            best = good;
+            best_it = sc_it;
+            if (P.adaptive_stop) niters = sfd::update_num_iters(0.99, (double)(m - good) / (double)m, 4, niters);
+          }
+          ++sc_it;
+        }
+        L.misc[0] = best_it;
+        L.misc[1] = (sc_it >= niters) ? 1 : 0;
+      }
+      __syncthreads();
+      if (L.misc[1]) break;
+    }
+    __syncthreads();
+  }
+  const int best_it = L.misc[0];
+  if (best_it < 0) {   // solvePnPRansac returned false: no inliers
+    if (tid == 0) pass[pair] = ps;
+    return;
+  }
+
+  // ---- winning model (recomputed redundantly in every lane) and its inlier mask ---------------------
+  float coef[12];
+  pnp_hypothesis(L, cam, P.seed, (uint32_t)best_it, (uint32_t)m, coef);
+  int n_inl = 0;
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    const bool in = pnp_inlier(L, cam, coef, i);
+    L.mask[i] = in ? 1 : 0;
+    n_inl += in ? 1 : 0;
+  }
+  n_inl = block_sum_i(n_inl, L.misc, tid);   // also orders the mask writes before the reads below
+
+  // ---- final solve on the inliers: Levenberg-Marquardt, at most 20 evaluations ------------------------
+  double q[4], t[3];
+  {
+    double Rb[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Rb[3 * i + j] = (double)coef[4 * i + j];
+      t[i] = (double)coef[4 * i + 3];
+    }
+    sfd::R_to_quat(Rb, q);
+  }
+  double ne[PNP_NSUM];
+  pnp_normal_eq(L, cam, m, q, t, ne, tid);
+  {
+    double lambda = 1e-3;
+    for (int iter = 0; iter < 20; ++iter) {
+      double d[6];
+      if (!sfd::solve6(ne, lambda, d)) {
+        lambda = lambda * 10.0;
+        if (lambda > 1e12) break;
+        continue;
+      }
+      const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
+      const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
+      const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
+      double qc[4], tc[3];
+      qc[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
+      qc[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
+      qc[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
+      qc[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
+      const double qn = 1.0 / sqrt(((qc[0] * qc[0] + qc[1] * qc[1]) + qc[2] * qc[2]) + qc[3] * qc[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
+      double nc[PNP_NSUM];
+      pnp_normal_eq(L, cam, m, qc, tc, nc, tid);
+      if (nc[27] < ne[27]) {
+        const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
+        const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = qc[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = tc[i];
+#pragma unroll
+        for (int i = 0; i < PNP_NSUM; ++i) ne[i] = nc[i];
+        lambda = lambda * 0.1;
+        if (lambda < 1e-16) lambda = 1e-16;
+        if (dd <= 1.4e-14 * tt) break;
+      } else {
+        lambda = lambda * 10.0;
+        if (lambda > 1e12) break;
+      }
+    }
+  }
+
+  ps.inliers = n_inl;
+  if (n_inl < P.min_inliers) {
+    if (tid == 0) pass[pair] = ps;
+    return;
+  }
+
+  // ---- transform = (localTransform * pnp).inverse()  (rtabmap::Transform is float) ----------------------
+  float T[12];
+  {
+    double Rd[9];
+    sfd::quat_to_R(q, Rd);
+    float Rf[9], tf[3], MR[9], Mt[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tf[i] = (float)t[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        MR[3 * i + j] = (P.L[4 * i] * Rf[j] + P.L[4 * i + 1] * Rf[3 + j]) + P.L[4 * i + 2] * Rf[6 + j];
+      Mt[i] = ((P.L[4 * i] * tf[0] + P.L[4 * i + 1] * tf[1]) + P.L[4 * i + 2] * tf[2]) + P.L[4 * i + 3];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T[4 * i + j] = MR[3 * j + i];
+      T[4 * i + 3] = -((MR[i] * Mt[0] + MR[3 + i] * Mt[1]) + MR[6 + i] * Mt[2]);
+    }
+  }
+  bool allz = true;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { ps.T[i] = T[i]; allz = allz && (T[i] == 0.f); }
+  ps.is_null = allz ? 1 : 0;
+
+  // ---- covariance [upstream estimateMotion3DTo2D] ---------------------------------------------------------
+  if (to_has_3d) {
+    const int m4 = (m + 3) & ~3;
+    int cnt = 0;
+    for (int i = tid; i < m4; i += SF_BLOCK) {
+      float v1 = __int_as_float(0x7F800000), v2 = __int_as_float(0x7F800000);
+      if (i < m && L.mask[i]) {
+        const float* b = xT + 3 * (L.cidx[i] >> 16);
+        const float bx = b[0], by = b[1], bz = b[2];
+        if (sfd::finite3(bx, by, bz)) {
+          const float4 a = L.obj[i];
+          const float nx = __fmaf_rn(T[2], bz, __fmaf_rn(T[1], by, __fmaf_rn(T[0], bx, T[3])));
+          const float ny = __fmaf_rn(T[6], bz, __fmaf_rn(T[5], by, __fmaf_rn(T[4], bx, T[7])));
+          const float nz = __fmaf_rn(T[10], bz, __fmaf_rn(T[9], by, __fmaf_rn(T[8], bx, T[11])));
+          const float dx = nx - a.x, dy = ny - a.y, dz = nz - a.z;
+          v1 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+          const double u1[3] = {(double)(a.x - T[3]), (double)(a.y - T[7]), (double)(a.z - T[11])};
+          const double u2[3] = {(double)(nx - T[3]), (double)(ny - T[7]), (double)(nz - T[11])};
+          const double cr[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2],
+                                u1[0] * u2[1] - u1[1] * u2[0]};
+          v2 = (float)sfd::canon_atan2(sqrt(sfd::dot3(cr, cr)), sfd::dot3(u1, u2));
+          ++cnt;
+        }
+      }
+      L.e1[i] = v1;
+      L.e2[i] = v2;
+    }
+    const int oi = block_sum_i(cnt, L.misc, tid);
+    if (oi > 0) {
+      ps.var = 2.1981 * (double)rank_value(L.e1, m, oi >> 2, &L.red[120], tid);
+      ps.var_ang = 2.1981 * (double)rank_value(L.e2, m, oi >> 2, &L.red[121], tid);
+    }
+  } else {
+    const double v = (double)sqrtf((float)ne[27] / (float)n_inl);
+    ps.var = v;
+    ps.var_ang = v;
+  }
+  if (tid == 0) pass[pair] = ps;
+}
+
+}  // namespace
+
+size_t sf_pnp_lds_bytes(int kcap, int iterations) {
+  const int it = iterations > 0 ? iterations : 0;
+  return (size_t)kcap * (16 + 8 + 4 + 4 + 4 + 1) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4;
+}
+
+int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = sf_pnp_lds_bytes(st.kcap, c->dparams.iterations);
+  if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "PnP workgroup needs %zu B of LDS (> 160 KiB)", lds);
+  if (!c->pnp_attr_set) {   // per handle = per device
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->pnp_attr_set = true;
+  }
+  int32_t* counters = (int32_t*)c->counters.p;
+  const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
+  sf_prof_begin(c, kid);
+  hipLaunchKernelGGL(k_pnp, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
+                     (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
+                     (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
+                     (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  sf_prof_end(c, kid);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

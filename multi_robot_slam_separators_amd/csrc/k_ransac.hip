@@ -263,7 +263,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   PassState ps;
 #pragma unroll
   for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-  ps.var = 1.0;
+  ps.var = 1.0; ps.var_ang = 1.0;
   ps.is_null = 1;
   ps.inliers = 0;
   ps.matches = m;
@@ -431,6 +431,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   if (n_inl >= 3) {
     const double variance = variance_of(L, m, n_last, tid);
     ps.var = variance;
+    ps.var_ang = variance;
     ps.inliers = n_inl;
     if (n_inl >= P.min_inliers) {
       double R[9], t[3];

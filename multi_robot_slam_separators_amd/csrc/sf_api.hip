@@ -371,11 +371,20 @@ extern "C" void sf_default_params(sf_params* p) {
   p->store_capacity = 1024;
   p->max_features = 512;
   p->desc_bytes = 32;
+  p->pnp_reproj_error = 2.0f;        // Vis/PnPReprojError
+  p->pnp_flags = 0;                  // Vis/PnPFlags (cv::SOLVEPNP_ITERATIVE)
+  p->pnp_refine_iterations = 0;      // Vis/PnPRefineIterations
 }
 
 static int fill_device_params(sf_context* c) {
   const sf_params& p = c->params;
-  if (p.estimation_type != 0) return sf_fail(c, SF_EINVAL, "estimation_type %d not implemented (0 = 3D->3D only)", p.estimation_type);
+  if (p.estimation_type != 0 && p.estimation_type != 1)
+    return sf_fail(c, SF_EINVAL, "estimation_type %d not implemented (0 = 3D->3D, 1 = PnP)", p.estimation_type);
+  if (p.estimation_type == 1) {
+    if (p.pnp_flags != 0) return sf_fail(c, SF_EINVAL, "pnp_flags %d not implemented (0 = SOLVEPNP_ITERATIVE only)", p.pnp_flags);
+    if (p.pnp_refine_iterations != 0) return sf_fail(c, SF_EINVAL, "pnp_refine_iterations %d not implemented (0 only)", p.pnp_refine_iterations);
+    if (!(p.pnp_reproj_error > 0.f)) return sf_fail(c, SF_EINVAL, "pnp_reproj_error must be > 0");
+  }
   if (p.min_inliers < 1) return sf_fail(c, SF_EINVAL, "min_inliers must be >= 1 (myRegistrationVis.cpp:117)");
   if (!(p.inlier_distance > 0.f)) return sf_fail(c, SF_EINVAL, "inlier_distance must be > 0 (:118)");
   if (p.iterations < 1) return sf_fail(c, SF_EINVAL, "iterations must be > 0 (:119)");
@@ -399,6 +408,11 @@ static int fill_device_params(sf_context* c) {
   d.wlim = (float)(p.image_width - 1);
   d.hlim = (float)(p.image_height - 1);
   memcpy(d.L, p.local_transform, sizeof(d.L));
+  d.estimation_type = p.estimation_type;
+  {
+    const double thr = (double)p.pnp_reproj_error;
+    d.pnp_thr2f = (float)(thr * thr);     // OpenCV: float t = (float)(thresh*thresh); err <= t
+  }
   if (const char* v = getenv("SF_RANSAC_STOP")) d.dbg_stop = atoi(v);
   {
     // grid for the guided pass: cell >= window radius, at most 48 x 48 cells
@@ -548,9 +562,10 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     const int m = std::min(SF_CHUNK, n - off);
     SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
     if ((rc = sf_launch_match_global(c, view, d_from + off, d_to + off, m)) != SF_OK) return rc;
-    if ((rc = sf_launch_ransac(c, view, d_from + off, d_to + off, m, 1)) != SF_OK) return rc;
+    const bool pnp = c->dparams.estimation_type == 1;
+    if ((rc = (pnp ? sf_launch_pnp : sf_launch_ransac)(c, view, d_from + off, d_to + off, m, 1)) != SF_OK) return rc;
     if ((rc = sf_launch_guided(c, view, d_from + off, d_to + off, m)) != SF_OK) return rc;
-    if ((rc = sf_launch_ransac(c, view, d_from + off, d_to + off, m, 2)) != SF_OK) return rc;
+    if ((rc = (pnp ? sf_launch_pnp : sf_launch_ransac)(c, view, d_from + off, d_to + off, m, 2)) != SF_OK) return rc;
     if ((rc = sf_launch_finalize(c, m, d_out + off)) != SF_OK) return rc;
   }
   return SF_OK;

@@ -29,7 +29,8 @@ struct StoreView {
 // Outcome of one registration pass for one pair (RegistrationVis result + RegistrationInfo)
 struct PassState {
   float T[12];      // row-major 3x4, p_from = T p_to ; all zero when null
-  double var;       // covariance = var * I6 (before the 1e-9 clamp)
+  double var;       // covariance diagonal before the 1e-9 clamp: linear block (all six for 3D-3D)
+  double var_ang;   // angular block (PnP estimator; equals var for 3D-3D)
   int32_t is_null;
   int32_t inliers;
   int32_t matches;
@@ -62,6 +63,8 @@ struct DeviceParams {
   int32_t dbg_stop;        // diagnostics only: truncate k_ransac after phase N (0 = full kernel)
   int32_t grid_gx, grid_gy;   // guided matching: uniform grid over the image (cell >= window radius)
   float grid_inv_cell;
+  int32_t estimation_type;    // 0 = 3D->3D, 1 = PnP
+  float pnp_thr2f;            // (float)(pnp_reproj_error^2)
 };
 
 struct Buf {
@@ -132,6 +135,7 @@ struct sf_context {
 
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
+  bool pnp_attr_set = false;
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
 
@@ -153,6 +157,11 @@ StoreView sf_store_view(const Store& s);
 void sf_prof_begin(sf_context* c, int kernel);
 void sf_prof_end(sf_context* c, int kernel);
 
+// gate selector of the matching kernels: 0 = 3D->3D, 1 = PnP, 2 = PnP without a calibrated camera
+inline int sf_est_mode(const sf_context* c) {
+  return c->dparams.estimation_type == 1 ? (c->dparams.calibrated ? 1 : 2) : 0;
+}
+
 #define SF_HIP(c, expr)                                                                      \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \
@@ -164,6 +173,8 @@ void sf_prof_end(sf_context* c, int kernel);
 int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
 // RANSAC for the pairs in work list `list` (count in counters[ctr]); pass = 1 or 2.
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass);
+// PnP (estimation_type = 1) for the pairs in the same work lists.
+int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass);
 // Guided matching for pairs whose pass 1 succeeded; builds the pass-2 RANSAC work list.
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
 // Assemble sf_result records.

@@ -19,7 +19,8 @@ _lib = None
 def build(force=False):
     """Compile oracle/libsf_oracle.so with gcc (Makefile in this directory)."""
     if force or not os.path.exists(_LIB_PATH) or (
-        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "sf_oracle.c"))
+        os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in
+                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle.h", "sf_oracle_internal.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -66,6 +67,18 @@ def lib():
         L.sfo_sample_triplet.restype = None
         L.sfo_sample_triplet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.sfo_num_threads.restype = C.c_int
+        L.sfo_estimate_motion_3d2d.restype = C.c_int
+        L.sfo_estimate_motion_3d2d.argtypes = [
+            P(_abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+            P(Motion), C.c_void_p]
+        L.sfo_sample_quad.restype = None
+        L.sfo_sample_quad.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.sfo_quartic_roots.restype = C.c_int
+        L.sfo_quartic_roots.argtypes = [C.c_void_p, C.c_void_p]
+        L.sfo_p3p.restype = C.c_int
+        L.sfo_p3p.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sfo_canon_atan2.restype = C.c_double
+        L.sfo_canon_atan2.argtypes = [C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -75,6 +88,7 @@ class Motion(C.Structure):
         ("transform", C.c_float * 12),
         ("is_null", C.c_int),
         ("variance", C.c_double),
+        ("variance_ang", C.c_double),
         ("matches", C.c_int),
         ("inliers", C.c_int),
         ("ransac_best_iteration", C.c_int),
@@ -158,6 +172,48 @@ def estimate_motion_3d3d(params, xyz_from, xyz_to, corr_from, corr_to):
     if rc != 0:
         raise RuntimeError("sfo_estimate_motion_3d3d -> %d" % rc)
     return mo, mask[: cf.size]
+
+
+def estimate_motion_3d2d(params, xyz_from, kp_to, xyz_to, corr_from, corr_to):
+    """util3d::estimateMotion3DTo2D restatement (sf_oracle_pnp.c).  xyz_to may be None."""
+    xf = np.ascontiguousarray(xyz_from, dtype=np.float32)
+    kt = np.ascontiguousarray(kp_to, dtype=_abi.KEYPOINT_DTYPE)
+    xt = None if xyz_to is None else np.ascontiguousarray(xyz_to, dtype=np.float32)
+    cf = np.ascontiguousarray(corr_from, dtype=np.uint16)
+    ct = np.ascontiguousarray(corr_to, dtype=np.uint16)
+    mo = Motion()
+    mask = np.zeros(max(1, cf.size), dtype=np.uint8)
+    rc = lib().sfo_estimate_motion_3d2d(C.byref(params), _ptr(xf), kt.ctypes.data, _ptr(xt), _ptr(cf), _ptr(ct),
+                                        cf.size, C.byref(mo), mask.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("sfo_estimate_motion_3d2d -> %d" % rc)
+    return mo, mask[: cf.size]
+
+
+def sample_quad(seed, it, attempt, m):
+    out = np.zeros(4, dtype=np.uint32)
+    lib().sfo_sample_quad(seed, it, attempt, m, out.ctypes.data)
+    return out
+
+
+def quartic_roots(c):
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    r = np.zeros(4)
+    n = lib().sfo_quartic_roots(c.ctypes.data, r.ctypes.data)
+    return r[:n]
+
+
+def p3p(P, f):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    R = np.zeros((4, 9))
+    t = np.zeros((4, 3))
+    n = lib().sfo_p3p(P.ctypes.data, f.ctypes.data, R.ctypes.data, t.ctypes.data)
+    return R[:n].reshape(n, 3, 3), t[:n]
+
+
+def canon_atan2(y, x):
+    return lib().sfo_canon_atan2(float(y), float(x))
 
 
 def estimate_transform(params, f_from, f_to, debug=False):

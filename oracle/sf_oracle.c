@@ -12,6 +12,7 @@
  * restated from their published sources.
  */
 #include "sf_oracle.h"
+#include "sf_oracle_internal.h"
 
 #include <float.h>
 #include <math.h>
@@ -21,7 +22,6 @@
 #include <omp.h>
 #endif
 
-#define SFO_LANES 256 /* virtual lanes of the canonical block reduction */
 
 /* ========================================================================================= */
 /* NN stage: DataHandler.find_matches, PKG/scripts/data_handler.py:166-209                    */
@@ -143,7 +143,7 @@ double sfo_canon_log(double x) {
   return 2.0 * z * s + (double)e * 0.69314718055994530942;
 }
 
-static uint64_t sfo_mix(uint64_t z) {
+uint64_t sfo_mix(uint64_t z) {
   z += 0x9E3779B97F4A7C15ULL;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
@@ -361,7 +361,7 @@ void sfo_fit_rigid(const double* src, const double* dst, int n, double R[9], dou
 
 /* Canonical block sum: SFO_LANES strided partials, xor-butterfly inside each group of 64,
  * then the four group sums folded left to right (what a 256-thread workgroup computes). */
-static double sfo_block_sum(const double* x, int n) {
+double sfo_block_sum(const double* x, int n) {
   double part[SFO_LANES], tmp[SFO_LANES];
   for (int l = 0; l < SFO_LANES; ++l) {
     double s = 0.0;
@@ -415,7 +415,7 @@ static void sfo_fit_rigid_masked(const float* src, const float* dst, int m, cons
 /* squared residual of one correspondence under float coefficients c[12] (row-major 3x4):
  * [upstream pcl::SampleConsensusModelRegistration::selectWithinDistance: float Matrix4f * Vector4f,
  *  (p_tr - pt_tgt).squaredNorm()] with the canonical fma chain. */
-static float sfo_residual2(const float c[12], const float* p, const float* q) {
+float sfo_residual2(const float c[12], const float* p, const float* q) {
   float px = fmaf(c[2], p[2], fmaf(c[1], p[1], fmaf(c[0], p[0], c[3])));
   float py = fmaf(c[6], p[2], fmaf(c[5], p[1], fmaf(c[4], p[0], c[7])));
   float pz = fmaf(c[10], p[2], fmaf(c[9], p[1], fmaf(c[8], p[0], c[11])));
@@ -423,7 +423,7 @@ static float sfo_residual2(const float c[12], const float* p, const float* q) {
   return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
-static int sfo_finite3(const float* p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
+int sfo_finite3(const float* p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
 static int sfo_nonzero3(const float* p) { return p[0] != 0.0f || p[1] != 0.0f || p[2] != 0.0f; }
 
 static int sfo_popcount_row(const uint8_t* a, const uint8_t* b, int cols) {
@@ -631,6 +631,7 @@ int sfo_estimate_motion_3d3d(const sf_params* p,
   memset(out, 0, sizeof(*out));
   out->is_null = 1;
   out->variance = 1.0;            /* *covariance = eye(6) */
+  out->variance_ang = 1.0;
   out->ransac_best_iteration = -1;
 
   /* [upstream util3d::findCorrespondences] id-matched, finite and non-zero 3D pairs,
@@ -818,6 +819,7 @@ int sfo_estimate_motion_3d3d(const sf_params* p,
       if (n_inl >= 3) {
         double variance = sfo_variance(d2_list, n_last, scratch); /* model->computeVariance() */
         out->variance = variance;                                 /* *covariance *= variance   */
+        out->variance_ang = variance;
         have_model = 1;
         n_inliers = n_inl;
         if (inlier_mask_out) for (int i = 0; i < m; ++i) if (inl[i]) inlier_mask_out[orig[i]] = 1;
@@ -853,7 +855,8 @@ int sfo_estimate_motion_3d3d(const sf_params* p,
 typedef struct {
   float transform[12];
   int is_null;
-  double cov_diag;   /* covariance = cov_diag * I6 (before the clamp) */
+  double cov_diag;   /* covariance diagonal before the clamp: linear block ...   */
+  double cov_diag_ang;   /* ... and angular block (equal for the 3D-3D estimator)  */
   int inliers, matches;
 } sfo_pass;
 
@@ -875,13 +878,14 @@ static int sfo_validate(const sf_features* f) {
 }
 
 /* One computeTransformationFromFeats call (myRegistration.cpp:225-303 ->
- * myRegistrationVis.cpp:441-1410) with estimation type 0 and forward-only estimation. */
+ * myRegistrationVis.cpp:441-1410) with estimation type 0 or 1 and forward-only estimation. */
 static int sfo_registration_pass(const sf_params* p, const sf_features* from, const sf_features* to,
                                  const float* guess, int guess_is_null, sfo_pass* out, int* guided,
                                  uint16_t* cf, uint16_t* ct, int* nc) {
   memset(out, 0, sizeof(*out));
   out->is_null = 1;
   out->cov_diag = 1.0;  /* myRegistrationVis.cpp:923 */
+  out->cov_diag_ang = 1.0;
   *guided = 0;
   *nc = 0;
   int kf = from->rows, kt = to->rows;
@@ -905,12 +909,19 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
   }
   /* :928 if (wordsTo.size()) ... else "Missing correspondences" */
   if (n_words_to_2d > 0) {
-    /* :1117-1118 */
-    if (n_words_from >= p->min_inliers && n_words_to >= p->min_inliers) {
+    const int calibrated = p->image_width > 0 && p->image_height > 0 && p->fx > 0.0 && p->fy > 0.0;
+    /* 3D-3D gate :1117-1118 ; PnP gate :1059 (isValidForProjection) and :1070-1071 */
+    const int gate = p->estimation_type == 1
+                         ? (calibrated && n_words_from >= p->min_inliers && n_words_to_2d >= p->min_inliers)
+                         : (n_words_from >= p->min_inliers && n_words_to >= p->min_inliers);
+    if (gate) {
       sfo_motion mo;
-      rc = sfo_estimate_motion_3d3d(p, from->xyz, to->xyz, cf, ct, *nc, &mo, NULL);
+      rc = p->estimation_type == 1
+               ? sfo_estimate_motion_3d2d(p, from->xyz, to->kpts, to->n3d > 0 ? to->xyz : NULL, cf, ct, *nc, &mo, NULL)
+               : sfo_estimate_motion_3d3d(p, from->xyz, to->xyz, cf, ct, *nc, &mo, NULL);
       if (rc != SF_OK) return rc;
       out->cov_diag = mo.variance;
+      out->cov_diag_ang = mo.variance_ang;
       out->inliers = mo.inliers;
       out->matches = mo.matches;
       if (!mo.is_null) { memcpy(out->transform, mo.transform, sizeof(out->transform)); out->is_null = 0; }
@@ -955,7 +966,8 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if (!p || !out) return SF_EINVAL;
   if ((rc = sfo_validate(from)) != SF_OK) return rc;
   if ((rc = sfo_validate(to)) != SF_OK) return rc;
-  if (p->estimation_type != 0) return SF_EINVAL;
+  if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
+  if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations != 0)) return SF_EINVAL;
   memset(out, 0, sizeof(*out));
   int cap = from->rows > to->rows ? from->rows : to->rows;
   if (cap < 1) cap = 1;
@@ -981,9 +993,10 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if (n_c2) *n_c2 = nc2;
 
   /* myRegistration.cpp:279-295: covariance (never empty here) with diagonal clamped to 1e-9 */
-  double cd = r2.cov_diag;
+  double cd = r2.cov_diag, ca = r2.cov_diag_ang;
   if (cd <= 1e-9) cd = 1e-9;
-  for (int i = 0; i < 6; ++i) out->covariance[7 * i] = cd;
+  if (ca <= 1e-9) ca = 1e-9;
+  for (int i = 0; i < 3; ++i) { out->covariance[7 * i] = cd; out->covariance[7 * (i + 3)] = ca; }
   out->inliers = r2.inliers; out->matches = r2.matches;
   out->inliers_pass1 = r1.inliers; out->matches_pass1 = r1.matches;
   out->pass1_success = (uint8_t)!r1.is_null;

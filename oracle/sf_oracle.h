@@ -69,7 +69,8 @@ int sfo_match_guided(const sf_params* p, const float* guess,
 typedef struct sfo_motion {
   float  transform[12];
   int    is_null;
-  double variance;      /* covariance = variance * I6 */
+  double variance;      /* covariance = variance * I6 (3D-3D); linear block (PnP)  */
+  double variance_ang;  /* angular block of the covariance (PnP); = variance for 3D-3D */
   int    matches;
   int    inliers;
   int    ransac_best_iteration;   /* diagnostics */
@@ -80,6 +81,15 @@ typedef struct sfo_motion {
 
 int sfo_estimate_motion_3d3d(const sf_params* p,
                              const float* xyz_from, const float* xyz_to,
+                             const uint16_t* corr_from, const uint16_t* corr_to, int n_corr,
+                             sfo_motion* out, uint8_t* inlier_mask /* optional, n_corr */);
+
+/* util3d::estimateMotion3DTo2D as called at PKG/src/myRegistrationVis.cpp:1077-1091
+ * [upstream rtabmap util3d_motion_estimation.cpp; cv::solvePnPRansac].  Restated in
+ * sf_oracle_pnp.c (see its header for what is and is not OpenCV's arithmetic).
+ * xyz_to may be NULL ("to" frame without 3D points). */
+int sfo_estimate_motion_3d2d(const sf_params* p,
+                             const float* xyz_from, const sf_keypoint* kp_to, const float* xyz_to,
                              const uint16_t* corr_from, const uint16_t* corr_to, int n_corr,
                              sfo_motion* out, uint8_t* inlier_mask /* optional, n_corr */);
 
@@ -103,6 +113,10 @@ double sfo_canon_log(double x);
 void   sfo_sample_triplet(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m,
                           uint32_t out[3]);
 int    sfo_num_threads(void);
+void   sfo_sample_quad(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m, uint32_t out[4]);
+int    sfo_quartic_roots(const double c[5], double r[4]);
+int    sfo_p3p(const double P[3][3], const double f[3][3], double R[4][9], double t[4][3]);
+double sfo_canon_atan2(double y, double x);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,118 @@
+"""GPU parity tests of the PnP estimator (estimation_type = 1, myRegistrationVis.cpp:1055-1112) through
+the C-ABI against the CPU oracle on identical seeded inputs.
+
+Bars: correspondences, counts and flags bit-exact; pose within BASELINE.json's 1e-4 m / 1e-3 rad of the
+oracle (the canonical arithmetic is expected to make them bit-identical); covariance 1e-9 relative."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi, synth
+from test_gpu_verify import assert_result_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def pnp_params(iters=500):
+    p = synth.camera_params()
+    p.iterations = iters
+    p.estimation_type = 1
+    return p
+
+
+@pytest.fixture(scope="module")
+def finder():
+    from multi_robot_slam_separators_amd import lib
+    f = lib.SeparatorFinder(pnp_params())
+    yield f
+    f.close()
+
+
+def test_pnp_batch_parity_mixed_pairs(finder, oracle):
+    A, B, is_true, Ts = synth.make_pairs(4242, 48, k=500, cols=32, true_frac=0.4)
+    got = finder.estimate_transform_batch(A, B)
+    n_exact = 0
+    for i in range(len(A)):
+        o, c1, c2 = oracle.estimate_transform(finder.params, A[i], B[i], debug=True)
+        g1 = finder.debug_correspondences(i, 1)
+        assert np.array_equal(g1[0], c1[0]) and np.array_equal(g1[1], c1[1]), "pass-1 correspondences %d" % i
+        if o["pass2_guided"]:
+            g2 = finder.debug_correspondences(i, 2)
+            assert np.array_equal(g2[0], c2[0]) and np.array_equal(g2[1], c2[1]), "pass-2 correspondences %d" % i
+        assert_result_parity(got[i], o, "pair %d" % i)
+        assert bool(got[i]["success"]) == bool(is_true[i])
+        if is_true[i]:
+            dt, dr = synth.pose_error(got[i], Ts[i])
+            assert dt < 0.1 and dr < 0.01
+        n_exact += int(got[i].tobytes() == o.tobytes())
+    print("bit-identical PnP results: %d / %d" % (n_exact, len(A)))
+    assert n_exact >= len(A) - 2
+
+
+@pytest.mark.parametrize("k,cols,iters", [(1000, 32, 2000), (500, 64, 300), (77, 32, 100), (200, 16, 1)])
+def test_pnp_other_configs(oracle, k, cols, iters):
+    from multi_robot_slam_separators_amd import lib
+    p = pnp_params(iters)
+    p.max_features = k
+    A, B, is_true, _ = synth.make_pairs(900 + k, 10, k=k, cols=cols, true_frac=0.5)
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    for i in range(len(A)):
+        assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "k=%d pair %d" % (k, i))
+    if iters >= 100:
+        assert got["success"][is_true].all()
+
+
+def test_pnp_fixed_iteration_count_and_seed(oracle):
+    from multi_robot_slam_separators_amd import lib
+    A, B, _, _ = synth.make_pairs(31, 8, k=300, true_frac=1.0)
+    for adaptive, seed in ((0, 12345), (1, 99), (0, 7)):
+        p = pnp_params(300)
+        p.ransac_adaptive_stop = adaptive
+        p.seed = seed
+        with lib.SeparatorFinder(p) as f:
+            got = f.estimate_transform_batch(A, B)
+        for i in range(len(A)):
+            assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "adaptive=%d pair %d" % (adaptive, i))
+
+
+def test_pnp_edge_cases(finder, oracle):
+    rng = np.random.default_rng(3)
+    p = finder.params
+    A, B, _, _ = synth.make_pairs(77, 2, k=300, true_frac=1.0)
+    a, b = A[0], B[0]
+    no3d_to = _abi.FeatureArrays(b.desc, np.zeros((0, 3), np.float32), b.kpts)      # rms-reprojection covariance
+    no3d_from = _abi.FeatureArrays(a.desc, np.zeros((0, 3), np.float32), a.kpts)    # nothing to estimate from
+    nan_to = _abi.FeatureArrays(b.desc, b.xyz.copy(), b.kpts)
+    nan_to.xyz[::2] = np.nan                                                          # covariance from the finite half
+    nan_from = _abi.FeatureArrays(a.desc, a.xyz.copy(), a.kpts)
+    nan_from.xyz[::3] = np.nan
+    zero_from = _abi.FeatureArrays(a.desc, a.xyz.copy(), a.kpts)
+    zero_from.xyz[5] = 0.0                                                            # zero points are NOT dropped by PnP
+    small = synth.make_keyframe(rng, 4)
+    empty = _abi.FeatureArrays(np.zeros((0, 32), np.uint8), np.zeros((0, 3), np.float32),
+                               np.zeros(0, _abi.KEYPOINT_DTYPE))
+    cases = [(a, no3d_to), (no3d_from, b), (a, nan_to), (nan_from, b), (zero_from, b), (small, small),
+             (empty, b), (a, empty), (a, a)]
+    got = finder.estimate_transform_batch([c[0] for c in cases], [c[1] for c in cases])
+    for i, (x, y) in enumerate(cases):
+        assert_result_parity(got[i], oracle.estimate_transform(p, x, y), "edge case %d" % i)
+    assert got[0]["success"] == 1 and got[1]["success"] == 0 and got[2]["success"] == 1
+    d = np.diag(got[0]["covariance"].reshape(6, 6))
+    assert np.all(d == d[0])
+
+
+def test_pnp_uncalibrated_and_unsupported_flags(oracle):
+    from multi_robot_slam_separators_amd import lib
+    A, B, _, _ = synth.make_pairs(5, 3, k=200, true_frac=1.0)
+    p = pnp_params(100)
+    p.image_width = 0           # stereoCamModelB->isValidForProjection() false: :1059-1065
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    for i in range(3):
+        assert got[i]["success"] == 0
+        assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "uncalibrated %d" % i)
+    for field, val in (("pnp_flags", 1), ("pnp_refine_iterations", 1), ("estimation_type", 2)):
+        q = pnp_params(100)
+        setattr(q, field, val)
+        with pytest.raises(Exception):
+            lib.SeparatorFinder(q)
