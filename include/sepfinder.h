@@ -99,7 +99,8 @@ typedef struct sf_params {
   /* PnP branch (estimation_type = 1): myRegistrationVis.cpp:59-61,1083-1085 [upstream defaults]  */
   float   pnp_reproj_error;        /* 2.0  Vis/PnPReprojError (px); inlier iff error <= this  */
   int32_t pnp_flags;               /* 0    Vis/PnPFlags: only 0 (cv::SOLVEPNP_ITERATIVE)      */
-  int32_t pnp_refine_iterations;   /* 0    Vis/PnPRefineIterations: only 0                    */
+  int32_t pnp_refine_iterations;   /* 0    Vis/PnPRefineIterations (rtabmap util3d::solvePnPRansac
+                                           re-solve / re-select rounds, 3-sigma threshold)        */
   int32_t reserved[5];
 } sf_params;
 

@@ -40,6 +40,7 @@ struct PnpLds {
   float* e1;        // [kcap] squared 3D error of the members (+inf elsewhere)
   float* e2;        // [kcap] angular error
   uint8_t* mask;    // [kcap]
+  uint8_t* mask_b;  // [kcap] second inlier set of the refinement rounds
   int* counts;      // [iterations]
   double* red;      // [4][32]
   int* misc;        // [16]
@@ -115,14 +116,14 @@ __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64
 }
 
 // Normal equations of the reprojection error over the members of L.mask at pose (q, t).
-__device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, const double (&q)[4],
-                                     const double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
+__device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask,
+                                     const double (&q)[4], const double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
   double R[9];
   sfd::quat_to_R(q, R);
 #pragma unroll
   for (int k = 0; k < PNP_NSUM; ++k) ne[k] = 0.0;
   for (int i = tid; i < m; i += SF_BLOCK) {
-    if (!L.mask[i]) continue;
+    if (!mask[i]) continue;
     const float4 p = L.obj[i];
     const float2 o = L.img[i];
     const double Px = (double)p.x, Py = (double)p.y, Pz = (double)p.z;
@@ -157,6 +158,89 @@ __device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, 
     }
   }
   block_sum_vec32<PNP_NSUM>(ne, L.red, tid);
+}
+
+// Levenberg-Marquardt over the members of `mask` from pose (q, t): at most 20 evaluations, diagonal
+// scaled by 1 + lambda [upstream cvFindExtrinsicCameraParams2 / CvLevMarq].  Every lane runs the same
+// scalar control flow on the block-reduced sums.  ne returns the normal equations at the final pose.
+__device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask, double (&q)[4],
+                              double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
+  pnp_normal_eq(L, cam, m, mask, q, t, ne, tid);
+  double lambda = 1e-3;
+  for (int iter = 0; iter < 20; ++iter) {
+    double d[6];
+    if (!sfd::solve6(ne, lambda, d)) {
+      lambda = lambda * 10.0;
+      if (lambda > 1e12) break;
+      continue;
+    }
+    const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
+    const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
+    const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
+    double qc[4], tc[3];
+    qc[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
+    qc[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
+    qc[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
+    qc[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
+    const double qn = 1.0 / sqrt(((qc[0] * qc[0] + qc[1] * qc[1]) + qc[2] * qc[2]) + qc[3] * qc[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
+    double nc[PNP_NSUM];
+    pnp_normal_eq(L, cam, m, mask, qc, tc, nc, tid);
+    // a step below float epsilon relative to the parameters ends the iteration either way
+    const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
+    const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
+    if (nc[27] < ne[27]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = qc[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[i] = tc[i];
+#pragma unroll
+      for (int i = 0; i < PNP_NSUM; ++i) ne[i] = nc[i];
+      lambda = lambda * 0.1;
+      if (lambda < 1e-16) lambda = 1e-16;
+    } else {
+      lambda = lambda * 10.0;
+      if (lambda > 1e12) break;
+    }
+    if (dd <= 1.4e-14 * tt) break;
+  }
+}
+
+// rtabmap computeReprojErrors: members = points in front of the camera with reprojection error (px,
+// not squared) <= thr under the float-rounded pose; L.e1[i] receives member i's error.
+__device__ inline int pnp_select(const PnpLds& L, const PnpCam& cam, int m, const double (&q)[4],
+                                 const double (&t)[3], float thr, uint8_t* mask, int tid) {
+  double Rd[9];
+  sfd::quat_to_R(q, Rd);
+  float c[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[4 * i + j] = (float)Rd[3 * i + j];
+    c[4 * i + 3] = (float)t[i];
+  }
+  int n = 0;
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    const float4 P = L.obj[i];
+    const float2 o = L.img[i];
+    const float X = __fmaf_rn(c[2], P.z, __fmaf_rn(c[1], P.y, __fmaf_rn(c[0], P.x, c[3])));
+    const float Y = __fmaf_rn(c[6], P.z, __fmaf_rn(c[5], P.y, __fmaf_rn(c[4], P.x, c[7])));
+    const float Z = __fmaf_rn(c[10], P.z, __fmaf_rn(c[9], P.y, __fmaf_rn(c[8], P.x, c[11])));
+    bool in = false;
+    if (Z > 0.0f) {
+      const float du = __fmaf_rn(cam.fxf, __fdiv_rn(X, Z), -o.x);
+      const float dv = __fmaf_rn(cam.fyf, __fdiv_rn(Y, Z), -o.y);
+      const float e = __fsqrt_rn(__fmaf_rn(dv, dv, du * du));
+      in = e <= thr;
+      if (in) L.e1[i] = e;
+    }
+    mask[i] = in ? 1 : 0;
+    n += in ? 1 : 0;
+  }
+  return block_sum_i(n, L.misc, tid);
 }
 
 // value of rank `rank` among the finite entries of arr[0..m4) (+inf padded): rank counting, 4 per read
@@ -205,7 +289,8 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     L.cidx = (uint32_t*)p; p += (size_t)kcap * 4;
     L.counts = (int*)p; p += (size_t)((max_it + 4) & ~3) * 4;
     L.misc = (int*)p; p += 16 * 4;
-    L.mask = p;
+    L.mask = p; p += kcap;
+    L.mask_b = p;
   }
 
   // ---- estimateMotion3DTo2D: ids of words2B found in words3A with a finite 3D point ---------------
@@ -266,6 +351,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     return;
   }
 
+  if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
   PnpCam cam;
   cam.fx = P.fx; cam.fy = P.fy;
   cam.fxf = (float)P.fx; cam.fyf = (float)P.fy;
@@ -306,6 +392,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     }
     __syncthreads();
   }
+  if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return; }
   const int best_it = L.misc[0];
   if (best_it < 0) {   // solvePnPRansac returned false: no inliers
     if (tid == 0) pass[pair] = ps;
@@ -323,6 +410,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
   }
   n_inl = block_sum_i(n_inl, L.misc, tid);   // also orders the mask writes before the reads below
 
+  if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }
   // ---- final solve on the inliers: Levenberg-Marquardt, at most 20 evaluations ------------------------
   double q[4], t[3];
   {
@@ -336,50 +424,64 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     sfd::R_to_quat(Rb, q);
   }
   double ne[PNP_NSUM];
-  pnp_normal_eq(L, cam, m, q, t, ne, tid);
-  {
-    double lambda = 1e-3;
-    for (int iter = 0; iter < 20; ++iter) {
-      double d[6];
-      if (!sfd::solve6(ne, lambda, d)) {
-        lambda = lambda * 10.0;
-        if (lambda > 1e12) break;
+  pnp_lm(L, cam, m, L.mask, q, t, ne, tid);
+
+  // ---- rtabmap util3d::solvePnPRansac refinement rounds (Vis/PnPRefineIterations > 0) ---------------------
+  const uint8_t* inl = L.mask;
+  const int min_count = P.min_inliers > 4 ? P.min_inliers : 4;
+  if (n_inl >= min_count && P.pnp_refine_iterations > 0) {
+    const float inlier_thr = P.pnp_reproj_error;
+    float error_threshold = inlier_thr;
+    int refine_iterations = 0;
+    bool inlier_changed = false;
+    uint8_t* prev = L.mask;
+    uint8_t* neu = L.mask_b;
+    int n_prev = n_inl, n_new = 0;
+    for (int i = tid; i < m; i += SF_BLOCK) neu[i] = 0;
+    int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;   // last four pushed sizes (z1 newest)
+    do {
+      pnp_lm(L, cam, m, prev, q, t, ne, tid);            // solvePnP from the current model
+      z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
+      ++n_sizes;
+      __syncthreads();
+      n_new = pnp_select(L, cam, m, q, t, error_threshold, neu, tid);
+      if (n_new < min_count) {
+        ++refine_iterations;
+        if (refine_iterations >= P.pnp_refine_iterations) break;
         continue;
       }
-      const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
-      const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
-      const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
-      double qc[4], tc[3];
-      qc[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
-      qc[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
-      qc[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
-      qc[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
-      const double qn = 1.0 / sqrt(((qc[0] * qc[0] + qc[1] * qc[1]) + qc[2] * qc[2]) + qc[3] * qc[3]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
-      double nc[PNP_NSUM];
-      pnp_normal_eq(L, cam, m, qc, tc, nc, tid);
-      if (nc[27] < ne[27]) {
-        const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
-        const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = qc[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = tc[i];
-#pragma unroll
-        for (int i = 0; i < PNP_NSUM; ++i) ne[i] = nc[i];
-        lambda = lambda * 0.1;
-        if (lambda < 1e-16) lambda = 1e-16;
-        if (dd <= 1.4e-14 * tt) break;
-      } else {
-        lambda = lambda * 10.0;
-        if (lambda > 1e12) break;
+      // uMean / uVariance of the members' errors (block-order sums, float results)
+      double s1[1] = {0.0};
+      for (int i = tid; i < m; i += SF_BLOCK) if (neu[i]) s1[0] += (double)L.e1[i];
+      block_sum_vec32<1>(s1, L.red, tid);
+      const float mean = (float)(s1[0] / (double)n_new);
+      float variance = 0.0f;
+      if (n_new > 1) {
+        double s2[1] = {0.0};
+        for (int i = tid; i < m; i += SF_BLOCK) {
+          if (neu[i]) { const float dlt = L.e1[i] - mean; s2[0] += (double)(dlt * dlt); }
+        }
+        block_sum_vec32<1>(s2, L.red, tid);
+        variance = (float)(s2[0] / (double)(n_new - 1));
       }
-    }
+      const float sthr = (float)P.refine_sigma * __fsqrt_rn(variance);
+      error_threshold = sthr < inlier_thr ? sthr : inlier_thr;
+      inlier_changed = false;
+      { uint8_t* tp = prev; prev = neu; neu = tp; const int tn = n_prev; n_prev = n_new; n_new = tn; }
+      if (n_new != n_prev) {
+        if (n_sizes >= 4 && z1 == z3 && z2 == z4) break;   // oscillating
+        inlier_changed = true;
+        continue;
+      }
+      int diff = 0;
+      for (int i = tid; i < m; i += SF_BLOCK) diff |= (prev[i] != neu[i]) ? 1 : 0;
+      inlier_changed = block_sum_i(diff, L.misc, tid) != 0;
+    } while (inlier_changed && ++refine_iterations < P.pnp_refine_iterations);
+    inl = neu;
+    n_inl = n_new;
   }
 
+  if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }
   ps.inliers = n_inl;
   if (n_inl < P.min_inliers) {
     if (tid == 0) pass[pair] = ps;
@@ -421,7 +523,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     int cnt = 0;
     for (int i = tid; i < m4; i += SF_BLOCK) {
       float v1 = __int_as_float(0x7F800000), v2 = __int_as_float(0x7F800000);
-      if (i < m && L.mask[i]) {
+      if (i < m && inl[i]) {
         const float* b = xT + 3 * (L.cidx[i] >> 16);
         const float bx = b[0], by = b[1], bz = b[2];
         if (sfd::finite3(bx, by, bz)) {
@@ -448,7 +550,8 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
       ps.var_ang = 2.1981 * (double)rank_value(L.e2, m, oi >> 2, &L.red[121], tid);
     }
   } else {
-    const double v = (double)sqrtf((float)ne[27] / (float)n_inl);
+    pnp_normal_eq(L, cam, m, inl, q, t, ne, tid);
+    const double v = (double)__fsqrt_rn((float)ne[27] / (float)n_inl);
     ps.var = v;
     ps.var_ang = v;
   }
@@ -459,7 +562,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
 
 size_t sf_pnp_lds_bytes(int kcap, int iterations) {
   const int it = iterations > 0 ? iterations : 0;
-  return (size_t)kcap * (16 + 8 + 4 + 4 + 4 + 1) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4;
+  return (size_t)kcap * (16 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4;
 }
 
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {

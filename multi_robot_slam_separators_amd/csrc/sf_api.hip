@@ -382,7 +382,7 @@ static int fill_device_params(sf_context* c) {
     return sf_fail(c, SF_EINVAL, "estimation_type %d not implemented (0 = 3D->3D, 1 = PnP)", p.estimation_type);
   if (p.estimation_type == 1) {
     if (p.pnp_flags != 0) return sf_fail(c, SF_EINVAL, "pnp_flags %d not implemented (0 = SOLVEPNP_ITERATIVE only)", p.pnp_flags);
-    if (p.pnp_refine_iterations != 0) return sf_fail(c, SF_EINVAL, "pnp_refine_iterations %d not implemented (0 only)", p.pnp_refine_iterations);
+    if (p.pnp_refine_iterations < 0) return sf_fail(c, SF_EINVAL, "pnp_refine_iterations must be >= 0");
     if (!(p.pnp_reproj_error > 0.f)) return sf_fail(c, SF_EINVAL, "pnp_reproj_error must be > 0");
   }
   if (p.min_inliers < 1) return sf_fail(c, SF_EINVAL, "min_inliers must be >= 1 (myRegistrationVis.cpp:117)");
@@ -409,6 +409,8 @@ static int fill_device_params(sf_context* c) {
   d.hlim = (float)(p.image_height - 1);
   memcpy(d.L, p.local_transform, sizeof(d.L));
   d.estimation_type = p.estimation_type;
+  d.pnp_reproj_error = p.pnp_reproj_error;
+  d.pnp_refine_iterations = p.pnp_refine_iterations;
   {
     const double thr = (double)p.pnp_reproj_error;
     d.pnp_thr2f = (float)(thr * thr);     // OpenCV: float t = (float)(thresh*thresh); err <= t

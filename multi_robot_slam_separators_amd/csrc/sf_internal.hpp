@@ -65,6 +65,8 @@ struct DeviceParams {
   float grid_inv_cell;
   int32_t estimation_type;    // 0 = 3D->3D, 1 = PnP
   float pnp_thr2f;            // (float)(pnp_reproj_error^2)
+  float pnp_reproj_error;
+  int32_t pnp_refine_iterations;
 };
 
 struct Buf {

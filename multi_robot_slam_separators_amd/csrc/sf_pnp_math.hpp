@@ -80,7 +80,7 @@ __device__ inline void quartic_roots(const double (&c)[5], double (&r)[4], bool 
       if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
       const double step = fabs(mn - m);
       m = mn;
-      if (step <= 1e-16 * fabs(m)) break;
+      if (step <= 4e-16 * fabs(m)) break;   // within two ulps: converged
     }
     if (!(m > 0.0)) return;
     const double s = sqrt(2.0 * m);

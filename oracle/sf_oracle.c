@@ -967,7 +967,7 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if ((rc = sfo_validate(from)) != SF_OK) return rc;
   if ((rc = sfo_validate(to)) != SF_OK) return rc;
   if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
-  if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations != 0)) return SF_EINVAL;
+  if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations < 0)) return SF_EINVAL;
   memset(out, 0, sizeof(*out));
   int cap = from->rows > to->rows ? from->rows : to->rows;
   if (cap < 1) cap = 1;

@@ -93,7 +93,7 @@ int sfo_quartic_roots(const double c[5], double r[4]) {
       if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
       const double step = fabs(mn - m);
       m = mn;
-      if (step <= 1e-16 * fabs(m)) break;
+      if (step <= 4e-16 * fabs(m)) break;   /* within two ulps: converged */
     }
     if (!(m > 0.0)) return 0;
     const double s = sqrt(2.0 * m);
@@ -437,20 +437,51 @@ static int sfo_pnp_refine(const sfo_pnp_problem* pb, const uint8_t* mask, double
     for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
     sfo_pnp_normal_eq(pb, mask, qc, tc, nc, scratch);
     ++evals;
+    /* a step below float epsilon relative to the parameters ends the iteration whether or not it
+     * lowered the error [upstream CvLevMarq: |param - prevParam| / |prevParam| < FLT_EPSILON] */
+    const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
+    const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
     if (nc[27] < ne[27]) {
-      const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
-      const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
       memcpy(q, qc, sizeof(qc)); memcpy(t, tc, sizeof(tc)); memcpy(ne, nc, sizeof(nc));
       lambda = lambda * 0.1;
       if (lambda < 1e-16) lambda = 1e-16;
-      if (dd <= 1.4e-14 * tt) break;
     } else {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
     }
+    if (dd <= 1.4e-14 * tt) break;
   }
   *final_err = ne[27];
   return evals;
+}
+
+/* [upstream rtabmap util3d computeReprojErrors] members = points in front of the camera whose
+ * reprojection error (pixels, NOT squared) is <= thr under the float-rounded pose; errs[i] receives
+ * member i's error.  Canonical fma chain, IEEE float division and sqrt. */
+static int sfo_pnp_select(const sfo_pnp_problem* pb, const double q[4], const double t[3], float thr,
+                          uint8_t* mask, float* errs) {
+  double Rd[9];
+  sfo_quat_to_R(q, Rd);
+  float c[12];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c[4 * i + j] = (float)Rd[3 * i + j]; c[4 * i + 3] = (float)t[i]; }
+  int n = 0;
+  for (int i = 0; i < pb->m; ++i) {
+    const float* P = pb->obj + 3 * i;
+    const float X = fmaf(c[2], P[2], fmaf(c[1], P[1], fmaf(c[0], P[0], c[3])));
+    const float Y = fmaf(c[6], P[2], fmaf(c[5], P[1], fmaf(c[4], P[0], c[7])));
+    const float Z = fmaf(c[10], P[2], fmaf(c[9], P[1], fmaf(c[8], P[0], c[11])));
+    int in = 0;
+    if (Z > 0.0f) {
+      const float du = fmaf(pb->fxf, X / Z, -pb->dpx[i]);
+      const float dv = fmaf(pb->fyf, Y / Z, -pb->dpy[i]);
+      const float e = sqrtf(fmaf(dv, dv, du * du));
+      in = e <= thr;
+      if (in) errs[i] = e;
+    }
+    mask[i] = (uint8_t)in;
+    n += in;
+  }
+  return n;
 }
 
 /* value of rank `rank` (0-based) among v[0..n): only the VALUE matters */
@@ -489,6 +520,7 @@ int sfo_estimate_motion_3d2d(const sf_params* p,
   float* dpy = (float*)malloc((size_t)cap * sizeof(float));
   int32_t* orig = (int32_t*)malloc((size_t)cap * sizeof(int32_t));
   uint8_t* mask = (uint8_t*)calloc((size_t)cap, 1);
+  uint8_t* mask_b = (uint8_t*)calloc((size_t)cap, 1);
   uint8_t* has3 = (uint8_t*)calloc((size_t)cap, 1);
   float* e1 = (float*)malloc((size_t)cap * sizeof(float));
   float* e2 = (float*)malloc((size_t)cap * sizeof(float));
@@ -496,7 +528,7 @@ int sfo_estimate_motion_3d2d(const sf_params* p,
   const int max_it = p->iterations > 0 ? p->iterations : 0;
   int32_t* counts = (int32_t*)malloc((size_t)(max_it + 1) * sizeof(int32_t));
   int rc = SF_OK;
-  if (!obj || !dst3 || !dpx || !dpy || !orig || !mask || !has3 || !e1 || !e2 || !scratch || !counts) {
+  if (!obj || !dst3 || !dpx || !dpy || !orig || !mask || !mask_b || !has3 || !e1 || !e2 || !scratch || !counts) {
     rc = SF_ENOMEM;
     goto done;
   }
@@ -567,8 +599,63 @@ int sfo_estimate_motion_3d2d(const sf_params* p,
     double err = 0.0;
     out->refine_rounds = sfo_pnp_refine(&pb, mask, q, t, &err, scratch);
 
+    /* ---- [upstream rtabmap util3d::solvePnPRansac] refinement rounds (Vis/PnPRefineIterations > 0):
+     * re-solve on the current inliers, re-select with threshold min(reprojError, sigma * stddev of
+     * the inlier errors), until the inlier set is stable -- the same loop shape as PCL's refineModel */
+    uint8_t* inl = mask;
+    const int min_count = p->min_inliers > 4 ? p->min_inliers : 4;
+    if (n_inl >= min_count && p->pnp_refine_iterations > 0) {
+      const float inlier_thr = p->pnp_reproj_error;
+      float error_threshold = inlier_thr;
+      int refine_iterations = 0, inlier_changed = 0;
+      uint8_t* prev = mask;     /* prev_inliers = inliers */
+      uint8_t* neu = mask_b;    /* new_inliers (empty)    */
+      int n_prev = n_inl, n_new = 0;
+      int sizes[64], n_sizes = 0;
+      double qn[4], tn[3];
+      memcpy(qn, q, sizeof(qn)); memcpy(tn, t, sizeof(tn));
+      do {
+        double e_unused;
+        out->refine_rounds += sfo_pnp_refine(&pb, prev, qn, tn, &e_unused, scratch);   /* solvePnP, extrinsic guess */
+        if (n_sizes < 64) sizes[n_sizes] = n_prev;
+        ++n_sizes;
+        n_new = sfo_pnp_select(&pb, qn, tn, error_threshold, neu, e1);
+        if (n_new < min_count) {
+          ++refine_iterations;
+          if (refine_iterations >= p->pnp_refine_iterations) break;
+          continue;
+        }
+        /* uMean / uVariance of the inlier errors (block-order sums, float results) */
+        for (int i = 0; i < m; ++i) scratch[i] = neu[i] ? (double)e1[i] : 0.0;
+        const float mean = (float)(sfo_block_sum(scratch, m) / (double)n_new);
+        float variance = 0.0f;
+        if (n_new > 1) {
+          for (int i = 0; i < m; ++i) {
+            const float d = e1[i] - mean;
+            scratch[i] = neu[i] ? (double)(d * d) : 0.0;
+          }
+          variance = (float)(sfo_block_sum(scratch, m) / (double)(n_new - 1));
+        }
+        const float sthr = (float)p->refine_sigma * sqrtf(variance);
+        error_threshold = sthr < inlier_thr ? sthr : inlier_thr;
+        inlier_changed = 0;
+        { uint8_t* tmp = prev; prev = neu; neu = tmp; int tn_ = n_prev; n_prev = n_new; n_new = tn_; }
+        if (n_new != n_prev) {
+          if (n_sizes >= 4 && n_sizes <= 64 &&
+              sizes[n_sizes - 1] == sizes[n_sizes - 3] && sizes[n_sizes - 2] == sizes[n_sizes - 4])
+            break;   /* oscillating */
+          inlier_changed = 1;
+          continue;
+        }
+        for (int i = 0; i < m; ++i) if (prev[i] != neu[i]) { inlier_changed = 1; break; }
+      } while (inlier_changed && ++refine_iterations < p->pnp_refine_iterations);
+      /* std::swap(inliers, new_inliers); rvec = new_model_rvec; tvec = new_model_tvec */
+      inl = neu; n_inl = n_new;
+      memcpy(q, qn, sizeof(qn)); memcpy(t, tn, sizeof(tn));
+    }
+
     out->inliers = n_inl;
-    if (inlier_mask_out) for (int i = 0; i < m; ++i) if (mask[i]) inlier_mask_out[orig[i]] = 1;
+    if (inlier_mask_out) for (int i = 0; i < m; ++i) if (inl[i]) inlier_mask_out[orig[i]] = 1;
     if (n_inl < p->min_inliers) goto done;
 
     /* ---- transform = (localTransform * pnp).inverse()   (rtabmap::Transform is float) ------------- */
@@ -602,7 +689,7 @@ int sfo_estimate_motion_3d2d(const sf_params* p,
        * linear block from squared distances, angular block from pcl::getAngle3D */
       int oi = 0;
       for (int i = 0; i < m; ++i) {
-        if (!mask[i] || !has3[i]) continue;
+        if (!inl[i] || !has3[i]) continue;
         const float* b = dst3 + 3 * i;
         const float* a = obj + 3 * i;
         const float nx = fmaf(T[2], b[2], fmaf(T[1], b[1], fmaf(T[0], b[0], T[3])));
@@ -622,13 +709,15 @@ int sfo_estimate_motion_3d2d(const sf_params* p,
       }
     } else {
       /* no 3D in the "to" frame: rms reprojection error of the inliers scales the whole matrix */
-      const double v = (double)sqrtf((float)err / (float)n_inl);
+      double ne[SFO_PNP_NSUM];
+      sfo_pnp_normal_eq(&pb, inl, q, t, ne, scratch);
+      const double v = (double)sqrtf((float)ne[27] / (float)n_inl);
       out->variance = v;
       out->variance_ang = v;
     }
   }
 done:
-  free(obj); free(dst3); free(dpx); free(dpy); free(orig); free(mask); free(has3); free(e1); free(e2);
+  free(obj); free(dst3); free(dpx); free(dpy); free(orig); free(mask); free(mask_b); free(has3); free(e1); free(e2);
   free(scratch); free(counts);
   return rc;
 }

@@ -75,6 +75,30 @@ def test_pnp_fixed_iteration_count_and_seed(oracle):
             assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "adaptive=%d pair %d" % (adaptive, i))
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 5])
+def test_pnp_refinement_rounds(oracle, rounds):
+    """Vis/PnPRefineIterations > 0: rtabmap's re-solve / re-select loop after cv::solvePnPRansac."""
+    from multi_robot_slam_separators_amd import lib
+    p = pnp_params(300)
+    p.pnp_refine_iterations = rounds
+    A, B, is_true, Ts = synth.make_pairs(600 + rounds, 16, k=400, true_frac=0.6)
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    n_exact = n_ok = 0
+    for i in range(len(A)):
+        o = oracle.estimate_transform(p, A[i], B[i])
+        assert_result_parity(got[i], o, "rounds=%d pair %d" % (rounds, i))
+        n_exact += int(got[i].tobytes() == o.tobytes())
+        if is_true[i] and got[i]["success"]:
+            n_ok += 1
+            dt, dr = synth.pose_error(got[i], Ts[i])
+            assert dt < 0.15 and dr < 0.015
+        assert is_true[i] or not got[i]["success"]
+    assert n_exact >= len(A) - 1
+    # the 3-sigma re-selection may starve a pair of inliers ("Refinement failed" upstream): most survive
+    assert n_ok >= 0.7 * is_true.sum()
+
+
 def test_pnp_edge_cases(finder, oracle):
     rng = np.random.default_rng(3)
     p = finder.params
@@ -111,7 +135,7 @@ def test_pnp_uncalibrated_and_unsupported_flags(oracle):
     for i in range(3):
         assert got[i]["success"] == 0
         assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "uncalibrated %d" % i)
-    for field, val in (("pnp_flags", 1), ("pnp_refine_iterations", 1), ("estimation_type", 2)):
+    for field, val in (("pnp_flags", 1), ("pnp_refine_iterations", -1), ("estimation_type", 2)):
         q = pnp_params(100)
         setattr(q, field, val)
         with pytest.raises(Exception):

@@ -146,3 +146,62 @@ def test_estimate_transform_pnp_two_pass(oracle):
     q.pnp_flags = 1
     with pytest.raises(RuntimeError):
         oracle.estimate_transform(q, A[i], B[i])
+
+
+def test_refinement_rounds_shrink_the_threshold(oracle):
+    """util3d::solvePnPRansac's loop: one round returns the RANSAC inliers (the swap quirk of the
+    PCL-style loop), more rounds re-select with min(reprojError, 3 sigma) and stay near the truth."""
+    A, B, is_true, Ts = synth.make_pairs(7, 12, k=500, true_frac=1.0)
+    base = _pnp_params(500)
+    for i in range(4):
+        r0 = oracle.estimate_transform(base, A[i], B[i])
+        res = {}
+        for rounds in (1, 5):
+            p = _abi.copy_params(base)
+            p.pnp_refine_iterations = rounds
+            res[rounds] = oracle.estimate_transform(p, A[i], B[i])
+            assert res[rounds]["success"] == 1
+            dt, dr = synth.pose_error(res[rounds], Ts[i])
+            assert dt < 0.15 and dr < 0.015
+        assert res[1]["inliers"] == r0["inliers"]
+        assert 5 <= res[5]["inliers"] <= r0["inliers"]
+
+
+def test_final_pose_is_the_reprojection_optimum_scipy(oracle):
+    """Independent check of the final solve: on the oracle's own inlier set, scipy's least_squares
+    (rotation vector + translation, trust-region) reaches the same pose as the canonical LM."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    p = _pnp_params(300)
+    L = np.eye(4)
+    L[:3] = synth.LOCAL_TRANSFORM
+    for trial in range(4):
+        a = synth.make_keyframe(rng, 160)
+        T = synth.random_transform(rng)
+        b, gt = synth.make_true_partner(rng, a, T, overlap=1.0, noise=0.03, flip=0.0)
+        order = np.argsort(gt)
+        cf, ct = gt[order].astype(np.uint16), np.arange(160, dtype=np.uint16)[order]
+        mo, mask = oracle.estimate_motion_3d2d(p, a.xyz, b.kpts, b.xyz, cf, ct)
+        assert not mo.is_null and mask.sum() >= 20
+        obj = a.xyz[cf[mask > 0]].astype(np.float64)
+        img = np.stack([b.kpts["x"][ct[mask > 0]], b.kpts["y"][ct[mask > 0]]], 1).astype(np.float64)
+
+        def resid(x):
+            Xc = obj @ Rotation.from_rotvec(x[:3]).as_matrix().T + x[3:]
+            return np.concatenate([synth.FX * Xc[:, 0] / Xc[:, 2] + synth.CX - img[:, 0],
+                                   synth.FY * Xc[:, 1] / Xc[:, 2] + synth.CY - img[:, 1]])
+
+        # start from the ground truth pose of the camera: x_cam = (T L)^-1 x_from
+        M0 = np.linalg.inv(T @ L)
+        x0 = np.concatenate([Rotation.from_matrix(M0[:3, :3]).as_rotvec(), M0[:3, 3]])
+        sol = least_squares(resid, x0, xtol=1e-14, ftol=1e-14, gtol=1e-14)
+        Msol = np.eye(4)
+        Msol[:3, :3] = Rotation.from_rotvec(sol.x[:3]).as_matrix()
+        Msol[:3, 3] = sol.x[3:]
+        T_scipy = np.linalg.inv(L @ Msol)            # rtabmap: (localTransform * pnp).inverse()
+        T_or = np.eye(4)
+        T_or[:3] = np.array(mo.transform).reshape(3, 4)
+        assert np.max(np.abs(T_or[:3, 3] - T_scipy[:3, 3])) < 1e-4          # BASELINE tolerance: 1e-4 m
+        dR = T_or[:3, :3] @ T_scipy[:3, :3].T
+        assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 1e-3     # 1e-3 rad
