@@ -3,7 +3,7 @@
  *
  * This is the drop-in surface for ONE hot path of bramtoula/multi_robot_SLAM_separators
  * (SURVEY.md section 8): NetVLAD nearest-neighbour candidate search + binary local-descriptor
- * matching + RANSAC 3D-3D relative pose.  Everything is `extern "C"`, plain pointers and sizes,
+ * matching + RANSAC relative pose (3D-3D, or 3D-2D PnP with estimation_type = 1).  Everything is `extern "C"`, plain pointers and sizes,
  * no torch / ROS / OpenCV types.  All citations are relative to the reference tree, with
  * PKG = ros_ws/src/multi_robot_separators.
  *

@@ -9,7 +9,7 @@
  *   - NN stage (sfo_find_matches): PINNED against scipy.spatial.distance.cdist + numpy.argsort
  *     driven through the statement sequence of data_handler.py:170-205 (tests/golden/nn_*.npz,
  *     generator oracle/gen_golden.py).
- *   - Matching / RANSAC stage: PARITY UNPINNED.  The reference delegates that arithmetic to
+ *   - Matching / RANSAC / PnP stage: PARITY UNPINNED.  The reference delegates that arithmetic to
  *     rtabmap (unpinned master), PCL >= 1.7, OpenCV and FLANN, none of which are vendored under
  *     /root/reference or installed here, and the reference ships no tests or golden vectors.
  *     The restatement follows the reference's call sites line by line and the published
