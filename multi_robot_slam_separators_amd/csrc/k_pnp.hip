@@ -231,9 +231,9 @@ __device__ inline int pnp_select(const PnpLds& L, const PnpCam& cam, int m, cons
     const float Z = __fmaf_rn(c[10], P.z, __fmaf_rn(c[9], P.y, __fmaf_rn(c[8], P.x, c[11])));
     bool in = false;
     if (Z > 0.0f) {
-      const float du = __fmaf_rn(cam.fxf, __fdiv_rn(X, Z), -o.x);
-      const float dv = __fmaf_rn(cam.fyf, __fdiv_rn(Y, Z), -o.y);
-      const float e = __fsqrt_rn(__fmaf_rn(dv, dv, du * du));
+      const float du = __fmaf_rn(cam.fxf, (X / Z), -o.x);
+      const float dv = __fmaf_rn(cam.fyf, (Y / Z), -o.y);
+      const float e = sqrtf(__fmaf_rn(dv, dv, du * du));
       in = e <= thr;
       if (in) L.e1[i] = e;
     }
@@ -464,7 +464,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
         block_sum_vec32<1>(s2, L.red, tid);
         variance = (float)(s2[0] / (double)(n_new - 1));
       }
-      const float sthr = (float)P.refine_sigma * __fsqrt_rn(variance);
+      const float sthr = (float)P.refine_sigma * sqrtf(variance);
       error_threshold = sthr < inlier_thr ? sthr : inlier_thr;
       inlier_changed = false;
       { uint8_t* tp = prev; prev = neu; neu = tp; const int tn = n_prev; n_prev = n_new; n_new = tn; }
@@ -551,7 +551,9 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     }
   } else {
     pnp_normal_eq(L, cam, m, inl, q, t, ne, tid);
-    const double v = (double)__fsqrt_rn((float)ne[27] / (float)n_inl);
+    // sqrtf and operator/ are IEEE-exact on gfx950; __fsqrt_rn is NOT (native v_sqrt_f32, ~1 ulp:
+    // tools/ubench/fp_case.hip) and must not appear in canonical arithmetic
+    const double v = (double)sqrtf((float)ne[27] / (float)n_inl);
     ps.var = v;
     ps.var_ang = v;
   }

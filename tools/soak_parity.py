@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Parity soak: many random candidate pairs through the C-ABI vs the oracle; reports how many results
-are bit-identical and fails on any integer-output difference.  Usage: soak_parity.py [rounds] [pairs]"""
+are bit-identical and fails on any integer-output difference.
+Usage: soak_parity.py [rounds] [pairs] [estimator: 3d3d | pnp | mixed]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +12,7 @@ from test_gpu_fuzz import corrupt, random_frame
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 npairs = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+estimator = sys.argv[3] if len(sys.argv) > 3 else "3d3d"
 tot = exact = succ = 0
 t0 = time.time()
 for rd in range(rounds):
@@ -27,6 +29,12 @@ for rd in range(rounds):
     p.refine_sigma = float(rng.choice([1.5, 3.0]))
     p.seed = int(rng.integers(0, 2**40))
     p.max_features = 64
+    if estimator == "pnp" or (estimator == "mixed" and rd % 2 == 1):
+        p.estimation_type = 1
+        p.pnp_reproj_error = float(rng.choice([0.5, 2.0, 4.0, 10.0]))
+        p.pnp_refine_iterations = int(rng.choice([0, 0, 1, 3, 5]))
+        if rng.random() < 0.1:
+            p.image_width = 0        # uncalibrated: the estimation never runs
     A, B = [], []
     for i in range(npairs):
         k = int(rng.choice([0, 1, 3, 9, 64, 100, 255, 256, 257, 500, 777, 1024]))
