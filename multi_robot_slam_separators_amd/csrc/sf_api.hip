@@ -8,6 +8,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <utility>
+#include <vector>
 
 #include "sf_internal.hpp"
 
@@ -133,37 +137,50 @@ k_ingest(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __restric
   if (tid == 0) meta[slot] = make_int4(rows, n3d > 0 ? rows : 0, rows, cols);
 }
 
-// ragged variant for host-buffer batches: per-keyframe table {rows, cols, n3d, desc_off, xyz_off, kp_off}
+// ragged variant for host-buffer batches: per-keyframe table of byte offsets into ONE packed
+// staging buffer.  The host packs each keyframe as [descriptors | xyz | keypoints reduced to
+// {x, y, raw octave} (12 of the wire's 28 bytes)], every part 16-byte aligned.
 struct IngestEntry {
   int32_t rows, cols, n3d, pad;
-  uint64_t desc_off, xyz_off, kp_off;   // byte offsets into the packed staging buffers
+  uint64_t desc_off, xyz_off, kp_off;   // byte offsets from the start of the staging buffer
 };
+struct PackedKp { float x, y; int32_t octave; };
 
 __global__ void __launch_bounds__(SF_BLOCK)
 k_ingest_ragged(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __restrict__ kp, int4* __restrict__ meta,
                 int kcap, int w, int first_slot, const IngestEntry* __restrict__ table,
-                const uint8_t* __restrict__ s_desc, const uint8_t* __restrict__ s_xyz,
-                const uint8_t* __restrict__ s_kp) {
+                const uint8_t* __restrict__ stage) {
   const int k = blockIdx.x;
   const int slot = first_slot + k;
   const int tid = threadIdx.x;
   const IngestEntry e = table[k];
-  uint8_t* d8 = reinterpret_cast<uint8_t*>(desc + (size_t)slot * kcap * w);
-  const uint8_t* sd = s_desc + e.desc_off;
-  const int rowb = w * 4;
-  for (int i = tid; i < e.rows * rowb; i += SF_BLOCK) {
-    const int r = i / rowb, b = i - r * rowb;
-    d8[i] = (b < e.cols) ? sd[(size_t)r * e.cols + b] : (uint8_t)0;
+  const uint8_t* sd = stage + e.desc_off;
+  if ((e.cols & 3) == 0) {
+    // dword path (descriptor bytes a multiple of 4; rows start 16-byte aligned in the staging buffer)
+    uint32_t* d32 = desc + (size_t)slot * kcap * w;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(sd);
+    const int cw = e.cols >> 2;
+    for (int i = tid; i < e.rows * w; i += SF_BLOCK) {
+      const int r = i / w, b = i - r * w;
+      d32[i] = (b < cw) ? s32[(size_t)r * cw + b] : 0u;
+    }
+  } else {
+    uint8_t* d8 = reinterpret_cast<uint8_t*>(desc + (size_t)slot * kcap * w);
+    const int rowb = w * 4;
+    for (int i = tid; i < e.rows * rowb; i += SF_BLOCK) {
+      const int r = i / rowb, b = i - r * rowb;
+      d8[i] = (b < e.cols) ? sd[(size_t)r * e.cols + b] : (uint8_t)0;
+    }
   }
   if (e.n3d > 0) {
     float* dx = xyz + (size_t)slot * kcap * 3;
-    const float* sx = reinterpret_cast<const float*>(s_xyz + e.xyz_off);
+    const float* sx = reinterpret_cast<const float*>(stage + e.xyz_off);
     for (int i = tid; i < e.rows * 3; i += SF_BLOCK) dx[i] = sx[i];
   }
   float4* dk = kp + (size_t)slot * kcap;
-  const sf_keypoint* sk = reinterpret_cast<const sf_keypoint*>(s_kp + e.kp_off);
+  const PackedKp* sk = reinterpret_cast<const PackedKp*>(stage + e.kp_off);
   for (int i = tid; i < e.rows; i += SF_BLOCK) {
-    const sf_keypoint q = sk[i];
+    const PackedKp q = sk[i];
     int o = q.octave & 255;
     o = o < 128 ? o : (-128 | o);
     dk[i] = make_float4(q.x, q.y, __int_as_float(o), 0.f);
@@ -285,13 +302,25 @@ static int pinned_reserve(sf_context* c, PinnedBuf& b, size_t bytes) {
   return SF_OK;
 }
 
-// n host keyframes -> consecutive slots: features are packed into pinned staging, copied with one
-// H2D per field and converted by ONE ragged ingest launch (no per-keyframe synchronisation).
+// n host keyframes -> consecutive slots.  Features are packed into ONE pinned staging buffer in
+// chunks of a few MB: worker threads pack chunk k+1 while the H2D copy of chunk k is in flight, then
+// ONE ragged ingest launch converts everything (no per-keyframe synchronisation).  Small batches
+// (a single service call) are packed inline by the calling thread.
+static inline size_t pad16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static void pack_keyframe(uint8_t* hp, const IngestEntry& e, const sf_features* f) {
+  if (f->rows == 0) return;
+  memcpy(hp + e.desc_off, f->desc, (size_t)f->rows * f->cols);
+  if (f->n3d > 0) memcpy(hp + e.xyz_off, f->xyz, (size_t)f->rows * 12);
+  PackedKp* k = reinterpret_cast<PackedKp*>(hp + e.kp_off);
+  const sf_keypoint* src = f->kpts;
+  for (int i = 0; i < (int)f->rows; ++i) { k[i].x = src[i].x; k[i].y = src[i].y; k[i].octave = src[i].octave; }
+}
+
 static int store_add_host_batch(sf_context* c, Store& st, const sf_features* const* feats, int n, int* first_slot) {
   if (n <= 0) return SF_OK;
   int rc;
   int max_rows = 0, cols = 0;
-  size_t bd = 0, bx = 0, bk = 0;
   for (int i = 0; i < n; ++i) {
     if ((rc = validate_features(c, feats[i])) != SF_OK) return rc;
     max_rows = std::max<int>(max_rows, feats[i]->rows);
@@ -300,45 +329,75 @@ static int store_add_host_batch(sf_context* c, Store& st, const sf_features* con
       if ((feats[i]->cols <= 32) != (cols <= 32)) return sf_fail(c, SF_EINVAL, "descriptor width classes differ inside one batch");
       if (feats[i]->cols > SF_MAX_DESC_BYTES) return sf_fail(c, SF_ERANGE, "descriptor bytes %d > %d", (int)feats[i]->cols, SF_MAX_DESC_BYTES);
     }
-    bd += ((size_t)feats[i]->rows * feats[i]->cols + 15) & ~(size_t)15;
-    bx += feats[i]->n3d > 0 ? (size_t)feats[i]->rows * 12 + 4 : 0;
-    bk += (size_t)feats[i]->rows * sizeof(sf_keypoint) + 4;
   }
   if (cols == 0) cols = st.slots > 0 ? (st.w == 8 ? 32 : 64) : std::max(1, c->params.desc_bytes);
   if ((rc = store_reserve(c, st, st.slots + n, max_rows, cols)) != SF_OK) return rc;
+
+  // layout: [table][keyframe 0: desc | xyz | kp][keyframe 1 ...], chunk boundaries every ~4 MB
+  static thread_local std::vector<IngestEntry> tab;
+  static thread_local std::vector<std::pair<size_t, int>> chunks;   // (end offset, end keyframe)
+  tab.resize(n);
+  chunks.clear();
+  const size_t tb = pad16((size_t)n * sizeof(IngestEntry));
+  const size_t chunk_bytes = (size_t)4 << 20;
+  size_t off = tb, chunk_start = tb;
+  for (int i = 0; i < n; ++i) {
+    const sf_features* f = feats[i];
+    IngestEntry& e = tab[i];
+    e.rows = f->rows; e.cols = f->rows > 0 ? f->cols : cols; e.n3d = f->n3d; e.pad = 0;
+    e.desc_off = off; off += pad16((size_t)f->rows * f->cols);
+    e.xyz_off = off;  off += f->n3d > 0 ? pad16((size_t)f->rows * 12) : 0;
+    e.kp_off = off;   off += pad16((size_t)f->rows * sizeof(PackedKp));
+    if (off - chunk_start >= chunk_bytes || i == n - 1) { chunks.push_back({off, i + 1}); chunk_start = off; }
+  }
+  const size_t total = off;
   static thread_local PinnedBuf pin;   // host staging (process lifetime)
-  const size_t tb = (size_t)n * sizeof(IngestEntry);
-  const size_t off_d = (tb + 255) & ~(size_t)255, off_x = (off_d + bd + 255) & ~(size_t)255,
-               off_k = (off_x + bx + 255) & ~(size_t)255, total = off_k + bk + 256;
   if ((rc = pinned_reserve(c, pin, total)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->stage_desc, total)) != SF_OK) return rc;
   uint8_t* hp = (uint8_t*)pin.p;
-  IngestEntry* tab = (IngestEntry*)hp;
-  size_t pd = 0, px = 0, pk = 0;
-  for (int i = 0; i < n; ++i) {
-    const sf_features* f = feats[i];
-    IngestEntry e;
-    e.rows = f->rows; e.cols = f->rows > 0 ? f->cols : cols; e.n3d = f->n3d; e.pad = 0;
-    e.desc_off = pd; e.xyz_off = px; e.kp_off = pk;
-    if (f->rows > 0) {
-      memcpy(hp + off_d + pd, f->desc, (size_t)f->rows * f->cols);
-      memcpy(hp + off_k + pk, f->kpts, (size_t)f->rows * sizeof(sf_keypoint));
-      if (f->n3d > 0) memcpy(hp + off_x + px, f->xyz, (size_t)f->rows * 12);
-    }
-    pd += ((size_t)f->rows * f->cols + 15) & ~(size_t)15;
-    px += f->n3d > 0 ? (size_t)f->rows * 12 + 4 : 0;
-    px = (px + 3) & ~(size_t)3;
-    pk += (size_t)f->rows * sizeof(sf_keypoint) + 4;
-    pk = (pk + 3) & ~(size_t)3;
-    tab[i] = e;
-  }
   uint8_t* dp = (uint8_t*)c->stage_desc.p;
-  SF_HIP(c, hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream));
+  memcpy(hp, tab.data(), (size_t)n * sizeof(IngestEntry));
+
+  const int n_chunks = (int)chunks.size();
+  int workers = 0;
+  if (n_chunks >= 2) workers = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+  hipError_t herr = hipSuccess;
+  if (workers <= 1) {
+    for (int i = 0; i < n; ++i) pack_keyframe(hp, tab[i], feats[i]);
+    herr = hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream);
+  } else {
+    // done[k] counts the workers that finished their share of chunk k
+    std::vector<std::atomic<int>> done(n_chunks);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    const IngestEntry* tabp = tab.data();
+    const std::pair<size_t, int>* chp = chunks.data();
+    std::vector<std::thread> pool;
+    pool.reserve(workers);
+    for (int t = 0; t < workers; ++t) {
+      pool.emplace_back([=, &done]() {
+        int lo = 0;
+        for (int k = 0; k < n_chunks; ++k) {
+          const int hi = chp[k].second;
+          for (int i = lo + t; i < hi; i += workers) pack_keyframe(hp, tabp[i], feats[i]);
+          done[k].fetch_add(1, std::memory_order_release);
+          lo = hi;
+        }
+      });
+    }
+    size_t sent = 0;
+    for (int k = 0; k < n_chunks; ++k) {
+      while (done[k].load(std::memory_order_acquire) < workers) std::this_thread::yield();
+      const size_t end = chunks[k].first;
+      if (herr == hipSuccess) herr = hipMemcpyAsync(dp + sent, hp + sent, end - sent, hipMemcpyHostToDevice, c->stream);
+      sent = end;
+    }
+    for (auto& th : pool) th.join();
+  }
+  if (herr != hipSuccess) return sf_fail(c, SF_EHIP, "staging H2D copy -> %s", hipGetErrorString(herr));
   hipLaunchKernelGGL(k_ingest_ragged, dim3(n), dim3(SF_BLOCK), 0, c->stream, (uint32_t*)st.desc.p, (float*)st.xyz.p,
-                     (float4*)st.kp.p, (int4*)st.meta.p, st.kcap, st.w, st.slots, (const IngestEntry*)dp, dp + off_d,
-                     dp + off_x, dp + off_k);
+                     (float4*)st.kp.p, (int4*)st.meta.p, st.kcap, st.w, st.slots, (const IngestEntry*)dp, dp);
   SF_HIP(c, hipGetLastError());
-  // the pinned staging is reused by the next call: the copy must have left host memory
+  // the pinned staging is reused by the next call: the copies must have left host memory
   SF_HIP(c, hipStreamSynchronize(c->stream));
   if (first_slot) *first_slot = st.slots;
   st.slots += n;
