@@ -252,3 +252,34 @@ def test_rccl_allgather_separators_single_rank(finder):
             finder.allgather_separators(d_local.data_ptr(), cap + 1, d_all.data_ptr(), cap, 1)
     finally:
         finder.comm_destroy()
+
+
+def test_torch_rccl_allgather_records_single_rank():
+    """bench.py's exchange (torch.distributed, backend "nccl" = RCCL) on a 1-rank group: the same
+    dist.allgather_records call the N > 1 bench makes, on device tensors."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import dist
+    if td.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rec = torch.arange(5 * 368, dtype=torch.int64, device=dev).remainder(251).to(torch.uint8).reshape(5, 368)
+        out, counts = dist.allgather_records(rec)
+        assert counts == [5] and torch.equal(out, rec)
+        out, counts = dist.allgather_records(rec[:0])
+        assert counts == [0] and out.shape == (0, 368)
+        t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        td.barrier()
+        assert float(t.item()) == 3.5
+    finally:
+        td.destroy_process_group()
