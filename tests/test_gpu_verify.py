@@ -283,3 +283,19 @@ def test_torch_rccl_allgather_records_single_rank():
         assert float(t.item()) == 3.5
     finally:
         td.destroy_process_group()
+
+
+@pytest.mark.parametrize("est", [0, 1])
+def test_verification_regression_vectors_on_gpu(est):
+    """The HIP kernels reproduce tests/golden/verify_regression.npz byte for byte (both estimators)."""
+    from multi_robot_slam_separators_amd import lib
+    from test_oracle_geometry import _load_regression
+    z, A, B = _load_regression()
+    p = synth.camera_params()
+    p.iterations = 200
+    p.estimation_type = est
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    want = z["result_est%d" % est]
+    for i in range(len(A)):
+        assert got[i].tobytes() == want[i].tobytes(), "estimation_type %d pair %d" % (est, i)

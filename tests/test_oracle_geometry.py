@@ -262,3 +262,30 @@ def test_guided_matching_semantics(oracle):
     back[:3, :3] = np.diag([-1, -1, 1])
     *_, outside = oracle.match_guided(p, back[:3].astype(np.float32), a, b)
     assert outside == 1
+
+
+def _load_regression():
+    import os
+    from multi_robot_slam_separators_amd import _abi
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "verify_regression.npz"))
+    n = int(z["n"])
+    A = [_abi.FeatureArrays(z["desc_a%d" % i], z["xyz_a%d" % i], z["kp_a%d" % i]) for i in range(n)]
+    B = [_abi.FeatureArrays(z["desc_b%d" % i], z["xyz_b%d" % i], z["kp_b%d" % i]) for i in range(n)]
+    return z, A, B
+
+
+def test_verification_regression_vectors(oracle):
+    """tests/golden/verify_regression.npz (oracle/gen_regression.py): the canonical arithmetic of the
+    matching / RANSAC / PnP restatement is frozen byte for byte.  These are regression vectors of the
+    restatement, not reference outputs (that stage is PARITY UNPINNED)."""
+    from multi_robot_slam_separators_amd import synth
+    z, A, B = _load_regression()
+    for est in (0, 1):
+        p = synth.camera_params()
+        p.iterations = 200
+        p.estimation_type = est
+        want = z["result_est%d" % est]
+        for i in range(len(A)):
+            got = oracle.estimate_transform(p, A[i], B[i])
+            assert got.tobytes() == want[i].tobytes(), "estimation_type %d pair %d" % (est, i)
+            assert bool(got["success"]) == bool(z["is_true"][i])
