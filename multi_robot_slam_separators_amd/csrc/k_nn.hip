@@ -373,10 +373,11 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
 
 // one wavefront per candidate: exact float64 distance in cdist's direct form
 __global__ void __launch_bounds__(256)
-k_nn_refine(const uint2* __restrict__ cand, unsigned n_cand, const float* __restrict__ A,
-            const float* __restrict__ B, int dim, int ld, double* __restrict__ out) {
+k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned limit,
+            const float* __restrict__ A, const float* __restrict__ B, int dim, int ld, double* __restrict__ out) {
   const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  const unsigned n_cand = min(*count, limit);   // the grid is sized for `limit`; the filter's count lives on the device
   if (c >= n_cand) return;
   const uint2 rc = cand[c];
   const float* a = A + (size_t)rc.x * ld;
@@ -500,6 +501,18 @@ struct NnTrace {
   }
 };
 
+static int nn_pinned_reserve(sf_context* c, size_t need) {
+  if (need <= c->nn_pinned_bytes) return SF_OK;
+  if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
+  c->nn_pinned = nullptr;
+  c->nn_pinned_bytes = 0;
+  const size_t want = need + need / 2;
+  if (hipHostMalloc(&c->nn_pinned, want, hipHostMallocDefault) != hipSuccess)
+    return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", want);
+  c->nn_pinned_bytes = want;
+  return SF_OK;
+}
+
 static int nn_run_filter(sf_context* c, int* done) {
   *done = 0;
   NnTrace tr;
@@ -542,6 +555,8 @@ static int nn_run_filter(sf_context* c, int* done) {
   thr2 = nextafterf(thr2, INFINITY);
   unsigned n_cand = 0;
   bool ok = false;
+  uint2* h_cand = nullptr;     // pinned staging of the candidate list (pageable D2H copies are staged and slow)
+  double* h_dist = nullptr;
   for (; level < n_levels && !ok; ++level) {
     const int kdims = levels[level];
     if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16, kdims)) != SF_OK) return rc;
@@ -563,12 +578,54 @@ static int nn_run_filter(sf_context* c, int* done) {
                        ld16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
     sf_prof_end(c, SF_K_NN_FILTER);
     SF_HIP(c, hipGetLastError());
-    SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
-    SF_HIP(c, hipStreamSynchronize(c->stream));
+    const bool prefix_level = level < n_levels - 1;
     // a dense prefix result would make the exact refinement the expensive part: insist on a sparse
     // candidate set from a prefix level, accept anything that fits the buffer from the full-length level
-    tr.mark("filter + count", n_cand);
-    ok = (level < n_levels - 1) ? n_cand <= (unsigned)(8 * (size_t)n_l + 4096) : n_cand <= cap;
+    const unsigned limit = prefix_level ? (unsigned)(8 * (size_t)n_l + 4096) : cap;
+    if (prefix_level) {
+      // no host round trip between the filter and the refinement: the refine grid is sized for the
+      // sparse limit and reads the count on the device; count, candidates and distances come back
+      // behind ONE synchronisation (a speculative prefix of 2N + 1024 entries, the rest if needed)
+      if ((rc = nn_pinned_reserve(c, (size_t)limit * 16 + 64)) != SF_OK) return rc;
+      h_cand = (uint2*)((char*)c->nn_pinned + 64);
+      h_dist = (double*)((char*)c->nn_pinned + 64 + (size_t)limit * 8);
+      sf_prof_begin(c, SF_K_NN_REFINE);
+      hipLaunchKernelGGL(k_nn_refine, dim3((limit + 3) / 4), dim3(256), 0, c->stream, cand, count, limit,
+                         (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
+      sf_prof_end(c, SF_K_NN_REFINE);
+      const unsigned spec = std::min<unsigned>(limit, (unsigned)(2 * (size_t)n_l + 1024));
+      SF_HIP(c, hipMemcpyAsync(c->nn_pinned, count, 4, hipMemcpyDeviceToHost, c->stream));
+      SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)spec * 8, hipMemcpyDeviceToHost, c->stream));
+      SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)spec * 8, hipMemcpyDeviceToHost, c->stream));
+      SF_HIP(c, hipStreamSynchronize(c->stream));
+      n_cand = *(const unsigned*)c->nn_pinned;
+      tr.mark("filter + refine + D2H", n_cand);
+      ok = n_cand <= limit;
+      if (ok && n_cand > spec) {
+        SF_HIP(c, hipMemcpyAsync(h_cand + spec, cand + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, c->stream));
+        SF_HIP(c, hipMemcpyAsync(h_dist + spec, cdist + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, c->stream));
+        SF_HIP(c, hipStreamSynchronize(c->stream));
+      }
+    } else {
+      SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
+      SF_HIP(c, hipStreamSynchronize(c->stream));
+      tr.mark("filter + count", n_cand);
+      ok = n_cand <= limit;
+      if (ok) {
+        if ((rc = nn_pinned_reserve(c, (size_t)n_cand * 16 + 64)) != SF_OK) return rc;
+        h_cand = (uint2*)((char*)c->nn_pinned + 64);
+        h_dist = (double*)((char*)c->nn_pinned + 64 + (size_t)n_cand * 8);
+        if (n_cand) {
+          sf_prof_begin(c, SF_K_NN_REFINE);
+          hipLaunchKernelGGL(k_nn_refine, dim3((n_cand + 3) / 4), dim3(256), 0, c->stream, cand, count, n_cand,
+                             (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
+          sf_prof_end(c, SF_K_NN_REFINE);
+          SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+          SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
+          SF_HIP(c, hipStreamSynchronize(c->stream));
+        }
+      }
+    }
     if (ok) {
       c->nn_level = level;
       c->nn_last_kdims = kdims;
@@ -577,31 +634,6 @@ static int nn_run_filter(sf_context* c, int* done) {
   if (!ok) {   // too dense for the filter: exact path
     c->nn_last_kdims = 0;
     return SF_OK;
-  }
-  // pinned staging for the candidate list (pageable D2H copies are staged and slow)
-  {
-    const size_t need = (size_t)n_cand * 16 + 64;
-    if (need > c->nn_pinned_bytes) {
-      if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
-      c->nn_pinned = nullptr;
-      c->nn_pinned_bytes = 0;
-      const size_t want = need + need / 2;
-      if (hipHostMalloc(&c->nn_pinned, want, hipHostMallocDefault) != hipSuccess)
-        return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", want);
-      c->nn_pinned_bytes = want;
-    }
-  }
-  tr.mark("pinned staging");
-  uint2* h_cand = (uint2*)c->nn_pinned;
-  double* h_dist = (double*)((char*)c->nn_pinned + (size_t)n_cand * 8);
-  if (n_cand) {
-    sf_prof_begin(c, SF_K_NN_REFINE);
-    hipLaunchKernelGGL(k_nn_refine, dim3((n_cand + 3) / 4), dim3(256), 0, c->stream, cand, n_cand,
-                       (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
-    sf_prof_end(c, SF_K_NN_REFINE);
-    SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
-    SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)n_cand * 8, hipMemcpyDeviceToHost, c->stream));
-    SF_HIP(c, hipStreamSynchronize(c->stream));
   }
   tr.mark("refine + D2H");
   // per-row minimum over the exact candidate distances (ties: lowest column), ignored pairs skipped.
@@ -700,6 +732,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   // others; once they are exhausted the reference's loop can only `continue` or `break`.  So the
   // sort is restricted to those rows: LSD radix sort on the float64 bit patterns (non-negative
   // doubles order like unsigned integers; the sort is stable, so ties keep the lowest row first).
+  NnTrace tr2;
   const std::vector<double>& rm = c->last_row_min;
   const double thr_d = c->params.netvlad_distance;
   std::vector<uint64_t>& keys = c->nn_sort_keys;
@@ -717,19 +750,28 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   }
   const size_t nu = keys.size();
   if (nu > 1) {
+    // LSD radix sort, 11-bit digits (6 passes cover 64 bits); all digit histograms come from ONE read
+    // of the keys, and a pass whose digit is identical in every key is skipped
+    constexpr int DIG = 11, NB = 1 << DIG, NP = (64 + DIG - 1) / DIG;
     std::vector<uint64_t>& k2 = c->nn_sort_keys2;
     std::vector<int32_t>& r2 = c->nn_sort_rows2;
     k2.resize(nu);
     r2.resize(nu);
-    uint64_t diff = 0;
-    for (size_t i = 1; i < nu; ++i) diff |= keys[i] ^ keys[0];
-    for (int shift = 0; shift < 64; shift += 8) {
-      if (((diff >> shift) & 0xFF) == 0) continue;   // this byte is identical in every key
-      size_t hist[257] = {0};
-      for (size_t i = 0; i < nu; ++i) hist[((keys[i] >> shift) & 0xFF) + 1]++;
-      for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+    std::vector<uint32_t>& hist = c->nn_sort_hist;
+    hist.assign((size_t)NP * NB, 0u);
+    for (size_t i = 0; i < nu; ++i) {
+      const uint64_t k = keys[i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hist[(size_t)p * NB + ((k >> (p * DIG)) & (NB - 1))]++;
+    }
+    for (int p = 0; p < NP; ++p) {
+      uint32_t* h = hist.data() + (size_t)p * NB;
+      const int shift = p * DIG;
+      if (h[(keys[0] >> shift) & (NB - 1)] == nu) continue;   // this digit is identical in every key
+      uint32_t run = 0;
+      for (int b2 = 0; b2 < NB; ++b2) { const uint32_t cnt = h[b2]; h[b2] = run; run += cnt; }
       for (size_t i = 0; i < nu; ++i) {
-        const size_t pos = hist[(keys[i] >> shift) & 0xFF]++;
+        const uint32_t pos = h[(keys[i] >> shift) & (NB - 1)]++;
         k2[pos] = keys[i];
         r2[pos] = rows[i];
       }
@@ -737,6 +779,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
       rows.swap(r2);
     }
   }
+  tr2.mark("host sort", (long long)nu);
   const int lim = std::min(n_l, c->params.netvlad_max_matches_nb);
   int n = 0;
   std::vector<uint8_t>& taken = c->nn_taken;
@@ -751,5 +794,6 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     if (n >= cap) break;
   }
   *n_out = std::min(n, cap);
+  tr2.mark("host walk", n);
   return SF_OK;
 }

@@ -133,6 +133,7 @@ struct sf_context {
   std::vector<int32_t> last_row_arg;
   std::vector<uint64_t> nn_sort_keys, nn_sort_keys2;   // host scratch of the walk (kept to avoid reallocation)
   std::vector<int32_t> nn_sort_rows, nn_sort_rows2;
+  std::vector<uint32_t> nn_sort_hist;
   std::vector<uint8_t> nn_taken;
 
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
