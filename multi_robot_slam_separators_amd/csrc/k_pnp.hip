@@ -12,12 +12,13 @@
 //   * correspondences with a finite "from" point are compacted once into LDS: world point (float4),
 //     pixel offsets from the principal point (float2), and the packed index pair for the late
 //     covariance gather;
-//   * one LANE per hypothesis: keyed 4-sample, P3P in fp64 (Grunert's quartic by Ferrari + bracketed
-//     Newton, frames of the two triangles), the 4th point picks the root, then the inlier count over
-//     all points with LDS BROADCAST reads and a division-free test (A^2 + B^2 <= thr^2 Z^2, Z > 0:
-//     9 + 2 fma, 4 mul, 2 compares per point);
+//   * hypotheses in rounds of 64, one LANE each: wavefront 0 draws the keyed 4-sample and solves P3P
+//     in fp64 (Grunert's quartic by Ferrari + bracketed Newton, frames of the two triangles, the
+//     4th point picks the root) and parks the 64 models in LDS; then all four wavefronts count
+//     inliers, each over a quarter of the points, with LDS BROADCAST reads and a division-free test
+//     (A^2 + B^2 <= thr^2 Z^2, Z > 0: 9 + 2 fma, 4 mul, 2 compares per point);
 //   * OpenCV's sequential "best so far / update niters" rule is replayed by thread 0 after every
-//     round of 256 hypotheses, so later rounds are skipped exactly when the sequential loop would
+//     round of 64 hypotheses, so later rounds are skipped exactly when the sequential loop would
 //     have stopped;
 //   * Levenberg-Marquardt on the inliers: per-lane partial normal equations (21 + 6 + 1 doubles),
 //     block-wide reduction in the FIXED order of DESIGN.md section 4, then every lane solves the same
@@ -36,6 +37,7 @@ namespace {
 struct PnpLds {
   float4* obj;      // [kcap] world ("from" base frame) point
   float2* img;      // [kcap] pixel - principal point of the "to" keypoint
+  double* bear;     // [kcap][3] unit bearing vector of the "to" keypoint (fp64, computed once per point)
   uint32_t* cidx;   // [kcap] packed (to << 16 | from) feature indices
   float* e1;        // [kcap] squared 3D error of the members (+inf elsewhere)
   float* e2;        // [kcap] angular error
@@ -44,6 +46,9 @@ struct PnpLds {
   int* counts;      // [iterations]
   double* red;      // [4][32]
   int* misc;        // [16]
+  float* hyp;       // [12][64] models of the current round of hypotheses
+  int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
+  float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the replay)
 };
 
 template <int N>
@@ -94,7 +99,7 @@ __device__ __forceinline__ bool pnp_inlier(const PnpLds& L, const PnpCam& cam, c
 }
 
 // model of RANSAC iteration `it`: keyed 4-sample, P3P on the first three, the 4th picks the root
-__device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
+__device__ __attribute__((noinline)) bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
                                       float (&coef)[12]) {
   uint32_t s0, s1, s2, s3;
   sfd::sample_quad(seed, it, 0u, m, s0, s1, s2, s3);
@@ -103,11 +108,9 @@ __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float4 p = L.obj[sk[k]];
-    const float2 o = L.img[sk[k]];
     P[k][0] = (double)p.x; P[k][1] = (double)p.y; P[k][2] = (double)p.z;
-    const double un = (double)o.x / cam.fx, vn = (double)o.y / cam.fy;
-    const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
-    f[k][0] = un * inv; f[k][1] = vn * inv; f[k][2] = inv;
+    const double* b = L.bear + 3 * sk[k];
+    f[k][0] = b[0]; f[k][1] = b[1]; f[k][2] = b[2];
   }
   const float4 p4 = L.obj[s3];
   const float2 o4 = L.img[s3];
@@ -283,6 +286,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     unsigned char* p = smem_raw;
     L.obj = (float4*)p; p += (size_t)kcap * 16;
     L.red = (double*)p; p += 128 * 8;
+    L.bear = (double*)p; p += (size_t)kcap * 24;
     L.img = (float2*)p; p += (size_t)kcap * 8;
     L.e1 = (float*)p; p += (size_t)kcap * 4;
     L.e2 = (float*)p; p += (size_t)kcap * 4;
@@ -290,7 +294,10 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     L.counts = (int*)p; p += (size_t)((max_it + 4) & ~3) * 4;
     L.misc = (int*)p; p += 16 * 4;
     L.mask = p; p += kcap;
-    L.mask_b = p;
+    L.mask_b = p; p += kcap;
+    L.hyp = (float*)p; p += 12 * 64 * 4;
+    L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
+    L.best = (float*)p;
   }
 
   // ---- estimateMotion3DTo2D: ids of words2B found in words3A with a finite 3D point ---------------
@@ -337,6 +344,15 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     __syncthreads();
   }
 
+  // unit bearings of the observations, once per point (the P3P of every hypothesis reads three of them)
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    const float2 o = L.img[i];
+    const double un = (double)o.x / P.fx, vn = (double)o.y / P.fy;
+    const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
+    L.bear[3 * i] = un * inv; L.bear[3 * i + 1] = vn * inv; L.bear[3 * i + 2] = inv;
+  }
+  __syncthreads();
+
   PassState ps;
 #pragma unroll
   for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
@@ -361,26 +377,49 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
   {
     int niters = max_it, best = 0, best_it = -1, sc_it = 0;   // thread 0 only
     if (tid == 0) { L.misc[0] = -1; L.misc[1] = 1; }
-    for (int base = 0; base < max_it; base += SF_BLOCK) {
-      const int it = base + tid;
-      if (it < max_it) {
-        float coef[12];
-        int cnt = 0;
-        if (pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
-          for (int i = 0; i < m; ++i) cnt += pnp_inlier(L, cam, coef, i) ? 1 : 0;   // LDS broadcast reads
+    const int slice = (m + 3) >> 2;                        // points counted by each wavefront
+    const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
+    int* hv = L.hyp_cnt + 4 * 64;
+    for (int base = 0; base < max_it; base += 64) {
+      const int it = base + lane;
+      if (wave == 0) {
+        int valid = 0;
+        if (it < max_it) {
+          float coef[12];
+          if (P.dbg_stop != 21 && pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane] = coef[k];
+            valid = 1;
+          }
         }
-        L.counts[it] = cnt;
+        hv[lane] = valid;
       }
       __syncthreads();
+      {
+        int cnt = 0;
+        if (hv[lane]) {
+          float coef[12];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) coef[k] = L.hyp[k * 64 + lane];
+          for (int i = i0; i < i1; ++i) cnt += pnp_inlier(L, cam, coef, i) ? 1 : 0;   // LDS broadcast reads
+        }
+        L.hyp_cnt[wave * 64 + lane] = cnt;
+      }
+      __syncthreads();
+      if (wave == 0 && it < max_it)
+        L.counts[it] = ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane];
+      __syncthreads();
       if (tid == 0) {
-        const int lim = min(max_it, base + SF_BLOCK);   // counts exist for iterations < lim
+        const int lim = min(max_it, base + 64);   // counts exist for iterations < lim
         while (sc_it < niters && sc_it < lim) {
           const int good = L.counts[sc_it];
           const int bar = best > 3 ? best : 3;          // max(maxGoodCount, modelPoints - 1)
           if (good > bar) {
             best = good;
             best_it = sc_it;
-            if (P.adaptive_stop) niters = sfd::update_num_iters(0.99, (double)(m - good) / (double)m, 4, niters);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) L.best[k] = L.hyp[k * 64 + (sc_it - base)];   // keep the winning model
+            if (P.adaptive_stop && P.dbg_stop != 22) niters = sfd::update_num_iters(0.99, (double)(m - good) / (double)m, 4, niters);
           }
           ++sc_it;
         }
@@ -392,16 +431,17 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     }
     __syncthreads();
   }
-  if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 2 || P.dbg_stop == 21 || P.dbg_stop == 22) { if (tid == 0) pass[pair] = ps; return; }
   const int best_it = L.misc[0];
   if (best_it < 0) {   // solvePnPRansac returned false: no inliers
     if (tid == 0) pass[pair] = ps;
     return;
   }
 
-  // ---- winning model (recomputed redundantly in every lane) and its inlier mask ---------------------
+  // ---- winning model (parked in LDS by the replay) and its inlier mask ---------------------------------
   float coef[12];
-  pnp_hypothesis(L, cam, P.seed, (uint32_t)best_it, (uint32_t)m, coef);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) coef[k] = L.best[k];
   int n_inl = 0;
   for (int i = tid; i < m; i += SF_BLOCK) {
     const bool in = pnp_inlier(L, cam, coef, i);
@@ -564,7 +604,8 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
 
 size_t sf_pnp_lds_bytes(int kcap, int iterations) {
   const int it = iterations > 0 ? iterations : 0;
-  return (size_t)kcap * (16 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4;
+  return (size_t)kcap * (16 + 24 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
+         5 * 64 * 4 + 16 * 4;
 }
 
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {

@@ -8,10 +8,13 @@
 //
 // CDNA4 mapping:
 //   * the finite, non-zero correspondences are gathered once into LDS as float4 pairs;
-//   * one LANE per hypothesis: stateless keyed sampling, PCL's sample-distance test, a closed-form
-//     3-point rigid fit in fp64 (Horn quaternion, Jacobi 4x4 in registers), then the inlier count
-//     over all points with LDS BROADCAST reads (every lane reads the same address -> one LDS
-//     cycle, no bank conflicts) -- 12 fma + compare per point, no cross-lane traffic at all;
+//   * hypotheses in rounds of 64, one LANE each: wavefront 0 does the stateless keyed sampling, PCL's
+//     sample-distance test and the closed-form 3-point rigid fit in fp64 (Horn quaternion) and
+//     parks the 64 models in LDS; then all four wavefronts count inliers, each over a quarter of the
+//     points, with LDS BROADCAST reads (every lane reads the same address -> one LDS cycle, no bank
+//     conflicts) -- 12 fma + compare per point.  With the usual inlier ratios PCL's adaptive rule
+//     stops inside the first round, so a round of 64 (not 256) quarters the wasted fits and the
+//     point split quarters the counting time;
 //   * PCL's sequential adaptive-termination rule is applied afterwards to the per-hypothesis
 //     counts, which reproduces the sequential algorithm's choice exactly;
 //   * refinement: block-wide fp64 moment reductions in a FIXED order (strided partials, xor
@@ -32,6 +35,9 @@ struct RansacLds {
   int* counts;      // [iterations + 2]
   double* red;      // [4][16]
   int* misc;        // [16]
+  float* hyp;       // [12][64] models of the current round of hypotheses
+  int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
+  float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the scan)
 };
 
 template <int N>
@@ -217,7 +223,10 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     L.counts = (int*)p; p += (size_t)((P.iterations + 2 + 3) & ~3) * 4;
     L.misc = (int*)p; p += 16 * 4;
     L.mask_a = p; p += kcap;
-    L.mask_b = p;
+    L.mask_b = p; p += kcap;
+    L.hyp = (float*)p; p += 12 * 64 * 4;
+    L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
+    L.best = (float*)p;
   }
 
   // ---- util3d::findCorrespondences: finite, non-zero, id-ordered ---------------------------------
@@ -309,32 +318,53 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   float thr2f = (float)thr2;                       // largest float strictly below thr2
   if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
   const int max_it = P.iterations;
-  // Hypotheses are evaluated in rounds of SF_BLOCK (one lane each); after every round thread 0
-  // advances PCL's sequential loop (adaptive k) over the counts available so far.  Once that loop
-  // has terminated the remaining rounds are skipped: their counts would never be read.
+  // Hypotheses are evaluated in rounds of 64 (one lane each); after every round thread 0 advances
+  // PCL's sequential loop (adaptive k) over the counts available so far.  Once that loop has
+  // terminated the remaining rounds are skipped: their counts would never be read.
   double k_adapt = 1.0;                                  // thread 0 only
   const double log_probability = sfd::canon_log(1.0 - 0.99);
   int sc_best = -1, sc_best_it = -1, sc_it = 0;          // thread 0 only
-  for (int base = 0; base <= max_it; base += SF_BLOCK) {
-    const int it = base + tid;
-    if (it <= max_it) {
-      uint32_t s0, s1, s2;
-      int cnt = -1;
-      if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
+  const int slice = (m + 3) >> 2;                        // points counted by each wavefront
+  const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
+  int* hv = L.hyp_cnt + 4 * 64;
+  for (int base = 0; base <= max_it; base += 64) {
+    const int it = base + lane;
+    if (wave == 0) {
+      int valid = 0;
+      if (it <= max_it) {
+        uint32_t s0, s1, s2;
+        if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
+          float coef[12];
+          fit3(L, s0, s1, s2, coef);
+#pragma unroll
+          for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane] = coef[k];
+          valid = 1;
+        }
+      }
+      hv[lane] = valid;
+    }
+    __syncthreads();
+    {
+      int cnt = 0;
+      if (hv[lane]) {
         float coef[12];
-        fit3(L, s0, s1, s2, coef);
-        cnt = 0;
-        for (int i = 0; i < m; ++i) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) coef[k] = L.hyp[k * 64 + lane];
+        for (int i = i0; i < i1; ++i) {
           const float4 p = L.src[i], q = L.dst[i];  // same address in every lane: LDS broadcast
           const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
           cnt += (r2 <= thr2f) ? 1 : 0;
         }
       }
-      L.counts[it] = cnt;
+      L.hyp_cnt[wave * 64 + lane] = cnt;
     }
     __syncthreads();
+    if (wave == 0 && it <= max_it)
+      L.counts[it] = hv[lane] ? ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane]
+                              : -1;
+    __syncthreads();
     if (tid == 0) {
-      const int lim = min(max_it, base + SF_BLOCK - 1);  // last iteration whose count exists
+      const int lim = min(max_it, base + 63);  // last iteration whose count exists
       bool stop = false;
       while (true) {
         if (P.adaptive_stop && !((double)sc_it < k_adapt)) { stop = true; break; }
@@ -345,6 +375,8 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
         if (c > sc_best) {
           sc_best = c;
           sc_best_it = sc_it;
+#pragma unroll
+          for (int k = 0; k < 12; ++k) L.best[k] = L.hyp[k * 64 + (sc_it - base)];   // keep the winning model
           const double w = (double)sc_best * inv_m;
           double pno = 1.0 - (w * w) * w;
           if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
@@ -369,13 +401,10 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
 
   if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
 
-  // ---- winning model (recomputed redundantly in every lane: identical arithmetic, no broadcast) ----
+  // ---- winning model (parked in LDS by the scan) --------------------------------------------------
   float coef[12];
-  {
-    uint32_t s0 = 0, s1 = 1, s2 = 2;
-    draw_sample(L, P.seed, (uint32_t)best_it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2);
-    fit3(L, s0, s1, s2, coef);
-  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) coef[k] = L.best[k];
   uint8_t* inl = L.mask_a;
   int n_inl = select_within(L, m, coef, thr2, inl, tid);
   int n_last = n_inl;
@@ -460,7 +489,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
 
 size_t sf_ransac_lds_bytes(int kcap, int iterations) {
   return (size_t)kcap * 32 + 64 * 8 + (size_t)kcap * 4 + (size_t)((iterations + 2 + 3) & ~3) * 4 + 16 * 4 +
-         (size_t)kcap * 2;
+         (size_t)kcap * 2 + 12 * 64 * 4 + 5 * 64 * 4 + 16 * 4;
 }
 
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {

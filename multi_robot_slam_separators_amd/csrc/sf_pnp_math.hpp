@@ -66,21 +66,28 @@ __device__ inline void quartic_roots(const double (&c)[5], double (&r)[4], bool 
     }
   } else {
     const double g1 = 0.25 * (p * p) - rr, g0 = -0.125 * (q * q);
+    // Fujiwara's bound on the roots, 2 max(|p|, |g1|^(1/2), |g0 / 2|^(1/3)), with the cube root
+    // replaced by the next power of two above it (frexp / ldexp: exact)
     double hi = fabs(p);
-    if (fabs(g1) > hi) hi = fabs(g1);
-    if (fabs(g0) > hi) hi = fabs(g0);
-    hi = 1.0 + hi;
+    { const double sg = sqrt(fabs(g1)); if (sg > hi) hi = sg; }
+    {
+      int ex;
+      (void)frexp(0.5 * fabs(g0), &ex);                 // |g0|/2 = f 2^ex, f in [0.5, 1)
+      const double cb = ldexp(1.0, ex >= 0 ? (ex + 2) / 3 : -((-ex) / 3));   // 2^ceil(ex/3) >= cbrt
+      if (cb > hi) hi = cb;
+    }
+    hi = 2.0 * hi;
     double lo = 0.0;
-    double m = 0.5 * hi;
+    double m = hi;
     for (int it = 0; it < 128; ++it) {
       const double gm = ((m + p) * m + g1) * m + g0;
       const double dg = (3.0 * m + 2.0 * p) * m + g1;
       if (gm > 0.0) hi = m; else lo = m;
       double mn = m - gm / dg;
+      if (fabs(mn - m) <= 4e-16 * fabs(m)) break;   // Newton step within two ulps: converged
+      if (hi - lo <= 4e-16 * fabs(m)) break;        // bracket collapsed onto the root
       if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
-      const double step = fabs(mn - m);
       m = mn;
-      if (step <= 4e-16 * fabs(m)) break;   // within two ulps: converged
     }
     if (!(m > 0.0)) return;
     const double s = sqrt(2.0 * m);
@@ -111,19 +118,27 @@ __device__ __forceinline__ double dot3(const double (&a)[3], const double (&b)[3
 }
 
 // Orthonormal frame of the triangle (A, B, C): rows e1 (along AB), e2 = e3 x e1, e3 (normal).
+// COMPUTE = true returns the two normalisation factors in inv[]; COMPUTE = false reuses them: the
+// camera-frame triangle of a P3P root is congruent to the world triangle, so its frame needs no
+// square root or division of its own.
+template <bool COMPUTE>
 __device__ inline bool tri_frame(const double (&A)[3], const double (&B)[3], const double (&C)[3],
-                                 double (&E)[3][3]) {
+                                 double (&E)[3][3], double (&inv)[2]) {
   double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-  const double n1 = dot3(e1, e1);
-  if (!(n1 > 0.0)) return false;
-  const double i1 = 1.0 / sqrt(n1);
-  e1[0] *= i1; e1[1] *= i1; e1[2] *= i1;
+  if (COMPUTE) {
+    const double n1 = dot3(e1, e1);
+    if (!(n1 > 0.0)) return false;
+    inv[0] = 1.0 / sqrt(n1);
+  }
+  e1[0] *= inv[0]; e1[1] *= inv[0]; e1[2] *= inv[0];
   const double w[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
   double e3[3] = {e1[1] * w[2] - e1[2] * w[1], e1[2] * w[0] - e1[0] * w[2], e1[0] * w[1] - e1[1] * w[0]};
-  const double n3 = dot3(e3, e3);
-  if (!(n3 > 0.0)) return false;
-  const double i3 = 1.0 / sqrt(n3);
-  e3[0] *= i3; e3[1] *= i3; e3[2] *= i3;
+  if (COMPUTE) {
+    const double n3 = dot3(e3, e3);
+    if (!(n3 > 0.0)) return false;
+    inv[1] = 1.0 / sqrt(n3);
+  }
+  e3[0] *= inv[1]; e3[1] *= inv[1]; e3[2] *= inv[1];
 #pragma unroll
   for (int j = 0; j < 3; ++j) { E[0][j] = e1[j]; E[2][j] = e3[j]; }
   E[1][0] = e3[1] * e1[2] - e3[2] * e1[1];
@@ -162,8 +177,8 @@ __device__ inline bool p3p_best(const double (&P)[3][3], const double (&f)[3][3]
   double v[4];
   bool ok[4];
   quartic_roots(c, v, ok);
-  double E[3][3];
-  if (!tri_frame(P[0], P[1], P[2], E)) return false;
+  double E[3][3], finv[2];
+  if (!tri_frame<true>(P[0], P[1], P[2], E, finv)) return false;
   bool have = false;
   double best_e = __longlong_as_double(0x7FF0000000000000LL);
   for (int k = 0; k < 4; ++k) {
@@ -184,7 +199,7 @@ __device__ inline bool p3p_best(const double (&P)[3][3], const double (&f)[3][3]
     const double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
     const double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
     double G[3][3];
-    if (!tri_frame(C1, C2, C3, G)) continue;
+    tri_frame<false>(C1, C2, C3, G, finv);
     double R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -197,7 +212,8 @@ __device__ inline bool p3p_best(const double (&P)[3][3], const double (&f)[3][3]
     const double Y = ((R[3] * P4[0] + R[4] * P4[1]) + R[5] * P4[2]) + t[1];
     const double Z = ((R[6] * P4[0] + R[7] * P4[1]) + R[8] * P4[2]) + t[2];
     if (!(Z > 0.0)) continue;
-    const double du = fx * (X / Z) - ox, dv = fy * (Y / Z) - oy;
+    const double iz = 1.0 / Z;
+    const double du = fx * (X * iz) - ox, dv = fy * (Y * iz) - oy;
     const double e = du * du + dv * dv;
     if (e < best_e) {
       best_e = e;

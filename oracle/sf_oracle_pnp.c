@@ -79,21 +79,28 @@ int sfo_quartic_roots(const double c[5], double r[4]) {
     }
   } else {
     const double g1 = 0.25 * (p * p) - rr, g0 = -0.125 * (q * q);
+    /* Fujiwara's bound on the roots, 2 max(|p|, |g1|^(1/2), |g0 / 2|^(1/3)), with the cube root
+     * replaced by the next power of two above it (frexp / ldexp: exact) */
     double hi = fabs(p);
-    if (fabs(g1) > hi) hi = fabs(g1);
-    if (fabs(g0) > hi) hi = fabs(g0);
-    hi = 1.0 + hi;
+    { const double sg = sqrt(fabs(g1)); if (sg > hi) hi = sg; }
+    {
+      int ex;
+      (void)frexp(0.5 * fabs(g0), &ex);                 /* |g0|/2 = f 2^ex, f in [0.5, 1) */
+      const double cb = ldexp(1.0, ex >= 0 ? (ex + 2) / 3 : -((-ex) / 3));   /* 2^ceil(ex/3) >= cbrt */
+      if (cb > hi) hi = cb;
+    }
+    hi = 2.0 * hi;
     double lo = 0.0;
-    double m = 0.5 * hi;
+    double m = hi;
     for (int it = 0; it < 128; ++it) {
       const double gm = ((m + p) * m + g1) * m + g0;
       const double dg = (3.0 * m + 2.0 * p) * m + g1;
       if (gm > 0.0) hi = m; else lo = m;
       double mn = m - gm / dg;
+      if (fabs(mn - m) <= 4e-16 * fabs(m)) break;   /* Newton step within two ulps: converged */
+      if (hi - lo <= 4e-16 * fabs(m)) break;        /* bracket collapsed onto the root */
       if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
-      const double step = fabs(mn - m);
       m = mn;
-      if (step <= 4e-16 * fabs(m)) break;   /* within two ulps: converged */
     }
     if (!(m > 0.0)) return 0;
     const double s = sqrt(2.0 * m);
@@ -121,19 +128,27 @@ int sfo_quartic_roots(const double c[5], double r[4]) {
 
 static double dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 
-/* orthonormal frame of the triangle (A, B, C): e1 along AB, e3 normal, e2 = e3 x e1 */
-static int sfo_tri_frame(const double* A, const double* B, const double* C, double E[3][3]) {
+/* orthonormal frame of the triangle (A, B, C): e1 along AB, e3 normal, e2 = e3 x e1.
+ * inv[0] = 1/|AB|, inv[1] = 1/|AB x AC|/|AB| are RETURNED when compute != 0 and REUSED otherwise:
+ * the camera-frame triangle of a P3P root is congruent to the world triangle, so its frame is
+ * normalised with the world triangle's factors (no square root or division per root). */
+static int sfo_tri_frame(const double* A, const double* B, const double* C, double E[3][3], double inv[2],
+                         int compute) {
   double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-  const double n1 = dot3(e1, e1);
-  if (!(n1 > 0.0)) return 0;
-  const double i1 = 1.0 / sqrt(n1);
-  e1[0] *= i1; e1[1] *= i1; e1[2] *= i1;
+  if (compute) {
+    const double n1 = dot3(e1, e1);
+    if (!(n1 > 0.0)) return 0;
+    inv[0] = 1.0 / sqrt(n1);
+  }
+  e1[0] *= inv[0]; e1[1] *= inv[0]; e1[2] *= inv[0];
   const double w[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
   double e3[3] = {e1[1] * w[2] - e1[2] * w[1], e1[2] * w[0] - e1[0] * w[2], e1[0] * w[1] - e1[1] * w[0]};
-  const double n3 = dot3(e3, e3);
-  if (!(n3 > 0.0)) return 0;
-  const double i3 = 1.0 / sqrt(n3);
-  e3[0] *= i3; e3[1] *= i3; e3[2] *= i3;
+  if (compute) {
+    const double n3 = dot3(e3, e3);
+    if (!(n3 > 0.0)) return 0;
+    inv[1] = 1.0 / sqrt(n3);
+  }
+  e3[0] *= inv[1]; e3[1] *= inv[1]; e3[2] *= inv[1];
   for (int j = 0; j < 3; ++j) { E[0][j] = e1[j]; E[2][j] = e3[j]; }
   E[1][0] = e3[1] * e1[2] - e3[2] * e1[1];
   E[1][1] = e3[2] * e1[0] - e3[0] * e1[2];
@@ -174,8 +189,8 @@ int sfo_p3p(const double P[3][3], const double f[3][3], double R[4][9], double t
   c[4] = NN4 - rcb * QD4;
   double v[4];
   const int nr = sfo_quartic_roots(c, v);
-  double E[3][3];
-  if (!sfo_tri_frame(P[0], P[1], P[2], E)) return 0;
+  double E[3][3], finv[2];
+  if (!sfo_tri_frame(P[0], P[1], P[2], E, finv, 1)) return 0;
   int ns = 0;
   for (int k = 0; k < nr; ++k) {
     const double vv = v[k];
@@ -192,7 +207,7 @@ int sfo_p3p(const double P[3][3], const double f[3][3], double R[4][9], double t
     const double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
     const double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
     double G[3][3];
-    if (!sfo_tri_frame(C1, C2, C3, G)) continue;
+    sfo_tri_frame(C1, C2, C3, G, finv, 0);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) R[ns][3 * i + j] = (G[0][i] * E[0][j] + G[1][i] * E[1][j]) + G[2][i] * E[2][j];
     for (int i = 0; i < 3; ++i)
@@ -284,7 +299,8 @@ static int sfo_pnp_hypothesis(const sfo_pnp_problem* pb, uint64_t seed, uint32_t
     const double Y = ((R[k][3] * P4[0] + R[k][4] * P4[1]) + R[k][5] * P4[2]) + t[k][1];
     const double Z = ((R[k][6] * P4[0] + R[k][7] * P4[1]) + R[k][8] * P4[2]) + t[k][2];
     if (!(Z > 0.0)) continue;
-    const double du = pb->fx * (X / Z) - ox, dv = pb->fy * (Y / Z) - oy;
+    const double iz = 1.0 / Z;
+    const double du = pb->fx * (X * iz) - ox, dv = pb->fy * (Y * iz) - oy;
     const double e = du * du + dv * dv;
     if (e < best_e) { best_e = e; best = k; }
   }
