@@ -53,20 +53,7 @@ struct PnpLds {
 
 template <int N>
 __device__ __forceinline__ void block_sum_vec32(double (&v)[N], double* red, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = v[k] + __shfl_xor(v[k], off);
-  }
-  __syncthreads();  // previous users of `red` are done
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) red[wave * 32 + k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[32 + k]) + red[64 + k]) + red[96 + k];
+  sfd::block_sum_canon<N, 32>(v, red, tid);
 }
 
 __device__ __forceinline__ int block_sum_i(int v, int* misc, int tid) {

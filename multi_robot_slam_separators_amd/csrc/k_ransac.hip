@@ -42,20 +42,7 @@ struct RansacLds {
 
 template <int N>
 __device__ __forceinline__ void block_sum_vec(double (&v)[N], double* red, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = v[k] + __shfl_xor(v[k], off);
-  }
-  __syncthreads();  // previous users of `red` are done
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) red[wave * 16 + k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[16 + k]) + red[32 + k]) + red[48 + k];
+  sfd::block_sum_canon<N, 16>(v, red, tid);
 }
 
 __device__ __forceinline__ int block_sum_int(int v, int* misc, int tid) {

@@ -261,6 +261,54 @@ __device__ __forceinline__ float residual2(const float (&c)[12], float px, float
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
 }
 
+
+// Block-wide sum of N doubles per thread (256 threads) in the canonical order of DESIGN.md section 4:
+// inside each wavefront the xor butterfly over lane distances 32, 16, 8, 4, 2, 1 (own + partner), then
+// the four wave totals folded left to right.  The butterfly is evaluated TRANSPOSED: at every stage a
+// lane keeps half of the values it still holds and trades the other half with its partner, so the
+// additions are exactly the butterfly's (a + b is commutative in IEEE arithmetic, both lanes of a pair
+// would have computed the same sum) but only ~N cross-lane moves are issued instead of 6 N -- the
+// full butterfly made the LDS crossbar the bottleneck of the refinement loops.
+// red: [4][STRIDE] doubles of LDS scratch, STRIDE >= the power of two above N.
+template <int C>
+__device__ __forceinline__ void sum_stage(double (&w)[32], int& idx, int lane, int off) {
+  if constexpr (C > 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int k = 0; k < C / 2; ++k) {
+      const double send = up ? w[k] : w[k + C / 2];
+      const double keep = up ? w[k + C / 2] : w[k];
+      w[k] = keep + __shfl_xor(send, off);
+    }
+    idx += up ? C / 2 : 0;
+  } else {
+    w[0] = w[0] + __shfl_xor(w[0], off);
+  }
+}
+
+template <int N, int STRIDE>
+__device__ __forceinline__ void block_sum_canon(double (&v)[N], double* red, int tid) {
+  static_assert(N >= 1 && N <= 32 && STRIDE >= N, "at most 32 values");
+  constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : 32;
+  static_assert(STRIDE >= P, "scratch rows must hold the padded count");
+  const int lane = tid & 63, wave = tid >> 6;
+  double w[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) w[k] = k < N ? v[k] : 0.0;
+  int idx = 0;
+  sum_stage<P>(w, idx, lane, 32);
+  sum_stage<(P / 2 > 1 ? P / 2 : 1)>(w, idx, lane, 16);
+  sum_stage<(P / 4 > 1 ? P / 4 : 1)>(w, idx, lane, 8);
+  sum_stage<(P / 8 > 1 ? P / 8 : 1)>(w, idx, lane, 4);
+  sum_stage<(P / 16 > 1 ? P / 16 : 1)>(w, idx, lane, 2);
+  sum_stage<(P / 32 > 1 ? P / 32 : 1)>(w, idx, lane, 1);
+  __syncthreads();  // previous users of `red` are done
+  red[wave * STRIDE + idx] = w[0];   // every lane of a group holds the same total: identical writes
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[STRIDE + k]) + red[2 * STRIDE + k]) + red[3 * STRIDE + k];
+}
+
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
