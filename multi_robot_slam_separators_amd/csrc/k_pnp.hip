@@ -86,7 +86,7 @@ __device__ __forceinline__ bool pnp_inlier(const PnpLds& L, const PnpCam& cam, c
 }
 
 // model of RANSAC iteration `it`: keyed 4-sample, P3P on the first three, the 4th picks the root
-__device__ __attribute__((noinline)) bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
+__device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
                                       float (&coef)[12]) {
   uint32_t s0, s1, s2, s3;
   sfd::sample_quad(seed, it, 0u, m, s0, s1, s2, s3);
@@ -373,7 +373,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
         int valid = 0;
         if (it < max_it) {
           float coef[12];
-          if (P.dbg_stop != 21 && pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
+          if (pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane] = coef[k];
             valid = 1;
@@ -406,7 +406,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
             best_it = sc_it;
 #pragma unroll
             for (int k = 0; k < 12; ++k) L.best[k] = L.hyp[k * 64 + (sc_it - base)];   // keep the winning model
-            if (P.adaptive_stop && P.dbg_stop != 22) niters = sfd::update_num_iters(0.99, (double)(m - good) / (double)m, 4, niters);
+            if (P.adaptive_stop) niters = sfd::update_num_iters(0.99, (double)(m - good) / (double)m, 4, niters);
           }
           ++sc_it;
         }
@@ -418,7 +418,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     }
     __syncthreads();
   }
-  if (P.dbg_stop == 2 || P.dbg_stop == 21 || P.dbg_stop == 22) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return; }
   const int best_it = L.misc[0];
   if (best_it < 0) {   // solvePnPRansac returned false: no inliers
     if (tid == 0) pass[pair] = ps;

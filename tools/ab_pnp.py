@@ -12,8 +12,8 @@ def up(x):
     x = np.ascontiguousarray(x)
     return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
 T = {key: up(d[key]) for key in ("desc_a", "desc_b", "xyz_a", "xyz_b", "kp_a", "kp_b")}
-names = {1: "gather", 2: "+hypotheses+replay", 21: "hyp phase without P3P", 22: "hyp phase, no niters update", 3: "+best model+mask", 4: "+LM", 0: "full (+covariance)"}
-for stop in (1, 2, 21, 22, 3, 4, 0):
+names = {1: "gather", 2: "+hypotheses+replay", 3: "+best model+mask", 4: "+LM", 0: "full (+covariance)"}
+for stop in (1, 2, 3, 4, 0):
     os.environ["SF_RANSAC_STOP"] = str(stop)
     p = synth.camera_params(); p.iterations = 500; p.estimation_type = 1; p.max_features = k; p.store_capacity = 2 * n
     f = lib.SeparatorFinder(p)
