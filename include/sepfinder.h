@@ -260,7 +260,8 @@ enum {
   SF_K_NN_SELECT = 5,  /* f64 re-evaluation of the row minima                                 */
   SF_K_NN_FILTER = 6,  /* fp16 MFMA candidate filter (nn_precision = 1)                       */
   SF_K_NN_REFINE = 7,  /* exact f64 distance of every filter survivor                         */
-  SF_K_COUNT = 8
+  SF_K_FUSED = 8,      /* fused per-pair pipeline: match + RANSAC + guided + RANSAC + result    */
+  SF_K_COUNT = 9
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);

@@ -21,14 +21,15 @@
 
 namespace {
 
+// Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
+// needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
 template <int W>
-__global__ void __launch_bounds__(SF_BLOCK)
-k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-         const PassState* __restrict__ pass1, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
-         uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr, int32_t* __restrict__ list,
-         int32_t* __restrict__ counter, DeviceParams P) {
-  extern __shared__ __attribute__((aligned(16))) int smem[];
-  const int pair = blockIdx.x;
+__device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
+                                            const int32_t* __restrict__ pair_to, const PassState* __restrict__ pass1,
+                                            PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
+                                            uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                                            int32_t* __restrict__ list, int32_t* __restrict__ counter,
+                                            const DeviceParams& P, int* smem) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
@@ -51,7 +52,7 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
       CorrHeader h = {0, 0, 0, 0};
       hdr[pair] = h;
     }
-    return;
+    return false;
   }
 
   int* claim = smem;               // [kcap] lowest "from" index that matched each "to" row
@@ -61,6 +62,9 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   int* cell_start = misc + 16;     // [NC + 1] CSR of "to" keypoints bucketed on a uniform grid
   int* cell_fill = cell_start + NC + 1;   // [NC]
   int* items = cell_fill + NC;     // [kcap] "to" indices grouped by cell
+  float* item_x = reinterpret_cast<float*>(items + kcap);   // [kcap] keypoint x, y and octave bits in the same
+  float* item_y = item_x + kcap;                            //        order: the window test never leaves LDS
+  int* item_o = reinterpret_cast<int*>(item_y + kcap);
   for (int i = tid; i < Kt; i += SF_BLOCK) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += SF_BLOCK) matched[i] = -1;
   for (int i = tid; i <= NC; i += SF_BLOCK) cell_start[i] = 0;
@@ -142,8 +146,11 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
       const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
       const int cidx = cy * P.grid_gx + cx;
-      const int pos = atomicAdd(&cell_fill[cidx], 1);
-      items[cell_start[cidx] + pos] = t;
+      const int pos = cell_start[cidx] + atomicAdd(&cell_fill[cidx], 1);
+      items[pos] = t;
+      item_x[pos] = k.x;
+      item_y[pos] = k.y;
+      item_o[pos] = __float_as_int(k.z);
     }
   }
   __syncthreads();
@@ -191,11 +198,10 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
         // cells cx0..cx1 of one grid row are contiguous in the CSR
         const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
         for (int e = e0; e < e1; ++e) {
-          const int t = items[e];
-          const float4 k = kT[t];
-          const float dx = u - k.x, dy = v - k.y;
+          const float dx = u - item_x[e], dy = v - item_y[e];
           const float d2 = dx * dx + dy * dy;
-          if (d2 < r2lim && __float_as_int(k.z) == octf) {
+          if (d2 < r2lim && item_o[e] == octf) {
+            const int t = items[e];
             const uint32_t* r = dT + (size_t)t * W;
             uint32_t d = 0;
 #pragma unroll
@@ -295,19 +301,28 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     ps.matches = (motion && !survivor) ? misc[2] : 0;
     ps.pad = 0;
     pass2[pair] = ps;
-    if (survivor) {
+    if (survivor && list) {
       int pos = atomicAdd(counter, 1);
       list[pos] = pair;
     }
   }
+  return survivor;
+}
+
+template <int W>
+__global__ void __launch_bounds__(SF_BLOCK)
+k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+         const PassState* __restrict__ pass1, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
+         uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr, int32_t* __restrict__ list,
+         int32_t* __restrict__ counter, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  guided_body<W>(st, (int)blockIdx.x, pair_from, pair_to, pass1, pass2, guided_flag, corr, hdr, list, counter, P, smem);
 }
 
 // ---- result assembly: myRegistration.cpp:279-295 covariance clamp + MsgConversion.cpp:61-81 ------
-__global__ void __launch_bounds__(SF_BLOCK)
-k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restrict__ pass2,
-           const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
-  const int i = blockIdx.x * SF_BLOCK + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void finalize_one(int i, const PassState* __restrict__ pass1,
+                                             const PassState* __restrict__ pass2,
+                                             const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
   const PassState a = pass1[i], b = pass2[i];
   sf_result r;
 #pragma unroll
@@ -376,12 +391,24 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
   out[i] = r;
 }
 
+__global__ void __launch_bounds__(SF_BLOCK)
+k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restrict__ pass2,
+           const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
+  const int i = blockIdx.x * SF_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  finalize_one(i, pass1, pass2, guided_flag, out);
+}
+
 }  // namespace
+
+size_t sf_guided_lds_bytes(int kcap, int n_cells) {
+  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1) * sizeof(int);
+}
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t lds = (size_t)(3 * st.kcap + 16 + 2 * nc + 1) * sizeof(int);
+  const size_t lds = sf_guided_lds_bytes(st.kcap, nc);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_GUIDED);
   if (st.w == 8) {

@@ -290,14 +290,16 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
   }
 }
 
+// Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
+// LDS.  Returns whether the pair goes on to motion estimation (block-uniform).  With list == nullptr
+// the pair is not appended to a work list (fused pipeline, k_verify.hip).
 template <int W, int NQ, int NT>
-__global__ void __launch_bounds__(NT)
-k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-                  float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
-                  PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
-  extern __shared__ __attribute__((aligned(16))) int smem[];
+__device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
+                                              const int32_t* __restrict__ pair_to, float nndr, int min_inliers, int est,
+                                              uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                                              PassState* __restrict__ pass, int32_t* __restrict__ list,
+                                              int32_t* __restrict__ counter, int* smem) {
   constexpr int NW = NT / 64;
-  const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
@@ -312,7 +314,7 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
       ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
       pass[pair] = ps;
     }
-    return;
+    return false;
   }
   const int4 mF = st.meta[sF], mT = st.meta[sT];
   const int Kf = mF.x, Kt = mT.x;
@@ -452,16 +454,28 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
     ps.matches = (motion && !survivor) ? misc[2] : 0;
     ps.pad = 0;
     pass[pair] = ps;
-    if (survivor) {
+    if (survivor && list) {
       int pos = atomicAdd(counter, 1);
       list[pos] = pair;
     }
   }
+  return survivor;
+}
+
+template <int W, int NQ, int NT>
+__global__ void __launch_bounds__(NT)
+k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                  float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                  PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  match_v2_body<W, NQ, NT>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
+                           counter, smem);
 }
 
 template <int W, int NQ, int NT>
 void launch_match_v2(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
-  const size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
+  size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
+  if (const char* v = getenv("SF_MATCH_LDS_PAD")) lds += (size_t)atoi(v);   // occupancy experiment (diagnostic)
   int32_t* counters = (int32_t*)c->counters.p;
   hipLaunchKernelGGL((k_match_global_v2<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
                      c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,

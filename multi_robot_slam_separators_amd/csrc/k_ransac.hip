@@ -187,17 +187,14 @@ __device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) 
   return 2.1981 * medv;
 }
 
-__global__ void __launch_bounds__(SF_BLOCK, 4)
-k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-         const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
-         const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
-         PassState* __restrict__ pass, DeviceParams P) {
-  if ((int)blockIdx.x >= *counter) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// Body of one RANSAC pass for ONE pair (the calling workgroup); smem_raw is the workgroup's dynamic LDS.
+__device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
+                                            const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
+                                            const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
+                                            const DeviceParams& P, unsigned char* smem_raw) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const int pair = list[blockIdx.x];
   const int sF = pair_from[pair], sT = pair_to[pair];
 
   RansacLds L;
@@ -470,6 +467,16 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
     }
   }
   if (tid == 0) pass[pair] = ps;
+}
+
+__global__ void __launch_bounds__(SF_BLOCK, 4)
+k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+         const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+         const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+         PassState* __restrict__ pass, DeviceParams P) {
+  if ((int)blockIdx.x >= *counter) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ransac_body(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
 }
 
 }  // namespace

@@ -1,0 +1,90 @@
+// k_verify.hip -- the verification kernels as ONE translation unit, plus the fused per-pair pipeline.
+//
+// The three stage files are included (not linked) so that their per-pair bodies can be inlined into
+// k_verify_fused: one 256-thread workgroup takes a candidate pair through the whole of
+// StereoCamGeometricTools::estimateTransformation (stereoCamGeometricTools.cpp:122-178) --
+// global matching, RANSAC, guess-guided matching, RANSAC again, result assembly -- without leaving the
+// CU.  Why fuse: the motion-estimation stages are short dependent fp64 chains that occupy a few
+// hundred workgroups for ~0.1 ms each and leave the VALU pipes idle, while matching is bound by VALU
+// issue and (measured, tools/exp_match_occupancy.py) loses 1 % when only 4 instead of 7 workgroups are
+// resident per CU.  In the fused kernel the 20 % of pairs that survive matching run their RANSAC chain
+// while the other workgroups of the same CU are still matching, so the chain's latency is hidden
+// instead of serialised behind four more launches.  The stage kernels remain for the PnP estimator
+// (k_pnp needs 256 VGPRs) and as the A/B reference (SF_FUSED=0): both paths run the same bodies and
+// produce identical bytes.
+// Compiled with -ffp-contract=off (canonical arithmetic of the RANSAC / guided bodies).
+#include "k_match.hip"
+#include "k_ransac.hip"
+#include "k_guided.hip"
+
+namespace {
+
+template <int W, int NQ>
+__global__ void __launch_bounds__(SF_BLOCK, 4)
+k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+               uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
+               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int pair = blockIdx.x;
+  // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
+  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
+                                                   pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
+  __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
+  if (est1) {
+    ransac_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    __syncthreads();
+  }
+  // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
+  const bool est2 = guided_body<W>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr, nullptr,
+                                   P, reinterpret_cast<int*>(smem_raw));
+  __syncthreads();
+  if (est2) {
+    ransac_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
+}
+
+template <int W, int NQ>
+int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
+                 size_t lds) {
+  if (lds > 64 * 1024 && !c->fused_attr_set) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    c->fused_attr_set = true;
+  }
+  hipLaunchKernelGGL((k_verify_fused<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
+                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
+  return SF_OK;
+}
+
+}  // namespace
+
+// Dynamic LDS of the fused kernel = the largest stage; 0 when the fused pipeline does not apply
+// (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
+size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
+  if (c->dparams.estimation_type != 0 || !c->fused) return 0;
+  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  const size_t guided = sf_guided_lds_bytes(st.kcap, nc);
+  const size_t ransac = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  const size_t lds = std::max(match, std::max(guided, ransac));
+  return lds <= 160 * 1024 ? lds : 0;
+}
+
+int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
+                           sf_result* d_out) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = sf_fused_lds_bytes(c, st);
+  if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
+  int rc;
+  sf_prof_begin(c, SF_K_FUSED);
+  if (st.w == 8) rc = launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds);
+  else rc = launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds);
+  sf_prof_end(c, SF_K_FUSED);
+  if (rc != SF_OK) return rc;
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

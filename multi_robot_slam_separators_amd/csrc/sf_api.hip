@@ -69,7 +69,7 @@ StoreView sf_store_view(const Store& s) {
 // ---- profiling ------------------------------------------------------------------------------
 static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "k_guided",
                                           "k_ransac(pass2)", "k_nn_argmin", "k_nn_select",
-                                          "k_nn_filter_f16", "k_nn_refine"};
+                                          "k_nn_filter_f16", "k_nn_refine", "k_verify_fused"};
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
 void sf_prof_begin(sf_context* c, int kernel) {
@@ -510,6 +510,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   }
   c->own_stream = true;
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
+  if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
   *out = c;
   return SF_OK;
@@ -622,6 +623,11 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
   for (int off = 0; off < n; off += SF_CHUNK) {
     const int m = std::min(SF_CHUNK, n - off);
     SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+    if (sf_fused_lds_bytes(c, view) != 0) {
+      // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip)
+      if ((rc = sf_launch_verify_fused(c, view, d_from + off, d_to + off, m, d_out + off)) != SF_OK) return rc;
+      continue;
+    }
     if ((rc = sf_launch_match_global(c, view, d_from + off, d_to + off, m)) != SF_OK) return rc;
     const bool pnp = c->dparams.estimation_type == 1;
     if ((rc = (pnp ? sf_launch_pnp : sf_launch_ransac)(c, view, d_from + off, d_to + off, m, 1)) != SF_OK) return rc;

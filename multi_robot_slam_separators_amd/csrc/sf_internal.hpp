@@ -139,6 +139,8 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
+  bool fused_attr_set = false;
+  bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
 
@@ -180,6 +182,12 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass);
 // Guided matching for pairs whose pass 1 succeeded; builds the pass-2 RANSAC work list.
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
+// Fused per-pair pipeline (k_verify.hip): match -> RANSAC -> guided -> RANSAC -> result in one launch.
+size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
+int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
+                           sf_result* d_out);
+size_t sf_ransac_lds_bytes(int kcap, int iterations);
+size_t sf_guided_lds_bytes(int kcap, int n_cells);
 // Assemble sf_result records.
 int sf_launch_finalize(sf_context* c, int n, sf_result* d_out);
 // Ingest kernels

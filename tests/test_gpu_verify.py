@@ -299,3 +299,28 @@ def test_verification_regression_vectors_on_gpu(est):
     want = z["result_est%d" % est]
     for i in range(len(A)):
         assert got[i].tobytes() == want[i].tobytes(), "estimation_type %d pair %d" % (est, i)
+
+
+def test_fused_pipeline_equals_stage_kernels(monkeypatch):
+    """k_verify_fused (one launch per chunk) and the five stage kernels (SF_FUSED=0) run the same
+    per-pair bodies: results, correspondences and counts must be identical byte for byte."""
+    from multi_robot_slam_separators_amd import lib
+    A, B, is_true, _ = synth.make_pairs(515, 40, k=500, cols=32, true_frac=0.4)
+    A2, B2, _, _ = synth.make_pairs(516, 12, k=300, cols=64, true_frac=0.5)
+    for AA, BB in ((A, B), (A2, B2)):
+        p = synth.camera_params()
+        p.iterations = 300
+        out = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("SF_FUSED", fused)
+            with lib.SeparatorFinder(p) as f:
+                f.prof_enable(True)
+                res = f.estimate_transform_batch(AA, BB)
+                corr = [f.debug_correspondences(i, w) for i in range(len(AA)) for w in (1, 2)]
+                prof = f.prof_get()
+            out[fused] = (res, corr, prof)
+        assert out["1"][2]["k_verify_fused"][0] >= 1 and out["1"][2]["k_match_global"][0] == 0
+        assert out["0"][2]["k_verify_fused"][0] == 0 and out["0"][2]["k_match_global"][0] >= 1
+        assert out["1"][0].tobytes() == out["0"][0].tobytes()
+        for c1, c0 in zip(out["1"][1], out["0"][1]):
+            assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
