@@ -126,6 +126,8 @@ def main():
                     help="motion estimator of both registration passes: 3d3d = RANSAC 3D->3D (north_star, "
                          "myRegistrationVis.cpp:1113-1152), pnp = RANSAC 3D->2D (:1055-1112, rtabmap's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined-extra", action="store_true",
+                    help="skip the informational two-stream pipelined measurement")
     ap.add_argument("--cpu-sample-pairs", type=int, default=2048)
     ap.add_argument("--cpu-sample-rows", type=int, default=64)
     args = ap.parse_args()
@@ -190,7 +192,6 @@ def main():
     f.nn_append_received_device(ta.data_ptr(), n_kf, dim)    # robot A's descriptors, as received by B
     f.nn_append_local_device(tb.data_ptr(), n_kf, dim)       # robot B's own descriptors
     torch.cuda.synchronize()
-    del ta, tb
 
     d_from = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_to = torch.empty(n_kf, dtype=torch.int32, device=dev)
@@ -274,6 +275,64 @@ def main():
         f.nn_set_precision(1)
         step()
 
+    # ---- informational: the same steps software-pipelined over two streams (untimed by the driver) ----
+    # A deployment that serves a stream of independent batches can run the NN stage of batch i+1 (MFMA +
+    # HBM + host walk, on a second handle with its own stream) while batch i is being verified (VALU).
+    # `value` above is NOT measured this way: its steps run strictly one after the other.
+    piped = None
+    if world == 1 and args.nn_precision == 1 and not args.no_pipelined_extra:
+        f_nn = lib.SeparatorFinder(p, device=dev_index)          # own non-blocking stream
+        f_nn.nn_append_received_device(ta.data_ptr(), n_kf, dim)
+        f_nn.nn_append_local_device(tb.data_ptr(), n_kf, dim)
+        f_nn.synchronize()
+
+        def launch_verify(m):
+            n = len(m)
+            h_from[:n] = torch.from_numpy(m["idx_other"].astype(np.int32) + slot_a)
+            h_to[:n] = torch.from_numpy(m["idx_local"].astype(np.int32) + slot_b)
+            d_from[:n].copy_(h_from[:n], non_blocking=True)
+            d_to[:n].copy_(h_to[:n], non_blocking=True)
+            f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+            return n
+
+        h_res_p = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+        h_flags_p = torch.empty(n_kf, dtype=torch.bool).pin_memory()
+
+        def finish(n):
+            res2d = d_res[:n]
+            succ = res2d[:, OFF_SUCCESS] != 0
+            acc = res2d[succ]
+            h_flags_p[:n].copy_(succ, non_blocking=True)
+            h_res_p[: acc.shape[0]].copy_(acc, non_blocking=True)
+            torch.cuda.synchronize()
+            return int(acc.shape[0])
+
+        def run_piped(k_steps):
+            pairs = 0
+            m = f_nn.nn_find_matches(cap=n_kf)
+            for i in range(k_steps):
+                n = launch_verify(m)                      # asynchronous on the verification stream
+                if i + 1 < k_steps:
+                    m_next = f_nn.nn_find_matches(cap=n_kf)   # overlaps the verification of batch i
+                got = finish(n)
+                pairs += n
+                if i + 1 < k_steps:
+                    m = m_next
+            return pairs, got
+
+        run_piped(3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_p, got_p = run_piped(max(10, args.steps))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        piped = {"value": n_p / dt, "unit": "pairs/s", "ms_per_step": dt / max(10, args.steps) * 1e3,
+                 "accepted_last_step": got_p,
+                 "note": "NN stage of batch i+1 on a second handle/stream while batch i is verified; "
+                         "informational, `value` runs its steps strictly in sequence"}
+        f_nn.close()
+    del ta, tb
+
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
     flags = h_flags[:n].numpy().copy()
@@ -348,6 +407,8 @@ def main():
                       "gathered_records_all_accepted": all_ok},
             "input_generation_s": t_gen,
         }
+        if piped is not None:
+            out["pipelined_two_streams"] = piped
         if alt is not None:
             out["value_with_fp32_nn_ranking"] = alt * world
             out["check"]["nn_matches_identical_fp32_vs_f16filter"] = bool(
