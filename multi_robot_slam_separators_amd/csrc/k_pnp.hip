@@ -367,9 +367,10 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     const int slice = (m + 3) >> 2;                        // points counted by each wavefront
     const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
     int* hv = L.hyp_cnt + 4 * 64;
+    const int fit_wave = pair & 3;   // rotate the solving wavefront (SIMD) with the pair
     for (int base = 0; base < max_it; base += 64) {
       const int it = base + lane;
-      if (wave == 0) {
+      if (wave == fit_wave) {
         int valid = 0;
         if (it < max_it) {
           float coef[12];
@@ -393,7 +394,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
         L.hyp_cnt[wave * 64 + lane] = cnt;
       }
       __syncthreads();
-      if (wave == 0 && it < max_it)
+      if (wave == fit_wave && it < max_it)
         L.counts[it] = ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane];
       __syncthreads();
       if (tid == 0) {

@@ -311,9 +311,12 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   const int slice = (m + 3) >> 2;                        // points counted by each wavefront
   const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
   int* hv = L.hyp_cnt + 4 * 64;
+  // the wavefront that samples and fits rotates with the pair, so that the workgroups sharing a CU do
+  // not all put this serial fp64 section on the same SIMD
+  const int fit_wave = pair & 3;
   for (int base = 0; base <= max_it; base += 64) {
     const int it = base + lane;
-    if (wave == 0) {
+    if (wave == fit_wave) {
       int valid = 0;
       if (it <= max_it) {
         uint32_t s0, s1, s2;
@@ -343,7 +346,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
       L.hyp_cnt[wave * 64 + lane] = cnt;
     }
     __syncthreads();
-    if (wave == 0 && it <= max_it)
+    if (wave == fit_wave && it <= max_it)
       L.counts[it] = hv[lane] ? ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane]
                               : -1;
     __syncthreads();
