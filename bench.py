@@ -111,8 +111,8 @@ def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--keyframes", type=int, default=10000, help="keyframes per robot (configs[1]: 10k)")
     ap.add_argument("--features", type=int, default=500)
     ap.add_argument("--desc-bytes", type=int, default=32)
@@ -203,8 +203,12 @@ def main():
     h_to = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     state = {"pairs": 0, "accepted": 0, "last": None}
 
+    trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
+
     def step():
+        t_0 = time.perf_counter()
         m = f.nn_find_matches(cap=n_kf)                       # NN kernels + row minima to host + walk
+        t_1 = time.perf_counter()
         n = len(m)
         # pair (from = querying robot A's keyframe idx_other, to = computing robot B's idx_local),
         # find_separators.py:85-91
@@ -213,6 +217,10 @@ def main():
         d_from[:n].copy_(h_from[:n], non_blocking=True)
         d_to[:n].copy_(h_to[:n], non_blocking=True)
         f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+        if trace:
+            t_2 = time.perf_counter()
+            torch.cuda.synchronize()
+            t_3 = time.perf_counter()
         # every candidate's success flag goes back to the two robots involved (failures feed the ignore
         # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
         # the back-end (data_handler.py:352-368).
@@ -227,6 +235,11 @@ def main():
         host = h_res[: rec.shape[0]]
         host.copy_(rec, non_blocking=True)                    # accepted separators delivered to the host (pinned)
         torch.cuda.synchronize()
+        if trace:
+            t_4 = time.perf_counter()
+            print("[bench step] nn %.3f ms, pair upload + verify launch %.3f, verify wait %.3f, accepted-only "
+                  "gather + copies %.3f" % ((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3),
+                  file=sys.stderr)
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = int(rec.shape[0])

@@ -30,7 +30,10 @@ f.nn_append_received_device(ta.data_ptr(), n_kf, dim); f.nn_append_local_device(
 d_from = torch.empty(n_kf, dtype=torch.int32, device=dev); d_to = torch.empty_like(d_from)
 d_res = torch.empty((n_kf, 368), dtype=torch.uint8, device=dev)
 h_res = torch.empty((n_kf, 368), dtype=torch.uint8).pin_memory()
-T = {"nn": [], "idx": [], "verify_launch": [], "verify_wait": [], "d2h_pageable": [], "d2h_pinned": []}
+h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
+OFF = _abi.RESULT_DTYPE.fields["success"][1]
+T = {"nn": [], "idx": [], "verify_launch": [], "verify_wait": [], "d2h_pageable": [], "d2h_pinned": [],
+     "accepted_compaction+copies (bench step tail)": []}
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     t0 = time.perf_counter(); m = f.nn_find_matches(cap=n_kf); t1 = time.perf_counter()
     n = len(m)
@@ -40,5 +43,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     torch.cuda.synchronize(); t4 = time.perf_counter()
     x = d_res[:n].cpu(); t5 = time.perf_counter()
     h_res[:n].copy_(d_res[:n], non_blocking=True); torch.cuda.synchronize(); t6 = time.perf_counter()
-    for key, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)): T[key].append(v * 1e3)
-for key, v in T.items(): print("%-16s median %.3f ms" % (key, np.median(v[2:])))
+    res2d = d_res[:n]; succ = res2d[:, OFF] != 0; acc = res2d[succ]
+    h_flags[:n].copy_(succ, non_blocking=True); h_res[: acc.shape[0]].copy_(acc, non_blocking=True); torch.cuda.synchronize(); t7 = time.perf_counter()
+    for key, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6)): T[key].append(v * 1e3)
+for key, v in T.items(): print("%-46s median %.3f ms" % (key, np.median(v[2:])))
