@@ -70,6 +70,9 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
   const size_t guided = sf_guided_lds_bytes(st.kcap, nc);
   const size_t ransac = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
+  // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
+  if (match > 64 * 1024 || c->match_variant != 0) return 0;
   const size_t lds = std::max(match, std::max(guided, ransac));
   return lds <= 160 * 1024 ? lds : 0;
 }
