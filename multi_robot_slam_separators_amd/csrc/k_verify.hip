@@ -49,10 +49,11 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 template <int W, int NQ>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds) {
-  if (lds > 64 * 1024 && !c->fused_attr_set) {
+  bool& attr_set = W == 8 ? c->fused_attr_set : c->fused_attr_set_w16;   // one flag per instantiation
+  if (lds > 64 * 1024 && !attr_set) {
     SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
-    c->fused_attr_set = true;
+    attr_set = true;
   }
   hipLaunchKernelGGL((k_verify_fused<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,

@@ -139,7 +139,7 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
-  bool fused_attr_set = false;
+  bool fused_attr_set = false, fused_attr_set_w16 = false;
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
