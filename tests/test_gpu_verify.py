@@ -324,3 +324,21 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch):
         assert out["1"][0].tobytes() == out["0"][0].tobytes()
         for c1, c0 in zip(out["1"][1], out["0"][1]):
             assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
+
+
+def test_fused_pipeline_with_more_than_64k_of_lds(oracle):
+    """K = 700 (kcap 1024) and 6 000 iterations: the fused kernel's dynamic LDS exceeds 64 KiB (RANSAC
+    count table), which needs the raised per-kernel limit."""
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = 6000
+    p.ransac_adaptive_stop = 0
+    p.max_features = 700
+    A, B, is_true, _ = synth.make_pairs(808, 6, k=700, cols=32, true_frac=0.5)
+    with lib.SeparatorFinder(p) as f:
+        f.prof_enable(True)
+        got = f.estimate_transform_batch(A, B)
+        assert f.prof_get()["k_verify_fused"][0] >= 1
+    for i in range(len(A)):
+        assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "pair %d" % i)
+    assert got["success"][is_true].all()
