@@ -228,7 +228,8 @@ def main():
         succ = res2d[:, OFF_SUCCESS] != 0
         acc = res2d[succ]                                     # device-side compaction
         if world > 1:
-            rec, counts = dist.allgather_records(acc.to(coll_dev))
+            # one collective: capacity for a 25 % acceptance rate + slack (overflow falls back to two-phase)
+            rec, counts = dist.allgather_records_fixed(acc.to(coll_dev), n_kf // 4 + 256)
         else:
             rec = acc
         h_flags[:n].copy_(succ, non_blocking=True)

@@ -46,6 +46,42 @@ def allgather_records(local, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+def allgather_records_fixed(local, cap, group=None):
+    """All-gather a ragged set of fixed-size records with ONE collective.
+
+    Every rank sends `cap` record slots preceded by a header slot that carries its true count (int64 in
+    the first 8 bytes), so no count exchange precedes the payload: one all_gather_into_tensor, one
+    device-to-host read of the `world` headers.  If some rank holds more than `cap` records (the caller
+    sized `cap` from the expected acceptance rate) the overflow is exchanged with the two-phase
+    allgather_records -- correct for any input, one collective in the common case.
+    Returns (records [sum n, record_bytes], counts list), rank-major like allgather_records."""
+    import torch
+    td = _dist()
+    world = td.get_world_size(group)
+    n_local, rec = int(local.shape[0]), int(local.shape[1])
+    if rec < 8:
+        return allgather_records(local, group)
+    cap = max(int(cap), 1)
+    send = torch.zeros((cap + 1, rec), dtype=torch.uint8, device=local.device)
+    send[0, :8] = torch.tensor([n_local], dtype=torch.int64).view(torch.uint8).to(local.device)
+    k = min(n_local, cap)
+    if k:
+        send[1: 1 + k] = local[:k]
+    recv = torch.empty((world * (cap + 1), rec), dtype=torch.uint8, device=local.device)
+    td.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, cap + 1, rec)
+    counts = [int(c) for c in recv[:, 0, :8].contiguous().view(torch.int64).reshape(-1).tolist()]
+    parts = [recv[r, 1: 1 + min(counts[r], cap)] for r in range(world)]
+    if max(counts) > cap:   # rare: exchange what did not fit
+        extra, ecounts = allgather_records(local[cap:] if n_local > cap else local[:0], group)
+        off = 0
+        for r in range(world):
+            if ecounts[r]:
+                parts[r] = torch.cat([parts[r], extra[off: off + ecounts[r]]], dim=0)
+            off += ecounts[r]
+    return torch.cat(parts, dim=0), counts
+
+
 def interleave_round_robin(records, counts):
     """Undo shard_pairs: records gathered rank-major -> global pair order (p = i*world + rank)."""
     import torch

@@ -277,6 +277,9 @@ def test_torch_rccl_allgather_records_single_rank():
         assert counts == [5] and torch.equal(out, rec)
         out, counts = dist.allgather_records(rec[:0])
         assert counts == [0] and out.shape == (0, 368)
+        for cap in (8, 5, 2):        # the one-collective variant, with and without the overflow fallback
+            out, counts = dist.allgather_records_fixed(rec, cap)
+            assert counts == [5] and torch.equal(out, rec)
         t = torch.tensor([3.5], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         td.barrier()

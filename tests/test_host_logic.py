@@ -147,10 +147,16 @@ assert counts == [len(dist.shard_pairs(n_pairs, r, world)) for r in range(world)
 assert out["inliers"].tolist() == [p * 7 + 1 for p in range(n_pairs)], out["inliers"]
 assert out["success"].tolist() == [p %% 2 for p in range(n_pairs)]
 assert np.allclose(out["position"][:, 0], np.arange(n_pairs) + 0.25)
+# --- the same exchange with ONE collective (fixed capacity + header), incl. the overflow fallback ------
+for cap in (8, 4, 2, 1):
+    allrec2, counts2 = dist.allgather_records_fixed(local, cap)
+    assert counts2 == counts and torch.equal(allrec2, allrec), cap
 # --- empty shard on one rank ---------------------------------------------------------------------------
 few = torch.zeros((1 if rank == 0 else 0, 8), dtype=torch.uint8)
 g, c = dist.allgather_records(few)
 assert c == [1] + [0] * (world - 1) and g.shape == (1, 8)
+g2, c2 = dist.allgather_records_fixed(few, 4)
+assert c2 == c and torch.equal(g2, g)
 # --- NN stage sharded over local rows: gather the row minima, replicate the walk ----------------------
 rng = np.random.default_rng(3)
 rmin = rng.random(40); rarg = rng.integers(0, 25, 40).astype(np.int32)
