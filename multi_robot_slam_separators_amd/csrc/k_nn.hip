@@ -281,6 +281,7 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
                 uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
   __shared__ __attribute__((aligned(16))) float sA[NN_BM * NN_PITCH];   // 128 rows x 64 halfs (+ pad)
   __shared__ __attribute__((aligned(16))) float sB[NN_BN * NN_PITCH];
+  __shared__ float2 sRowC[NN_BM], sColC[NN_BN];   // epilogue coefficients of this tile (no global loads there)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -289,6 +290,8 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
   const int row0 = tile_y * NN_BM, col0 = tile_x * NN_BN;
   const int l31 = lane & 31, h = lane >> 5;
   const int ldw = ld / 2;                      // row pitch in dwords (ld halfs)
+  if (tid < NN_BM) sRowC[tid] = rowc[row0 + tid];
+  else sColC[tid - NN_BM] = colc[col0 + tid - NN_BM];   // visible after the K loop's barriers
   const float* Aw = reinterpret_cast<const float*>(A);
   const float* Bw = reinterpret_cast<const float*>(B);
 
@@ -350,21 +353,29 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
   int colj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    colj[j] = col0 + 64 * wc + 32 * j + l31;
-    cj[j] = colc[colj[j]];
+    colj[j] = 64 * wc + 32 * j + l31;
+    cj[j] = sColC[colj[j]];
   }
+  // both columns of a lane at once: packed fp32 add / fma (v_pk_add_f32, v_pk_fma_f32), 2 instead of 4
+  // VALU operations per row; the N^2 compare epilogue is what bounds a short-prefix contraction
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 Bv = {cj[0].x, cj[1].x}, Dv = {cj[0].y, cj[1].y};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float2 ci = rowc[row];
+      const int row = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float2 ci = sRowC[row];
+      const f32x2 Av = {ci.x, ci.x}, Cv = {-ci.y, -ci.y};
+      const f32x2 rhs = __builtin_elementwise_fma(Cv, Dv, Av + Bv);
+      const bool hit0 = acc[i][0][r] > rhs.x, hit1 = acc[i][1][r] > rhs.y;   // false for +inf / NaN (masked / padding)
+      if (hit0 | hit1) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float rhs = fmaf(-ci.y, cj[j].y, ci.x + cj[j].x);
-        if (acc[i][j][r] > rhs) {           // false for +inf / NaN (masked or padding rows / columns)
-          const unsigned pos = atomicAdd(cand_count, 1u);
-          if (pos < cand_cap) cand[pos] = make_uint2((unsigned)row, (unsigned)colj[j]);
+        for (int j = 0; j < 2; ++j) {
+          if (j == 0 ? hit0 : hit1) {
+            const unsigned pos = atomicAdd(cand_count, 1u);
+            if (pos < cand_cap) cand[pos] = make_uint2((unsigned)(row0 + row), (unsigned)(col0 + colj[j]));
+          }
         }
       }
     }
@@ -559,8 +570,11 @@ static int nn_run_filter(sf_context* c, int* done) {
   double* h_dist = nullptr;
   for (; level < n_levels && !ok; ++level) {
     const int kdims = levels[level];
-    if ((rc = nn_prepare_f16(c, c->nn_local, ld, ld16, kdims)) != SF_OK) return rc;
-    if ((rc = nn_prepare_f16(c, c->nn_recv, ld, ld16, kdims)) != SF_OK) return rc;
+    // the fp16 copy of a prefix level is stored COMPACT (pitch = prefix length): a 128-row operand tile is
+    // then one contiguous 32 / 128 KB block instead of 128 pieces 2 * dim bytes apart
+    const int pitch16 = kdims;
+    if ((rc = nn_prepare_f16(c, c->nn_local, ld, pitch16, kdims)) != SF_OK) return rc;
+    if ((rc = nn_prepare_f16(c, c->nn_recv, ld, pitch16, kdims)) != SF_OK) return rc;
     if (tr.on) { (void)hipStreamSynchronize(c->stream); tr.mark("prepare f16", kdims); }
     // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
     const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
@@ -575,7 +589,7 @@ static int nn_run_filter(sf_context* c, int* done) {
     sf_prof_begin(c, SF_K_NN_FILTER);
     hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                        (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
-                       ld16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
+                       pitch16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
     sf_prof_end(c, SF_K_NN_FILTER);
     SF_HIP(c, hipGetLastError());
     const bool prefix_level = level < n_levels - 1;
