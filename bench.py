@@ -238,9 +238,12 @@ def main():
         torch.cuda.synchronize()
         if trace:
             t_4 = time.perf_counter()
+            pr = f.prof_get()
+            kv = sum(v[1] for kname, v in pr.items() if kname.startswith("k_verify") or kname.startswith("k_match")
+                     or kname.startswith("k_ransac") or kname.startswith("k_guided"))
             print("[bench step] nn %.3f ms, pair upload + verify launch %.3f, verify wait %.3f, accepted-only "
-                  "gather + copies %.3f" % ((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3),
-                  file=sys.stderr)
+                  "gather + copies %.3f; verification kernels so far %.3f ms (hipEvents)"
+                  % ((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3, kv), file=sys.stderr)
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = int(rec.shape[0])
