@@ -101,7 +101,8 @@ def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
     return {
         "value": n_kf / t_full, "unit": "pairs/s", "cores": threads, "kind": "port",
         "sample": "%d of %d candidate pairs verified in %.2f s + NN rows %d of %d x %d x %d in %.2f s, "
-                  "both scaled to the full step; OpenMP over pairs / rows" % (
+                  "both scaled to the full step; OpenMP over pairs / rows, one thread per CPU of this process' "
+                  "cgroup share" % (
                       S, n_kf, t_ver, R, n_kf, n_kf, nv_a.shape[1], t_nn),
         "verify_pairs_per_s": S / t_ver, "accepted_in_sample": int(res["success"].sum()),
         "verify_pairs_per_s_single_thread": S1 / t_one,
@@ -128,8 +129,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined-extra", action="store_true",
                     help="skip the informational two-stream pipelined measurement")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=2048)
-    ap.add_argument("--cpu-sample-rows", type=int, default=64)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=10000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,6 +138,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as td
+    from multi_robot_slam_separators_amd.hostinfo import cpu_share
+    # torch sizes its intra-op pool from the host's CPU count; on a box that grants a cgroup share of the
+    # host that oversubscribes the quota and CFS throttling stalls the process (periodic 40-80 ms gaps)
+    torch.set_num_threads(max(1, min(8, cpu_share())))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the separator-finder path has no CPU fallback")
     backend = os.environ.get("BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on one GPU
@@ -214,8 +219,11 @@ def main():
         # find_separators.py:85-91
         h_from[:n] = torch.from_numpy(m["idx_other"].astype(np.int32) + slot_a)
         h_to[:n] = torch.from_numpy(m["idx_local"].astype(np.int32) + slot_b)
-        d_from[:n].copy_(h_from[:n], non_blocking=True)
-        d_to[:n].copy_(h_to[:n], non_blocking=True)
+        nb = os.environ.get("BENCH_BLOCKING_IDX") is None
+        d_from[:n].copy_(h_from[:n], non_blocking=nb)
+        d_to[:n].copy_(h_to[:n], non_blocking=nb)
+        if trace:
+            t_1b = time.perf_counter()
         f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
         if trace:
             t_2 = time.perf_counter()
@@ -241,9 +249,10 @@ def main():
             pr = f.prof_get()
             kv = sum(v[1] for kname, v in pr.items() if kname.startswith("k_verify") or kname.startswith("k_match")
                      or kname.startswith("k_ransac") or kname.startswith("k_guided"))
-            print("[bench step] nn %.3f ms, pair upload + verify launch %.3f, verify wait %.3f, accepted-only "
+            print("[bench step] nn %.3f ms, pair upload %.3f, verify launch %.3f, verify wait %.3f, accepted-only "
                   "gather + copies %.3f; verification kernels so far %.3f ms (hipEvents)"
-                  % ((t_1 - t_0) * 1e3, (t_2 - t_1) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3, kv), file=sys.stderr)
+                  % ((t_1 - t_0) * 1e3, (t_1b - t_1) * 1e3, (t_2 - t_1b) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3, kv),
+                  file=sys.stderr)
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = int(rec.shape[0])
@@ -252,7 +261,7 @@ def main():
     for _ in range(args.warmup):
         step()
     f.prof_reset()
-    f.prof_enable(True)
+    f.prof_enable(os.environ.get("BENCH_NO_PROF") is None)
     state["pairs"] = 0
     if world > 1:
         td.barrier()

@@ -30,7 +30,14 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        # size the OpenMP team to the CPU share of this process (cgroup quota), not to the host's CPU
+        # count: an oversubscribed quota is throttled by the kernel and the timing means nothing
+        from multi_robot_slam_separators_amd.hostinfo import cpu_share
+        os.environ.setdefault("OMP_NUM_THREADS", str(cpu_share()))
         L = C.CDLL(_LIB_PATH)
+        L.sfo_set_num_threads.restype = None
+        L.sfo_set_num_threads.argtypes = [C.c_int]
+        L.sfo_set_num_threads(cpu_share())     # explicit: another OpenMP user in the process may have shrunk the team
         P = C.POINTER
         L.sfo_find_matches.restype = C.c_int
         L.sfo_find_matches.argtypes = [

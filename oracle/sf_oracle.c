@@ -1013,6 +1013,14 @@ int sfo_estimate_transform(const sf_params* p, const sf_features* from, const sf
   return sfo_estimate_transform_dbg(p, from, to, out, NULL, NULL, NULL, NULL, NULL, NULL);
 }
 
+void sfo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int sfo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -113,6 +113,7 @@ double sfo_canon_log(double x);
 void   sfo_sample_triplet(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m,
                           uint32_t out[3]);
 int    sfo_num_threads(void);
+void   sfo_set_num_threads(int n);   /* size of the OpenMP team of the batch / NN helpers */
 void   sfo_sample_quad(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m, uint32_t out[4]);
 int    sfo_quartic_roots(const double c[5], double r[4]);
 int    sfo_p3p(const double P[3][3], const double f[3][3], double R[4][9], double t[4][3]);
