@@ -58,6 +58,20 @@ def pmc_traffic(kernel_prefix, pairs_per_launch):
     return None
 
 
+def sq_evidence(kernel_prefix):
+    """VALU-busy estimate of the dominant kernel from the committed SQ counter passes (profiles/*_sq_*.json)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if kernel_prefix.replace("k_match_global", "k_match") in os.path.basename(path) and "valu_busy_estimate" in d:
+            return {"frac": d["valu_busy_estimate"], "SQ_INSTS_VALU": d.get("SQ_INSTS_VALU"),
+                    "GRBM_GUI_ACTIVE": d.get("GRBM_GUI_ACTIVE"), "source": os.path.basename(path)}
+    return None
+
+
 def generate_inputs(seed, n_kf, k, cols, dim, true_frac):
     from multi_robot_slam_separators_amd import synth
     t0 = time.time()
@@ -421,7 +435,8 @@ def main():
                 "valu": {"note": "the kernel is VALU-bound, not HBM-bound (its matching phase dominates): per 256-bit descriptor pair 8 v_xor (full "
                                  "rate) + 8 v_bcnt_u32_b32 (HALF rate on gfx950, tools/ubench/valu_rate.hip) + 6 "
                                  "16-bit min/max",
-                         "descriptor_pairs_per_s": pairs_per_step * k * k / (match_ms * 1e-3) if match_ms > 0 else 0.0},
+                         "descriptor_pairs_per_s": pairs_per_step * k * k / (match_ms * 1e-3) if match_ms > 0 else 0.0,
+                         "valu_busy_from_counters": sq_evidence(dom)},
                 "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_step, "avg_launch_ms": match_ms,
             },
             "roofline_nn": {
