@@ -31,6 +31,10 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
                                                    pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
   __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
+  // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
+  // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
+  // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
+  __builtin_amdgcn_s_setprio(3);
   if (est1) {
     ransac_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
     __syncthreads();
