@@ -215,6 +215,8 @@ def main():
     d_from = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_to = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_acc = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    d_flags = torch.empty(n_kf, dtype=torch.bool, device=dev)
     h_res = torch.empty((n_kf * world, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
     h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
@@ -231,13 +233,10 @@ def main():
         n = len(m)
         # pair (from = querying robot A's keyframe idx_other, to = computing robot B's idx_local),
         # find_separators.py:85-91
-        h_from[:n] = torch.from_numpy(m["idx_other"].astype(np.int32) + slot_a)
-        h_to[:n] = torch.from_numpy(m["idx_local"].astype(np.int32) + slot_b)
-        d_from[:n].copy_(h_from[:n], non_blocking=True)
-        d_to[:n].copy_(h_to[:n], non_blocking=True)
+        # (sf_verify_matches_device builds the two slot lists in pinned memory and uploads them itself)
         if trace:
             t_1b = time.perf_counter()
-        f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+        f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())
         if trace:
             t_2 = time.perf_counter()
             torch.cuda.synchronize()
@@ -245,9 +244,9 @@ def main():
         # every candidate's success flag goes back to the two robots involved (failures feed the ignore
         # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
         # the back-end (data_handler.py:352-368).
-        res2d = d_res[:n]
-        succ = res2d[:, OFF_SUCCESS] != 0
-        acc = res2d[succ]                                     # device-side compaction
+        n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
+        acc = d_acc[:n_acc]                                   # ordered device-side compaction (one kernel)
+        succ = d_flags[:n]
         if world > 1:
             # one collective: capacity for a 25 % acceptance rate + slack (overflow falls back to two-phase)
             rec, counts = dist.allgather_records_fixed(acc.to(coll_dev), n_kf // 4 + 256)

@@ -224,6 +224,19 @@ int  sf_verify_pairs(sf_handle h, const int32_t* from_slot, const int32_t* to_sl
    tensor's data_ptr()); asynchronous on the handle's stream.                                 */
 int  sf_verify_pairs_device(sf_handle h, const int32_t* d_from_slot, const int32_t* d_to_slot,
                             int32_t n, sf_result* d_out);
+/* Verify the candidates an NN query returned: candidate i is the pair (store slot slot_base_other +
+   matches[i].idx_other  ->  slot slot_base_local + matches[i].idx_local), i.e. the (frame of the
+   querying robot, frame of the computing robot) pair find_separators.py:85-91 sends to
+   estimate_transformation.  `matches` is HOST memory (the output of sf_nn_find_matches), d_out device
+   memory for n records.  Asynchronous on the handle's stream; `matches` may be reused on return.   */
+int  sf_verify_matches_device(sf_handle h, const sf_match* matches, int32_t n, int32_t slot_base_other,
+                              int32_t slot_base_local, sf_result* d_out);
+/* Compact the ACCEPTED results (success != 0) of a verification, in candidate order, into d_accepted
+   (device, room for n records) and write every candidate's success flag to d_flags (device, n bytes,
+   may be NULL): what find_separators.py:97-131 forwards as separators, resp. feeds back as failures.
+   Returns the number of accepted records in *n_accepted (host); synchronises the stream.           */
+int  sf_compact_accepted_device(sf_handle h, const sf_result* d_results, int32_t n, sf_result* d_accepted,
+                                uint8_t* d_flags, int32_t* n_accepted);
 /* Correspondences found by the two matching passes of the LAST verify call for pair `i`
    (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.  Calls with more
    than 32768 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */

@@ -188,6 +188,69 @@ k_ingest_ragged(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __
   if (tid == 0) meta[slot] = make_int4(e.rows, e.n3d > 0 ? e.rows : 0, e.rows, e.cols);
 }
 
+// Ordered compaction of the accepted results, 1024 candidates per workgroup: k_compact_count leaves the
+// number of accepted candidates of every chunk (and the per-candidate flags), k_compact_move lets each
+// workgroup sum the counts of the chunks before it (at most a few hundred values) and moves its records
+// as 23 x 16 bytes each, consecutive threads taking consecutive pieces.
+__global__ void __launch_bounds__(1024)
+k_compact_count(const sf_result* __restrict__ res, int n, uint8_t* __restrict__ flags, int32_t* __restrict__ chunk_count) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * 1024 + tid;
+  const bool ok = i < n && res[i].success != 0;
+  if (i < n && flags) flags[i] = ok ? 1 : 0;
+  const unsigned long long bal = __ballot(ok);
+  if (lane == 0) wsum[wave] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    chunk_count[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_compact_move(const sf_result* __restrict__ res, int n, sf_result* __restrict__ acc,
+               const int32_t* __restrict__ chunk_count, int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int s_dst[1024];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * 1024;
+  // offset of this chunk = accepted candidates of all earlier chunks
+  int part = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += 1024) part += chunk_count[b];
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) wsum[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    s_base = t;
+    if (blockIdx.x == gridDim.x - 1) *total = t + chunk_count[blockIdx.x];
+  }
+  __syncthreads();
+  const int i = base + tid;
+  const bool ok = i < n && res[i].success != 0;
+  const unsigned long long bal = __ballot(ok);
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wave] = __popcll(bal);
+  __syncthreads();
+  int woff = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) woff += (w < wave) ? wsum[w] : 0;
+  s_dst[tid] = ok ? s_base + woff + before : -1;
+  __syncthreads();
+  const int m = min(1024, n - base);
+  for (int e = tid; e < m * 23; e += 1024) {
+    const int c = e / 23, piece = e - c * 23;
+    const int dst = s_dst[c];
+    if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + base + c)[piece];
+  }
+}
+
 }  // namespace
 
 static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, int cols) {
@@ -527,9 +590,12 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
-                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
   for (Buf* b : bufs) buf_free(*b);
   if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
+  if (c->pairs_pinned) (void)hipHostFree(c->pairs_pinned);
+  if (c->count_pinned) (void)hipHostFree(c->count_pinned);
+  if (c->pairs_staged) (void)hipEventDestroy(c->pairs_staged);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -643,6 +709,63 @@ extern "C" int sf_verify_pairs_device(sf_handle c, const int32_t* d_from, const 
   if (!c || n < 0 || (n > 0 && (!d_from || !d_to || !d_out))) return SF_EINVAL;
   SF_HIP(c, hipSetDevice(c->device));
   return verify_device(c, c->store, d_from, d_to, n, d_out);
+}
+
+extern "C" int sf_verify_matches_device(sf_handle c, const sf_match* matches, int32_t n, int32_t slot_base_other,
+                                        int32_t slot_base_local, sf_result* d_out) {
+  if (!c || n < 0 || (n > 0 && (!matches || !d_out))) return SF_EINVAL;
+  if (n == 0) return SF_OK;
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->pair_from, (size_t)n * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pair_to, (size_t)n * 4)) != SF_OK) return rc;
+  // pinned staging of the two slot lists; the previous call's copies must have left it
+  if (c->pairs_staged) SF_HIP(c, hipEventSynchronize(c->pairs_staged));
+  const size_t need = (size_t)n * 8;
+  if (need > c->pairs_pinned_bytes) {
+    if (c->pairs_pinned) (void)hipHostFree(c->pairs_pinned);
+    c->pairs_pinned = nullptr;
+    c->pairs_pinned_bytes = 0;
+    if (hipHostMalloc(&c->pairs_pinned, need + need / 2, hipHostMallocDefault) != hipSuccess)
+      return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", need + need / 2);
+    c->pairs_pinned_bytes = need + need / 2;
+  }
+  int32_t* hf = (int32_t*)c->pairs_pinned;
+  int32_t* ht = hf + n;
+  for (int i = 0; i < n; ++i) {
+    hf[i] = slot_base_other + matches[i].idx_other;   // "from" = the querying robot's frame
+    ht[i] = slot_base_local + matches[i].idx_local;   // "to"   = the computing robot's frame
+    if (hf[i] < 0 || hf[i] >= c->store.slots || ht[i] < 0 || ht[i] >= c->store.slots)
+      return sf_fail(c, SF_ERANGE, "match %d: slot (%d,%d) outside the store (%d slots)", i, hf[i], ht[i], c->store.slots);
+  }
+  SF_HIP(c, hipMemcpyAsync(c->pair_from.p, hf, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  SF_HIP(c, hipMemcpyAsync(c->pair_to.p, ht, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  if (!c->pairs_staged) SF_HIP(c, hipEventCreateWithFlags(&c->pairs_staged, hipEventDisableTiming));
+  SF_HIP(c, hipEventRecord(c->pairs_staged, c->stream));
+  return verify_device(c, c->store, (const int32_t*)c->pair_from.p, (const int32_t*)c->pair_to.p, n, d_out);
+}
+
+extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_results, int32_t n, sf_result* d_accepted,
+                                          uint8_t* d_flags, int32_t* n_accepted) {
+  if (!c || n < 0 || !n_accepted || (n > 0 && (!d_results || !d_accepted))) return SF_EINVAL;
+  *n_accepted = 0;
+  if (n == 0) return SF_OK;
+  SF_HIP(c, hipSetDevice(c->device));
+  const int chunks = (n + 1023) / 1024;
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 1) * 4)) != SF_OK) return rc;
+  int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
+  int32_t* d_count = d_chunk + chunks;
+  hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
+  hipLaunchKernelGGL(k_compact_move, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted,
+                     (const int32_t*)d_chunk, d_count);
+  SF_HIP(c, hipGetLastError());
+  if (!c->count_pinned && hipHostMalloc((void**)&c->count_pinned, 64, hipHostMallocDefault) != hipSuccess)
+    return sf_fail(c, SF_ENOMEM, "hipHostMalloc(64) failed");
+  SF_HIP(c, hipMemcpyAsync(c->count_pinned, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  *n_accepted = *c->count_pinned;
+  return SF_OK;
 }
 
 static int verify_host_indices(sf_context* c, const Store& st, const int32_t* from, const int32_t* to, int n,

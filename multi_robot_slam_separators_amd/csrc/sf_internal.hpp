@@ -144,6 +144,13 @@ struct sf_context {
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
 
+  // sf_verify_matches_device / sf_compact_accepted_device staging
+  void* pairs_pinned = nullptr;
+  size_t pairs_pinned_bytes = 0;
+  hipEvent_t pairs_staged = nullptr;
+  int32_t* count_pinned = nullptr;
+  Buf compact_scratch;          // per-chunk counts of sf_compact_accepted_device
+
   // multi-GPU exchange (sf_comm.hip)
   void* comm = nullptr;    // ncclComm_t
   int comm_rank = 0, comm_world = 1;

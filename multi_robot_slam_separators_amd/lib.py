@@ -81,6 +81,8 @@ def load():
         "sf_estimate_transform_batch": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), i32, vp]),
         "sf_verify_pairs": (C.c_int, [vp, vp, vp, i32, vp]),
         "sf_verify_pairs_device": (C.c_int, [vp, vp, vp, i32, vp]),
+        "sf_verify_matches_device": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
         "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
         "sf_comm_unique_id": (C.c_int, [vp, i32]),
@@ -110,7 +112,7 @@ EXPORTED = [
     "sf_nn_set_precision",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
-    "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device",
+    "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_compact_accepted_device",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
@@ -270,6 +272,20 @@ class SeparatorFinder:
     def verify_pairs_device(self, d_from, d_to, n, d_out):
         self._check(self._L.sf_verify_pairs_device(self._h, C.c_void_p(d_from), C.c_void_p(d_to), n,
                                                    C.c_void_p(d_out)))
+
+    def verify_matches_device(self, matches, slot_base_other, slot_base_local, d_out):
+        """Verify the candidates of an NN query (structured array of MATCH_DTYPE, host) -> d_out (device)."""
+        m = np.ascontiguousarray(matches, dtype=_abi.MATCH_DTYPE)
+        self._check(self._L.sf_verify_matches_device(self._h, _ptr(m), m.size, slot_base_other, slot_base_local,
+                                                     C.c_void_p(d_out)))
+        return m.size
+
+    def compact_accepted_device(self, d_results, n, d_accepted, d_flags=None):
+        """Ordered device-side compaction of the accepted results; returns their number."""
+        k = C.c_int32()
+        self._check(self._L.sf_compact_accepted_device(self._h, C.c_void_p(d_results), n, C.c_void_p(d_accepted),
+                                                       C.c_void_p(d_flags) if d_flags else None, C.byref(k)))
+        return k.value
 
     def debug_correspondences(self, pair, which_pass, cap=4096):
         cf = np.zeros(cap, dtype=np.uint16)

@@ -345,3 +345,46 @@ def test_fused_pipeline_with_more_than_64k_of_lds(oracle):
     for i in range(len(A)):
         assert_result_parity(got[i], oracle.estimate_transform(p, A[i], B[i]), "pair %d" % i)
     assert got["success"][is_true].all()
+
+
+def test_verify_matches_and_compaction_entry_points(finder):
+    """sf_verify_matches_device (candidates straight from an NN query) and sf_compact_accepted_device (ordered
+    accepted-only compaction) against the explicit slot lists / a numpy mask."""
+    import torch
+    rng = np.random.default_rng(9)
+    A, B, is_true, _ = synth.make_pairs(901, 30, k=300, true_frac=0.5)
+    finder.store_clear()
+    sa = [finder.store_add_keyframe(a) for a in A][0]
+    sb = [finder.store_add_keyframe(b) for b in B][0]
+    # a synthetic match list: local (computing robot B) index i <-> other (querying robot A) index perm[i]
+    perm = np.arange(30)
+    perm[20:] = 20 + rng.permutation(10)           # the first 20 candidates keep their planted partner
+    m = np.zeros(30, dtype=_abi.MATCH_DTYPE)
+    m["idx_local"], m["idx_other"], m["distance"] = np.arange(30), perm, rng.random(30)
+    dev = torch.device("cuda", 0)
+    d_res = torch.zeros((30, 368), dtype=torch.uint8, device=dev)
+    d_acc = torch.zeros((30, 368), dtype=torch.uint8, device=dev)
+    d_flags = torch.zeros(30, dtype=torch.uint8, device=dev)
+    assert finder.verify_matches_device(m, sa, sb, d_res.data_ptr()) == 30
+    n_acc = finder.compact_accepted_device(d_res.data_ptr(), 30, d_acc.data_ptr(), d_flags.data_ptr())
+    got = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+    want = finder.verify_pairs([sa + int(p) for p in perm], [sb + i for i in range(30)])
+    assert got.tobytes() == want.tobytes()
+    ok = want["success"] != 0
+    assert n_acc == int(ok.sum()) and n_acc >= 1
+    assert np.array_equal(d_flags.cpu().numpy().astype(bool), ok)
+    acc = np.frombuffer(d_acc[:n_acc].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+    assert acc.tobytes() == want[ok].tobytes()                     # candidate order preserved
+    # more than one 1024-candidate chunk, no flags, nothing accepted / everything accepted
+    big = torch.zeros((2500, 368), dtype=torch.uint8, device=dev)
+    out = torch.zeros((2500, 368), dtype=torch.uint8, device=dev)
+    assert finder.compact_accepted_device(big.data_ptr(), 2500, out.data_ptr()) == 0
+    off = _abi.RESULT_DTYPE.fields["success"][1]
+    big[::3, off] = 1
+    big[:, 0] = torch.arange(2500, device=dev).remainder(251).to(torch.uint8)
+    k = finder.compact_accepted_device(big.data_ptr(), 2500, out.data_ptr())
+    assert k == len(range(0, 2500, 3)) and torch.equal(out[:k], big[::3])
+    with pytest.raises(Exception):
+        m_bad = m.copy(); m_bad["idx_other"][0] = 10_000
+        finder.verify_matches_device(m_bad, sa, sb, d_res.data_ptr())
+    finder.store_clear()
