@@ -178,6 +178,28 @@ k_nn_argmin(const float* __restrict__ A, const float* __restrict__ B, const floa
   }
 }
 
+// Exact squared distance of two float32 rows, accumulated in float64 by one wavefront: lane l owns the
+// float4 groups l, l + 64, ... (16-byte loads; the rows are zero padded to the pitch `ld`, a multiple of
+// 32 floats, so the padding adds exact zeros).  Shared by k_nn_select and k_nn_refine: both precisions
+// report bit-identical distances.
+__device__ __forceinline__ double nn_exact_sq_dist(const float* __restrict__ a, const float* __restrict__ b, int ld,
+                                                   int lane) {
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  double s = 0.0;
+  for (int k = lane; k < ld / 4; k += 64) {
+    const float4 x = a4[k], y = b4[k];
+    const double d0 = (double)x.x - (double)y.x, d1 = (double)x.y - (double)y.y;
+    const double d2 = (double)x.z - (double)y.z, d3 = (double)x.w - (double)y.w;
+    s += d0 * d0;
+    s += d1 * d1;
+    s += d2 * d2;
+    s += d3 * d3;
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  return s;
+}
+
 // one wavefront per local row: reduce strips, re-evaluate in float64, apply row mask
 __global__ void __launch_bounds__(256)
 k_nn_select(const unsigned long long* __restrict__ part, int n_strips, int n_l, int n_l_pad,
@@ -199,13 +221,7 @@ k_nn_select(const unsigned long long* __restrict__ part, int n_strips, int n_l, 
   const bool finite = ((unsigned)(best >> 32) < 0x7F800000u) && !mask_local[row];
   double s = 0.0;
   if (finite) {
-    const float* a = A + (size_t)row * ld;
-    const float* b = B + (size_t)j * ld;
-    for (int k = lane; k < dim; k += 64) {
-      const double d = (double)a[k] - (double)b[k];
-      s += d * d;
-    }
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    s = nn_exact_sq_dist(A + (size_t)row * ld, B + (size_t)j * ld, ld, lane);
   }
   if (lane == 0) {
     out_dist[row] = finite ? sqrt(s) : (double)INFINITY;
@@ -391,14 +407,7 @@ k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, 
   const unsigned n_cand = min(*count, limit);   // the grid is sized for `limit`; the filter's count lives on the device
   if (c >= n_cand) return;
   const uint2 rc = cand[c];
-  const float* a = A + (size_t)rc.x * ld;
-  const float* b = B + (size_t)rc.y * ld;
-  double s = 0.0;
-  for (int k = lane; k < dim; k += 64) {
-    const double d = (double)a[k] - (double)b[k];
-    s += d * d;
-  }
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  const double s = nn_exact_sq_dist(A + (size_t)rc.x * ld, B + (size_t)rc.y * ld, ld, lane);
   if (lane == 0) out[c] = sqrt(s);
 }
 
