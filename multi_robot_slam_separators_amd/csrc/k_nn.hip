@@ -589,12 +589,22 @@ static int nn_run_filter(sf_context* c, int* done) {
     const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
     const float scale = c->nn_local.h_scale * c->nn_recv.h_scale;   // product of two powers of two: exact
     SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
+    // the per-row / per-column coefficients depend only on the norms, the masks, the threshold and the
+    // prefix level: rebuilt when one of them changed, not per query
+    const bool coef_ok = c->nn_coef_level == level && c->nn_coef_nl == n_l && c->nn_coef_nr == n_r &&
+                         c->nn_coef_thr == thr && c->nn_coef_ptr == (const void*)rowc && c->nn_coef_scale == scale;
+    if (!coef_ok)
     hipLaunchKernelGGL(k_nn_filter_row_coef, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, rowc,
                        (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad,
                        0.5f * scale, thr2, eps_rel * scale);
-    hipLaunchKernelGGL(k_nn_filter_col_coef, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, colc,
-                       (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad,
-                       0.5f * scale);
+    if (!coef_ok) {
+      hipLaunchKernelGGL(k_nn_filter_col_coef, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, colc,
+                         (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad,
+                         0.5f * scale);
+      c->nn_coef_level = level; c->nn_coef_nl = n_l; c->nn_coef_nr = n_r; c->nn_coef_thr = thr;
+      c->nn_coef_ptr = (const void*)rowc;
+      c->nn_coef_scale = scale;
+    }
     sf_prof_begin(c, SF_K_NN_FILTER);
     hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                        (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
@@ -712,6 +722,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     SF_HIP(c, hipMemcpyAsync(c->d_ign_col.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
     c->masks_dirty = false;
+    c->nn_coef_level = -1;     // masks / database changed: the filter coefficients must be rebuilt
   }
   int filtered = 0;
   c->nn_last_kdims = 0;
@@ -719,6 +730,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     if ((rc = nn_run_filter(c, &filtered)) != SF_OK) return rc;
   }
   if (!filtered) {
+  c->nn_coef_level = -1;   // the exact path re-uses the coefficient buffer for its partial minima
   // workspace: partial minima, effective column norms, per-row results
   const size_t part_bytes = (size_t)n_strips * n_l_pad * 8;
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, part_bytes + (size_t)n_r_pad * 4)) != SF_OK) return rc;

@@ -129,6 +129,10 @@ struct sf_context {
   Buf nn_cand;       // filter path: counter + candidate (row, col) pairs + exact distances
   Buf nn_scalar;     // small reduction scratch
   int nn_level = 0, nn_level_cooldown = 32, nn_last_kdims = 0;   // adaptive prefix ladder of the filter
+  int nn_coef_level = -1, nn_coef_nl = 0, nn_coef_nr = 0;         // what the cached filter coefficients were built for
+  double nn_coef_thr = 0.0;
+  float nn_coef_scale = 0.f;
+  const void* nn_coef_ptr = nullptr;
   std::vector<double> last_row_min;
   std::vector<int32_t> last_row_arg;
   std::vector<uint64_t> nn_sort_keys, nn_sort_keys2;   // host scratch of the walk (kept to avoid reallocation)
