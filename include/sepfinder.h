@@ -239,7 +239,7 @@ int  sf_compact_accepted_device(sf_handle h, const sf_result* d_results, int32_t
                                 uint8_t* d_flags, int32_t* n_accepted);
 /* Correspondences found by the two matching passes of the LAST verify call for pair `i`
    (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.  Calls with more
-   than 32768 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */
+   than 131072 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */
 int  sf_debug_correspondences(sf_handle h, int32_t pair, int32_t pass, uint16_t* from_idx,
                               uint16_t* to_idx, int32_t cap, int32_t* n_out);
 

@@ -676,7 +676,8 @@ static int ws_reserve(sf_context* c, int n, int kcap) {
   return SF_OK;
 }
 
-static const int SF_CHUNK = 32768;  // pairs per launch sequence (bounds the workspace: ~4 KiB / pair)
+static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the workspace: ~4 KiB / pair at K = 500);
+                                     // every launch ends with the latency tail of its last surviving pairs, so few, big chunks
 
 // d_from / d_to / d_out: device pointers. Asynchronous on the handle's stream.
 static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, const int32_t* d_to, int n,

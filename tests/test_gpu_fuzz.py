@@ -124,7 +124,7 @@ def test_nn_large_database(oracle):
 
 def test_chunked_batches_beyond_workspace_chunk():
     """BASELINE configs[3] shape: far more pairs than one launch sequence holds (the library chunks at
-    32 768 pairs): results are those of the same pairs verified alone, whatever their batch position."""
+    131 072 pairs): results are those of the same pairs verified alone, whatever their batch position."""
     from multi_robot_slam_separators_amd import lib
     p = synth.camera_params()
     p.iterations = 100
@@ -134,7 +134,7 @@ def test_chunked_batches_beyond_workspace_chunk():
         sa = [f.store_add_keyframe(a) for a in A]
         sb = [f.store_add_keyframe(b) for b in B]
         base = f.verify_pairs(sa, sb)
-        n = 70000
+        n = 140000
         rng = np.random.default_rng(0)
         pick = rng.integers(0, len(A), size=n)
         big = f.verify_pairs(np.array(sa)[pick], np.array(sb)[pick])
