@@ -49,6 +49,8 @@ struct PnpLds {
   float* hyp;       // [12][64] models of the current round of hypotheses
   int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
   float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the replay)
+  double* ne_a;     // [32] normal equations of the current pose   (totals live in LDS, not in VGPRs)
+  double* ne_b;     // [32] normal equations of the candidate pose
 };
 
 template <int N>
@@ -107,9 +109,10 @@ __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64
 
 // Normal equations of the reprojection error over the members of L.mask at pose (q, t).
 __device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask,
-                                     const double (&q)[4], const double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
+                                     const double (&q)[4], const double (&t)[3], double* out, int tid) {
   double R[9];
   sfd::quat_to_R(q, R);
+  double ne[PNP_NSUM];
 #pragma unroll
   for (int k = 0; k < PNP_NSUM; ++k) ne[k] = 0.0;
   for (int i = tid; i < m; i += SF_BLOCK) {
@@ -147,19 +150,22 @@ __device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, 
       ne[27] += 1e30;   // a member behind the camera makes the pose unacceptable
     }
   }
-  block_sum_vec32<PNP_NSUM>(ne, L.red, tid);
+  sfd::block_sum_canon_to_lds<PNP_NSUM, 32>(ne, L.red, out, tid);
 }
 
 // Levenberg-Marquardt over the members of `mask` from pose (q, t): at most 20 evaluations, diagonal
 // scaled by 1 + lambda [upstream cvFindExtrinsicCameraParams2 / CvLevMarq].  Every lane runs the same
 // scalar control flow on the block-reduced sums.  ne returns the normal equations at the final pose.
 __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask, double (&q)[4],
-                              double (&t)[3], double (&ne)[PNP_NSUM], int tid) {
-  pnp_normal_eq(L, cam, m, mask, q, t, ne, tid);
+                              double (&t)[3], int tid) {
+  // L.ne_a holds the normal equations of the accepted pose on return
+  double* cur = L.ne_a;
+  double* cand = L.ne_b;
+  pnp_normal_eq(L, cam, m, mask, q, t, cur, tid);
   double lambda = 1e-3;
   for (int iter = 0; iter < 20; ++iter) {
     double d[6];
-    if (!sfd::solve6(ne, lambda, d)) {
+    if (!sfd::solve6(cur, lambda, d)) {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
       continue;
@@ -177,18 +183,16 @@ __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const u
     for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
-    double nc[PNP_NSUM];
-    pnp_normal_eq(L, cam, m, mask, qc, tc, nc, tid);
+    pnp_normal_eq(L, cam, m, mask, qc, tc, cand, tid);
     // a step below float epsilon relative to the parameters ends the iteration either way
     const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
     const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
-    if (nc[27] < ne[27]) {
+    if (cand[27] < cur[27]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) q[i] = qc[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) t[i] = tc[i];
-#pragma unroll
-      for (int i = 0; i < PNP_NSUM; ++i) ne[i] = nc[i];
+      double* sw = cur; cur = cand; cand = sw;
       lambda = lambda * 0.1;
       if (lambda < 1e-16) lambda = 1e-16;
     } else {
@@ -196,6 +200,11 @@ __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const u
       if (lambda > 1e12) break;
     }
     if (dd <= 1.4e-14 * tt) break;
+  }
+  if (cur != L.ne_a) {   // leave the accepted pose's sums in ne_a (uniform branch)
+    __syncthreads();
+    if (tid < PNP_NSUM) L.ne_a[tid] = cur[tid];
+    __syncthreads();
   }
 }
 
@@ -254,7 +263,7 @@ __device__ inline float rank_value(const float* arr, int m, int rank, double* sl
   return (float)*slot;
 }
 
-__global__ void __launch_bounds__(SF_BLOCK, 2)
+__global__ void __launch_bounds__(SF_BLOCK, 3)
 k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
@@ -284,7 +293,9 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     L.mask_b = p; p += kcap;
     L.hyp = (float*)p; p += 12 * 64 * 4;
     L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
-    L.best = (float*)p;
+    L.best = (float*)p; p += 16 * 4;
+    L.ne_a = (double*)p; p += 32 * 8;
+    L.ne_b = (double*)p;
   }
 
   // ---- estimateMotion3DTo2D: ids of words2B found in words3A with a finite 3D point ---------------
@@ -451,8 +462,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     }
     sfd::R_to_quat(Rb, q);
   }
-  double ne[PNP_NSUM];
-  pnp_lm(L, cam, m, L.mask, q, t, ne, tid);
+  pnp_lm(L, cam, m, L.mask, q, t, tid);
 
   // ---- rtabmap util3d::solvePnPRansac refinement rounds (Vis/PnPRefineIterations > 0) ---------------------
   const uint8_t* inl = L.mask;
@@ -468,7 +478,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     for (int i = tid; i < m; i += SF_BLOCK) neu[i] = 0;
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;   // last four pushed sizes (z1 newest)
     do {
-      pnp_lm(L, cam, m, prev, q, t, ne, tid);            // solvePnP from the current model
+      pnp_lm(L, cam, m, prev, q, t, tid);                // solvePnP from the current model
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
       __syncthreads();
@@ -578,10 +588,10 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
       ps.var_ang = 2.1981 * (double)rank_value(L.e2, m, oi >> 2, &L.red[121], tid);
     }
   } else {
-    pnp_normal_eq(L, cam, m, inl, q, t, ne, tid);
+    pnp_normal_eq(L, cam, m, inl, q, t, L.ne_a, tid);
     // sqrtf and operator/ are IEEE-exact on gfx950; __fsqrt_rn is NOT (native v_sqrt_f32, ~1 ulp:
     // tools/ubench/fp_case.hip) and must not appear in canonical arithmetic
-    const double v = (double)sqrtf((float)ne[27] / (float)n_inl);
+    const double v = (double)sqrtf((float)L.ne_a[27] / (float)n_inl);
     ps.var = v;
     ps.var_ang = v;
   }
@@ -593,7 +603,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
 size_t sf_pnp_lds_bytes(int kcap, int iterations) {
   const int it = iterations > 0 ? iterations : 0;
   return (size_t)kcap * (16 + 24 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
-         5 * 64 * 4 + 16 * 4;
+         5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
 }
 
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {

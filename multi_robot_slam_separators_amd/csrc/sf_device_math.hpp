@@ -309,6 +309,32 @@ __device__ __forceinline__ void block_sum_canon(double (&v)[N], double* red, int
   for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[STRIDE + k]) + red[2 * STRIDE + k]) + red[3 * STRIDE + k];
 }
 
+// Same sums, but the N totals are left in LDS (out[0..N)) instead of in every thread's registers: for
+// callers that only need them as operands of a short scalar computation (k_pnp's 28-value normal
+// equations would otherwise pin 56 VGPRs per copy).  out must not alias red.
+template <int N, int STRIDE>
+__device__ __forceinline__ void block_sum_canon_to_lds(const double (&v)[N], double* red, double* out, int tid) {
+  static_assert(N >= 1 && N <= 32 && STRIDE >= N, "at most 32 values");
+  constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : 32;
+  static_assert(STRIDE >= P, "scratch rows must hold the padded count");
+  const int lane = tid & 63, wave = tid >> 6;
+  double w[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) w[k] = k < N ? v[k] : 0.0;
+  int idx = 0;
+  sum_stage<P>(w, idx, lane, 32);
+  sum_stage<(P / 2 > 1 ? P / 2 : 1)>(w, idx, lane, 16);
+  sum_stage<(P / 4 > 1 ? P / 4 : 1)>(w, idx, lane, 8);
+  sum_stage<(P / 8 > 1 ? P / 8 : 1)>(w, idx, lane, 4);
+  sum_stage<(P / 16 > 1 ? P / 16 : 1)>(w, idx, lane, 2);
+  sum_stage<(P / 32 > 1 ? P / 32 : 1)>(w, idx, lane, 1);
+  __syncthreads();  // previous users of `red` / `out` are done
+  red[wave * STRIDE + idx] = w[0];
+  __syncthreads();
+  if (tid < N) out[tid] = ((red[tid] + red[STRIDE + tid]) + red[2 * STRIDE + tid]) + red[3 * STRIDE + tid];
+  __syncthreads();
+}
+
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }

@@ -300,7 +300,7 @@ __device__ inline void R_to_quat(const double (&R)[9], double (&q)[4]) {
 
 // (H with its diagonal scaled by 1 + lambda) d = -g by Cholesky.  ne[0..20] = upper triangle of H
 // (row-major j <= k), ne[21..26] = g.  false when H is not positive definite.
-__device__ inline bool solve6(const double (&ne)[28], double lambda, double (&d)[6]) {
+__device__ inline bool solve6(const double* __restrict__ ne, double lambda, double (&d)[6]) {
   double A[6][6], Lm[6][6];
   {
     int o = 0;
