@@ -304,7 +304,6 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
   const float* xF = st.xyz + (size_t)sF * kcap * 3;
   const float* xT = st.xyz + (size_t)sT * kcap * 3;
   const float4* kT = st.kp + (size_t)sT * kcap;
-  const bool to_has_3d = st.meta[sT].y > 0;
   const float cxf = (float)P.cx, cyf = (float)P.cy;
   if (tid < 16) L.misc[tid] = 0;
   __syncthreads();
@@ -556,7 +555,10 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
   ps.is_null = allz ? 1 : 0;
 
   // ---- covariance [upstream estimateMotion3DTo2D] ---------------------------------------------------------
-  if (to_has_3d) {
+  // (the "to" frame's 3D flag is read HERE, not kept from the top of the function: in an experimental build
+  //  that inlined this body into a larger kernel a wave-uniform bool carried across these ~250 lines came
+  //  back wrong after the compiler's SGPR spilling; long-lived uniform predicates are re-derived at their use)
+  if (st.meta[sT].y > 0) {
     const int m4 = (m + 3) & ~3;
     int cnt = 0;
     for (int i = tid; i < m4; i += SF_BLOCK) {
