@@ -290,6 +290,136 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 3 ("fp4 matrix cores", NQ == 0): the K_from x K_to Hamming table as a matrix product.
+// With every descriptor bit b mapped to the fp4 (E2M1) value 1 - 2b, the dot product of two rows is
+// (bits - 2 * hamming): +-1 products are exact in fp4 and their sums (|.| <= 512) are exact in the f32
+// accumulator, so the distances are the integers the VALU variants compute.  v_mfma_f32_32x32x64_f8f6f4
+// does 32 x 32 x 64 of them per instruction (tools/ubench/mfma_fp4_hamming.hip pins operand layout and
+// exactness on the device); the order of the 64 bits inside one instruction is irrelevant as long as
+// both operands use the same one, so a lane simply spreads the raw dwords it loaded.
+//   * "from" rows = matrix rows (A, re-read from the LDS copy per 32-row tile), "to" rows = columns
+//     (B, kept in VGPRs for the whole scan); a wavefront owns 32-column tiles, two at a time;
+//   * the accumulator starts at -(from row index)/2048 instead of 0, so one f32 per (from, to) cell
+//     orders by distance first (steps of 2) and by the LOWER from index second (fraction < 1): the
+//     BFMatcher tie rule with no separate index bookkeeping;
+//   * best / second best per column: v_max_f32 + v_med3_f32 per cell, then one cross-half merge.
+typedef int mf_v8i __attribute__((ext_vector_type(8)));
+typedef float mf_v16f __attribute__((ext_vector_type(16)));
+constexpr float MF_FR = 1.f / 2048.f;        // index fraction (kcap <= 2048 rows on this path)
+constexpr int MF_MAX_ROWS = 2048;
+
+// 32 descriptor bits -> 32 fp4 values (4 dwords of nibbles): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2).
+// (x << k) & 0x88888888 | 0x22222222 as shift + v_and_or_b32 with both constants in VGPRs (a VOP3 takes no
+// literal on gfx9, and an SGPR operand halves the issue rate): 7 VALU ops per dword instead of the 11 the
+// compiler emits from the C expression.
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t c) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(m), "v"(c));
+  return r;
+}
+__device__ __forceinline__ mf_v8i fp4_spread(uint32_t x, uint32_t m88, uint32_t c22) {
+  mf_v8i o = {0, 0, 0, 0, 0, 0, 0, 0};
+  o[0] = (int)and_or(x << 3, m88, c22);
+  o[1] = (int)and_or(x << 2, m88, c22);
+  o[2] = (int)and_or(x << 1, m88, c22);
+  o[3] = (int)and_or(x, m88, c22);
+  return o;
+}
+template <int KS>
+__device__ __forceinline__ void load_raw(const uint32_t* p, uint32_t (&raw)[KS]) {
+#pragma unroll
+  for (int c = 0; c < KS / 4; ++c) {
+    const uint4 v = reinterpret_cast<const uint4*>(p)[c];
+    raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+  }
+}
+
+// One 32-row "from" tile against the NTL resident "to" tiles of this wavefront.
+template <int W, int NTL, bool TAIL>
+__device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, int mt, int r, int h,
+                                               const mf_v8i (&Bf)[NTL][W / 2], const float (&cin)[16],
+                                               float (&b)[NTL], float (&s)[NTL], uint32_t m88, uint32_t c22, float inf) {
+  constexpr int KS = W / 2;
+  int row = mt * 32 + r;
+  if (TAIL) row = min(row, Kf - 1);
+  uint32_t raw[KS];
+  load_raw<KS>(fromD + (size_t)row * W + KS * h, raw);
+  mf_v16f c0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
+    c0[i] = (TAIL && mt * 32 + ro >= Kf) ? -INFINITY : cin[i];
+  }
+  mf_v8i Af[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) Af[k] = fp4_spread(raw[k], m88, c22);
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    // the scores kept so far move with the origin (the first row of the current tile)
+    b[j] += 32.f * MF_FR;
+    s[j] += 32.f * MF_FR;
+  }
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    mf_v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[0], Bf[j][0], c0, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+    for (int k = 1; k < KS; ++k)
+      acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[k], Bf[j][k], acc, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = acc[i];
+      s[j] = __builtin_amdgcn_fmed3f(b[j], s[j], v);
+      b[j] = __builtin_amdgcn_fmed3f(b[j], v, inf);   // = max(b, v): fmaxf would cost a canonicalising self-max per call
+    }
+  }
+}
+
+// kNN-2 of the "to" rows of NTL 32-column tiles over all "from" rows; on return lanes 0..31 hold, for
+// column tile[j] * 32 + lane: d1 / d2 (Hamming, 0xFFFF when absent) and the from index of d1.
+template <int W, int NTL>
+__device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
+                                          const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
+                                          int (&idx)[NTL]) {
+  constexpr int KS = W / 2;
+  const int r = lane & 31, h = lane >> 5;
+  uint32_t m88, c22;   // constants pinned in VGPRs (see fp4_spread)
+  asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+  float inf;
+  asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(inf));
+  mf_v8i Bf[NTL][KS];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int t = tile[j] * 32 + r;
+    uint32_t raw[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) raw[k] = 0;
+    if (t < Kt) load_raw<KS>(dT + (size_t)t * W + KS * h, raw);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) Bf[j][k] = fp4_spread(raw[k], m88, c22);
+  }
+  float cin[16], b[NTL], s[NTL];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) * MF_FR;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) { b[j] = -INFINITY; s[j] = -INFINITY; }
+  const int n_full = Kf >> 5;
+  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22, inf);
+  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22, inf);
+  const float org = (float)(32 * (((Kf + 31) >> 5) - 1)) * MF_FR;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const float ob = __shfl_xor(b[j], 32), os = __shfl_xor(s[j], 32);
+    const float nb = fmaxf(b[j], ob) - org;
+    const float ns = fmaxf(fminf(b[j], ob), fmaxf(s[j], os)) - org;
+    const float dot1 = 2.f * ceilf(nb * 0.5f), dot2 = 2.f * ceilf(ns * 0.5f);
+    idx[j] = (int)((dot1 - nb) * 2048.f);
+    d1[j] = (uint32_t)((32 * W - (int)dot1) >> 1);
+    d2[j] = ns == -INFINITY ? 0xFFFFu : (uint32_t)((32 * W - (int)dot2) >> 1);
+  }
+}
+
 // Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
 // LDS.  Returns whether the pair goes on to motion estimation (block-uniform).  With list == nullptr
 // the pair is not appended to a work list (fused pipeline, k_verify.hip).
@@ -336,8 +466,41 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, con
   __syncthreads();
 
   int rejected = 0;
-  if (Kf > 0) {
+  if constexpr (NQ == 0) {
+    if (Kf > 0) {
+      constexpr int NTL = W == 8 ? 2 : 1;
+      const int n_nt = (Kt + 31) >> 5;
+      auto settle = [&](int t, uint32_t b1, uint32_t b2, int f) {
+        if (lane < 32 && t < Kt) {
+          const bool acc = (Kf >= 2) && !((float)b1 > nndr * (float)b2);
+          if (acc) {
+            atomicAdd(&cnt[f], 1);
+            owner[f] = t;
+          } else {
+            ++rejected;
+          }
+        }
+      };
+      for (int t0 = wave; t0 < n_nt; t0 += NW * NTL) {
+        if (NTL == 2 && t0 + NW < n_nt) {
+          const int tl[2] = {t0, t0 + NW};
+          uint32_t a1[2], a2[2];
+          int f[2];
+          knn2_mfma<W, 2>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
+          settle(tl[0] * 32 + lane, a1[0], a2[0], f[0]);
+          settle(tl[1] * 32 + lane, a1[1], a2[1], f[1]);
+        } else {
+          const int tl[1] = {t0};
+          uint32_t a1[1], a2[1];
+          int f[1];
+          knn2_mfma<W, 1>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
+          settle(tl[0] * 32 + lane, a1[0], a2[0], f[0]);
+        }
+      }
+    }
+  } else if (Kf > 0) {
     for (int base = 0; base < Kt; base += NQ * NT) {
+
       uint32_t q[NQ][W], d1[NQ], d2[NQ], chunk[NQ];
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
@@ -500,7 +663,7 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
   if (variant == 0) {
     // default: LDS + u16 variant while the staged "from" block keeps >= 2 workgroups per CU
     const size_t lds_v2 = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
-    variant = lds_v2 <= 64 * 1024 ? 12256 : 2256;
+    variant = lds_v2 <= 64 * 1024 ? (c->match_mfma ? 10256 : 12256) : 2256;
   }
   sf_prof_begin(c, SF_K_MATCH);
 #define SF_CASE(NQ_, NT_)                                                        \
@@ -521,6 +684,7 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
     if (st.w == 8) launch_match_v2<8, NQ_, NT_>(c, st, d_from, d_to, n);            \
     else launch_match_v2<16, NQ_, NT_>(c, st, d_from, d_to, n);                     \
     break;
+    SF_CASE2(0, 256)   // NQ = 0: fp4 matrix-core variant
     SF_CASE2(2, 256)
     SF_CASE2(1, 256)
     SF_CASE2(4, 128)

@@ -53,7 +53,8 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 template <int W, int NQ>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds) {
-  bool& attr_set = W == 8 ? c->fused_attr_set : c->fused_attr_set_w16;   // one flag per instantiation
+  bool& attr_set = NQ == 0 ? (W == 8 ? c->fused_attr_set_mf : c->fused_attr_set_mf_w16)
+                           : (W == 8 ? c->fused_attr_set : c->fused_attr_set_w16);   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
     SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
@@ -89,8 +90,13 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
-  if (st.w == 8) rc = launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds);
-  else rc = launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds);
+  if (c->match_mfma) {
+    if (st.w == 8) rc = launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds);
+    else rc = launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds);
+  } else {
+    if (st.w == 8) rc = launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds);
+    else rc = launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds);
+  }
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());

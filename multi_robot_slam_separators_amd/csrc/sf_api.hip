@@ -574,6 +574,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   c->own_stream = true;
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
   if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
+  if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
   *out = c;
   return SF_OK;

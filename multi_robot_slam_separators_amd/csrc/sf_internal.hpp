@@ -145,6 +145,8 @@ struct sf_context {
   bool pnp_attr_set = false;
   bool fused_attr_set = false, fused_attr_set_w16 = false;
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
+  bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)
+  bool fused_attr_set_mf = false, fused_attr_set_mf_w16 = false;
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
 
