@@ -310,22 +310,19 @@ constexpr float MF_FR = 1.f / 2048.f;        // index fraction (kcap <= 2048 row
 constexpr int MF_MAX_ROWS = 2048;
 
 // 32 descriptor bits -> 32 fp4 values (4 dwords of nibbles): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2).
-// (x << k) & 0x88888888 | 0x22222222 as shift + v_and_or_b32 with both constants in VGPRs (a VOP3 takes no
-// literal on gfx9, and an SGPR operand halves the issue rate): 7 VALU ops per dword instead of the 11 the
-// compiler emits from the C expression.
-__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t c) {
-  uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(m), "v"(c));
-  return r;
-}
+// m88 / c22 hold 0x88888888 / 0x22222222 in VGPRs the compiler cannot see through (knn2_mfma), so that
+// ((x << k) & m88) | c22 becomes shift + v_and_or_b32 (7 VALU ops per dword); with literal constants a
+// VOP3 cannot encode them on gfx9 and the expression costs 11.  No asm on this path: the results are MFMA
+// operands and the hazard recogniser must see the instructions that write them.
 __device__ __forceinline__ mf_v8i fp4_spread(uint32_t x, uint32_t m88, uint32_t c22) {
   mf_v8i o = {0, 0, 0, 0, 0, 0, 0, 0};
-  o[0] = (int)and_or(x << 3, m88, c22);
-  o[1] = (int)and_or(x << 2, m88, c22);
-  o[2] = (int)and_or(x << 1, m88, c22);
-  o[3] = (int)and_or(x, m88, c22);
+  o[0] = (int)(((x << 3) & m88) | c22);
+  o[1] = (int)(((x << 2) & m88) | c22);
+  o[2] = (int)(((x << 1) & m88) | c22);
+  o[3] = (int)((x & m88) | c22);
   return o;
 }
+
 template <int KS>
 __device__ __forceinline__ void load_raw(const uint32_t* p, uint32_t (&raw)[KS]) {
 #pragma unroll
@@ -335,11 +332,44 @@ __device__ __forceinline__ void load_raw(const uint32_t* p, uint32_t (&raw)[KS])
   }
 }
 
+// (b, s) <- the two largest of {b, s, v[0..15]} (b >= s on entry and exit), 20 VALU ops:
+//   per pair (v0, v1):  x = med3(b, v0, v1) is the second largest of {b, v0, v1}, b' = max3(b, v0, v1),
+//   and the second largest of {b, s, v0, v1} is max(s, x) -- so two pairs cost 2 med3 + 3 max3.
+// Written as asm because fmaxf() costs a canonicalising self-max per operand; the FIRST read of the
+// accumulator is left to the compiler (a builtin), which places the MFMA-result wait states in front of
+// it -- the hazard recogniser does not look inside an asm statement.
+__device__ __forceinline__ void top2_update16(const mf_v16f& v, float& b, float& s) {
+  const float x0 = __builtin_amdgcn_fmed3f(b, v[0], v[1]);
+  float ta, tb;
+  asm("v_max3_f32 %0, %0, %4, %5\n\t"
+      "v_med3_f32 %2, %0, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %6, %7\n\t"
+      "v_max3_f32 %1, %1, %20, %2\n\t"
+      "v_med3_f32 %2, %0, %8, %9\n\t"
+      "v_max3_f32 %0, %0, %8, %9\n\t"
+      "v_med3_f32 %3, %0, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %10, %11\n\t"
+      "v_max3_f32 %1, %1, %2, %3\n\t"
+      "v_med3_f32 %2, %0, %12, %13\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\t"
+      "v_med3_f32 %3, %0, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %14, %15\n\t"
+      "v_max3_f32 %1, %1, %2, %3\n\t"
+      "v_med3_f32 %2, %0, %16, %17\n\t"
+      "v_max3_f32 %0, %0, %16, %17\n\t"
+      "v_med3_f32 %3, %0, %18, %19\n\t"
+      "v_max3_f32 %0, %0, %18, %19\n\t"
+      "v_max3_f32 %1, %1, %2, %3"
+      : "+v"(b), "+v"(s), "=&v"(ta), "=&v"(tb)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+        "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(x0));
+}
+
 // One 32-row "from" tile against the NTL resident "to" tiles of this wavefront.
 template <int W, int NTL, bool TAIL>
 __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, int mt, int r, int h,
                                                const mf_v8i (&Bf)[NTL][W / 2], const float (&cin)[16],
-                                               float (&b)[NTL], float (&s)[NTL], uint32_t m88, uint32_t c22, float inf) {
+                                               float (&b)[NTL], float (&s)[NTL], uint32_t m88, uint32_t c22) {
   constexpr int KS = W / 2;
   int row = mt * 32 + r;
   if (TAIL) row = min(row, Kf - 1);
@@ -366,12 +396,7 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
 #pragma unroll
     for (int k = 1; k < KS; ++k)
       acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[k], Bf[j][k], acc, 4, 4, 0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float v = acc[i];
-      s[j] = __builtin_amdgcn_fmed3f(b[j], s[j], v);
-      b[j] = __builtin_amdgcn_fmed3f(b[j], v, inf);   // = max(b, v): fmaxf would cost a canonicalising self-max per call
-    }
+    top2_update16(acc, b[j], s[j]);
   }
 }
 
@@ -386,8 +411,6 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
   uint32_t m88, c22;   // constants pinned in VGPRs (see fp4_spread)
   asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
   asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
-  float inf;
-  asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(inf));
   mf_v8i Bf[NTL][KS];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -405,8 +428,8 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 #pragma unroll
   for (int j = 0; j < NTL; ++j) { b[j] = -INFINITY; s[j] = -INFINITY; }
   const int n_full = Kf >> 5;
-  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22, inf);
-  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22, inf);
+  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22);
+  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22);
   const float org = (float)(32 * (((Kf + 31) >> 5) - 1)) * MF_FR;
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -635,14 +658,32 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
                            counter, smem);
 }
 
+// the matrix-core variant as a stage kernel: 4 workgroups per CU (<= 128 VGPRs), which also keeps the
+// MFMA results in VGPRs (with the full 512-register budget the compiler accumulates in AGPRs and pays a
+// v_accvgpr_read per value in the epilogue)
+template <int W, int NT>
+__global__ void __launch_bounds__(NT, 4)
+k_match_global_mf(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                  float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
+                  PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  match_v2_body<W, 0, NT>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
+                          counter, smem);
+}
+
 template <int W, int NQ, int NT>
 void launch_match_v2(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
   if (const char* v = getenv("SF_MATCH_LDS_PAD")) lds += (size_t)atoi(v);   // occupancy experiment (diagnostic)
   int32_t* counters = (int32_t*)c->counters.p;
-  hipLaunchKernelGGL((k_match_global_v2<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
-                     c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
-                     (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+  if constexpr (NQ == 0)
+    hipLaunchKernelGGL((k_match_global_mf<W, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
+                       c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p,
+                       (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+  else
+    hipLaunchKernelGGL((k_match_global_v2<W, NQ, NT>), dim3(n), dim3(NT), lds, c->stream, st, d_from, d_to,
+                       c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p,
+                       (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
 }
 
 template <int W, int NQ, int NT>
