@@ -30,6 +30,7 @@ METRIC = "candidate keyframe-pair verifications/sec (NetVLAD NN + ORB match + RA
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak
 MFMA_F16_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: bf16/fp16 dense matrix peak
+MFMA_FP4_PEAK_TF = 10000.0   # MI355X_MICROARCH.md: fp6/fp4 dense matrix peak (~10 PF; the 20 PF spec is 2:1 sparse)
 
 
 def bytes_per_pair(k, cols):
@@ -66,10 +67,45 @@ def sq_evidence(kernel_prefix):
             d = json.load(open(path))
         except Exception:
             continue
-        if kernel_prefix.replace("k_match_global", "k_match") in os.path.basename(path) and "valu_busy_estimate" in d:
+        if (kernel_prefix.replace("k_match_global", "k_match") in os.path.basename(path) and "valu_busy_estimate" in d
+                and "SQ_INSTS_MFMA" not in d):      # passes of the VALU matcher only
             return {"frac": d["valu_busy_estimate"], "SQ_INSTS_VALU": d.get("SQ_INSTS_VALU"),
                     "GRBM_GUI_ACTIVE": d.get("GRBM_GUI_ACTIVE"), "source": os.path.basename(path)}
     return None
+
+
+def sq_counters(kernel_prefix):
+    """The newest committed SQ counter pass of a kernel (profiles/*_sq_<kernel>.json), whole."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_*.json")), reverse=True):
+        if kernel_prefix.replace("k_match_global", "k_match") in os.path.basename(path):
+            try:
+                d = json.load(open(path))
+            except Exception:
+                continue
+            d.pop("_note", None)
+            d["source"] = os.path.basename(path)
+            return d
+    return None
+
+
+def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
+    """What actually bounds the dominant kernel: on-chip issue, not HBM (SURVEY section 8(d) asks for both).
+    Default build: the K x K Hamming table runs on the fp4 matrix cores (+-1 encoding, exact); with
+    SF_MATCH_MFMA=0 on the VALU (xor + popcount)."""
+    per_s = pairs_per_launch * k * k / (launch_ms * 1e-3) if launch_ms > 0 else 0.0
+    if os.environ.get("SF_MATCH_MFMA", "1") != "0":
+        flop = 2.0 * k * k * cols * 8          # one multiply-add per descriptor bit pair
+        tf = pairs_per_launch * flop / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        return {"note": "matching = v_mfma_f32_32x32x64_f8f6f4 over +-1-encoded descriptor bits (2*K*K*bits flop per pair, "
+                        "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan"
+                        + ("; the launch also holds both motion-estimation chains of the surviving pairs, which are "
+                           "latency-bound" if dom == "k_verify_fused" else ""),
+                "matrix_core": {"achieved": tf, "peak": MFMA_FP4_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_FP4_PEAK_TF},
+                "descriptor_pairs_per_s": per_s, "counters": sq_counters(dom)}
+    return {"note": "VALU matcher (SF_MATCH_MFMA=0): per 256-bit descriptor pair 8 v_xor (full rate) + 8 v_bcnt_u32_b32 "
+                    "(HALF rate on gfx950, tools/ubench/valu_rate.hip) + 6 16-bit min/max",
+            "descriptor_pairs_per_s": per_s, "valu_busy_from_counters": sq_evidence(dom)}
 
 
 def generate_inputs(seed, n_kf, k, cols, dim, true_frac):
@@ -212,16 +248,12 @@ def main():
     f.nn_append_local_device(tb.data_ptr(), n_kf, dim)       # robot B's own descriptors
     torch.cuda.synchronize()
 
-    d_from = torch.empty(n_kf, dtype=torch.int32, device=dev)
-    d_to = torch.empty(n_kf, dtype=torch.int32, device=dev)
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     d_acc = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     d_flags = torch.empty(n_kf, dtype=torch.bool, device=dev)
     h_res = torch.empty((n_kf * world, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
     h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
-    h_from = torch.empty(n_kf, dtype=torch.int32).pin_memory()
-    h_to = torch.empty(n_kf, dtype=torch.int32).pin_memory()
     state = {"pairs": 0, "accepted": 0, "last": None}
 
     trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
@@ -315,7 +347,7 @@ def main():
 
     # ---- informational: the same steps software-pipelined over two streams (untimed by the driver) ----
     # A deployment that serves a stream of independent batches can run the NN stage of batch i+1 (MFMA +
-    # HBM + host walk, on a second handle with its own stream) while batch i is being verified (VALU).
+    # HBM + host walk, on a second handle with its own stream) while batch i is being verified.
     # `value` above is NOT measured this way: its steps run strictly one after the other.
     piped = None
     if world == 1 and args.nn_precision == 1 and not args.no_pipelined_extra:
@@ -325,25 +357,18 @@ def main():
         f_nn.synchronize()
 
         def launch_verify(m):
-            n = len(m)
-            h_from[:n] = torch.from_numpy(m["idx_other"].astype(np.int32) + slot_a)
-            h_to[:n] = torch.from_numpy(m["idx_local"].astype(np.int32) + slot_b)
-            d_from[:n].copy_(h_from[:n], non_blocking=True)
-            d_to[:n].copy_(h_to[:n], non_blocking=True)
-            f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
-            return n
+            f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())   # asynchronous on the verification stream
+            return len(m)
 
         h_res_p = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
         h_flags_p = torch.empty(n_kf, dtype=torch.bool).pin_memory()
 
         def finish(n):
-            res2d = d_res[:n]
-            succ = res2d[:, OFF_SUCCESS] != 0
-            acc = res2d[succ]
-            h_flags_p[:n].copy_(succ, non_blocking=True)
-            h_res_p[: acc.shape[0]].copy_(acc, non_blocking=True)
+            n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
+            h_flags_p[:n].copy_(d_flags[:n], non_blocking=True)
+            h_res_p[:n_acc].copy_(d_acc[:n_acc], non_blocking=True)
             torch.cuda.synchronize()
-            return int(acc.shape[0])
+            return int(n_acc)
 
         def run_piped(k_steps):
             pairs = 0
@@ -431,11 +456,7 @@ def main():
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": (pmc or {}).get("bytes") if abs(pairs_per_step - 10000) < 1 else None,
                 "traffic_source": pmc,
-                "valu": {"note": "the kernel is VALU-bound, not HBM-bound (its matching phase dominates): per 256-bit descriptor pair 8 v_xor (full "
-                                 "rate) + 8 v_bcnt_u32_b32 (HALF rate on gfx950, tools/ubench/valu_rate.hip) + 6 "
-                                 "16-bit min/max",
-                         "descriptor_pairs_per_s": pairs_per_step * k * k / (match_ms * 1e-3) if match_ms > 0 else 0.0,
-                         "valu_busy_from_counters": sq_evidence(dom)},
+                "compute": compute_note(dom, k, cols, pairs_per_step, match_ms),
                 "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_step, "avg_launch_ms": match_ms,
             },
             "roofline_nn": {

@@ -16,6 +16,7 @@
 // The kernel is VALU-bound (~19 lane-ops per descriptor pair); HBM traffic is the two descriptor
 // blocks, read once (the "to" block coalesced 16 B/lane, the "from" block via the scalar cache).
 #include "sf_internal.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -446,7 +447,7 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 // Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
 // LDS.  Returns whether the pair goes on to motion estimation (block-uniform).  With list == nullptr
 // the pair is not appended to a work list (fused pipeline, k_verify.hip).
-template <int W, int NQ, int NT>
+template <int W, int NQ, int NT, int MF_NTL = 2>
 __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                               const int32_t* __restrict__ pair_to, float nndr, int min_inliers, int est,
                                               uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
@@ -491,34 +492,39 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, con
   int rejected = 0;
   if constexpr (NQ == 0) {
     if (Kf > 0) {
-      constexpr int NTL = W == 8 ? 2 : 1;
+      // "to" tiles resident per wavefront and scan: 2 keeps the fused kernel within 128 VGPRs (4 workgroups
+      // per CU, which its motion-estimation chains need); the stage kernel takes 4 at 2 workgroups per CU
+      // (the spread of the "from" tile is then shared by twice the columns: 0.293 -> 0.276 ms per 10 000 pairs)
+      constexpr int NTL = W == 8 ? MF_NTL : 1;
       const int n_nt = (Kt + 31) >> 5;
-      auto settle = [&](int t, uint32_t b1, uint32_t b2, int f) {
-        if (lane < 32 && t < Kt) {
-          const bool acc = (Kf >= 2) && !((float)b1 > nndr * (float)b2);
-          if (acc) {
-            atomicAdd(&cnt[f], 1);
-            owner[f] = t;
-          } else {
-            ++rejected;
+      // a wavefront owns tiles wave, wave + NW, ...; it scans them in groups of up to NTL (a group that is
+      // short of tiles drops to the next smaller instantiation; a 3-tile group runs as 4 with an empty tile)
+      auto group = [&](auto g, int t0) {
+        constexpr int G = decltype(g)::value;
+        int tl[G], f[G];
+        uint32_t a1[G], a2[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) tl[j] = t0 + j * NW;
+        knn2_mfma<W, G>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const int t = tl[j] * 32 + lane;
+          if (lane < 32 && t < Kt) {
+            const bool acc = (Kf >= 2) && !((float)a1[j] > nndr * (float)a2[j]);
+            if (acc) {
+              atomicAdd(&cnt[f[j]], 1);
+              owner[f[j]] = t;
+            } else {
+              ++rejected;
+            }
           }
         }
       };
       for (int t0 = wave; t0 < n_nt; t0 += NW * NTL) {
-        if (NTL == 2 && t0 + NW < n_nt) {
-          const int tl[2] = {t0, t0 + NW};
-          uint32_t a1[2], a2[2];
-          int f[2];
-          knn2_mfma<W, 2>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
-          settle(tl[0] * 32 + lane, a1[0], a2[0], f[0]);
-          settle(tl[1] * 32 + lane, a1[1], a2[1], f[1]);
-        } else {
-          const int tl[1] = {t0};
-          uint32_t a1[1], a2[1];
-          int f[1];
-          knn2_mfma<W, 1>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
-          settle(tl[0] * 32 + lane, a1[0], a2[0], f[0]);
-        }
+        const int avail = (n_nt - t0 + NW - 1) / NW;
+        if (NTL >= 4 && avail >= 3) group(std::integral_constant<int, 4>{}, t0);
+        else if (NTL >= 2 && avail >= 2) group(std::integral_constant<int, 2>{}, t0);
+        else group(std::integral_constant<int, 1>{}, t0);
       }
     }
   } else if (Kf > 0) {
@@ -658,17 +664,18 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
                            counter, smem);
 }
 
-// the matrix-core variant as a stage kernel: 4 workgroups per CU (<= 128 VGPRs), which also keeps the
-// MFMA results in VGPRs (with the full 512-register budget the compiler accumulates in AGPRs and pays a
-// v_accvgpr_read per value in the epilogue)
+// the matrix-core variant as a stage kernel: 4 column tiles per scan at 2 workgroups per CU (<= 256
+// VGPRs; measured equal to 3 and 4 workgroups per CU -- the kernel is bound by VALU issue, not by
+// occupancy).  A register budget <= 256 also keeps the MFMA results in VGPRs: with the full 512 the
+// compiler accumulates in AGPRs and pays a v_accvgpr_read per value in the epilogue.
 template <int W, int NT>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, 2)
 k_match_global_mf(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                   float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                   PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
-  match_v2_body<W, 0, NT>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
-                          counter, smem);
+  match_v2_body<W, 0, NT, 4>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
+                             counter, smem);
 }
 
 template <int W, int NQ, int NT>
@@ -704,7 +711,7 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
   if (variant == 0) {
     // default: LDS + u16 variant while the staged "from" block keeps >= 2 workgroups per CU
     const size_t lds_v2 = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
-    variant = lds_v2 <= 64 * 1024 ? (c->match_mfma ? 10256 : 12256) : 2256;
+    variant = lds_v2 <= 64 * 1024 ? (c->match_mfma && st.kcap <= MF_MAX_ROWS ? 10256 : 12256) : 2256;
   }
   sf_prof_begin(c, SF_K_MATCH);
 #define SF_CASE(NQ_, NT_)                                                        \

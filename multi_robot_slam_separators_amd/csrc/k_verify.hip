@@ -90,7 +90,7 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
-  if (c->match_mfma) {
+  if (c->match_mfma && st.kcap <= MF_MAX_ROWS) {
     if (st.w == 8) rc = launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds);
     else rc = launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds);
   } else {

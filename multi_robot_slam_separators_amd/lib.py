@@ -14,7 +14,7 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsepfinder.so")
+LIB_PATH = os.environ.get("SEPFINDER_LIB") or os.path.join(_HERE, "libsepfinder.so")   # override: A/B builds
 _lib = None
 
 

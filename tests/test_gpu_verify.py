@@ -329,6 +329,51 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch):
             assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_matrix_core_matcher_equals_valu_matcher(monkeypatch, fused):
+    """The Hamming table on the fp4 matrix cores (default) and on the VALU (SF_MATCH_MFMA=0) must give the
+    same correspondences -- exact +-1 products, lowest-index tie rule carried in the accumulator's fraction
+    -- for ragged sizes (rows not a multiple of the 32-row tile, fewer rows than one tile, 1 and 0 rows),
+    both descriptor widths, short descriptors and duplicated descriptors (distance ties)."""
+    from multi_robot_slam_separators_amd import lib
+    from test_gpu_fuzz import random_frame
+    rng = np.random.default_rng(99)
+    for cols in (32, 64, 16):
+        A, B = [], []
+        for ka, kb in ((500, 500), (257, 31), (31, 257), (33, 500), (1, 40), (40, 1), (0, 10), (10, 0), (2, 2), (96, 64)):
+            a = random_frame(rng, ka, cols)
+            if ka >= 8 and kb >= 8:
+                b, _ = synth.make_true_partner(rng, a, synth.random_transform(rng, 20, 1.0), overlap=0.6, noise=0.02,
+                                               flip=0.05)
+                if kb < ka:
+                    b = _abi.FeatureArrays(b.desc[:kb].copy(), b.xyz[:kb].copy(), b.kpts[:kb].copy())
+                elif kb > ka:      # pad with unrelated features
+                    e = random_frame(rng, kb - ka, cols)
+                    b = _abi.FeatureArrays(np.concatenate([b.desc, e.desc]), np.concatenate([b.xyz, e.xyz]),
+                                           np.concatenate([b.kpts, e.kpts]))
+            else:
+                b = random_frame(rng, kb, cols)
+            if ka >= 40:      # exact duplicates inside the "from" frame: equal best distances, lowest row wins
+                a.desc[ka // 2] = a.desc[3]
+                a.desc[ka - 1] = a.desc[3]
+            A.append(a); B.append(b)
+        p = synth.camera_params()
+        p.iterations = 100
+        p.max_features = 500
+        out = {}
+        for mf in ("1", "0"):
+            monkeypatch.setenv("SF_MATCH_MFMA", mf)
+            monkeypatch.setenv("SF_FUSED", fused)
+            with lib.SeparatorFinder(p) as f:
+                res = f.estimate_transform_batch(A, B)
+                corr = [f.debug_correspondences(i, w) for i in range(len(A)) for w in (1, 2)]
+            out[mf] = (res, corr)
+        assert out["1"][0].tobytes() == out["0"][0].tobytes(), cols
+        for c1, c0 in zip(out["1"][1], out["0"][1]):
+            assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
+        assert sum(len(c[0]) for c in out["1"][1]) > 100      # the comparison is not vacuous
+
+
 def test_fused_pipeline_with_more_than_64k_of_lds(oracle):
     """K = 700 (kcap 1024) and 6 000 iterations: the fused kernel's dynamic LDS exceeds 64 KiB (RANSAC
     count table), which needs the raised per-kernel limit."""

@@ -1,0 +1,17 @@
+#!/bin/bash
+# One round of rocprofv3 evidence for `python bench.py` (run on the GPU box; outputs under gpurun_out/prof_<tag>):
+# kernel stats, FETCH_SIZE / WRITE_SIZE passes and an SQ pass (each --pmc set in its own run).
+# Usage: tools/profile_round.sh <tag> [bench args...]
+set -e
+tag=$1; shift
+out=gpurun_out/prof_$tag
+mkdir -p $out
+B="python bench.py --steps 6 --warmup 2 --no-pipelined-extra --cpu-sample-pairs 200 --cpu-sample-rows 64 $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $B > $out/write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/sq -- $B > $out/sq.log 2>&1
+python tools/summarize_prof.py $tag $out/stats $out/fetch $out/write > $out/summary.txt
+python tools/pmc_kernel.py $out/sq > $out/sq.txt
+cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv $out/
+tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_global_mf" $out/sq.txt
