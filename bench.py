@@ -251,7 +251,13 @@ def main():
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     d_acc = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     d_flags = torch.empty(n_kf, dtype=torch.bool, device=dev)
-    h_res = torch.empty((n_kf * world, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    h_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    # N > 1: the accepted separators of every rank are all-gathered on the devices (persistent buffers, one
+    # collective per step, capacity for a 25 % acceptance rate + slack; overflow falls back to two-phase);
+    # each rank hands ITS OWN accepted separators to the host, so the node delivers every record once.
+    exch = None
+    if world > 1:
+        exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf, n_kf // 4 + 256, coll_dev)
     h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
@@ -276,17 +282,21 @@ def main():
         # every candidate's success flag goes back to the two robots involved (failures feed the ignore
         # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
         # the back-end (data_handler.py:352-368).
-        n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
-        acc = d_acc[:n_acc]                                   # ordered device-side compaction (one kernel)
-        succ = d_flags[:n]
-        if world > 1:
-            # one collective: capacity for a 25 % acceptance rate + slack (overflow falls back to two-phase)
-            rec, counts = dist.allgather_records_fixed(acc.to(coll_dev), n_kf // 4 + 256)
+        if exch is not None and coll_dev.type == "cuda":
+            # compaction writes straight into the exchange's send buffer (no staging copy)
+            n_acc = f.compact_accepted_device(d_res.data_ptr(), n, exch.payload.data_ptr(), d_flags.data_ptr())
+            acc = exch.payload[:n_acc]
+            exch.exchange(n_acc)                              # count stamped on the device + ONE all-gather
         else:
-            rec = acc
+            n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
+            acc = d_acc[:n_acc]                               # ordered device-side compaction (one kernel)
+            if exch is not None:                              # gloo rehearsal: the collective runs on CPU tensors
+                exch.payload[:n_acc].copy_(acc)
+                exch.exchange(n_acc)
+        succ = d_flags[:n]
         h_flags[:n].copy_(succ, non_blocking=True)
-        host = h_res[: rec.shape[0]]
-        host.copy_(rec, non_blocking=True)                    # accepted separators delivered to the host (pinned)
+        host = h_res[:n_acc]
+        host.copy_(acc, non_blocking=True)                    # accepted separators delivered to the host (pinned)
         torch.cuda.synchronize()
         if trace:
             t_4 = time.perf_counter()
@@ -299,7 +309,7 @@ def main():
                   file=sys.stderr)
         state["pairs"] += n
         state["last"] = (m, host, n)
-        state["gathered"] = int(rec.shape[0])
+        state["gathered"] = sum(exch.counts()) if exch is not None else n_acc
         return n
 
     for _ in range(args.warmup):
@@ -407,7 +417,14 @@ def main():
     accepted = int(flags.sum())
     correct = int((flags == (truth & same)).sum())
     sep = np.frombuffer(host.numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
-    all_ok = bool(sep["success"].all()) and len(sep) == state["gathered"]
+    if exch is not None:      # outside the timed region: every gathered record is an accepted separator
+        allrec, cts = exch.all_gathered()
+        gat = np.frombuffer(allrec.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+        mine = gat[sum(cts[:rank]): sum(cts[:rank + 1])]
+        all_ok = (bool(gat["success"].all()) and len(gat) == state["gathered"] and len(mine) == len(sep)
+                  and mine.tobytes() == sep.tobytes())
+    else:
+        all_ok = bool(sep["success"].all()) and len(sep) == state["gathered"]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

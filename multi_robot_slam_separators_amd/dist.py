@@ -82,6 +82,75 @@ def allgather_records_fixed(local, cap, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+class RecordExchange:
+    """The per-step separator exchange with persistent buffers: ONE all_gather_into_tensor per call, no
+    allocation, no host-to-device copy and no synchronisation of its own.
+
+    The producer writes its records straight into `payload` (rows 1.. of the send buffer: hand
+    `payload.data_ptr()` to sf_compact_accepted_device); `exchange(n)` stamps the count into the header
+    row ON THE DEVICE (a fill, not an upload), issues the collective over the first `cap + 1` rows and
+    queues a copy of the `world` header rows into pinned host memory.  After the caller's own stream
+    synchronisation `counts()` is a plain host read, and `gathered(r)` / `all_gathered()` are views of the
+    receive buffer (rank-major).  If some rank held more than `cap` records, `counts()` reports it and
+    `all_gathered()` fetches the overflow with the two-phase allgather_records (correct for any input, one
+    collective in the common case).  Works on CPU tensors too (gloo rehearsals and tests)."""
+
+    def __init__(self, record_bytes, max_rows, cap, device, group=None):
+        import torch
+        self.td = _dist()
+        self.group = group
+        self.world = self.td.get_world_size(group)
+        self.rec = int(record_bytes)
+        self.cap = max(1, min(int(cap), int(max_rows)))
+        self.device = torch.device(device)
+        assert self.rec >= 8
+        self.send = torch.zeros((int(max_rows) + 1, self.rec), dtype=torch.uint8, device=self.device)
+        self.payload = self.send[1:]
+        self._hdr = self.send[0, :8].view(torch.int64)           # this rank's record count
+        self.recv = torch.empty((self.world, self.cap + 1, self.rec), dtype=torch.uint8, device=self.device)
+        self._hdr_all = self.recv[:, 0, :8]                        # [world, 8] bytes, strided view
+        self._h_counts = torch.zeros((self.world, 8), dtype=torch.uint8)
+        if self.device.type == "cuda":
+            self._h_counts = self._h_counts.pin_memory()
+        self._n_local = 0
+
+    def exchange(self, n_local):
+        self._n_local = int(n_local)
+        self._hdr.fill_(self._n_local)
+        self.td.all_gather_into_tensor(self.recv.view(self.world * (self.cap + 1), self.rec), self.send[: self.cap + 1],
+                                       group=self.group)
+        self._h_counts.copy_(self._hdr_all, non_blocking=True)
+
+    def counts(self):
+        """Per-rank record counts; valid once the stream the exchange ran on has been synchronised."""
+        return [int(c) for c in self._h_counts.view(torch_int64()).reshape(-1).tolist()]
+
+    def gathered(self, r, counts=None):
+        c = (counts or self.counts())[r]
+        return self.recv[r, 1: 1 + min(c, self.cap)]
+
+    def all_gathered(self):
+        """(records [sum n, record_bytes] rank-major, counts) -- materialises a copy; the overflow of a rank
+        that held more than `cap` records is exchanged here."""
+        import torch
+        counts = self.counts()
+        parts = [self.gathered(r, counts) for r in range(self.world)]
+        if max(counts) > self.cap:
+            extra, ecounts = allgather_records(self.payload[self.cap: self._n_local] if self._n_local > self.cap
+                                               else self.payload[:0], self.group)
+            off = 0
+            for r in range(self.world):
+                if ecounts[r]:
+                    parts[r] = torch.cat([parts[r], extra[off: off + ecounts[r]]], dim=0)
+                off += ecounts[r]
+        return torch.cat(parts, dim=0), counts
+
+
+def torch_int64():
+    import torch
+    return torch.int64
+
+
 def interleave_round_robin(records, counts):
     """Undo shard_pairs: records gathered rank-major -> global pair order (p = i*world + rank)."""
     import torch

@@ -280,6 +280,15 @@ def test_torch_rccl_allgather_records_single_rank():
         for cap in (8, 5, 2):        # the one-collective variant, with and without the overflow fallback
             out, counts = dist.allgather_records_fixed(rec, cap)
             assert counts == [5] and torch.equal(out, rec)
+        for cap in (8, 2):           # the persistent-buffer form bench.py runs every step (device buffers, RCCL)
+            ex = dist.RecordExchange(368, 16, cap, dev)
+            for k in (5, 3, 0):
+                ex.payload[:k] = rec[:k]
+                ex.exchange(k)
+                torch.cuda.synchronize()
+                assert ex.counts() == [k]
+                out, counts = ex.all_gathered()
+                assert counts == [k] and torch.equal(out, rec[:k]), (cap, k)
         t = torch.tensor([3.5], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         td.barrier()

@@ -151,6 +151,23 @@ assert np.allclose(out["position"][:, 0], np.arange(n_pairs) + 0.25)
 for cap in (8, 4, 2, 1):
     allrec2, counts2 = dist.allgather_records_fixed(local, cap)
     assert counts2 == counts and torch.equal(allrec2, allrec), cap
+# --- the persistent-buffer form of it (what bench.py runs every step): two steps with different counts ---
+for cap in (8, 2):
+    ex = dist.RecordExchange(B, n_pairs, cap, "cpu")
+    for step in range(2):
+        k = len(mine) if step == 0 else max(0, len(mine) - 1 - rank)
+        ex.payload[:k] = local[:k]
+        ex.exchange(k)
+        got, cts = ex.all_gathered()
+        want_counts = [len(dist.shard_pairs(n_pairs, r, world)) if step == 0 else
+                       max(0, len(dist.shard_pairs(n_pairs, r, world)) - 1 - r) for r in range(world)]
+        assert cts == want_counts, (cap, step, cts)
+        off = 0
+        for r in range(world):
+            theirs = dist.shard_pairs(n_pairs, r, world)[: cts[r]]
+            chunk = np.frombuffer(got[off: off + cts[r]].numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+            assert chunk["inliers"].tolist() == [int(p) * 7 + 1 for p in theirs], (cap, step, r)
+            off += cts[r]
 # --- empty shard on one rank ---------------------------------------------------------------------------
 few = torch.zeros((1 if rank == 0 else 0, 8), dtype=torch.uint8)
 g, c = dist.allgather_records(few)
