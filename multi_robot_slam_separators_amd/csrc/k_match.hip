@@ -4,7 +4,11 @@
 // (VWDictionary::addNewWords in brute-force mode [upstream rtabmap] = cv::BFMatcher NORM_HAMMING
 // knnMatch k=2, accept nearest id unless d1 > nndr*d2, keep ids occurring exactly once per side).
 //
-// CDNA4 mapping (one 256-thread workgroup per candidate pair):
+// Three formulations of the same integers, all one 256-thread workgroup per candidate pair:
+//   variant 3 (default, NQ == 0, further down): the K_from x K_to distance table as an exact +-1 product
+//             on the fp4 matrix cores; variant 2 ("LDS + u16", SF_MATCH_MFMA=0): xor + popcount on the VALU
+//             with the "from" block in LDS; variant 1 (frames too large for the LDS copy): below.
+// Variant 1, CDNA4 mapping:
 //   * every lane keeps TWO "to" descriptors resident in VGPRs (8 or 16 dwords each);
 //   * the "from" descriptors are wave-uniform, so they are fetched with SCALAR loads
 //     (s_load_dwordx8/x16 through the scalar cache) and fed to v_xor_b32 as SGPR operands --

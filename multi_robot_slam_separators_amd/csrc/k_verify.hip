@@ -5,13 +5,14 @@
 // StereoCamGeometricTools::estimateTransformation (stereoCamGeometricTools.cpp:122-178) --
 // global matching, RANSAC, guess-guided matching, RANSAC again, result assembly -- without leaving the
 // CU.  Why fuse: the motion-estimation stages are short dependent fp64 chains that occupy a few
-// hundred workgroups for ~0.1 ms each and leave the VALU pipes idle, while matching is bound by VALU
-// issue and (measured, tools/exp_match_occupancy.py) loses 1 % when only 4 instead of 7 workgroups are
-// resident per CU.  In the fused kernel the 20 % of pairs that survive matching run their RANSAC chain
-// while the other workgroups of the same CU are still matching, so the chain's latency is hidden
-// instead of serialised behind four more launches.  The stage kernels remain for the PnP estimator
-// (k_pnp needs 256 VGPRs) and as the A/B reference (SF_FUSED=0): both paths run the same bodies and
-// produce identical bytes.
+// hundred workgroups for ~0.1 ms each and leave the issue ports idle, while matching is bound by
+// instruction issue (matrix pipe + VALU top-2 scan; measured insensitive to 2 / 3 / 4 resident workgroups
+// per CU).  In the fused kernel the 20 % of pairs that survive matching run their RANSAC chain while the
+// other workgroups of the same CU are still matching.  Since matching moved to the matrix cores the two
+// halves weigh about the same and the fused launch takes as long as the five stage launches (DESIGN.md
+// section 5); it still is one launch instead of five for small batches.  The stage kernels remain for the
+// PnP estimator (k_pnp: 177 VGPRs, 3 workgroups per CU) and as the A/B reference (SF_FUSED=0): both paths
+// run the same bodies and produce identical bytes.
 // Compiled with -ffp-contract=off (canonical arithmetic of the RANSAC / guided bodies).
 #include "k_match.hip"
 #include "k_ransac.hip"
