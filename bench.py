@@ -53,9 +53,12 @@ def pmc_traffic(kernel_prefix, pairs_per_launch):
             continue
         for name, v in pm.items():
             if name.startswith(kernel_prefix) and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+                ppl = v.get("pairs_per_launch", 10000.0)     # summaries before r01k: 10 000 pairs per launch
+                if abs(ppl - pairs_per_launch) > 1:
+                    return None
                 return {"bytes": (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0,
                         "source": os.path.basename(path), "kernel": name,
-                        "note": "measured at 10000 pairs per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB"}
+                        "note": "measured at %d pairs per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB" % ppl}
     return None
 
 
@@ -434,10 +437,12 @@ def main():
         # result: the whole verification the 44 352 B/pair figure of SURVEY 8(d) describes), or the
         # matching kernel when the stage kernels run (PnP estimator, SF_FUSED=0)
         dom = "k_verify_fused" if prof.get("k_verify_fused", (0, 0.0))[0] > 0 else "k_match_global"
-        pmc = pmc_traffic(dom, pairs_per_step)
         nm, tm = prof[dom]
         match_ms = tm / max(nm, 1)
-        ach = pairs_per_step * bpp / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+        # pairs one launch of the dominant kernel processes (big batches are cut in two halves on two streams)
+        pairs_per_launch = pairs_per_step * args.steps / max(nm, 1)
+        pmc = pmc_traffic(dom, pairs_per_launch)
+        ach = pairs_per_launch * bpp / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
         nn_kernel, nn_peak = (("k_nn_filter_f16", MFMA_F16_PEAK_TF) if args.nn_precision == 1
                               else ("k_nn_argmin", MFMA_F32_PEAK_TF))
         nn_n, nn_t = prof[nn_kernel]
@@ -471,10 +476,11 @@ def main():
             "roofline": {
                 "kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": (pmc or {}).get("bytes") if abs(pairs_per_step - 10000) < 1 else None,
+                "traffic": (pmc or {}).get("bytes"),
                 "traffic_source": pmc,
-                "compute": compute_note(dom, k, cols, pairs_per_step, match_ms),
-                "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_step, "avg_launch_ms": match_ms,
+                "compute": compute_note(dom, k, cols, pairs_per_launch, match_ms),
+                "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": match_ms,
+                "launches_per_step": nm / args.steps,
             },
             "roofline_nn": {
                 "kernel": nn_kernel, "bound": "mfma", "achieved": nn_tf, "peak": nn_peak,

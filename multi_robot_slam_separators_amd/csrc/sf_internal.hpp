@@ -162,6 +162,16 @@ struct sf_context {
   int comm_rank = 0, comm_world = 1;
   Buf comm_scratch;
 
+  // Two-stream verification of large batches (sf_api.hip, verify_device): the second half of a batch runs
+  // its stage kernels on `twin` -- a shadow context with its own stream, workspace and counters that shares
+  // this handle's keyframe store and parameters -- so that the latency-bound motion-estimation kernels of
+  // one half overlap the issue-bound matching kernel of the other.  Off unless SF_OVERLAP=1 (+3-6 %).
+  sf_context* twin = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = false;
+  int overlap_min_pairs = 4096;
+  int ws_split = 0;             // pairs [0, ws_split) of the last batch live in this workspace, the rest in twin's
+
   // profiling
   bool prof = false;
   ProfSlot prof_slots[SF_K_COUNT];

@@ -383,6 +383,34 @@ def test_matrix_core_matcher_equals_valu_matcher(monkeypatch, fused):
         assert sum(len(c[0]) for c in out["1"][1]) > 100      # the comparison is not vacuous
 
 
+@pytest.mark.parametrize("est", [0, 1])
+def test_two_stream_batches_equal_single_stream(monkeypatch, est):
+    """SF_OVERLAP=1 cuts a batch in two halves that run the stage kernels on two streams (the second on a
+    shadow workspace): results and correspondences (both halves, through sf_debug_correspondences) must be
+    identical to the single-stream path, also across repeated calls and odd batch sizes."""
+    from multi_robot_slam_separators_amd import lib
+    A, B, is_true, _ = synth.make_pairs(731, 37, k=300, cols=32, true_frac=0.5)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.estimation_type = est
+    out = {}
+    for mode in ("single", "two"):
+        monkeypatch.setenv("SF_OVERLAP", "1" if mode == "two" else "0")
+        monkeypatch.setenv("SF_OVERLAP_MIN", "2")
+        with lib.SeparatorFinder(p) as f:
+            f.prof_enable(True)
+            res = [f.estimate_transform_batch(A[:n], B[:n]) for n in (37, 5, 36)]
+            corr = [f.debug_correspondences(i, w) for i in range(36) for w in (1, 2)]
+            prof = f.prof_get()
+        out[mode] = (res, corr, prof)
+    assert out["two"][2]["k_match_global"][0] == 2 * out["single"][2]["k_match_global"][0] + 2 * out["single"][2]["k_verify_fused"][0]
+    for r2, r1 in zip(out["two"][0], out["single"][0]):
+        assert r2.tobytes() == r1.tobytes()
+    for c2, c1 in zip(out["two"][1], out["single"][1]):
+        assert np.array_equal(c2[0], c1[0]) and np.array_equal(c2[1], c1[1])
+    assert out["single"][0][0]["success"][is_true].all()
+
+
 def test_fused_pipeline_with_more_than_64k_of_lds(oracle):
     """K = 700 (kcap 1024) and 6 000 iterations: the fused kernel's dynamic LDS exceeds 64 KiB (RANSAC
     count table), which needs the raised per-kernel limit."""

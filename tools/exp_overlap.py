@@ -24,16 +24,24 @@ d_from = torch.arange(n, dtype=torch.int32, device=dev) + hs[0][1]
 d_to = torch.arange(n, dtype=torch.int32, device=dev) + hs[0][2]
 d_res = torch.empty((n, 368), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-def run(nchunks, two):
+def run(nchunks, two, stagger=False):
+    """nchunks equal chunks, alternating between the two handles/streams when `two`; with `stagger` the
+    first chunk is half-size, so that the two streams run out of phase (one matching while the other is in
+    its motion-estimation kernels) instead of in lock-step."""
     t0 = time.perf_counter()
     sz = (n + nchunks - 1) // nchunks
-    for c in range(nchunks):
+    bounds, o = [], 0
+    if stagger:
+        bounds.append((0, sz // 2)); o = sz // 2
+    while o < n:
+        bounds.append((o, min(sz, n - o))); o += sz
+    for c, (o, m) in enumerate(bounds):
         f = hs[c % 2 if two else 0][0]
-        o = c * sz; m = min(sz, n - o)
         f.verify_pairs_device(d_from.data_ptr() + 4 * o, d_to.data_ptr() + 4 * o, m, d_res.data_ptr() + 368 * o)
     for f, _, _ in hs: f.synchronize()
     return (time.perf_counter() - t0) * 1e3
-for cfg in [(1, False), (2, False), (4, False), (2, True), (4, True), (8, True), (16, True)]:
+print("SF_FUSED =", os.environ.get("SF_FUSED", "1"))
+for cfg in [(1, False), (2, False), (2, True), (2, True, True), (4, True), (4, True, True), (8, True, True), (16, True, True)]:
     run(*cfg)
     ts = [run(*cfg) for _ in range(15)]
-    print("chunks %2d  two-streams %-5s : median %.3f ms" % (cfg[0], cfg[1], np.median(ts)))
+    print("chunks %2d  two-streams %-5s stagger %-5s : median %.3f ms" % (cfg[0], cfg[1], len(cfg) > 2, np.median(ts)))
