@@ -358,6 +358,22 @@ def main():
         f.nn_set_precision(1)
         step()
 
+    # ---- the same step with the VALU matcher (xor + popcount; north_star's literal kernel mix), untimed ----
+    alt_valu = None
+    if os.environ.get("SF_MATCH_MFMA", "1") != "0":
+        f.set_option(_abi.SF_OPT_MATCH_MFMA, 0)
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_alt = 0
+        for _ in range(5):
+            n_alt += step()
+        torch.cuda.synchronize()
+        alt_valu = n_alt / (time.perf_counter() - t1)
+        alt_valu_m = state["last"]
+        f.set_option(_abi.SF_OPT_MATCH_MFMA, 1)
+        step()
+
     # ---- informational: the same steps software-pipelined over two streams (untimed by the driver) ----
     # A deployment that serves a stream of independent batches can run the NN stage of batch i+1 (MFMA +
     # HBM + host walk, on a second handle with its own stream) while batch i is being verified.
@@ -497,6 +513,9 @@ def main():
             out["pipelined_two_streams"] = piped
         if alt is not None:
             out["value_with_fp32_nn_ranking"] = alt * world
+        if alt_valu is not None:
+            # the Hamming table by xor + popcount on the VALU instead of the fp4 matrix cores (identical outputs)
+            out["value_with_valu_matcher"] = alt_valu * world
             out["check"]["nn_matches_identical_fp32_vs_f16filter"] = bool(
                 np.array_equal(alt_m["idx_local"], m["idx_local"]) and np.array_equal(alt_m["idx_other"], m["idx_other"])
                 and np.array_equal(alt_m["distance"], m["distance"]))

@@ -282,6 +282,15 @@ int  sf_prof_reset(sf_handle h);
 int  sf_prof_get(sf_handle h, int kernel, int64_t* launches, double* total_ms);
 const char* sf_kernel_name(int kernel);
 
+/* Execution options of a live handle (none changes any output byte; the same switches are read from the
+   environment at sf_create: SF_MATCH_MFMA, SF_FUSED, SF_OVERLAP).  Returns SF_EINVAL for an unknown option. */
+enum {
+  SF_OPT_MATCH_MFMA = 0,  /* 1 (default): Hamming table on the fp4 matrix cores; 0: xor + popcount on the VALU   */
+  SF_OPT_FUSED = 1,       /* 1 (default): one fused launch per chunk (3D-3D estimator); 0: the stage kernels     */
+  SF_OPT_OVERLAP = 2      /* 1: batches >= 4096 pairs as two halves on two streams; 0 (default): one stream     */
+};
+int  sf_set_option(sf_handle h, int32_t option, int32_t value);
+
 #ifdef __cplusplus
 }
 #endif

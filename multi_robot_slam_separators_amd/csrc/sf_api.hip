@@ -991,6 +991,16 @@ extern "C" int sf_prof_get(sf_handle c, int kernel, int64_t* launches, double* t
   return SF_OK;
 }
 
+extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
+  if (!c) return SF_EINVAL;
+  switch (option) {
+    case SF_OPT_MATCH_MFMA: c->match_mfma = value != 0; return SF_OK;
+    case SF_OPT_FUSED: c->fused = value != 0; return SF_OK;
+    case SF_OPT_OVERLAP: c->overlap = value != 0; return SF_OK;
+    default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
+  }
+}
+
 // ---- NN stage entry points (implementation in k_nn.hip) --------------------------------------------
 extern "C" int sf_nn_append_local(sf_handle c, const double* desc, int32_t n, int32_t dim) {
   if (!c) return SF_EINVAL;

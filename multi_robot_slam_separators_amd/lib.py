@@ -70,6 +70,7 @@ def load():
         "sf_nn_ignore_pair": (C.c_int, [vp, i32, i32]),
         "sf_nn_reset": (C.c_int, [vp]),
         "sf_nn_set_precision": (C.c_int, [vp, i32]),
+        "sf_set_option": (C.c_int, [vp, i32, i32]),
         "sf_nn_find_matches": (C.c_int, [vp, vp, i32, P(i32)]),
         "sf_nn_last_row_minima": (C.c_int, [vp, vp, vp, i32]),
         "sf_nn_last_filter_dims": (C.c_int, [vp, P(i32)]),
@@ -110,6 +111,7 @@ EXPORTED = [
     "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_sizes",
     "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
     "sf_nn_set_precision",
+    "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_compact_accepted_device",
@@ -202,6 +204,10 @@ class SeparatorFinder:
     def nn_set_precision(self, nn_precision):
         self._check(self._L.sf_nn_set_precision(self._h, int(nn_precision)))
         self.params.nn_precision = int(nn_precision)
+
+    def set_option(self, option, value):
+        """Execution options of a live handle (_abi.SF_OPT_*); none changes any output byte."""
+        self._check(self._L.sf_set_option(self._h, int(option), int(value)))
 
     def nn_find_matches(self, cap=None):
         n_l, _ = self.nn_sizes()

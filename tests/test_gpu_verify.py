@@ -411,6 +411,29 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     assert out["single"][0][0]["success"][is_true].all()
 
 
+def test_execution_options_on_a_live_handle():
+    """sf_set_option switches matcher / fusion / two-stream execution between calls of ONE handle; every
+    combination returns the same bytes; an unknown option is SF_EINVAL."""
+    from multi_robot_slam_separators_amd import lib
+    A, B, is_true, _ = synth.make_pairs(912, 24, k=400, cols=32, true_frac=0.5)
+    p = synth.camera_params()
+    p.iterations = 200
+    with lib.SeparatorFinder(p) as f:
+        base = f.estimate_transform_batch(A, B)
+        assert base["success"][is_true].all()
+        for mfma in (0, 1):
+            for fused in (0, 1):
+                f.set_option(_abi.SF_OPT_MATCH_MFMA, mfma)
+                f.set_option(_abi.SF_OPT_FUSED, fused)
+                f.prof_reset(); f.prof_enable(True)
+                got = f.estimate_transform_batch(A, B)
+                prof = f.prof_get()
+                assert got.tobytes() == base.tobytes(), (mfma, fused)
+                assert (prof["k_verify_fused"][0] > 0) == bool(fused)
+        with pytest.raises(Exception):
+            f.set_option(99, 1)
+
+
 def test_fused_pipeline_with_more_than_64k_of_lds(oracle):
     """K = 700 (kcap 1024) and 6 000 iterations: the fused kernel's dynamic LDS exceeds 64 KiB (RANSAC
     count table), which needs the raised per-kernel limit."""
