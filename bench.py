@@ -266,20 +266,26 @@ def main():
     state = {"pairs": 0, "accepted": 0, "last": None}
 
     trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
+    two_calls = os.environ.get("BENCH_TWO_CALLS") is not None
 
     def step():
         t_0 = time.perf_counter()
-        m = f.nn_find_matches(cap=n_kf)                       # NN kernels + row minima to host + walk
-        t_1 = time.perf_counter()
+        # NN kernels, then -- in ONE library call -- the verification of the candidates: the NN filter's
+        # candidates are verified speculatively on the device while the host reduces them to row minima, sorts
+        # and walks them (data_handler.py:187-205); the walk's matches then pick their results (sf_api.hip).
+        # BENCH_TWO_CALLS=1: the two separate calls (sf_nn_find_matches, then sf_verify_matches_device).
+        if two_calls:
+            m = f.nn_find_matches(cap=n_kf)                   # NN kernels + row minima to host + walk
+            t_1 = time.perf_counter()
+            f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())
+        else:
+            m = f.find_matches_and_verify_device(slot_a, slot_b, d_res.data_ptr(), cap=n_kf)
+            t_1 = time.perf_counter()
         n = len(m)
         # pair (from = querying robot A's keyframe idx_other, to = computing robot B's idx_local),
         # find_separators.py:85-91
-        # (sf_verify_matches_device builds the two slot lists in pinned memory and uploads them itself)
         if trace:
-            t_1b = time.perf_counter()
-        f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())
-        if trace:
-            t_2 = time.perf_counter()
+            t_1b = t_2 = time.perf_counter()
             torch.cuda.synchronize()
             t_3 = time.perf_counter()
         # every candidate's success flag goes back to the two robots involved (failures feed the ignore
@@ -306,7 +312,7 @@ def main():
             pr = f.prof_get()
             kv = sum(v[1] for kname, v in pr.items() if kname.startswith("k_verify") or kname.startswith("k_match")
                      or kname.startswith("k_ransac") or kname.startswith("k_guided"))
-            print("[bench step] nn %.3f ms, pair upload %.3f, verify launch %.3f, verify wait %.3f, accepted-only "
+            print("[bench step] nn (+ verify launch) %.3f ms, - %.3f, - %.3f, verify wait %.3f, accepted-only "
                   "gather + copies %.3f; verification kernels so far %.3f ms (hipEvents)"
                   % ((t_1 - t_0) * 1e3, (t_1b - t_1) * 1e3, (t_2 - t_1b) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3, kv),
                   file=sys.stderr)

@@ -262,6 +262,16 @@ int  sf_comm_destroy(sf_handle h);
 int  sf_allgather_separators(sf_handle h, const sf_separator* d_local, int32_t n_local,
                              sf_separator* d_all, int32_t cap_per_rank, int32_t* counts);
 
+/* sf_nn_find_matches followed by sf_verify_matches_device of what it returned, as ONE call (the loop body of
+   find_separators.py:59-133 when both robots' keyframes live in this handle): `out` / `*n_out` as
+   sf_nn_find_matches, d_out[i] (device, caller-allocated, >= cap records) = result of match i, asynchronous
+   on the handle's stream.  Same outputs as the two calls; when the walk may return every local row
+   (cap and netvlad_max_matches_nb >= local rows, nn_precision = 1) the candidates of the NN filter are
+   verified SPECULATIVELY on the device while the host still reduces / sorts / walks them, which takes the
+   host part of the NN stage off the critical path.                                                     */
+int  sf_find_matches_and_verify_device(sf_handle h, int32_t slot_base_other, int32_t slot_base_local,
+                                       sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */
 enum {

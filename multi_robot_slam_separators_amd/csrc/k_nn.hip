@@ -627,17 +627,37 @@ static int nn_run_filter(sf_context* c, int* done) {
                          (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
       sf_prof_end(c, SF_K_NN_REFINE);
       const unsigned spec = std::min<unsigned>(limit, (unsigned)(2 * (size_t)n_l + 1024));
-      SF_HIP(c, hipMemcpyAsync(c->nn_pinned, count, 4, hipMemcpyDeviceToHost, c->stream));
-      SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)spec * 8, hipMemcpyDeviceToHost, c->stream));
-      SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)spec * 8, hipMemcpyDeviceToHost, c->stream));
-      SF_HIP(c, hipStreamSynchronize(c->stream));
+      // With a speculative verification requested (sf_find_matches_and_verify_device) the candidates go back
+      // to the host on a second stream while the handle's stream continues straight into the verification of
+      // every candidate: the host's row minima / sort / walk then run beside the verification kernels.
+      const bool speculate = c->spec.requested && !c->spec.launched;
+      hipStream_t cs = c->stream;
+      if (speculate) {
+        SF_HIP(c, hipEventRecord(c->spec.ev_refined, c->stream));
+        SF_HIP(c, hipStreamWaitEvent(c->spec.copy_stream, c->spec.ev_refined, 0));
+        cs = c->spec.copy_stream;
+      }
+      SF_HIP(c, hipMemcpyAsync(c->nn_pinned, count, 4, hipMemcpyDeviceToHost, cs));
+      SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)spec * 8, hipMemcpyDeviceToHost, cs));
+      SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)spec * 8, hipMemcpyDeviceToHost, cs));
+      if (speculate) {
+        SF_HIP(c, hipEventRecord(c->spec.ev_copied, cs));
+        if ((rc = sf_spec_launch(c, cand, count)) != SF_OK) return rc;
+        c->spec.launched = true;
+        SF_HIP(c, hipEventSynchronize(c->spec.ev_copied));
+      } else {
+        SF_HIP(c, hipStreamSynchronize(c->stream));
+      }
       n_cand = *(const unsigned*)c->nn_pinned;
       tr.mark("filter + refine + D2H", n_cand);
       ok = n_cand <= limit;
+      if (speculate) c->spec.valid = ok && n_cand <= c->spec.grid;
       if (ok && n_cand > spec) {
-        SF_HIP(c, hipMemcpyAsync(h_cand + spec, cand + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, c->stream));
-        SF_HIP(c, hipMemcpyAsync(h_dist + spec, cdist + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, c->stream));
-        SF_HIP(c, hipStreamSynchronize(c->stream));
+        // (rare) the tail of the candidate list; on the copy stream when the handle's stream is already busy
+        // with the speculative verification
+        SF_HIP(c, hipMemcpyAsync(h_cand + spec, cand + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, cs));
+        SF_HIP(c, hipMemcpyAsync(h_dist + spec, cdist + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, cs));
+        SF_HIP(c, hipStreamSynchronize(cs));
       }
     } else {
       SF_HIP(c, hipMemcpyAsync(&n_cand, count, 4, hipMemcpyDeviceToHost, c->stream));
@@ -673,6 +693,7 @@ static int nn_run_filter(sf_context* c, int* done) {
   // Rows without a candidate have their true minimum >= netvlad_distance: reported as +inf.
   c->last_row_min.assign(n_l, (double)INFINITY);
   c->last_row_arg.assign(n_l, 0);
+  c->last_row_cand.assign(n_l, -1);
   std::vector<std::pair<int, int>> ign;
   for (size_t e = 0; e + 1 < c->ignored.size(); e += 2) ign.push_back({c->ignored[e], c->ignored[e + 1]});
   std::sort(ign.begin(), ign.end());
@@ -684,6 +705,7 @@ static int nn_run_filter(sf_context* c, int* done) {
     if (d < c->last_row_min[r] || (d == c->last_row_min[r] && col < c->last_row_arg[r])) {
       c->last_row_min[r] = d;
       c->last_row_arg[r] = col;
+      c->last_row_cand[r] = (int32_t)i;
     }
   }
   tr.mark("host row minima");
@@ -730,6 +752,8 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     if ((rc = nn_run_filter(c, &filtered)) != SF_OK) return rc;
   }
   if (!filtered) {
+  c->spec.valid = false;   // the exact path has no candidate list
+  c->last_row_cand.clear();
   c->nn_coef_level = -1;   // the exact path re-uses the coefficient buffer for its partial minima
   // workspace: partial minima, effective column norms, per-row results
   const size_t part_bytes = (size_t)n_strips * n_l_pad * 8;

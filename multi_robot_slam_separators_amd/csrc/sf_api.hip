@@ -188,6 +188,39 @@ k_ingest_ragged(uint32_t* __restrict__ desc, float* __restrict__ xyz, float4* __
   if (tid == 0) meta[slot] = make_int4(e.rows, e.n3d > 0 ? e.rows : 0, e.rows, e.cols);
 }
 
+// Speculative verification (sf_find_matches_and_verify_device): candidate i of the NN filter, (local row r,
+// received column c), becomes pair slot i = (slot_other + c, slot_local + r); slots past the candidate count
+// (and candidates outside the store) get -1, which every verification kernel answers with a null result.
+__global__ void __launch_bounds__(256)
+k_spec_pairs(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned grid, int n_l, int n_r,
+             int slot_other, int slot_local, int n_slots, int32_t* __restrict__ from, int32_t* __restrict__ to) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= grid) return;
+  int f = -1, t = -1;
+  if (i < *count) {
+    const uint2 rc = cand[i];
+    if ((int)rc.x < n_l && (int)rc.y < n_r) {
+      f = slot_other + (int)rc.y;
+      t = slot_local + (int)rc.x;
+      if ((unsigned)f >= (unsigned)n_slots || (unsigned)t >= (unsigned)n_slots) { f = -1; t = -1; }
+    }
+  }
+  from[i] = f;
+  to[i] = t;
+}
+
+// out[m] = spec[index[m]]: the results of the walk's matches, in walk order (23 x 16 bytes per record)
+__global__ void __launch_bounds__(256)
+k_spec_gather(const sf_result* __restrict__ spec, const int32_t* __restrict__ index, int n, sf_result* __restrict__ out) {
+  static_assert(sizeof(sf_result) % 16 == 0, "sf_result is moved in 16-byte pieces");
+  constexpr int PIECES = sizeof(sf_result) / 16;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int m = g / PIECES, piece = g % PIECES;
+  if (m >= n) return;
+  const uint4* src = reinterpret_cast<const uint4*>(spec + index[m]);
+  reinterpret_cast<uint4*>(out + m)[piece] = src[piece];
+}
+
 // Ordered compaction of the accepted results, 1024 candidates per workgroup: k_compact_count leaves the
 // number of accepted candidates of every chunk (and the per-candidate flags), k_compact_move lets each
 // workgroup sum the counts of the chunks before it (at most a few hundred values) and moves its records
@@ -611,6 +644,15 @@ extern "C" void sf_destroy(sf_handle c) {
   if (c->pairs_pinned) (void)hipHostFree(c->pairs_pinned);
   if (c->count_pinned) (void)hipHostFree(c->count_pinned);
   if (c->pairs_staged) (void)hipEventDestroy(c->pairs_staged);
+  {
+    Buf* sb[] = {&c->spec_from, &c->spec_to, &c->spec_results, &c->spec_index};
+    for (Buf* b : sb) buf_free(*b);
+    if (c->spec_index_pinned) (void)hipHostFree(c->spec_index_pinned);
+    if (c->spec_index_staged) (void)hipEventDestroy(c->spec_index_staged);
+    if (c->spec.ev_refined) (void)hipEventDestroy(c->spec.ev_refined);
+    if (c->spec.ev_copied) (void)hipEventDestroy(c->spec.ev_copied);
+    if (c->spec.copy_stream) { (void)hipStreamSynchronize(c->spec.copy_stream); (void)hipStreamDestroy(c->spec.copy_stream); }
+  }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -828,6 +870,90 @@ extern "C" int sf_verify_matches_device(sf_handle c, const sf_match* matches, in
   if (!c->pairs_staged) SF_HIP(c, hipEventCreateWithFlags(&c->pairs_staged, hipEventDisableTiming));
   SF_HIP(c, hipEventRecord(c->pairs_staged, c->stream));
   return verify_device(c, c->store, (const int32_t*)c->pair_from.p, (const int32_t*)c->pair_to.p, n, d_out);
+}
+
+// Called by the NN filter behind the refinement launch of a prefix level (k_nn.hip): candidate pair list on
+// the device, then the verification of every candidate slot, all on the handle's stream.
+int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
+  const unsigned grid = c->spec.grid;
+  hipLaunchKernelGGL(k_spec_pairs, dim3((grid + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_cand, d_count, grid,
+                     c->nn_local.n, c->nn_recv.n, c->spec.slot_other, c->spec.slot_local, c->store.slots,
+                     (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
+  SF_HIP(c, hipGetLastError());
+  return verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
+                       (sf_result*)c->spec_results.p);
+}
+
+extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_other, int32_t slot_base_local,
+                                                 sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out) {
+  if (!c || !n_out || cap < 0 || (cap > 0 && (!out || !d_out))) return SF_EINVAL;
+  *n_out = 0;
+  if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
+    return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
+  SF_HIP(c, hipSetDevice(c->device));
+  const int n_l = c->nn_local.n;
+  int rc;
+  // Speculate only when the walk may return (almost) every local row -- otherwise verifying every candidate
+  // would do far more work than the few matches need -- and on the filter path, which has a candidate list.
+  const bool speculate = c->params.nn_precision == 1 && c->store.slots > 0 &&
+                         std::min(cap, c->params.netvlad_max_matches_nb) >= n_l && getenv("SF_SPECULATE_OFF") == nullptr;
+  if (speculate) {
+    if (!c->spec.copy_stream) {
+      SF_HIP(c, hipStreamCreateWithFlags(&c->spec.copy_stream, hipStreamNonBlocking));
+      SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_refined, hipEventDisableTiming));
+      SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_copied, hipEventDisableTiming));
+      SF_HIP(c, hipEventCreateWithFlags(&c->spec_index_staged, hipEventDisableTiming));
+    }
+    c->spec.grid = (unsigned)(n_l + n_l / 8 + 256);       // room for rows with more than one candidate
+    if ((rc = sf_buf_reserve(c, c->spec_from, (size_t)c->spec.grid * 4)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->spec_to, (size_t)c->spec.grid * 4)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->spec_results, (size_t)c->spec.grid * sizeof(sf_result))) != SF_OK) return rc;
+    c->spec.slot_other = slot_base_other;
+    c->spec.slot_local = slot_base_local;
+  }
+  c->spec.requested = speculate;
+  c->spec.launched = false;
+  c->spec.valid = false;
+  rc = sf_nn_run(c, out, cap, n_out);
+  c->spec.requested = false;
+  if (rc != SF_OK) return rc;
+  const int n = *n_out;
+  if (n == 0) return SF_OK;
+  if (!(c->spec.launched && c->spec.valid)) {
+    // no speculation, or its candidate set was not the one the matches came from: verify the matches now
+    // (a wasted speculative verification, if any, is simply queued in front)
+    return sf_verify_matches_device(c, out, n, slot_base_other, slot_base_local, d_out);
+  }
+  // the matches' results are among the speculative ones: index of each match's candidate, then one gather
+  for (int i = 0; i < n; ++i) {
+    const int f = slot_base_other + out[i].idx_other, t = slot_base_local + out[i].idx_local;
+    if (f < 0 || f >= c->store.slots || t < 0 || t >= c->store.slots)
+      return sf_fail(c, SF_ERANGE, "match %d: slot (%d,%d) outside the store (%d slots)", i, f, t, c->store.slots);
+  }
+  if ((rc = sf_buf_reserve(c, c->spec_index, (size_t)n * 4)) != SF_OK) return rc;
+  SF_HIP(c, hipEventSynchronize(c->spec_index_staged));   // (never recorded: returns at once) previous upload done
+  const size_t need = (size_t)n * 4;
+  if (need > c->spec_index_pinned_bytes) {
+    if (c->spec_index_pinned) (void)hipHostFree(c->spec_index_pinned);
+    c->spec_index_pinned = nullptr;
+    c->spec_index_pinned_bytes = 0;
+    if (hipHostMalloc(&c->spec_index_pinned, need + need / 2, hipHostMallocDefault) != hipSuccess)
+      return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", need + need / 2);
+    c->spec_index_pinned_bytes = need + need / 2;
+  }
+  int32_t* hi = (int32_t*)c->spec_index_pinned;
+  for (int i = 0; i < n; ++i) {
+    const int ci = c->last_row_cand[out[i].idx_local];
+    if (ci < 0 || (unsigned)ci >= c->spec.grid) return sf_fail(c, SF_EHIP, "speculation: match %d has no candidate slot", i);
+    hi[i] = ci;
+  }
+  SF_HIP(c, hipMemcpyAsync(c->spec_index.p, hi, need, hipMemcpyHostToDevice, c->stream));
+  SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));
+  constexpr int PIECES = sizeof(sf_result) / 16;
+  hipLaunchKernelGGL(k_spec_gather, dim3(((size_t)n * PIECES + 255) / 256), dim3(256), 0, c->stream,
+                     (const sf_result*)c->spec_results.p, (const int32_t*)c->spec_index.p, n, d_out);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
 }
 
 extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_results, int32_t n, sf_result* d_accepted,

@@ -172,6 +172,24 @@ struct sf_context {
   int overlap_min_pairs = 4096;
   int ws_split = 0;             // pairs [0, ws_split) of the last batch live in this workspace, the rest in twin's
 
+  // Speculative verification (sf_find_matches_and_verify_device): every candidate (row, column) the NN filter
+  // emits is verified on the device while the host still reduces the candidates to row minima, sorts and
+  // walks them; the walk's matches then pick their results out of the speculative ones.
+  struct Spec {
+    bool requested = false;     // set by the entry point for the duration of one sf_nn_run
+    bool launched = false;      // the candidates of some filter level were handed to the verification
+    bool valid = false;         // ... and that level's candidate set was accepted (n_cand <= grid)
+    int32_t slot_other = 0, slot_local = 0;
+    unsigned grid = 0;          // speculative pair slots (candidates beyond it invalidate the speculation)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_refined = nullptr, ev_copied = nullptr;
+  } spec;
+  Buf spec_from, spec_to, spec_results, spec_index;
+  void* spec_index_pinned = nullptr;
+  size_t spec_index_pinned_bytes = 0;
+  hipEvent_t spec_index_staged = nullptr;
+  std::vector<int32_t> last_row_cand;   // candidate-list index of each row's minimum (filter path)
+
   // profiling
   bool prof = false;
   ProfSlot prof_slots[SF_K_COUNT];
@@ -218,4 +236,7 @@ int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, 
                      const uint8_t* d_desc, const float* d_xyz, const sf_keypoint* d_kp);
 // NN stage
 int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out);
+// Speculation hook (sf_api.hip), called by the NN filter right behind the refinement launch of a prefix level:
+// builds the candidate pair list on the device and queues the verification of every candidate.
+int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count);
 int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int src_kind);

@@ -83,6 +83,7 @@ def load():
         "sf_verify_pairs": (C.c_int, [vp, vp, vp, i32, vp]),
         "sf_verify_pairs_device": (C.c_int, [vp, vp, vp, i32, vp]),
         "sf_verify_matches_device": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+        "sf_find_matches_and_verify_device": (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(i32), vp]),
         "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
         "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
@@ -114,7 +115,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
-    "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_compact_accepted_device",
+    "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
@@ -285,6 +286,19 @@ class SeparatorFinder:
         self._check(self._L.sf_verify_matches_device(self._h, _ptr(m), m.size, slot_base_other, slot_base_local,
                                                      C.c_void_p(d_out)))
         return m.size
+
+    def find_matches_and_verify_device(self, slot_base_other, slot_base_local, d_out, cap=None):
+        """nn_find_matches + verify_matches_device as one call (speculative verification of the NN candidates
+        while the host walks them, when the walk may return every local row); returns the matches, their
+        results are written to d_out (device) asynchronously."""
+        n_l, _ = self.nn_sizes()
+        if cap is None:
+            cap = max(1, min(max(n_l, 1), self.params.netvlad_max_matches_nb))
+        out = np.zeros(max(cap, 1), dtype=_abi.MATCH_DTYPE)
+        n = C.c_int32()
+        self._check(self._L.sf_find_matches_and_verify_device(self._h, slot_base_other, slot_base_local, _ptr(out), cap,
+                                                              C.byref(n), C.c_void_p(d_out)))
+        return out[: n.value]
 
     def compact_accepted_device(self, d_results, n, d_accepted, d_flags=None):
         """Ordered device-side compaction of the accepted results; returns their number."""

@@ -411,6 +411,64 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     assert out["single"][0][0]["success"][is_true].all()
 
 
+@pytest.mark.parametrize("est", [0, 1])
+def test_find_matches_and_verify_speculative_equals_two_calls(est):
+    """sf_find_matches_and_verify_device (speculative verification of the NN candidates while the host walks
+    them) returns the matches of sf_nn_find_matches and, per match, the bytes sf_verify_matches_device writes --
+    with masked rows / columns, ignored pairs, several local rows sharing one nearest column (the walk keeps
+    the first), rows without a candidate, and on the fallback paths (small cap; exact NN precision)."""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    n_kf, k, cols, dim = 96, 200, 32, 512
+    feats = synth.make_store_batch(77, n_kf, k=k, cols=cols, true_frac=0.5)
+    rng = np.random.default_rng(5)
+    nv_a = rng.normal(size=(n_kf, dim)); nv_a /= np.linalg.norm(nv_a, axis=1, keepdims=True)
+    nv_b = nv_a + 0.002 * rng.normal(size=(n_kf, dim)); nv_b /= np.linalg.norm(nv_b, axis=1, keepdims=True)
+    nv_b[10] = nv_b[11] = nv_b[12]            # three local rows whose nearest received column is 12
+    nv_b[40:44] = rng.normal(size=(4, dim)) * 3.0      # rows with no candidate under the threshold
+    p = synth.camera_params()
+    p.iterations = 200
+    p.estimation_type = est
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.netvlad_distance = 0.13
+    p.max_features = k
+    dev = torch.device("cuda:0")
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+
+    for precision, cap in ((1, n_kf), (1, 7), (0, n_kf)):
+        p.nn_precision = precision
+        with lib.SeparatorFinder(p) as f:
+            f.set_stream(torch.cuda.current_stream().cuda_stream)
+            T = {key: up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}   # kept alive
+            sa = f.store_add_keyframes_device(n_kf, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+            sb = f.store_add_keyframes_device(n_kf, k, cols, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+            torch.cuda.synchronize()
+            f.nn_append_received(nv_a)
+            f.nn_append_local(nv_b)
+            f.nn_mark_local_used(3); f.nn_mark_other_used(5); f.nn_ignore_pair(20, 20); f.nn_ignore_pair(21, 22)
+            d1 = torch.zeros((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+            d2 = torch.zeros_like(d1)
+            for rep in range(2):                       # twice: buffers and events are reused
+                m1 = f.nn_find_matches(cap=cap)
+                f.verify_matches_device(m1, sa, sb, d1.data_ptr())
+                torch.cuda.synchronize()
+                m2 = f.find_matches_and_verify_device(sa, sb, d2.data_ptr(), cap=cap)
+                torch.cuda.synchronize()
+                assert m1.tobytes() == m2.tobytes(), (precision, cap)
+                n = len(m1)
+                assert n > 0 and bytes(d1[:n].cpu().numpy()) == bytes(d2[:n].cpu().numpy()), (precision, cap, rep)
+            if cap == n_kf:
+                rows = m1["idx_local"].tolist()
+                assert 3 not in rows and 20 not in rows and not set(range(40, 44)) & set(rows)
+                assert sum(r in (10, 11, 12) for r in rows) == 1
+                res = np.frombuffer(bytes(d2[:n].cpu().numpy()), dtype=_abi.RESULT_DTYPE)
+                assert res["success"].sum() >= 10
+
+
 def test_execution_options_on_a_live_handle():
     """sf_set_option switches matcher / fusion / two-stream execution between calls of ONE handle; every
     combination returns the same bytes; an unknown option is SF_EINVAL."""
