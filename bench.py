@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined-extra", action="store_true",
                     help="skip the informational two-stream pipelined measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps: none of the untimed comparison runs (fp32 NN ranking, VALU matcher, "
+                         "pipelined) -- what the profiling rounds use, so that every launch they see is a timed one")
     ap.add_argument("--cpu-sample-pairs", type=int, default=10000)
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     args = ap.parse_args()
@@ -350,7 +353,7 @@ def main():
 
     # ---- the same step with the fp32-ranking NN stage, for reference (untimed by the driver) -------
     alt = None
-    if args.nn_precision == 1:
+    if args.nn_precision == 1 and not args.no_extras:
         f.nn_set_precision(0)
         step()
         torch.cuda.synchronize()
@@ -366,7 +369,7 @@ def main():
 
     # ---- the same step with the VALU matcher (xor + popcount; north_star's literal kernel mix), untimed ----
     alt_valu = None
-    if os.environ.get("SF_MATCH_MFMA", "1") != "0":
+    if os.environ.get("SF_MATCH_MFMA", "1") != "0" and not args.no_extras:
         f.set_option(_abi.SF_OPT_MATCH_MFMA, 0)
         step()
         torch.cuda.synchronize()
@@ -385,7 +388,7 @@ def main():
     # HBM + host walk, on a second handle with its own stream) while batch i is being verified.
     # `value` above is NOT measured this way: its steps run strictly one after the other.
     piped = None
-    if world == 1 and args.nn_precision == 1 and not args.no_pipelined_extra:
+    if world == 1 and args.nn_precision == 1 and not args.no_pipelined_extra and not args.no_extras:
         f_nn = lib.SeparatorFinder(p, device=dev_index)          # own non-blocking stream
         f_nn.nn_append_received_device(ta.data_ptr(), n_kf, dim)
         f_nn.nn_append_local_device(tb.data_ptr(), n_kf, dim)
@@ -517,11 +520,11 @@ def main():
         }
         if piped is not None:
             out["pipelined_two_streams"] = piped
-        if alt is not None:
-            out["value_with_fp32_nn_ranking"] = alt * world
         if alt_valu is not None:
             # the Hamming table by xor + popcount on the VALU instead of the fp4 matrix cores (identical outputs)
             out["value_with_valu_matcher"] = alt_valu * world
+        if alt is not None:
+            out["value_with_fp32_nn_ranking"] = alt * world
             out["check"]["nn_matches_identical_fp32_vs_f16filter"] = bool(
                 np.array_equal(alt_m["idx_local"], m["idx_local"]) and np.array_equal(alt_m["idx_other"], m["idx_other"])
                 and np.array_equal(alt_m["distance"], m["distance"]))

@@ -6,7 +6,7 @@ set -e
 tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
-B="python bench.py --steps 6 --warmup 2 --no-pipelined-extra --cpu-sample-pairs 200 --cpu-sample-rows 64 $*"
+B="python bench.py --steps 6 --warmup 2 --no-extras --no-cpu-baseline $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $B > $out/write.log 2>&1
