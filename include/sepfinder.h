@@ -18,6 +18,10 @@
  *   sf_estimate_*      PKG/src/stereoCamGeometricTools.cpp:122-178  estimateTransformation service
  *                      (PKG/srv/EstTransform.srv:1-9), which drives
  *                      PKG/src/myRegistration.cpp:225-303 and PKG/src/myRegistrationVis.cpp:441-1410
+ *   sf_verify_*_device, sf_find_matches_and_verify_device, sf_compact_accepted_device
+ *                      PKG/scripts/find_separators.py:59-133  the caller's loop body (find_matches, then one
+ *                      estimate_transformation per returned candidate, then the accepted separators) for
+ *                      keyframes that already live in the handle's device store
  *   sf_result          geometry_msgs/PoseWithCovariance + bool success (EstTransform.srv:8-9),
  *                      packed as PKG/src/MsgConversion.cpp:61-64,71-81 do
  *   sf_separator       one row of PKG/srv/ReceiveSeparators.srv:1-10 (what the back-end consumes,
