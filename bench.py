@@ -298,7 +298,7 @@ def main():
             # compaction writes straight into the exchange's send buffer (no staging copy)
             n_acc = f.compact_accepted_device(d_res.data_ptr(), n, exch.payload.data_ptr(), d_flags.data_ptr())
             acc = exch.payload[:n_acc]
-            exch.exchange(n_acc)                              # count stamped on the device + ONE all-gather
+            exch.exchange(n_acc, finish=False)                # count stamped on the device + ONE all-gather, in flight
         else:
             n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
             acc = d_acc[:n_acc]                               # ordered device-side compaction (one kernel)
@@ -309,6 +309,8 @@ def main():
         h_flags[:n].copy_(succ, non_blocking=True)
         host = h_res[:n_acc]
         host.copy_(acc, non_blocking=True)                    # accepted separators delivered to the host (pinned)
+        if exch is not None:
+            exch.finish()                                     # the copies above ran beside the collective
         torch.cuda.synchronize()
         if trace:
             t_4 = time.perf_counter()

@@ -113,12 +113,24 @@ class RecordExchange:
         if self.device.type == "cuda":
             self._h_counts = self._h_counts.pin_memory()
         self._n_local = 0
+        self._work = None
 
-    def exchange(self, n_local):
+    def exchange(self, n_local, finish=True):
+        """Stamp the count and start the all-gather.  With finish=False the collective is left in flight (RCCL
+        runs it on its own stream) so that the caller can queue independent work -- e.g. the copy of its own
+        records to the host -- before calling finish()."""
         self._n_local = int(n_local)
         self._hdr.fill_(self._n_local)
-        self.td.all_gather_into_tensor(self.recv.view(self.world * (self.cap + 1), self.rec), self.send[: self.cap + 1],
-                                       group=self.group)
+        self._work = self.td.all_gather_into_tensor(self.recv.view(self.world * (self.cap + 1), self.rec),
+                                                    self.send[: self.cap + 1], group=self.group, async_op=True)
+        if finish:
+            self.finish()
+
+    def finish(self):
+        """Order the caller's stream behind the collective and queue the copy of the header rows to the host."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
         self._h_counts.copy_(self._hdr_all, non_blocking=True)
 
     def counts(self):
