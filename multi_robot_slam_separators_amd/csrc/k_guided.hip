@@ -23,14 +23,17 @@ namespace {
 
 // Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
-template <int W>
+// NW = 4: the 256-thread workgroup; NW = 1: one wavefront alone (single-wavefront chains, k_verify.hip); the
+// stage is integer work with index-ordered outputs, so only the strides and the cross-wave offsets change.
+template <int W, int NW = 4>
 __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                             const int32_t* __restrict__ pair_to, const PassState* __restrict__ pass1,
                                             PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
                                             uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                                             int32_t* __restrict__ list, int32_t* __restrict__ counter,
                                             const DeviceParams& P, int* smem) {
-  const int tid = threadIdx.x;
+  constexpr int NT = 64 * NW;
+  const int tid = NW == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
@@ -65,10 +68,10 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   float* item_x = reinterpret_cast<float*>(items + kcap);   // [kcap] keypoint x, y and octave bits in the same
   float* item_y = item_x + kcap;                            //        order: the window test never leaves LDS
   int* item_o = reinterpret_cast<int*>(item_y + kcap);
-  for (int i = tid; i < Kt; i += SF_BLOCK) claim[i] = 0x7FFFFFFF;
-  for (int i = tid; i < Kf; i += SF_BLOCK) matched[i] = -1;
-  for (int i = tid; i <= NC; i += SF_BLOCK) cell_start[i] = 0;
-  for (int i = tid; i < NC; i += SF_BLOCK) cell_fill[i] = 0;
+  for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
+  for (int i = tid; i < Kf; i += NT) matched[i] = -1;
+  for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
+  for (int i = tid; i < NC; i += NT) cell_fill[i] = 0;
   if (tid < 16) misc[tid] = 0;
 
   // :486-487 guessCameraRef = (guess * localTransform).inverse()
@@ -107,7 +110,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   // never pass the window test and are left out.
   const float inv_cell = P.grid_inv_cell;
   const int gxm = P.grid_gx - 1, gym = P.grid_gy - 1;
-  for (int t = tid; t < Kt; t += SF_BLOCK) {
+  for (int t = tid; t < Kt; t += NT) {
     const float4 k = kT[t];
     if (isfinite(k.x) && isfinite(k.y)) {
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
@@ -118,7 +121,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   __syncthreads();
   {
     // exclusive scan of the per-cell counts (each thread owns a run of consecutive cells)
-    const int per = (NC + SF_BLOCK - 1) / SF_BLOCK;
+    const int per = (NC + NT - 1) / NT;
     const int c0 = tid * per, c1 = min(c0 + per, NC);
     int local = 0;
     for (int cidx = c0; cidx < c1; ++cidx) local += cell_start[cidx + 1];
@@ -140,7 +143,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     }
   }
   __syncthreads();
-  for (int t = tid; t < Kt; t += SF_BLOCK) {
+  for (int t = tid; t < Kt; t += NT) {
     const float4 k = kT[t];
     if (isfinite(k.x) && isfinite(k.y)) {
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
@@ -157,7 +160,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   const float reach = (float)P.guess_win * 1.0001f + 1e-3f;   // window radius with a rounding margin
 
   int n_finite = 0, n_proj = 0;
-  for (int base = 0; base < Kf; base += SF_BLOCK) {
+  for (int base = 0; base < Kf; base += NT) {
     const int i = base + tid;
     bool inimg = false;
     float u = 0.f, v = 0.f;
@@ -241,7 +244,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   // id-ordered compaction
   uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
-  for (int base = 0; base < Kf; base += SF_BLOCK) {
+  for (int base = 0; base < Kf; base += NT) {
     const int i = base + tid;
     int m = (i < Kf) ? matched[i] : -1;
     const bool flag = (m >= 0) && (claim[m] == i);
@@ -251,7 +254,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
       int c = misc[4 + w];
       if (w < wave) woff += c;
       total += c;
@@ -272,7 +275,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   const bool survivor = motion && n_corr >= P.min_inliers && n_corr >= (pnp ? 4 : 3);
   if (motion && !survivor) {
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
-    for (int i = tid; i < n_corr; i += SF_BLOCK) {
+    for (int i = tid; i < n_corr; i += NT) {
       uint32_t c = out[i];
       const float* a = xF + 3 * (c & 0xFFFFu);
       const float* b = xT + 3 * (c >> 16);
@@ -316,7 +319,7 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
          uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr, int32_t* __restrict__ list,
          int32_t* __restrict__ counter, DeviceParams P) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
-  guided_body<W>(st, (int)blockIdx.x, pair_from, pair_to, pass1, pass2, guided_flag, corr, hdr, list, counter, P, smem);
+  guided_body<W, 4>(st, (int)blockIdx.x, pair_from, pair_to, pass1, pass2, guided_flag, corr, hdr, list, counter, P, smem);
 }
 
 // ---- result assembly: myRegistration.cpp:279-295 covariance clamp + MsgConversion.cpp:61-81 ------

@@ -45,11 +45,13 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[N], double* red, int t
   sfd::block_sum_canon<N, 16>(v, red, tid);
 }
 
+template <int NW>
 __device__ __forceinline__ int block_sum_int(int v, int* misc, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
   __syncthreads();
+  if constexpr (NW == 1) return v;   // one wavefront: the barrier above only orders its LDS traffic
   if (lane == 0) misc[8 + wave] = v;
   __syncthreads();
   return ((misc[8] + misc[9]) + misc[10]) + misc[11];
@@ -102,22 +104,22 @@ __device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32
 }
 
 // optimizeModelCoefficients over the members of `mask` (block-order reductions)
+template <int NW>
 __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask, int n_in, float (&coef)[12],
                                   int tid) {
   const double inv_n = 1.0 / (double)n_in;
-  double s6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  double s6[6];
+  sfd::canon_reduce<6, 16, NW>(m, tid, L.red, s6, [&](int i, double (&a)[6]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
-      s6[0] += (double)p.x; s6[1] += (double)p.y; s6[2] += (double)p.z;
-      s6[3] += (double)q.x; s6[4] += (double)q.y; s6[5] += (double)q.z;
+      a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
+      a[3] += (double)q.x; a[4] += (double)q.y; a[5] += (double)q.z;
     }
-  }
-  block_sum_vec<6>(s6, L.red, tid);
+  });
   double mp[3] = {s6[0] * inv_n, s6[1] * inv_n, s6[2] * inv_n};
   double mq[3] = {s6[3] * inv_n, s6[4] * inv_n, s6[5] * inv_n};
-  double s9[11] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // S (9), ga, gb
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  double s9[11];   // S (9), ga, gb
+  sfd::canon_reduce<11, 16, NW>(m, tid, L.red, s9, [&](int i, double (&acc)[11]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
       const double a[3] = {(double)p.x - mp[0], (double)p.y - mp[1], (double)p.z - mp[2]};
@@ -125,12 +127,11 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s9[3 * j + k] += a[j] * b[k];
-      s9[9] += (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
-      s9[10] += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+        for (int k = 0; k < 3; ++k) acc[3 * j + k] += a[j] * b[k];
+      acc[9] += (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+      acc[10] += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
     }
-  }
-  block_sum_vec<11>(s9, L.red, tid);
+  });
   double S[3][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -142,11 +143,12 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
 // selectWithinDistance: membership mask, member count, and the members' squared residuals in
 // L.d2 (non-members and the padding up to a multiple of 4 hold +inf, so order statistics over the
 // selected set can scan the array without consulting the mask).
+template <int NW>
 __device__ inline int select_within(const RansacLds& L, int m, const float (&coef)[12], double thr2,
                                     uint8_t* mask, int tid) {
   int n = 0;
   const int m4 = (m + 3) & ~3;
-  for (int i = tid; i < m4; i += SF_BLOCK) {
+  for (int i = tid; i < m4; i += 64 * NW) {
     bool in = false;
     float r2 = __int_as_float(0x7F800000);
     if (i < m) {
@@ -159,17 +161,18 @@ __device__ inline int select_within(const RansacLds& L, int m, const float (&coe
     L.d2[i] = r2;
     n += in ? 1 : 0;
   }
-  return block_sum_int(n, L.misc, tid);
+  return block_sum_int<NW>(n, L.misc, tid);
 }
 
 // 2.1981 * median (element n>>1 in sorted order) of the members' squared residuals
 // [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting
 // over the +inf-padded residual array (4 values per LDS read, broadcast).
+template <int NW>
 __device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) {
   const int med = n >> 1;
   const int m4 = (m + 3) & ~3;
   __syncthreads();
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  for (int i = tid; i < m; i += 64 * NW) {
     const float v = L.d2[i];
     if (v < __int_as_float(0x7F800000)) {   // member
       int lt = 0, eq = 0;
@@ -188,11 +191,15 @@ __device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) 
 }
 
 // Body of one RANSAC pass for ONE pair (the calling workgroup); smem_raw is the workgroup's dynamic LDS.
+// NW = 4: the whole 256-thread workgroup; NW = 1: ONE wavefront runs the pass alone (the other three of the
+// workgroup have ended, k_verify.hip) -- same canonical arithmetic (sfd::canon_reduce), same integers.
+template <int NW = 4>
 __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                             const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                             const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
                                             const DeviceParams& P, unsigned char* smem_raw) {
-  const int tid = threadIdx.x;
+  constexpr int NT = 64 * NW;
+  const int tid = NW == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
@@ -221,7 +228,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   if (tid < 16) L.misc[tid] = 0;
   __syncthreads();
   int m = 0;
-  for (int base = 0; base < n_corr; base += SF_BLOCK) {
+  for (int base = 0; base < n_corr; base += NT) {
     const int i = base + tid;
     bool ok = false;
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
       int c = L.misc[4 + w];
       if (w < wave) woff += c;
       total += c;
@@ -270,24 +277,22 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   const double inv_m = 1.0 / (double)m;
   double mean[3];
   {
-    double s3[3] = {0.0, 0.0, 0.0};
-    for (int i = tid; i < m; i += SF_BLOCK) {
+    double s3[3];
+    sfd::canon_reduce<3, 16, NW>(m, tid, L.red, s3, [&](int i, double (&a)[3]) {
       float4 p = L.src[i];
-      s3[0] += (double)p.x; s3[1] += (double)p.y; s3[2] += (double)p.z;
-    }
-    block_sum_vec<3>(s3, L.red, tid);
+      a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
+    });
     mean[0] = s3[0] * inv_m; mean[1] = s3[1] * inv_m; mean[2] = s3[2] * inv_m;
   }
   double sdt;
   {
-    double c6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // xx xy xz yy yz zz
-    for (int i = tid; i < m; i += SF_BLOCK) {
+    double c6[6];  // xx xy xz yy yz zz
+    sfd::canon_reduce<6, 16, NW>(m, tid, L.red, c6, [&](int i, double (&a)[6]) {
       float4 p = L.src[i];
       const double a0 = (double)p.x - mean[0], a1 = (double)p.y - mean[1], a2 = (double)p.z - mean[2];
-      c6[0] += a0 * a0; c6[1] += a0 * a1; c6[2] += a0 * a2;
-      c6[3] += a1 * a1; c6[4] += a1 * a2; c6[5] += a2 * a2;
-    }
-    block_sum_vec<6>(c6, L.red, tid);
+      a[0] += a0 * a0; a[1] += a0 * a1; a[2] += a0 * a2;
+      a[3] += a1 * a1; a[4] += a1 * a2; a[5] += a2 * a2;
+    });
     double ev[3];
     sfd::sym3_eigenvalues(c6[0] * inv_m, c6[1] * inv_m, c6[2] * inv_m, c6[3] * inv_m, c6[4] * inv_m, c6[5] * inv_m, ev);
     sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
@@ -308,12 +313,12 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   double k_adapt = 1.0;                                  // thread 0 only
   const double log_probability = sfd::canon_log(1.0 - 0.99);
   int sc_best = -1, sc_best_it = -1, sc_it = 0;          // thread 0 only
-  const int slice = (m + 3) >> 2;                        // points counted by each wavefront
+  const int slice = NW == 4 ? (m + 3) >> 2 : m;          // points counted by each wavefront
   const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
   int* hv = L.hyp_cnt + 4 * 64;
   // the wavefront that samples and fits rotates with the pair, so that the workgroups sharing a CU do
   // not all put this serial fp64 section on the same SIMD
-  const int fit_wave = pair & 3;
+  const int fit_wave = NW == 4 ? (pair & 3) : 0;
   for (int base = 0; base <= max_it; base += 64) {
     const int it = base + lane;
     if (wave == fit_wave) {
@@ -347,8 +352,9 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     }
     __syncthreads();
     if (wave == fit_wave && it <= max_it)
-      L.counts[it] = hv[lane] ? ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane]
-                              : -1;
+      L.counts[it] = !hv[lane] ? -1
+                     : NW == 4 ? ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane]
+                               : L.hyp_cnt[lane];
     __syncthreads();
     if (tid == 0) {
       const int lim = min(max_it, base + 63);  // last iteration whose count exists
@@ -393,7 +399,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
 #pragma unroll
   for (int k = 0; k < 12; ++k) coef[k] = L.best[k];
   uint8_t* inl = L.mask_a;
-  int n_inl = select_within(L, m, coef, thr2, inl, tid);
+  int n_inl = select_within<NW>(L, m, coef, thr2, inl, tid);
   int n_last = n_inl;
 
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
@@ -406,24 +412,24 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     uint8_t* prev = L.mask_a;
     uint8_t* neu = L.mask_b;
     int n_prev = n_inl, n_new = 0;
-    for (int i = tid; i < m; i += SF_BLOCK) neu[i] = 0;
+    for (int i = tid; i < m; i += NT) neu[i] = 0;
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;  // last four pushed sizes (z1 newest)
     float newc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) newc[i] = coef[i];
     do {
-      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, newc, tid);
+      if (n_prev >= 3) fit_masked<NW>(L, m, prev, n_prev, newc, tid);
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
       __syncthreads();
-      n_new = select_within(L, m, newc, error_threshold * error_threshold, neu, tid);
+      n_new = select_within<NW>(L, m, newc, error_threshold * error_threshold, neu, tid);
       n_last = n_new;
       if (n_new == 0) {
         ++refine_iterations;
         if (refine_iterations >= P.refine_iterations) break;
         continue;
       }
-      const double variance = variance_of(L, m, n_new, tid);
+      const double variance = variance_of<NW>(L, m, n_new, tid);
       const double sthr = P.refine_sigma * sqrt(variance);
       error_threshold = thr < sthr ? thr : sthr;
       inlier_changed = false;
@@ -434,8 +440,8 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
         continue;
       }
       int diff = 0;
-      for (int i = tid; i < m; i += SF_BLOCK) diff |= (prev[i] != neu[i]) ? 1 : 0;
-      inlier_changed = block_sum_int(diff, L.misc, tid) != 0;
+      for (int i = tid; i < m; i += NT) diff |= (prev[i] != neu[i]) ? 1 : 0;
+      inlier_changed = block_sum_int<NW>(diff, L.misc, tid) != 0;
     } while (inlier_changed && ++refine_iterations < P.refine_iterations);
     inl = neu;
     n_inl = n_new;
@@ -445,7 +451,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
 
   if (P.dbg_stop == 5) { if (tid == 0) pass[pair] = ps; return; }
   if (n_inl >= 3) {
-    const double variance = variance_of(L, m, n_last, tid);
+    const double variance = variance_of<NW>(L, m, n_last, tid);
     ps.var = variance;
     ps.var_ang = variance;
     ps.inliers = n_inl;
@@ -479,7 +485,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
          PassState* __restrict__ pass, DeviceParams P) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  ransac_body(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
+  ransac_body<4>(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
 }
 
 }  // namespace

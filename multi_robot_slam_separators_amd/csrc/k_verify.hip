@@ -20,7 +20,18 @@
 
 namespace {
 
-template <int W, int NQ>
+// CW = wavefronts that run the motion-estimation chain of a surviving pair.  4 (default): the whole
+// workgroup, as the stage kernels do.  1 (SF_CHAIN_WAVES=1 / SF_OPT_CHAIN_WAVES): after matching three of the
+// four wavefronts END and one carries the pair through RANSAC / guided matching / RANSAC alone
+// (ransac_body<1>, guided_body<W, 1>: same canonical sums, same integers, byte-identical results; the
+// barriers inside the chain see one live wavefront).  The idea: a chain holds four wavefront slots and
+// 4 x 128 VGPRs for ~100 us while using a fraction of one SIMD, and a CU whose four workgroup slots fill up
+// with chains stops matching; ended wavefronts give slots and registers back.  Measured: 0.75 ms per 10 000
+// pairs against 0.59 -- a chain is more arithmetic than it looks (inlier counts of 64 hypotheses, rank
+// counting for the median, the emulated 256-lane sums all take ~4x longer on one wavefront, ~200 us per
+// chain), and the workgroup's LDS (26-30 KB, held until its last wavefront ends) caps a CU at five chains.
+// Kept as an option and as a second implementation the tests compare against.
+template <int W, int NQ, int CW>
 __global__ void __launch_bounds__(SF_BLOCK, 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
@@ -32,36 +43,39 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
                                                    pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
   __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
+  if constexpr (CW == 1) {
+    // the wavefront that stays rotates with the pair, so that the chains of a CU spread over its SIMDs
+    if ((int)(threadIdx.x >> 6) != (pair & 3)) return;
+  }
   // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
   // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
   // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
   __builtin_amdgcn_s_setprio(3);
   if (est1) {
-    ransac_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    ransac_body<CW>(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
     __syncthreads();
   }
   // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
-  const bool est2 = guided_body<W>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr, nullptr,
-                                   P, reinterpret_cast<int*>(smem_raw));
+  const bool est2 = guided_body<W, CW>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr,
+                                       nullptr, P, reinterpret_cast<int*>(smem_raw));
   __syncthreads();
   if (est2) {
-    ransac_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    ransac_body<CW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
     __syncthreads();
   }
-  if (threadIdx.x == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
+  if ((CW == 4 ? threadIdx.x : (threadIdx.x & 63)) == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
 }
 
-template <int W, int NQ>
+template <int W, int NQ, int CW>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds) {
-  bool& attr_set = NQ == 0 ? (W == 8 ? c->fused_attr_set_mf : c->fused_attr_set_mf_w16)
-                           : (W == 8 ? c->fused_attr_set : c->fused_attr_set_w16);   // one flag per instantiation
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0][CW == 1];   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_verify_fused<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_verify_fused<W, NQ, CW>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
                      (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
   return SF_OK;
@@ -91,13 +105,16 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
-  if (c->match_mfma && st.kcap <= MF_MAX_ROWS) {
-    if (st.w == 8) rc = launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds);
-    else rc = launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds);
+  const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
+#define SF_FUSED_CASE(W_, NQ_)                                                                    \
+  rc = c->chain_waves == 1 ? launch_fused<W_, NQ_, 1>(c, st, d_from, d_to, n, d_out, lds)          \
+                           : launch_fused<W_, NQ_, 4>(c, st, d_from, d_to, n, d_out, lds)
+  if (mf) {
+    if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0);
   } else {
-    if (st.w == 8) rc = launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds);
-    else rc = launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds);
+    if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2);
   }
+#undef SF_FUSED_CASE
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());

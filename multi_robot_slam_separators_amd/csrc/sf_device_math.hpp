@@ -309,6 +309,52 @@ __device__ __forceinline__ void block_sum_canon(double (&v)[N], double* red, int
   for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[STRIDE + k]) + red[2 * STRIDE + k]) + red[3 * STRIDE + k];
 }
 
+// The same N sums computed by ONE wavefront for all 256 lanes of the canonical scheme (single-wavefront
+// motion-estimation chains, k_verify.hip): `acc(i, v)` adds element i's terms to v[0..N); lane l plays the
+// lanes l, l + 64, l + 128, l + 192 of the 256-thread version one after the other -- the same strided
+// partials, the same in-wave stages, the same four-row fold, hence the same bits.  NW = 4 is the 256-thread
+// form (partials + block_sum_canon).  `red` as above.
+template <int N, int STRIDE, int NW, class F>
+__device__ __forceinline__ void canon_reduce(int m, int tid, double* red, double (&out)[N], F acc) {
+  if constexpr (NW == 4) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = 0.0;
+    for (int i = tid; i < m; i += 256) acc(i, out);
+    block_sum_canon<N, STRIDE>(out, red, tid);
+  } else {
+    static_assert(NW == 1, "one or four wavefronts");
+    constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : 32;
+    static_assert(STRIDE >= P, "scratch rows must hold the padded count");
+    const int lane = tid & 63;
+    __syncthreads();  // previous users of `red` are done (one live wavefront: returns at once)
+#pragma unroll 1
+    for (int vw = 0; vw < 4; ++vw) {
+      double w[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w[k] = 0.0;
+      {
+        double v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0.0;
+        for (int i = lane + 64 * vw; i < m; i += 256) acc(i, v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] = v[k];
+      }
+      int idx = 0;
+      sum_stage<P>(w, idx, lane, 32);
+      sum_stage<(P / 2 > 1 ? P / 2 : 1)>(w, idx, lane, 16);
+      sum_stage<(P / 4 > 1 ? P / 4 : 1)>(w, idx, lane, 8);
+      sum_stage<(P / 8 > 1 ? P / 8 : 1)>(w, idx, lane, 4);
+      sum_stage<(P / 16 > 1 ? P / 16 : 1)>(w, idx, lane, 2);
+      sum_stage<(P / 32 > 1 ? P / 32 : 1)>(w, idx, lane, 1);
+      red[vw * STRIDE + idx] = w[0];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = ((red[k] + red[STRIDE + k]) + red[2 * STRIDE + k]) + red[3 * STRIDE + k];
+  }
+}
+
 // Same sums, but the N totals are left in LDS (out[0..N)) instead of in every thread's registers: for
 // callers that only need them as operands of a short scalar computation (k_pnp's 28-value normal
 // equations would otherwise pin 56 VGPRs per copy).  out must not alias red.

@@ -479,14 +479,15 @@ def test_execution_options_on_a_live_handle():
     with lib.SeparatorFinder(p) as f:
         base = f.estimate_transform_batch(A, B)
         assert base["success"][is_true].all()
-        for mfma in (0, 1):
-            for fused in (0, 1):
+        for mfma, fused, chain in ((0, 0, 4), (0, 1, 4), (1, 0, 4), (1, 1, 4), (1, 1, 1), (0, 1, 1)):
+            if True:
                 f.set_option(_abi.SF_OPT_MATCH_MFMA, mfma)
                 f.set_option(_abi.SF_OPT_FUSED, fused)
+                f.set_option(_abi.SF_OPT_CHAIN_WAVES, chain)   # 1: single-wavefront motion-estimation chains
                 f.prof_reset(); f.prof_enable(True)
                 got = f.estimate_transform_batch(A, B)
                 prof = f.prof_get()
-                assert got.tobytes() == base.tobytes(), (mfma, fused)
+                assert got.tobytes() == base.tobytes(), (mfma, fused, chain)
                 assert (prof["k_verify_fused"][0] > 0) == bool(fused)
         with pytest.raises(Exception):
             f.set_option(99, 1)
