@@ -303,7 +303,7 @@ enum {
   SF_OPT_FUSED = 1,       /* 1 (default): one fused launch per chunk (3D-3D estimator); 0: the stage kernels     */
   SF_OPT_OVERLAP = 2,     /* 1: batches >= 4096 pairs as two halves on two streams; 0 (default): one stream     */
   SF_OPT_CHAIN_WAVES = 3  /* fused kernel: 4 (default) = the whole workgroup runs a surviving pair's motion-
-                             estimation chain; 1 = one wavefront does, the other three end after matching     */
+                             estimation chain; 1 / 2 = that many wavefronts do, the others end after matching  */
 };
 int  sf_set_option(sf_handle h, int32_t option, int32_t value);
 

@@ -33,7 +33,9 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
                                             int32_t* __restrict__ list, int32_t* __restrict__ counter,
                                             const DeviceParams& P, int* smem) {
   constexpr int NT = 64 * NW;
-  const int tid = NW == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  // NW < 4: the live wavefronts are (pair & 3), (pair & 3) + 1, ... mod 4 (k_verify_fused), numbered from 0 here
+  const int tid = NW == 4 ? (int)threadIdx.x
+                          : (int)((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u));
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];

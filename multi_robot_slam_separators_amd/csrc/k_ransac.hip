@@ -54,7 +54,10 @@ __device__ __forceinline__ int block_sum_int(int v, int* misc, int tid) {
   if constexpr (NW == 1) return v;   // one wavefront: the barrier above only orders its LDS traffic
   if (lane == 0) misc[8 + wave] = v;
   __syncthreads();
-  return ((misc[8] + misc[9]) + misc[10]) + misc[11];
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) t += misc[8 + w];
+  return t;
 }
 
 // PCL isSampleGood on the source cloud + keyed sampler; returns false when max_checks attempts fail
@@ -199,7 +202,9 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
                                             const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
                                             const DeviceParams& P, unsigned char* smem_raw) {
   constexpr int NT = 64 * NW;
-  const int tid = NW == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+  // NW < 4: the live wavefronts are (pair & 3), (pair & 3) + 1, ... mod 4 (k_verify_fused), numbered from 0 here
+  const int tid = NW == 4 ? (int)threadIdx.x
+                          : (int)((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u));
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
@@ -313,12 +318,12 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   double k_adapt = 1.0;                                  // thread 0 only
   const double log_probability = sfd::canon_log(1.0 - 0.99);
   int sc_best = -1, sc_best_it = -1, sc_it = 0;          // thread 0 only
-  const int slice = NW == 4 ? (m + 3) >> 2 : m;          // points counted by each wavefront
+  const int slice = (m + NW - 1) / NW;                   // points counted by each wavefront
   const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
   int* hv = L.hyp_cnt + 4 * 64;
   // the wavefront that samples and fits rotates with the pair, so that the workgroups sharing a CU do
   // not all put this serial fp64 section on the same SIMD
-  const int fit_wave = NW == 4 ? (pair & 3) : 0;
+  const int fit_wave = NW == 4 ? (pair & 3) : 0;   // (NW < 4: the live wavefronts already rotate with the pair)
   for (int base = 0; base <= max_it; base += 64) {
     const int it = base + lane;
     if (wave == fit_wave) {
@@ -352,9 +357,12 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     }
     __syncthreads();
     if (wave == fit_wave && it <= max_it)
-      L.counts[it] = !hv[lane] ? -1
-                     : NW == 4 ? ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane]
-                               : L.hyp_cnt[lane];
+    {
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += L.hyp_cnt[w * 64 + lane];
+      L.counts[it] = hv[lane] ? tot : -1;
+    }
     __syncthreads();
     if (tid == 0) {
       const int lim = min(max_it, base + 63);  // last iteration whose count exists

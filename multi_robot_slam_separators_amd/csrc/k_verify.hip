@@ -21,16 +21,16 @@
 namespace {
 
 // CW = wavefronts that run the motion-estimation chain of a surviving pair.  4 (default): the whole
-// workgroup, as the stage kernels do.  1 (SF_CHAIN_WAVES=1 / SF_OPT_CHAIN_WAVES): after matching three of the
-// four wavefronts END and one carries the pair through RANSAC / guided matching / RANSAC alone
-// (ransac_body<1>, guided_body<W, 1>: same canonical sums, same integers, byte-identical results; the
-// barriers inside the chain see one live wavefront).  The idea: a chain holds four wavefront slots and
+// workgroup, as the stage kernels do.  1 or 2 (SF_CHAIN_WAVES / SF_OPT_CHAIN_WAVES): after matching the other
+// wavefronts END and one or two carry the pair through RANSAC / guided matching / RANSAC
+// (ransac_body<CW>, guided_body<W, CW>: same canonical sums, same integers, byte-identical results; the
+// barriers inside the chain only see the live wavefronts).  The idea: a chain holds four wavefront slots and
 // 4 x 128 VGPRs for ~100 us while using a fraction of one SIMD, and a CU whose four workgroup slots fill up
-// with chains stops matching; ended wavefronts give slots and registers back.  Measured: 0.75 ms per 10 000
-// pairs against 0.59 -- a chain is more arithmetic than it looks (inlier counts of 64 hypotheses, rank
-// counting for the median, the emulated 256-lane sums all take ~4x longer on one wavefront, ~200 us per
-// chain), and the workgroup's LDS (26-30 KB, held until its last wavefront ends) caps a CU at five chains.
-// Kept as an option and as a second implementation the tests compare against.
+// with chains stops matching; ended wavefronts give slots and registers back.  Measured per 10 000 pairs:
+// CW = 1 0.75 ms, CW = 2 0.68, CW = 4 0.59-0.61 -- a chain is more arithmetic than it looks (inlier counts
+// of 64 hypotheses, rank counting for the median, the replayed 256-lane sums: ~200 us on one wavefront
+// against ~106 on four), and the workgroup's LDS (26-30 KB, held until its last wavefront ends) caps a CU at
+// five chains whatever their width.  Kept as options and as second implementations the tests compare against.
 template <int W, int NQ, int CW>
 __global__ void __launch_bounds__(SF_BLOCK, 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
@@ -43,9 +43,9 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
                                                    pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
   __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
-  if constexpr (CW == 1) {
-    // the wavefront that stays rotates with the pair, so that the chains of a CU spread over its SIMDs
-    if ((int)(threadIdx.x >> 6) != (pair & 3)) return;
+  if constexpr (CW < 4) {
+    // the wavefronts that stay rotate with the pair, so that the chains of a CU spread over its SIMDs
+    if ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) >= (unsigned)CW) return;
   }
   // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
   // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
@@ -63,13 +63,14 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     ransac_body<CW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
     __syncthreads();
   }
-  if ((CW == 4 ? threadIdx.x : (threadIdx.x & 63)) == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
+  if ((CW == 4 ? threadIdx.x : ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u))) == 0)
+    finalize_one(pair, pass1, pass2, guided_flag, out);
 }
 
 template <int W, int NQ, int CW>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds) {
-  bool& attr_set = c->fused_attr[W == 16][NQ == 0][CW == 1];   // one flag per instantiation
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0][CW == 4 ? 0 : CW];   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
     SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
@@ -107,8 +108,9 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   sf_prof_begin(c, SF_K_FUSED);
   const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
 #define SF_FUSED_CASE(W_, NQ_)                                                                    \
-  rc = c->chain_waves == 1 ? launch_fused<W_, NQ_, 1>(c, st, d_from, d_to, n, d_out, lds)          \
-                           : launch_fused<W_, NQ_, 4>(c, st, d_from, d_to, n, d_out, lds)
+  rc = c->chain_waves == 1   ? launch_fused<W_, NQ_, 1>(c, st, d_from, d_to, n, d_out, lds)        \
+       : c->chain_waves == 2 ? launch_fused<W_, NQ_, 2>(c, st, d_from, d_to, n, d_out, lds)        \
+                             : launch_fused<W_, NQ_, 4>(c, st, d_from, d_to, n, d_out, lds)
   if (mf) {
     if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0);
   } else {

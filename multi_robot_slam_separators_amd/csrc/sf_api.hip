@@ -608,7 +608,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
   if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
-  if (const char* v = getenv("SF_CHAIN_WAVES")) c->chain_waves = atoi(v) == 1 ? 1 : 4;   // 1: single-wavefront chains
+  if (const char* v = getenv("SF_CHAIN_WAVES")) c->chain_waves = (atoi(v) == 1 || atoi(v) == 2) ? atoi(v) : 4;   // 1 / 2: chains on fewer wavefronts
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
   if (const char* v = getenv("SF_OVERLAP_MIN")) c->overlap_min_pairs = std::max(2, atoi(v));
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
@@ -1125,7 +1125,7 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
     case SF_OPT_MATCH_MFMA: c->match_mfma = value != 0; return SF_OK;
     case SF_OPT_FUSED: c->fused = value != 0; return SF_OK;
     case SF_OPT_OVERLAP: c->overlap = value != 0; return SF_OK;
-    case SF_OPT_CHAIN_WAVES: c->chain_waves = value == 1 ? 1 : 4; return SF_OK;
+    case SF_OPT_CHAIN_WAVES: c->chain_waves = (value == 1 || value == 2) ? value : 4; return SF_OK;
     default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
   }
 }

@@ -309,11 +309,11 @@ __device__ __forceinline__ void block_sum_canon(double (&v)[N], double* red, int
   for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[STRIDE + k]) + red[2 * STRIDE + k]) + red[3 * STRIDE + k];
 }
 
-// The same N sums computed by ONE wavefront for all 256 lanes of the canonical scheme (single-wavefront
-// motion-estimation chains, k_verify.hip): `acc(i, v)` adds element i's terms to v[0..N); lane l plays the
-// lanes l, l + 64, l + 128, l + 192 of the 256-thread version one after the other -- the same strided
-// partials, the same in-wave stages, the same four-row fold, hence the same bits.  NW = 4 is the 256-thread
-// form (partials + block_sum_canon).  `red` as above.
+// The same N sums computed by ONE or TWO wavefronts for all 256 lanes of the canonical scheme (motion-estimation
+// chains on fewer wavefronts, k_verify.hip): `acc(i, v)` adds element i's terms to v[0..N); a wavefront plays
+// 4 / NW wavefronts of the 256-thread version one after the other -- the same strided partials, the same in-wave
+// stages, the same four-row fold, hence the same bits.  NW = 4 is the 256-thread form (partials +
+// block_sum_canon).  tid = 64 * (wavefront index among the NW) + lane.  `red` as above.
 template <int N, int STRIDE, int NW, class F>
 __device__ __forceinline__ void canon_reduce(int m, int tid, double* red, double (&out)[N], F acc) {
   if constexpr (NW == 4) {
@@ -322,13 +322,14 @@ __device__ __forceinline__ void canon_reduce(int m, int tid, double* red, double
     for (int i = tid; i < m; i += 256) acc(i, out);
     block_sum_canon<N, STRIDE>(out, red, tid);
   } else {
-    static_assert(NW == 1, "one or four wavefronts");
+    static_assert(NW == 1 || NW == 2, "one, two or four wavefronts");
     constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : 32;
     static_assert(STRIDE >= P, "scratch rows must hold the padded count");
-    const int lane = tid & 63;
-    __syncthreads();  // previous users of `red` are done (one live wavefront: returns at once)
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();  // previous users of `red` are done (only the live wavefronts take part)
 #pragma unroll 1
-    for (int vw = 0; vw < 4; ++vw) {
+    for (int j = 0; j < 4 / NW; ++j) {
+      const int vw = wave * (4 / NW) + j;     // the wavefront of the 256-thread scheme this pass stands in for
       double w[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) w[k] = 0.0;

@@ -143,7 +143,7 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
-  bool fused_attr[2][2][2] = {};   // [W == 16][matrix-core matcher][single-wavefront chains]: LDS attribute set
+  bool fused_attr[2][2][3] = {};   // [W == 16][matrix-core matcher][single-wavefront chains]: LDS attribute set
   int chain_waves = 4;      // wavefronts that run a surviving pair's motion-estimation chain in the fused kernel
                             // (4: the whole workgroup; 1: three of the four end after matching; SF_CHAIN_WAVES)
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)

@@ -479,7 +479,7 @@ def test_execution_options_on_a_live_handle():
     with lib.SeparatorFinder(p) as f:
         base = f.estimate_transform_batch(A, B)
         assert base["success"][is_true].all()
-        for mfma, fused, chain in ((0, 0, 4), (0, 1, 4), (1, 0, 4), (1, 1, 4), (1, 1, 1), (0, 1, 1)):
+        for mfma, fused, chain in ((0, 0, 4), (0, 1, 4), (1, 0, 4), (1, 1, 4), (1, 1, 1), (0, 1, 1), (1, 1, 2)):
             if True:
                 f.set_option(_abi.SF_OPT_MATCH_MFMA, mfma)
                 f.set_option(_abi.SF_OPT_FUSED, fused)
