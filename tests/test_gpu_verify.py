@@ -469,6 +469,56 @@ def test_find_matches_and_verify_speculative_equals_two_calls(est):
                 assert res["success"].sum() >= 10
 
 
+def test_find_matches_and_verify_when_the_speculation_overflows():
+    """More NN candidates than speculative pair slots (every local row has four received columns under the
+    threshold): the speculative verification is abandoned and the call must still return exactly what the two
+    separate calls return."""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    n_l, k, cols, dim = 600, 64, 32, 512
+    feats = synth.make_store_batch(78, n_l, k=k, cols=cols, true_frac=0.5)
+    rng = np.random.default_rng(6)
+    base = rng.normal(size=(n_l, dim)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    recv = np.concatenate([base + 0.001 * rng.normal(size=base.shape) for _ in range(4)], axis=0)   # 4 copies each
+    recv /= np.linalg.norm(recv, axis=1, keepdims=True)
+    p = synth.camera_params()
+    p.iterations = 100
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_l
+    p.max_features = k
+    p.nn_precision = 1
+    dev = torch.device("cuda:0")
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        T = {key: up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}
+        # the received database has 4 n_l rows: keyframe slot = column modulo n_l is not needed here, the store
+        # simply holds 4 copies of robot A's keyframes so that every column has a slot
+        sa = None
+        for _ in range(4):
+            s0 = f.store_add_keyframes_device(n_l, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+            sa = s0 if sa is None else sa
+        sb = f.store_add_keyframes_device(n_l, k, cols, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+        torch.cuda.synchronize()
+        f.nn_append_received(recv)
+        f.nn_append_local(base)
+        d1 = torch.zeros((n_l, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d2 = torch.zeros_like(d1)
+        m1 = f.nn_find_matches(cap=n_l)
+        f.verify_matches_device(m1, sa, sb, d1.data_ptr())
+        torch.cuda.synchronize()
+        m2 = f.find_matches_and_verify_device(sa, sb, d2.data_ptr(), cap=n_l)
+        torch.cuda.synchronize()
+        assert len(m1) == n_l and m1.tobytes() == m2.tobytes()
+        assert bytes(d1.cpu().numpy()) == bytes(d2.cpu().numpy())
+        res = np.frombuffer(bytes(d2.cpu().numpy()), dtype=_abi.RESULT_DTYPE)
+        assert res["success"].sum() > n_l // 4
+
+
 def test_execution_options_on_a_live_handle():
     """sf_set_option switches matcher / fusion / two-stream execution between calls of ONE handle; every
     combination returns the same bytes; an unknown option is SF_EINVAL."""
