@@ -814,6 +814,7 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
       const int m = std::min(span, n - off);
       const int ma = (m + 1) / 2, mb = m - ma;
       if (off == 0) c->ws_split = ma;
+      // (stage kernels: two FUSED halves on two streams were measured too and gain nothing)
       if ((rc = verify_sequence(c, view, d_from + off, d_to + off, ma, d_out + off, false)) != SF_OK) return rc;
       if (mb > 0 && (rc = verify_sequence(t, view, d_from + off + ma, d_to + off + ma, mb, d_out + off + ma, false)) != SF_OK) {
         c->err = t->err;
