@@ -165,3 +165,67 @@ def test_store_regrows_feature_capacity_and_slots(oracle):
     for (a, b), g in zip(pairs, got):
         assert_result_parity(g, oracle.estimate_transform(p, frames[a], frames[b]), "slots %d,%d" % (a, b))
     assert got[0]["success"] == 1 and got[1]["success"] == 1 and got[3]["success"] == 1 and got[4]["success"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_speculative_find_and_verify_fuzz(seed):
+    """Random databases / thresholds / planted near-duplicates, with the caller's feedback (used rows and
+    columns, ignored pairs) between queries: sf_find_matches_and_verify_device must return the matches of
+    sf_nn_find_matches and the bytes of sf_verify_matches_device every time, whether it speculates or not."""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    rng = np.random.default_rng(900 + seed)
+    n_l, n_r = int(rng.integers(40, 160)), int(rng.integers(40, 160))
+    k, cols = 96, int(rng.choice([32, 64]))
+    dim = int(rng.choice([512, 1024]))
+    n_s = max(n_l, n_r)
+    feats = synth.make_store_batch(300 + seed, n_s, k=k, cols=cols, true_frac=0.6)
+    a = rng.normal(size=(n_l, dim)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.normal(size=(n_r, dim)); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    npl = int(min(n_l, n_r) * 0.8)
+    rows = rng.permutation(n_r)[:npl]; src = rng.permutation(n_l)[:npl]
+    b[rows] = a[src] + rng.normal(size=(npl, dim)) * rng.uniform(0.01, 0.12, size=(npl, 1)) / np.sqrt(dim)
+    b[rows[:5]] = b[rows[5]]                           # several columns equally near one row
+    p = synth.camera_params()
+    p.iterations = 100
+    p.max_features = k
+    p.netvlad_dimensions = dim
+    p.netvlad_distance = float(rng.choice([0.08, 0.13, 0.3]))
+    p.netvlad_max_matches_nb = int(rng.choice([n_l, n_l, 7]))      # 7: no speculation
+    p.nn_precision = 1
+    p.estimation_type = int(seed % 2)
+    dev = torch.device("cuda:0")
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        T = {key: up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}
+        sa = f.store_add_keyframes_device(n_s, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+        sb = f.store_add_keyframes_device(n_s, k, cols, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+        torch.cuda.synchronize()
+        f.nn_append_local(a)
+        f.nn_append_received(b)
+        cap = n_l
+        d1 = torch.zeros((cap, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d2 = torch.zeros_like(d1)
+        total = 0
+        for it in range(4):
+            m1 = f.nn_find_matches(cap=cap)
+            f.verify_matches_device(m1, sa, sb, d1.data_ptr())
+            torch.cuda.synchronize()
+            m2 = f.find_matches_and_verify_device(sa, sb, d2.data_ptr(), cap=cap)
+            torch.cuda.synchronize()
+            assert m1.tobytes() == m2.tobytes(), (seed, it)
+            n = len(m1)
+            assert bytes(d1[:n].cpu().numpy()) == bytes(d2[:n].cpu().numpy()), (seed, it)
+            total += n
+            for r in m1[: max(1, n // 3)]:                 # receive_separators_service-style feedback
+                if rng.random() < 0.5:
+                    f.nn_mark_local_used(int(r["idx_local"])); f.nn_mark_other_used(int(r["idx_other"]))
+                else:
+                    f.nn_ignore_pair(int(r["idx_local"]), int(r["idx_other"]))
+        assert total > 0

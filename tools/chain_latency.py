@@ -15,7 +15,9 @@ def up(x):
     x = np.ascontiguousarray(x)
     return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
 T = {key: up(d[key]) for key in ("desc_a", "desc_b", "xyz_a", "xyz_b", "kp_a", "kp_b")}
-for est in (0, 1):
+stops = [int(x) for x in sys.argv[1:]] or [0]        # optional: SF_RANSAC_STOP phases to truncate after (0 = full)
+for est, stop in [(e, st) for e in (0, 1) for st in stops]:
+    os.environ["SF_RANSAC_STOP"] = str(stop)
     p = synth.camera_params(); p.iterations = 500; p.max_features = k; p.store_capacity = 2 * n; p.estimation_type = est
     with lib.SeparatorFinder(p) as f:
         a = f.store_add_keyframes_device(n, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
@@ -27,5 +29,5 @@ for est in (0, 1):
             if r >= 1:
                 for kname, (cnt, ms) in pr.items():
                     if cnt: acc.setdefault(kname, []).append(ms * 1e3)
-        print("estimator %s, %d true pairs (%d accepted): per-stage latency in us:" % ("3D-3D" if est == 0 else "PnP", n, int(res["success"].sum())),
+        print("estimator %s, stop %d, %d true pairs (%d accepted): per-stage latency in us:" % ("3D-3D" if est == 0 else "PnP", stop, n, int(res["success"].sum())),
               {kn: round(float(np.median(v)), 1) for kn, v in acc.items()})
