@@ -66,10 +66,15 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   const int NC = P.grid_gx * P.grid_gy;
   int* cell_start = misc + 16;     // [NC + 1] CSR of "to" keypoints bucketed on a uniform grid
   int* cell_fill = cell_start + NC + 1;   // [NC]
-  int* items = cell_fill + NC;     // [kcap] "to" indices grouped by cell
-  float* item_x = reinterpret_cast<float*>(items + kcap);   // [kcap] keypoint x, y and octave bits in the same
-  float* item_y = item_x + kcap;                            //        order: the window test never leaves LDS
-  int* item_o = reinterpret_cast<int*>(item_y + kcap);
+  // [kcap] the "to" keypoints grouped by cell as {x, y, octave bits, index bits}: the window test never leaves
+  // LDS and takes ONE 16-byte read per entry (a dependent 4-byte read per field made the scan of the 3x3
+  // neighbourhood 14 of the stage's 24 us: one LDS latency per entry, no overlap)
+  float4* item4 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(cell_fill + NC) + 15) & ~(uintptr_t)15);
+  // [kcap * W] the "to" descriptors, when they fit (P.guided_stage): the window search computes the Hamming
+  // distance of every in-window candidate, and a lane that has to fetch a descriptor row from global memory
+  // stalls its whole wavefront for the load's latency on every such candidate (the search loop was 20 of the
+  // stage's 24 us); from LDS a candidate costs two ds_read_b128.
+  uint32_t* toD = reinterpret_cast<uint32_t*>(item4 + kcap);
   for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;
   for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
@@ -100,6 +105,12 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
 
   const uint32_t* dF = st.desc + (size_t)sF * kcap * W;
   const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
+  if (P.guided_stage) {
+    const uint4* src = reinterpret_cast<const uint4*>(dT);
+    uint4* dst = reinterpret_cast<uint4*>(toD);
+    for (int i = tid; i < Kt * (W / 4); i += NT) dst[i] = src[i];     // visible after the grid build's barriers
+  }
+  const uint32_t* descT = P.guided_stage ? toD : dT;
   const float* xF = st.xyz + (size_t)sF * kcap * 3;
   const float4* kF = st.kp + (size_t)sF * kcap;
   const float4* kT = st.kp + (size_t)sT * kcap;
@@ -112,9 +123,15 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   // never pass the window test and are left out.
   const float inv_cell = P.grid_inv_cell;
   const int gxm = P.grid_gx - 1, gym = P.grid_gy - 1;
+  const float reach = (float)P.guess_win * 1.0001f + 1e-3f;   // window radius with a rounding margin
+  // A keypoint farther than the window radius outside the image cannot be within the radius of any in-image
+  // projection (only those are searched, :503-512): it is not bucketed at all.  Clamping such points into the
+  // border cells instead made every search near a border walk through all of them (synthetic frames whose
+  // features fill a wider field of view than the image put a third of their keypoints there).
+  const float x_hi = P.wlim + reach, y_hi = P.hlim + reach;
   for (int t = tid; t < Kt; t += NT) {
     const float4 k = kT[t];
-    if (isfinite(k.x) && isfinite(k.y)) {
+    if (isfinite(k.x) && isfinite(k.y) && k.x >= -reach && k.x < x_hi && k.y >= -reach && k.y < y_hi) {
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
       const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
       atomicAdd(&cell_start[cy * P.grid_gx + cx + 1], 1);
@@ -147,19 +164,19 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   __syncthreads();
   for (int t = tid; t < Kt; t += NT) {
     const float4 k = kT[t];
-    if (isfinite(k.x) && isfinite(k.y)) {
+    if (isfinite(k.x) && isfinite(k.y) && k.x >= -reach && k.x < x_hi && k.y >= -reach && k.y < y_hi) {
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
       const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
       const int cidx = cy * P.grid_gx + cx;
       const int pos = cell_start[cidx] + atomicAdd(&cell_fill[cidx], 1);
-      items[pos] = t;
-      item_x[pos] = k.x;
-      item_y[pos] = k.y;
-      item_o[pos] = __float_as_int(k.z);
+      item4[pos] = make_float4(k.x, k.y, k.z, __int_as_float(t));
     }
   }
   __syncthreads();
-  const float reach = (float)P.guess_win * 1.0001f + 1e-3f;   // window radius with a rounding margin
+  if (P.dbg_stop == 11) {   // diagnostic truncation (SF_RANSAC_STOP=11: after the grid build; results invalid)
+    if (tid == 0) { pass2[pair] = p1; guided_flag[pair] = 0; CorrHeader h = {0, 0, 0, 0}; hdr[pair] = h; }
+    return false;
+  }
 
   int n_finite = 0, n_proj = 0;
   for (int base = 0; base < Kf; base += NT) {
@@ -181,6 +198,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
                 (zf > 0.f);
       }
     }
+    if (P.dbg_stop == 13) inimg = false;   // diagnostic (timing only): projection without the window search
     if (inimg) {
       ++n_proj;
       const int octf = __float_as_int(kF[i].z);
@@ -199,23 +217,35 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
       const int cx1 = min(max((int)floorf((u + reach) * inv_cell), 0), gxm);
       const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
       const int cy1 = min(max((int)floorf((v + reach) * inv_cell), 0), gym);
-      for (int cy = cy0; cy <= cy1; ++cy) {
+      for (int cy = cy0; cy <= cy1 && P.dbg_stop != 15; ++cy) {   // (15: diagnostic, no scan at all)
         // cells cx0..cx1 of one grid row are contiguous in the CSR
         const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
-        for (int e = e0; e < e1; ++e) {
-          const float dx = u - item_x[e], dy = v - item_y[e];
-          const float d2 = dx * dx + dy * dy;
-          if (d2 < r2lim && item_o[e] == octf) {
-            const int t = items[e];
-            const uint32_t* r = dT + (size_t)t * W;
-            uint32_t d = 0;
+        // four entries per trip: their reads are independent, so the LDS latency is paid once per four
+        for (int e = e0; e < e1; e += 4) {
+          float4 it[4];
 #pragma unroll
-            for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
-            const uint32_t key = (d << 16) | (uint32_t)t;
-            b1 = min(max(key, b0), b1);
-            b0 = min(b0, key);
-            ++oi;
-            if (last < 0 || t > last) last = t;
+          for (int j = 0; j < 4; ++j) it[j] = item4[min(e + j, e1 - 1)];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float dx = u - it[j].x, dy = v - it[j].y;
+            const float d2 = dx * dx + dy * dy;
+            if (e + j < e1 && d2 < r2lim && __float_as_int(it[j].z) == octf &&
+                P.dbg_stop != 14) {   // (14: diagnostic, search without Hamming)
+              const int t = __float_as_int(it[j].w);
+              const uint4* r = reinterpret_cast<const uint4*>(descT + (size_t)t * W);
+              uint32_t d = 0;
+#pragma unroll
+              for (int c = 0; c < W / 4; ++c) {
+                const uint4 v4 = r[c];
+                d += __popc(v4.x ^ q[4 * c]) + __popc(v4.y ^ q[4 * c + 1]) + __popc(v4.z ^ q[4 * c + 2]) +
+                     __popc(v4.w ^ q[4 * c + 3]);
+              }
+              const uint32_t key = (d << 16) | (uint32_t)t;
+              b1 = min(max(key, b0), b1);
+              b0 = min(b0, key);
+              ++oi;
+              if (last < 0 || t > last) last = t;
+            }
           }
         }
       }
@@ -243,6 +273,10 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   n_finite = misc[0];
   n_proj = misc[1];
 
+  if (P.dbg_stop == 12) {   // diagnostic truncation (SF_RANSAC_STOP=12: after the window search; results invalid)
+    if (tid == 0) { pass2[pair] = p1; guided_flag[pair] = 0; CorrHeader h = {0, 0, 0, 0}; hdr[pair] = h; }
+    return false;
+  }
   // id-ordered compaction
   uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
@@ -406,26 +440,32 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 
 }  // namespace
 
-size_t sf_guided_lds_bytes(int kcap, int n_cells) {
-  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1) * sizeof(int);
+size_t sf_guided_lds_bytes(int kcap, int n_cells, int stage_dwords) {
+  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3 + stage_dwords) * sizeof(int);   // (+3: 16-byte alignment of the item block)
+}
+
+bool sf_guided_stage(int kcap, int w, int n_cells) {
+  return sf_guided_lds_bytes(kcap, n_cells, kcap * w) <= 40 * 1024;
 }
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t lds = sf_guided_lds_bytes(st.kcap, nc);
+  DeviceParams P = c->dparams;
+  P.guided_stage = sf_guided_stage(st.kcap, st.w, nc) ? 1 : 0;
+  const size_t lds = sf_guided_lds_bytes(st.kcap, nc, P.guided_stage ? st.kcap * st.w : 0);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_GUIDED);
   if (st.w == 8) {
     hipLaunchKernelGGL(k_guided<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                        (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                        (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
-                       c->dparams);
+                       P);
   } else {
     hipLaunchKernelGGL(k_guided<16>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                        (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                        (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
-                       c->dparams);
+                       P);
   }
   sf_prof_end(c, SF_K_GUIDED);
   SF_HIP(c, hipGetLastError());
