@@ -70,11 +70,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   // LDS and takes ONE 16-byte read per entry (a dependent 4-byte read per field made the scan of the 3x3
   // neighbourhood 14 of the stage's 24 us: one LDS latency per entry, no overlap)
   float4* item4 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(cell_fill + NC) + 15) & ~(uintptr_t)15);
-  // [kcap * W] the "to" descriptors, when they fit (P.guided_stage): the window search computes the Hamming
-  // distance of every in-window candidate, and a lane that has to fetch a descriptor row from global memory
-  // stalls its whole wavefront for the load's latency on every such candidate (the search loop was 20 of the
-  // stage's 24 us); from LDS a candidate costs two ds_read_b128.
-  uint32_t* toD = reinterpret_cast<uint32_t*>(item4 + kcap);
   for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;
   for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
@@ -105,12 +100,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
 
   const uint32_t* dF = st.desc + (size_t)sF * kcap * W;
   const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
-  if (P.guided_stage) {
-    const uint4* src = reinterpret_cast<const uint4*>(dT);
-    uint4* dst = reinterpret_cast<uint4*>(toD);
-    for (int i = tid; i < Kt * (W / 4); i += NT) dst[i] = src[i];     // visible after the grid build's barriers
-  }
-  const uint32_t* descT = P.guided_stage ? toD : dT;
+
   const float* xF = st.xyz + (size_t)sF * kcap * 3;
   const float4* kF = st.kp + (size_t)sF * kcap;
   const float4* kT = st.kp + (size_t)sT * kcap;
@@ -232,7 +222,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
             if (e + j < e1 && d2 < r2lim && __float_as_int(it[j].z) == octf &&
                 P.dbg_stop != 14) {   // (14: diagnostic, search without Hamming)
               const int t = __float_as_int(it[j].w);
-              const uint4* r = reinterpret_cast<const uint4*>(descT + (size_t)t * W);
+              const uint4* r = reinterpret_cast<const uint4*>(dT + (size_t)t * W);
               uint32_t d = 0;
 #pragma unroll
               for (int c = 0; c < W / 4; ++c) {
@@ -440,32 +430,26 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 
 }  // namespace
 
-size_t sf_guided_lds_bytes(int kcap, int n_cells, int stage_dwords) {
-  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3 + stage_dwords) * sizeof(int);   // (+3: 16-byte alignment of the item block)
-}
-
-bool sf_guided_stage(int kcap, int w, int n_cells) {
-  return sf_guided_lds_bytes(kcap, n_cells, kcap * w) <= 40 * 1024;
+size_t sf_guided_lds_bytes(int kcap, int n_cells) {
+  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3) * sizeof(int);   // (+3: 16-byte alignment of the item block)
 }
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  DeviceParams P = c->dparams;
-  P.guided_stage = sf_guided_stage(st.kcap, st.w, nc) ? 1 : 0;
-  const size_t lds = sf_guided_lds_bytes(st.kcap, nc, P.guided_stage ? st.kcap * st.w : 0);
+  const size_t lds = sf_guided_lds_bytes(st.kcap, nc);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_GUIDED);
   if (st.w == 8) {
     hipLaunchKernelGGL(k_guided<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                        (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                        (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
-                       P);
+                       c->dparams);
   } else {
     hipLaunchKernelGGL(k_guided<16>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                        (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                        (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,
-                       P);
+                       c->dparams);
   }
   sf_prof_end(c, SF_K_GUIDED);
   SF_HIP(c, hipGetLastError());

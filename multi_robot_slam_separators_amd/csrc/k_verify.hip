@@ -76,11 +76,9 @@ int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32
                                   160 * 1024));
     attr_set = true;
   }
-  DeviceParams P = c->dparams;
-  P.guided_stage = sf_guided_stage(st.kcap, st.w, P.grid_gx * P.grid_gy) ? 1 : 0;
   hipLaunchKernelGGL((k_verify_fused<W, NQ, CW>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
-                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, P);
+                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
   return SF_OK;
 }
 
@@ -92,7 +90,7 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
   if (c->dparams.estimation_type != 0 || !c->fused) return 0;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
-  const size_t guided = sf_guided_lds_bytes(st.kcap, nc, sf_guided_stage(st.kcap, st.w, nc) ? st.kcap * st.w : 0);
+  const size_t guided = sf_guided_lds_bytes(st.kcap, nc);
   const size_t ransac = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)

@@ -61,7 +61,6 @@ struct DeviceParams {
   float wlim, hlim;        // image_width-1, image_height-1
   float L[12];             // local transform
   int32_t dbg_stop;        // diagnostics only: truncate k_ransac after phase N (0 = full kernel)
-  int32_t guided_stage;    // guided matching: the "to" descriptors are staged in LDS (set per launch, sf_guided_stage)
   int32_t grid_gx, grid_gy;   // guided matching: uniform grid over the image (cell >= window radius)
   float grid_inv_cell;
   int32_t estimation_type;    // 0 = 3D->3D, 1 = PnP
@@ -230,10 +229,7 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out);
 size_t sf_ransac_lds_bytes(int kcap, int iterations);
-size_t sf_guided_lds_bytes(int kcap, int n_cells, int stage_dwords = 0);
-// Whether guided matching stages the "to" frame's descriptors in LDS (kcap * w dwords on top of its own
-// buffers): yes while four workgroups still fit a CU's 160 KB.
-bool sf_guided_stage(int kcap, int w, int n_cells);
+size_t sf_guided_lds_bytes(int kcap, int n_cells);
 // Assemble sf_result records.
 int sf_launch_finalize(sf_context* c, int n, sf_result* d_out);
 // Ingest kernels
