@@ -622,28 +622,35 @@ static int nn_run_filter(sf_context* c, int* done) {
       if ((rc = nn_pinned_reserve(c, (size_t)limit * 16 + 64)) != SF_OK) return rc;
       h_cand = (uint2*)((char*)c->nn_pinned + 64);
       h_dist = (double*)((char*)c->nn_pinned + 64 + (size_t)limit * 8);
-      sf_prof_begin(c, SF_K_NN_REFINE);
-      hipLaunchKernelGGL(k_nn_refine, dim3((limit + 3) / 4), dim3(256), 0, c->stream, cand, count, limit,
-                         (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
-      sf_prof_end(c, SF_K_NN_REFINE);
       const unsigned spec = std::min<unsigned>(limit, (unsigned)(2 * (size_t)n_l + 1024));
-      // With a speculative verification requested (sf_find_matches_and_verify_device) the candidates go back
-      // to the host on a second stream while the handle's stream continues straight into the verification of
-      // every candidate: the host's row minima / sort / walk then run beside the verification kernels.
+      // With a speculative verification requested (sf_find_matches_and_verify_device) the handle's stream goes
+      // from the filter straight into the verification of every candidate -- which needs the candidates' (row,
+      // column), not their exact distances -- while the exact re-evaluation (HBM-bound) and the copies back to
+      // the host run on a second stream beside it; the host's row minima / sort / walk then run beside the
+      // verification kernels too.
       const bool speculate = c->spec.requested && !c->spec.launched;
       hipStream_t cs = c->stream;
       if (speculate) {
-        SF_HIP(c, hipEventRecord(c->spec.ev_refined, c->stream));
+        SF_HIP(c, hipEventRecord(c->spec.ev_refined, c->stream));          // = the filter has finished
         SF_HIP(c, hipStreamWaitEvent(c->spec.copy_stream, c->spec.ev_refined, 0));
         cs = c->spec.copy_stream;
+        if ((rc = sf_spec_launch(c, cand, count)) != SF_OK) return rc;     // handle's stream: pair list + verification
+        c->spec.launched = true;
+      }
+      {
+        const hipStream_t main_stream = c->stream;
+        c->stream = cs;                      // (sf_prof_begin / _end record on the stream the kernel runs on)
+        sf_prof_begin(c, SF_K_NN_REFINE);
+        hipLaunchKernelGGL(k_nn_refine, dim3((limit + 3) / 4), dim3(256), 0, cs, cand, count, limit,
+                           (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
+        sf_prof_end(c, SF_K_NN_REFINE);
+        c->stream = main_stream;
       }
       SF_HIP(c, hipMemcpyAsync(c->nn_pinned, count, 4, hipMemcpyDeviceToHost, cs));
       SF_HIP(c, hipMemcpyAsync(h_cand, cand, (size_t)spec * 8, hipMemcpyDeviceToHost, cs));
       SF_HIP(c, hipMemcpyAsync(h_dist, cdist, (size_t)spec * 8, hipMemcpyDeviceToHost, cs));
       if (speculate) {
         SF_HIP(c, hipEventRecord(c->spec.ev_copied, cs));
-        if ((rc = sf_spec_launch(c, cand, count)) != SF_OK) return rc;
-        c->spec.launched = true;
         SF_HIP(c, hipEventSynchronize(c->spec.ev_copied));
       } else {
         SF_HIP(c, hipStreamSynchronize(c->stream));
