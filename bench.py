@@ -265,6 +265,9 @@ def main():
     if world > 1:
         exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf, n_kf // 4 + 256, coll_dev)
     h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
+    h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    spec_cap = n_kf // 4 + 256
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
 
@@ -294,24 +297,35 @@ def main():
         # every candidate's success flag goes back to the two robots involved (failures feed the ignore
         # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
         # the back-end (data_handler.py:352-368).
-        if exch is not None and coll_dev.type == "cuda":
-            # compaction writes straight into the exchange's send buffer (no staging copy)
-            n_acc = f.compact_accepted_device(d_res.data_ptr(), n, exch.payload.data_ptr(), d_flags.data_ptr())
-            acc = exch.payload[:n_acc]
-            exch.exchange(n_acc, finish=False)                # count stamped on the device + ONE all-gather, in flight
-        else:
+        # The compaction leaves its count on the device; count, flags and a speculative prefix of the accepted
+        # records (capacity for a 25 % acceptance rate) go to the host behind the step's ONE synchronisation.
+        if exch is not None and coll_dev.type != "cuda":      # gloo rehearsal: the collective runs on CPU tensors
             n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
-            acc = d_acc[:n_acc]                               # ordered device-side compaction (one kernel)
-            if exch is not None:                              # gloo rehearsal: the collective runs on CPU tensors
-                exch.payload[:n_acc].copy_(acc)
-                exch.exchange(n_acc)
-        succ = d_flags[:n]
-        h_flags[:n].copy_(succ, non_blocking=True)
-        host = h_res[:n_acc]
-        host.copy_(acc, non_blocking=True)                    # accepted separators delivered to the host (pinned)
+            acc = d_acc
+            exch.payload[:n_acc].copy_(acc[:n_acc])
+            exch.exchange(n_acc)
+            h_cnt[0] = n_acc
+        else:
+            if exch is not None:
+                # compaction writes records AND count straight into the exchange's send buffer
+                acc, cnt_ptr, d_cnt_view = exch.payload, exch.count_ptr, exch.send[0, :4].view(torch.int32)
+            else:
+                acc, cnt_ptr, d_cnt_view = d_acc, d_cnt.data_ptr(), d_cnt
+            f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)
+            if exch is not None:
+                exch.exchange(None, finish=False)             # ONE all-gather, in flight beside the copies below
+            h_cnt.copy_(d_cnt_view, non_blocking=True)
+        h_flags[:n].copy_(d_flags[:n], non_blocking=True)
+        k_spec = min(n, spec_cap)
+        h_res[:k_spec].copy_(acc[:k_spec], non_blocking=True) # accepted separators delivered to the host (pinned)
         if exch is not None:
             exch.finish()                                     # the copies above ran beside the collective
         torch.cuda.synchronize()
+        n_acc = int(h_cnt[0])
+        if n_acc > k_spec:                                    # more accepted than the speculative prefix held
+            h_res[k_spec:n_acc].copy_(acc[k_spec:n_acc], non_blocking=True)
+            torch.cuda.synchronize()
+        host = h_res[:n_acc]
         if trace:
             t_4 = time.perf_counter()
             pr = f.prof_get()

@@ -241,6 +241,12 @@ int  sf_verify_matches_device(sf_handle h, const sf_match* matches, int32_t n, i
    Returns the number of accepted records in *n_accepted (host); synchronises the stream.           */
 int  sf_compact_accepted_device(sf_handle h, const sf_result* d_results, int32_t n, sf_result* d_accepted,
                                 uint8_t* d_flags, int32_t* n_accepted);
+/* The same compaction without the synchronisation: the count is left in device memory at d_n_accepted
+   (int32), everything asynchronous on the handle's stream -- for callers that ship count, flags and a
+   speculative prefix of the accepted records to the host (or stamp the count into an exchange buffer) behind
+   ONE synchronisation of their own.                                                                    */
+int  sf_compact_accepted_device_async(sf_handle h, const sf_result* d_results, int32_t n, sf_result* d_accepted,
+                                      uint8_t* d_flags, int32_t* d_n_accepted);
 /* Correspondences found by the two matching passes of the LAST verify call for pair `i`
    (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.  Calls with more
    than 131072 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */

@@ -959,6 +959,31 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   return SF_OK;
 }
 
+// The two compaction kernels, asynchronous: the number of accepted results is left at d_count (device).
+static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
+                          int32_t* d_count) {
+  const int chunks = (n + 1023) / 1024;
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 1) * 4)) != SF_OK) return rc;
+  int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
+  hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
+  hipLaunchKernelGGL(k_compact_move, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted,
+                     (const int32_t*)d_chunk, d_count);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
+extern "C" int sf_compact_accepted_device_async(sf_handle c, const sf_result* d_results, int32_t n,
+                                                sf_result* d_accepted, uint8_t* d_flags, int32_t* d_n_accepted) {
+  if (!c || n < 0 || !d_n_accepted || (n > 0 && (!d_results || !d_accepted))) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  if (n == 0) {
+    SF_HIP(c, hipMemsetAsync(d_n_accepted, 0, 4, c->stream));
+    return SF_OK;
+  }
+  return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted);
+}
+
 extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_results, int32_t n, sf_result* d_accepted,
                                           uint8_t* d_flags, int32_t* n_accepted) {
   if (!c || n < 0 || !n_accepted || (n > 0 && (!d_results || !d_accepted))) return SF_EINVAL;
@@ -968,12 +993,8 @@ extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_result
   const int chunks = (n + 1023) / 1024;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 1) * 4)) != SF_OK) return rc;
-  int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
-  int32_t* d_count = d_chunk + chunks;
-  hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
-  hipLaunchKernelGGL(k_compact_move, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted,
-                     (const int32_t*)d_chunk, d_count);
-  SF_HIP(c, hipGetLastError());
+  int32_t* d_count = (int32_t*)c->compact_scratch.p + chunks;
+  if ((rc = compact_launch(c, d_results, n, d_accepted, d_flags, d_count)) != SF_OK) return rc;
   if (!c->count_pinned && hipHostMalloc((void**)&c->count_pinned, 64, hipHostMallocDefault) != hipSuccess)
     return sf_fail(c, SF_ENOMEM, "hipHostMalloc(64) failed");
   SF_HIP(c, hipMemcpyAsync(c->count_pinned, d_count, 4, hipMemcpyDeviceToHost, c->stream));

@@ -115,12 +115,22 @@ class RecordExchange:
         self._n_local = 0
         self._work = None
 
+    @property
+    def count_ptr(self):
+        """Device address of this rank's count (int32 view of the header row), for a producer that stamps it."""
+        return self.send.data_ptr()
+
     def exchange(self, n_local, finish=True):
-        """Stamp the count and start the all-gather.  With finish=False the collective is left in flight (RCCL
+        """Stamp the count (n_local = None: the producer already did, on the device) and start the all-gather.  With finish=False the collective is left in flight (RCCL
         runs it on its own stream) so that the caller can queue independent work -- e.g. the copy of its own
         records to the host -- before calling finish()."""
-        self._n_local = int(n_local)
-        self._hdr.fill_(self._n_local)
+        if n_local is None:
+            # the producer stamped the count itself (sf_compact_accepted_device_async writes its int32 count into
+            # the first 4 bytes of the header row; the other 4 stay zero): no host knowledge of it is needed
+            self._n_local = None
+        else:
+            self._n_local = int(n_local)
+            self._hdr.fill_(self._n_local)
         self._work = self.td.all_gather_into_tensor(self.recv.view(self.world * (self.cap + 1), self.rec),
                                                     self.send[: self.cap + 1], group=self.group, async_op=True)
         if finish:
@@ -148,7 +158,8 @@ class RecordExchange:
         counts = self.counts()
         parts = [self.gathered(r, counts) for r in range(self.world)]
         if max(counts) > self.cap:
-            extra, ecounts = allgather_records(self.payload[self.cap: self._n_local] if self._n_local > self.cap
+            n_local = counts[self.td.get_rank(self.group)] if self._n_local is None else self._n_local
+            extra, ecounts = allgather_records(self.payload[self.cap: n_local] if n_local > self.cap
                                                else self.payload[:0], self.group)
             off = 0
             for r in range(self.world):

@@ -85,6 +85,7 @@ def load():
         "sf_verify_matches_device": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "sf_find_matches_and_verify_device": (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(i32), vp]),
         "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
+        "sf_compact_accepted_device_async": (C.c_int, [vp, vp, i32, vp, vp, vp]),
         "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
         "sf_comm_unique_id": (C.c_int, [vp, i32]),
@@ -116,6 +117,7 @@ EXPORTED = [
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
+    "sf_compact_accepted_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
@@ -306,6 +308,11 @@ class SeparatorFinder:
         self._check(self._L.sf_compact_accepted_device(self._h, C.c_void_p(d_results), n, C.c_void_p(d_accepted),
                                                        C.c_void_p(d_flags) if d_flags else None, C.byref(k)))
         return k.value
+
+    def compact_accepted_device_async(self, d_results, n, d_accepted, d_flags, d_count):
+        """The same without the synchronisation: the count (int32) is left on the device at d_count."""
+        self._check(self._L.sf_compact_accepted_device_async(self._h, C.c_void_p(d_results), n, C.c_void_p(d_accepted),
+                                                             C.c_void_p(d_flags) if d_flags else None, C.c_void_p(d_count)))
 
     def debug_correspondences(self, pair, which_pass, cap=4096):
         cf = np.zeros(cap, dtype=np.uint16)

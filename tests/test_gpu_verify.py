@@ -598,6 +598,17 @@ def test_verify_matches_and_compaction_entry_points(finder):
     big[:, 0] = torch.arange(2500, device=dev).remainder(251).to(torch.uint8)
     k = finder.compact_accepted_device(big.data_ptr(), 2500, out.data_ptr())
     assert k == len(range(0, 2500, 3)) and torch.equal(out[:k], big[::3])
+    # the asynchronous form: same records and flags, the count left on the device
+    out2 = torch.zeros_like(out)
+    flags2 = torch.zeros(2500, dtype=torch.uint8, device=dev)
+    cnt = torch.full((2,), -7, dtype=torch.int32, device=dev)
+    finder.compact_accepted_device_async(big.data_ptr(), 2500, out2.data_ptr(), flags2.data_ptr(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert cnt.tolist() == [k, -7] and torch.equal(out2[:k], big[::3])
+    assert torch.equal(flags2.bool(), big[:, off] != 0)
+    finder.compact_accepted_device_async(big.data_ptr(), 0, out2.data_ptr(), None, cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert cnt.tolist() == [0, -7]
     with pytest.raises(Exception):
         m_bad = m.copy(); m_bad["idx_other"][0] = 10_000
         finder.verify_matches_device(m_bad, sa, sb, d_res.data_ptr())
