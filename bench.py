@@ -165,8 +165,8 @@ def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--keyframes", type=int, default=10000, help="keyframes per robot (configs[1]: 10k)")
     ap.add_argument("--features", type=int, default=500)
     ap.add_argument("--desc-bytes", type=int, default=32)

@@ -67,8 +67,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   int* cell_start = misc + 16;     // [NC + 1] CSR of "to" keypoints bucketed on a uniform grid
   int* cell_fill = cell_start + NC + 1;   // [NC]
   // [kcap] the "to" keypoints grouped by cell as {x, y, octave bits, index bits}: the window test never leaves
-  // LDS and takes ONE 16-byte read per entry (a dependent 4-byte read per field made the scan of the 3x3
-  // neighbourhood 14 of the stage's 24 us: one LDS latency per entry, no overlap)
+  // LDS and takes ONE 16-byte read per entry
   float4* item4 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(cell_fill + NC) + 15) & ~(uintptr_t)15);
   for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;
@@ -163,10 +162,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     }
   }
   __syncthreads();
-  if (P.dbg_stop == 11) {   // diagnostic truncation (SF_RANSAC_STOP=11: after the grid build; results invalid)
-    if (tid == 0) { pass2[pair] = p1; guided_flag[pair] = 0; CorrHeader h = {0, 0, 0, 0}; hdr[pair] = h; }
-    return false;
-  }
 
   int n_finite = 0, n_proj = 0;
   for (int base = 0; base < Kf; base += NT) {
@@ -188,7 +183,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
                 (zf > 0.f);
       }
     }
-    if (P.dbg_stop == 13) inimg = false;   // diagnostic (timing only): projection without the window search
     if (inimg) {
       ++n_proj;
       const int octf = __float_as_int(kF[i].z);
@@ -207,35 +201,24 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
       const int cx1 = min(max((int)floorf((u + reach) * inv_cell), 0), gxm);
       const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
       const int cy1 = min(max((int)floorf((v + reach) * inv_cell), 0), gym);
-      for (int cy = cy0; cy <= cy1 && P.dbg_stop != 15; ++cy) {   // (15: diagnostic, no scan at all)
+      for (int cy = cy0; cy <= cy1; ++cy) {
         // cells cx0..cx1 of one grid row are contiguous in the CSR
         const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
-        // four entries per trip: their reads are independent, so the LDS latency is paid once per four
-        for (int e = e0; e < e1; e += 4) {
-          float4 it[4];
+        for (int e = e0; e < e1; ++e) {
+          const float4 it = item4[e];
+          const float dx = u - it.x, dy = v - it.y;
+          const float d2 = dx * dx + dy * dy;
+          if (d2 < r2lim && __float_as_int(it.z) == octf) {
+            const int t = __float_as_int(it.w);
+            const uint32_t* r = dT + (size_t)t * W;
+            uint32_t d = 0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) it[j] = item4[min(e + j, e1 - 1)];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float dx = u - it[j].x, dy = v - it[j].y;
-            const float d2 = dx * dx + dy * dy;
-            if (e + j < e1 && d2 < r2lim && __float_as_int(it[j].z) == octf &&
-                P.dbg_stop != 14) {   // (14: diagnostic, search without Hamming)
-              const int t = __float_as_int(it[j].w);
-              const uint4* r = reinterpret_cast<const uint4*>(dT + (size_t)t * W);
-              uint32_t d = 0;
-#pragma unroll
-              for (int c = 0; c < W / 4; ++c) {
-                const uint4 v4 = r[c];
-                d += __popc(v4.x ^ q[4 * c]) + __popc(v4.y ^ q[4 * c + 1]) + __popc(v4.z ^ q[4 * c + 2]) +
-                     __popc(v4.w ^ q[4 * c + 3]);
-              }
-              const uint32_t key = (d << 16) | (uint32_t)t;
-              b1 = min(max(key, b0), b1);
-              b0 = min(b0, key);
-              ++oi;
-              if (last < 0 || t > last) last = t;
-            }
+            for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
+            const uint32_t key = (d << 16) | (uint32_t)t;
+            b1 = min(max(key, b0), b1);
+            b0 = min(b0, key);
+            ++oi;
+            if (last < 0 || t > last) last = t;
           }
         }
       }
@@ -263,10 +246,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   n_finite = misc[0];
   n_proj = misc[1];
 
-  if (P.dbg_stop == 12) {   // diagnostic truncation (SF_RANSAC_STOP=12: after the window search; results invalid)
-    if (tid == 0) { pass2[pair] = p1; guided_flag[pair] = 0; CorrHeader h = {0, 0, 0, 0}; hdr[pair] = h; }
-    return false;
-  }
   // id-ordered compaction
   uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
