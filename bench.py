@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
     args = ap.parse_args()
 
+    # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with RCCL's streams in the process
+    # the library's second stream would share a queue with its first and lose the overlap it exists for
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,8 +207,12 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: run the N > 1 code path (process group, separator exchange) with whatever world size
+    # the launcher gave, including 1 -- the rehearsal of the RCCL path on a one-GPU box
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") is not None
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -262,7 +269,7 @@ def main():
     # collective per step, capacity for a 25 % acceptance rate + slack; overflow falls back to two-phase);
     # each rank hands ITS OWN accepted separators to the host, so the node delivers every record once.
     exch = None
-    if world > 1:
+    if dist_on:
         exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf, n_kf // 4 + 256, coll_dev)
     h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
     h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -345,14 +352,14 @@ def main():
     f.prof_reset()
     f.prof_enable(True)
     state["pairs"] = 0
-    if world > 1:
+    if dist_on:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         td.barrier()
     elapsed = time.perf_counter() - t0
     prof = f.prof_get()
@@ -361,7 +368,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     npairs = torch.tensor([state["pairs"]], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if dist_on:
         td.all_reduce(t, op=td.ReduceOp.MAX)
         td.all_reduce(npairs, op=td.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -549,7 +556,7 @@ def main():
                                                args.cpu_sample_rows)
         print(json.dumps(out))
     f.close()
-    if world > 1:
+    if dist_on:
         td.destroy_process_group()
 
 

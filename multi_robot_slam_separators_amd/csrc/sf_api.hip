@@ -902,7 +902,17 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
                          std::min(cap, c->params.netvlad_max_matches_nb) >= n_l && getenv("SF_SPECULATE_OFF") == nullptr;
   if (speculate) {
     if (!c->spec.copy_stream) {
-      SF_HIP(c, hipStreamCreateWithFlags(&c->spec.copy_stream, hipStreamNonBlocking));
+      // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and a
+      // second stream that lands on the queue of the handle's stream runs BEHIND the verification instead of
+      // beside it (seen as soon as another library -- RCCL -- had created streams of its own: +0.17 ms per step).
+      // Streams of another priority level get queues of their own, so unless the process raised the queue budget
+      // (bench.py sets GPU_MAX_HW_QUEUES=8, measured slightly better than the priority) this stream is created
+      // with the highest priority; its work (exact NN re-evaluation, small copies) is what the host waits for.
+      int prio_least = 0, prio_greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+      const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+      const int prio = (hwq && atoi(hwq) >= 8) ? 0 : prio_greatest;
+      SF_HIP(c, hipStreamCreateWithPriority(&c->spec.copy_stream, hipStreamNonBlocking, prio));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_refined, hipEventDisableTiming));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_copied, hipEventDisableTiming));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec_index_staged, hipEventDisableTiming));

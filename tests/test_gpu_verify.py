@@ -289,6 +289,23 @@ def test_torch_rccl_allgather_records_single_rank():
                 assert ex.counts() == [k]
                 out, counts = ex.all_gathered()
                 assert counts == [k] and torch.equal(out, rec[:k]), (cap, k)
+        # the count stamped by the producer on the device (bench.py: sf_compact_accepted_device_async writes records
+        # and count straight into the send buffer), the collective left in flight beside a copy to the host
+        from multi_robot_slam_separators_amd import lib as _lib
+        ex = dist.RecordExchange(368, 16, 8, dev)
+        big = torch.zeros((12, 368), dtype=torch.uint8, device=dev)
+        big[:, 0] = torch.arange(12, device=dev).to(torch.uint8)
+        big[::2, _abi.RESULT_DTYPE.fields["success"][1]] = 1
+        with _lib.SeparatorFinder(synth.camera_params()) as f2:
+            f2.set_stream(torch.cuda.current_stream().cuda_stream)
+            f2.compact_accepted_device_async(big.data_ptr(), 12, ex.payload.data_ptr(), None, ex.count_ptr)
+            ex.exchange(None, finish=False)
+            host = torch.empty((6, 368), dtype=torch.uint8).pin_memory()
+            host.copy_(ex.payload[:6], non_blocking=True)
+            ex.finish()
+            torch.cuda.synchronize()
+            out, counts = ex.all_gathered()
+            assert counts == [6] and torch.equal(out, big[::2]) and torch.equal(host, big[::2].cpu())
         t = torch.tensor([3.5], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         td.barrier()
