@@ -262,18 +262,24 @@ def main():
     torch.cuda.synchronize()
 
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_acc = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    d_flags = torch.empty(n_kf, dtype=torch.bool, device=dev)
-    h_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    # count | per-candidate flags | accepted records packed in ONE device buffer (and its pinned mirror), so that the
+    # count, the flags and a speculative prefix of the records reach the host with ONE copy
+    RB = _abi.RESULT_DTYPE.itemsize
+    flags_off, acc_off = 64, 64 + (n_kf + 63) // 64 * 64
+    d_pack = torch.zeros(acc_off + n_kf * RB, dtype=torch.uint8, device=dev)
+    h_pack = torch.zeros(acc_off + n_kf * RB, dtype=torch.uint8).pin_memory()
+    d_cnt = d_pack[:4].view(torch.int32)
+    d_flags = d_pack[flags_off: flags_off + n_kf].view(torch.bool)
+    d_acc = d_pack[acc_off:].view(n_kf, RB)
+    h_res = h_pack[acc_off:].view(n_kf, RB)
     # N > 1: the accepted separators of every rank are all-gathered on the devices (persistent buffers, one
     # collective per step, capacity for a 25 % acceptance rate + slack; overflow falls back to two-phase);
     # each rank hands ITS OWN accepted separators to the host, so the node delivers every record once.
     exch = None
     if dist_on:
         exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf, n_kf // 4 + 256, coll_dev)
-    h_flags = torch.empty(n_kf, dtype=torch.bool).pin_memory()
-    h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
-    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    h_flags = h_pack[flags_off: flags_off + n_kf].view(torch.bool)
+    h_cnt = h_pack[:4].view(torch.int32)
     spec_cap = n_kf // 4 + 256
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
@@ -311,7 +317,7 @@ def main():
             acc = d_acc
             exch.payload[:n_acc].copy_(acc[:n_acc])
             exch.exchange(n_acc)
-            h_cnt[0] = n_acc
+            d_cnt.fill_(n_acc)                                # (the packed copy below carries it to the host)
         else:
             if exch is not None:
                 # compaction writes records AND count straight into the exchange's send buffer
@@ -321,10 +327,16 @@ def main():
             f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)
             if exch is not None:
                 exch.exchange(None, finish=False)             # ONE all-gather, in flight beside the copies below
-            h_cnt.copy_(d_cnt_view, non_blocking=True)
-        h_flags[:n].copy_(d_flags[:n], non_blocking=True)
         k_spec = min(n, spec_cap)
-        h_res[:k_spec].copy_(acc[:k_spec], non_blocking=True) # accepted separators delivered to the host (pinned)
+        if acc is d_acc:
+            # count + flags + the speculative prefix of the accepted separators: one copy to the pinned mirror
+            nb = acc_off + k_spec * RB
+            h_pack[:nb].copy_(d_pack[:nb], non_blocking=True)
+        else:
+            if exch is not None and coll_dev.type == "cuda":
+                h_cnt.copy_(d_cnt_view, non_blocking=True)
+            h_flags[:n].copy_(d_flags[:n], non_blocking=True)
+            h_res[:k_spec].copy_(acc[:k_spec], non_blocking=True)   # accepted separators delivered to the host (pinned)
         if exch is not None:
             exch.finish()                                     # the copies above ran beside the collective
         torch.cuda.synchronize()
