@@ -741,10 +741,10 @@ static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the wo
 static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t* d_from, const int32_t* d_to, int m,
                            sf_result* d_out, bool allow_fused) {
   int rc;
-  SF_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
   if (allow_fused && sf_fused_lds_bytes(ctx, view) != 0)
-    // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip)
+    // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
     return sf_launch_verify_fused(ctx, view, d_from, d_to, m, d_out);
+  SF_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));   // work-list counters of the stage kernels
   if ((rc = sf_launch_match_global(ctx, view, d_from, d_to, m)) != SF_OK) return rc;
   const bool pnp = ctx->dparams.estimation_type == 1;
   if ((rc = (pnp ? sf_launch_pnp : sf_launch_ransac)(ctx, view, d_from, d_to, m, 1)) != SF_OK) return rc;
