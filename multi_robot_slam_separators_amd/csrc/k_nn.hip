@@ -401,8 +401,9 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
 // one wavefront per candidate: exact float64 distance in cdist's direct form
 __global__ void __launch_bounds__(256)
 k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned limit,
-            const float* __restrict__ A, const float* __restrict__ B, int dim, int ld, double* __restrict__ out) {
-  const unsigned c = blockIdx.x * 4 + (threadIdx.x >> 6);
+            const float* __restrict__ A, const float* __restrict__ B, int dim, int ld, double* __restrict__ out,
+            unsigned first = 0) {
+  const unsigned c = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const unsigned n_cand = min(*count, limit);   // the grid is sized for `limit`; the filter's count lives on the device
   if (c >= n_cand) return;
@@ -641,8 +642,11 @@ static int nn_run_filter(sf_context* c, int* done) {
         const hipStream_t main_stream = c->stream;
         c->stream = cs;                      // (sf_prof_begin / _end record on the stream the kernel runs on)
         sf_prof_begin(c, SF_K_NN_REFINE);
-        hipLaunchKernelGGL(k_nn_refine, dim3((limit + 3) / 4), dim3(256), 0, cs, cand, count, limit,
-                           (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist);
+        // sized like the speculative copy below (2N + 1024 candidates): a grid for the whole sparse limit
+        // (8N + 4096) is 4/5 empty workgroups that the dispatcher still has to walk through -- beside the
+        // verification kernel in the speculative path; the rare tail is re-evaluated once its size is known
+        hipLaunchKernelGGL(k_nn_refine, dim3((spec + 3) / 4), dim3(256), 0, cs, cand, count, spec,
+                           (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist, 0u);
         sf_prof_end(c, SF_K_NN_REFINE);
         c->stream = main_stream;
       }
@@ -662,6 +666,8 @@ static int nn_run_filter(sf_context* c, int* done) {
       if (ok && n_cand > spec) {
         // (rare) the tail of the candidate list; on the copy stream when the handle's stream is already busy
         // with the speculative verification
+        hipLaunchKernelGGL(k_nn_refine, dim3((n_cand - spec + 3) / 4), dim3(256), 0, cs, cand, count, n_cand,
+                           (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist, spec);
         SF_HIP(c, hipMemcpyAsync(h_cand + spec, cand + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, cs));
         SF_HIP(c, hipMemcpyAsync(h_dist + spec, cdist + spec, (size_t)(n_cand - spec) * 8, hipMemcpyDeviceToHost, cs));
         SF_HIP(c, hipStreamSynchronize(cs));
