@@ -263,17 +263,14 @@ __device__ inline float rank_value(const float* arr, int m, int rank, double* sl
   return (float)*slot;
 }
 
-__global__ void __launch_bounds__(SF_BLOCK, 3)
-k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-      const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
-      const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
-      PassState* __restrict__ pass, DeviceParams P) {
-  if ((int)blockIdx.x >= *counter) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// Body of one PnP pass for ONE pair (the calling 256-thread workgroup); smem_raw is the workgroup's dynamic LDS.
+__device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
+                                         const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
+                                         const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
+                                         const DeviceParams& P, unsigned char* smem_raw) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const int pair = list[blockIdx.x];
   const int sF = pair_from[pair], sT = pair_to[pair];
   const int max_it = P.iterations > 0 ? P.iterations : 0;
 
@@ -598,6 +595,16 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     ps.var_ang = v;
   }
   if (tid == 0) pass[pair] = ps;
+}
+
+__global__ void __launch_bounds__(SF_BLOCK, 3)
+k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+      const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+      const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+      PassState* __restrict__ pass, DeviceParams P) {
+  if ((int)blockIdx.x >= *counter) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  pnp_body(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
 }
 
 }  // namespace

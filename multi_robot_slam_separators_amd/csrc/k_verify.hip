@@ -17,6 +17,7 @@
 #include "k_match.hip"
 #include "k_ransac.hip"
 #include "k_guided.hip"
+#include "k_pnp.hip"
 
 namespace {
 
@@ -67,6 +68,53 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     finalize_one(pair, pass1, pass2, guided_flag, out);
 }
 
+// The same pipeline with the PnP estimator (estimation_type = 1, myRegistrationVis.cpp:1055-1112), opt-in
+// (SF_FUSED_PNP=1): k_pnp needs ~170 VGPRs, so three workgroups per CU, and a surviving pair's PnP chain is
+// ~200 us (66 + 30 + 107) -- twice the 3D-3D one on fewer slots.  Measured three times, last with the matrix-core
+// matcher: 0.95 ms per 10 000 pairs fused against 0.81 for the four stage launches.  Byte-identical either way
+// (test_fused_pipeline_equals_stage_kernels[1]).
+template <int W, int NQ>
+__global__ void __launch_bounds__(SF_BLOCK, 3)
+k_verify_fused_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                   uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+                   uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
+                   uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int pair = blockIdx.x;
+  const int est = P.calibrated ? 1 : 2;     // gate selector of the matching body (sf_est_mode)
+  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, est, corr1, hdr1,
+                                                   pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(3);
+  if (est1) {
+    pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    __syncthreads();
+  }
+  const bool est2 = guided_body<W, 4>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr,
+                                      nullptr, P, reinterpret_cast<int*>(smem_raw));
+  __syncthreads();
+  if (est2) {
+    pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
+}
+
+template <int W, int NQ>
+int launch_fused_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
+                     size_t lds) {
+  bool& attr_set = c->fused_pnp_attr[W == 16][NQ == 0];
+  if (lds > 64 * 1024 && !attr_set) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused_pnp<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_verify_fused_pnp<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
+                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
+  return SF_OK;
+}
+
 template <int W, int NQ, int CW>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds) {
@@ -87,11 +135,13 @@ int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32
 // Dynamic LDS of the fused kernel = the largest stage; 0 when the fused pipeline does not apply
 // (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
-  if (c->dparams.estimation_type != 0 || !c->fused) return 0;
+  if (!c->fused || c->dparams.estimation_type > 1) return 0;
+  if (c->dparams.estimation_type == 1 && !c->fused_pnp) return 0;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
   const size_t guided = sf_guided_lds_bytes(st.kcap, nc);
-  const size_t ransac = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  const size_t ransac = c->dparams.estimation_type == 1 ? sf_pnp_lds_bytes(st.kcap, c->dparams.iterations)
+                                                        : sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
   if (match > 64 * 1024 || c->match_variant != 0) return 0;
@@ -107,6 +157,16 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
   const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
+  if (c->dparams.estimation_type == 1) {
+    if (mf) rc = st.w == 8 ? launch_fused_pnp<8, 0>(c, st, d_from, d_to, n, d_out, lds)
+                           : launch_fused_pnp<16, 0>(c, st, d_from, d_to, n, d_out, lds);
+    else rc = st.w == 8 ? launch_fused_pnp<8, 2>(c, st, d_from, d_to, n, d_out, lds)
+                        : launch_fused_pnp<16, 2>(c, st, d_from, d_to, n, d_out, lds);
+    sf_prof_end(c, SF_K_FUSED);
+    if (rc != SF_OK) return rc;
+    SF_HIP(c, hipGetLastError());
+    return SF_OK;
+  }
 #define SF_FUSED_CASE(W_, NQ_)                                                                    \
   rc = c->chain_waves == 1   ? launch_fused<W_, NQ_, 1>(c, st, d_from, d_to, n, d_out, lds)        \
        : c->chain_waves == 2 ? launch_fused<W_, NQ_, 2>(c, st, d_from, d_to, n, d_out, lds)        \

@@ -608,6 +608,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
   if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
+  if (const char* v = getenv("SF_FUSED_PNP")) c->fused_pnp = atoi(v) != 0;     // 1: fused kernel for the PnP estimator
   if (const char* v = getenv("SF_CHAIN_WAVES")) c->chain_waves = (atoi(v) == 1 || atoi(v) == 2) ? atoi(v) : 4;   // 1 / 2: chains on fewer wavefronts
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
   if (const char* v = getenv("SF_OVERLAP_MIN")) c->overlap_min_pairs = std::max(2, atoi(v));
@@ -778,6 +779,7 @@ static int ensure_twin(sf_context* c) {
   t->match_variant = c->match_variant;
   t->match_mfma = c->match_mfma;
   t->fused = c->fused;
+  t->fused_pnp = c->fused_pnp;
   t->chain_waves = c->chain_waves;
   t->prof = c->prof;
   return SF_OK;

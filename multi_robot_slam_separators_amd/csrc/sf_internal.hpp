@@ -143,6 +143,8 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
+  bool fused_pnp_attr[2][2] = {};
+  bool fused_pnp = false;   // SF_FUSED_PNP=1: fused kernel for the PnP estimator too (slower than its stage kernels)
   bool fused_attr[2][2][3] = {};   // [W == 16][matrix-core matcher][single-wavefront chains]: LDS attribute set
   int chain_waves = 4;      // wavefronts that run a surviving pair's motion-estimation chain in the fused kernel
                             // (4: the whole workgroup; 1: three of the four end after matching; SF_CHAIN_WAVES)
@@ -229,6 +231,7 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out);
 size_t sf_ransac_lds_bytes(int kcap, int iterations);
+size_t sf_pnp_lds_bytes(int kcap, int iterations);
 size_t sf_guided_lds_bytes(int kcap, int n_cells);
 // Assemble sf_result records.
 int sf_launch_finalize(sf_context* c, int n, sf_result* d_out);

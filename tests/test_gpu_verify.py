@@ -330,7 +330,8 @@ def test_verification_regression_vectors_on_gpu(est):
         assert got[i].tobytes() == want[i].tobytes(), "estimation_type %d pair %d" % (est, i)
 
 
-def test_fused_pipeline_equals_stage_kernels(monkeypatch):
+@pytest.mark.parametrize("est", [0, 1])
+def test_fused_pipeline_equals_stage_kernels(monkeypatch, est):
     """k_verify_fused (one launch per chunk) and the five stage kernels (SF_FUSED=0) run the same
     per-pair bodies: results, correspondences and counts must be identical byte for byte."""
     from multi_robot_slam_separators_amd import lib
@@ -339,7 +340,9 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch):
     for AA, BB in ((A, B), (A2, B2)):
         p = synth.camera_params()
         p.iterations = 300
+        p.estimation_type = est
         out = {}
+        monkeypatch.setenv("SF_FUSED_PNP", "1")       # (the fused PnP kernel is opt-in)
         for fused in ("1", "0"):
             monkeypatch.setenv("SF_FUSED", fused)
             with lib.SeparatorFinder(p) as f:
