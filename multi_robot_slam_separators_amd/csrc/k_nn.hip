@@ -403,13 +403,15 @@ __global__ void __launch_bounds__(256)
 k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned limit,
             const float* __restrict__ A, const float* __restrict__ B, int dim, int ld, double* __restrict__ out,
             unsigned first = 0) {
-  const unsigned c = first + blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const unsigned n_cand = min(*count, limit);   // the grid is sized for `limit`; the filter's count lives on the device
-  if (c >= n_cand) return;
-  const uint2 rc = cand[c];
-  const double s = nn_exact_sq_dist(A + (size_t)rc.x * ld, B + (size_t)rc.y * ld, ld, lane);
-  if (lane == 0) out[c] = sqrt(s);
+  // grid-stride: a launch with fewer workgroups than candidates / 4 walks the list at a lower intensity (the
+  // speculative path runs this kernel beside the verification and has half a millisecond of slack for it)
+  for (unsigned c = first + blockIdx.x * 4 + (threadIdx.x >> 6); c < n_cand; c += gridDim.x * 4) {
+    const uint2 rc = cand[c];
+    const double s = nn_exact_sq_dist(A + (size_t)rc.x * ld, B + (size_t)rc.y * ld, ld, lane);
+    if (lane == 0) out[c] = sqrt(s);
+  }
 }
 
 __global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad) {
@@ -645,7 +647,19 @@ static int nn_run_filter(sf_context* c, int* done) {
         // sized like the speculative copy below (2N + 1024 candidates): a grid for the whole sparse limit
         // (8N + 4096) is 4/5 empty workgroups that the dispatcher still has to walk through -- beside the
         // verification kernel in the speculative path; the rare tail is re-evaluated once its size is known
-        hipLaunchKernelGGL(k_nn_refine, dim3((spec + 3) / 4), dim3(256), 0, cs, cand, count, spec,
+        // beside a speculative verification of full-size frames the re-evaluation has ~10x its own run time of
+        // slack: one workgroup per CU walks the list (grid-stride) instead of a workgroup per four candidates, which
+        // leaves the HBM and the dispatcher to the verification kernel's first third (k_verify_fused 0.60 -> 0.58 ms,
+        // the re-evaluation 0.09 -> 0.16 ms in its shadow)
+        unsigned refine_wgs = (spec + 3) / 4;
+        if (speculate && c->store.kcap >= 256) {
+          if (c->n_cus <= 0) {
+            int v = 0;
+            c->n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) ? v : 256;
+          }
+          refine_wgs = std::min(refine_wgs, (unsigned)c->n_cus);
+        }
+        hipLaunchKernelGGL(k_nn_refine, dim3(refine_wgs), dim3(256), 0, cs, cand, count, spec,
                            (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, cdist, 0u);
         sf_prof_end(c, SF_K_NN_REFINE);
         c->stream = main_stream;

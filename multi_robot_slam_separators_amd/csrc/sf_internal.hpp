@@ -98,6 +98,7 @@ struct sf_context {
   sf_params params;
   DeviceParams dparams;
   int device = 0;
+  int n_cus = 0;            // compute units of the device (queried on first use)
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
