@@ -186,6 +186,10 @@ int  sf_nn_append_received(sf_handle h, const double* desc, int32_t n, int32_t d
 /* Same, from float32 rows already resident in device memory (bulk ingest; MI355X-native).   */
 int  sf_nn_append_local_f32_device(sf_handle h, const float* d_desc, int32_t n, int32_t dim);
 int  sf_nn_append_received_f32_device(sf_handle h, const float* d_desc, int32_t n, int32_t dim);
+/* The same for IEEE binary16 descriptors (BASELINE configs[4] ships NetVLAD in fp16): n x dim halfs in device
+   memory, converted exactly to the fp32 database rows.                                                    */
+int  sf_nn_append_local_f16_device(sf_handle h, const uint16_t* d_desc, int32_t n, int32_t dim);
+int  sf_nn_append_received_f16_device(sf_handle h, const uint16_t* d_desc, int32_t n, int32_t dim);
 int  sf_nn_sizes(sf_handle h, int32_t* n_local, int32_t* n_received);
 /* local_kf_already_used.append / other_kf_already_used.append / add_frames_kept_pairs_to_ignore */
 int  sf_nn_mark_local_used(sf_handle h, int32_t idx_local);

@@ -83,6 +83,24 @@ k_nn_copy_rows(const float* __restrict__ src, float* __restrict__ dst, float* __
   if (lane == 0) norms[row] = (float)s;
 }
 
+// fp16 descriptors (BASELINE configs[4] ships NetVLAD in fp16): every half is exactly representable in fp32, so
+// the database holds the same numbers and everything downstream is unchanged.
+__global__ void __launch_bounds__(256)
+k_nn_copy_rows_f16(const _Float16* __restrict__ src, float* __restrict__ dst, float* __restrict__ norms, int n,
+                   int dim, int ld) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  double s = 0.0;
+  for (int k = lane; k < ld; k += 64) {
+    float v = (k < dim) ? (float)src[(size_t)row * dim + k] : 0.f;
+    dst[(size_t)row * ld + k] = v;
+    s += (double)v * (double)v;
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) norms[row] = (float)s;
+}
+
 // A: local rows [n_l_pad][ld], B: received rows [n_r_pad][ld] (both zero padded).
 // nb_eff[j] = ||b_j||^2, or +inf for masked / padding columns.
 // part[(strip) * n_l_pad + row] = packed min over the 64 columns of strip = blockIdx.x*2 + wave_col.
@@ -461,6 +479,9 @@ int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int s
     }
     (void)hipFree(tmp.p);
     if (e != hipSuccess) return sf_fail(c, SF_EHIP, "NN append -> %s", hipGetErrorString(e));
+  } else if (src_kind == 2) {
+    hipLaunchKernelGGL(k_nn_copy_rows_f16, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const _Float16*)src, dst, nrm, n, dim, ld);
+    SF_HIP(c, hipGetLastError());
   } else {
     hipLaunchKernelGGL(k_nn_copy_rows, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const float*)src, dst, nrm, n, dim, ld);
     SF_HIP(c, hipGetLastError());

@@ -1173,6 +1173,14 @@ extern "C" int sf_nn_append_received(sf_handle c, const double* desc, int32_t n,
   if (!c) return SF_EINVAL;
   return sf_nn_append(c, c->nn_recv, desc, n, dim, 0);
 }
+extern "C" int sf_nn_append_local_f16_device(sf_handle c, const uint16_t* d, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_local, d, n, dim, 2);
+}
+extern "C" int sf_nn_append_received_f16_device(sf_handle c, const uint16_t* d, int32_t n, int32_t dim) {
+  if (!c) return SF_EINVAL;
+  return sf_nn_append(c, c->nn_recv, d, n, dim, 2);
+}
 extern "C" int sf_nn_append_local_f32_device(sf_handle c, const float* d, int32_t n, int32_t dim) {
   if (!c) return SF_EINVAL;
   return sf_nn_append(c, c->nn_local, d, n, dim, 1);

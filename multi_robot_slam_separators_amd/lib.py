@@ -64,6 +64,8 @@ def load():
         "sf_nn_append_received": (C.c_int, [vp, vp, i32, i32]),
         "sf_nn_append_local_f32_device": (C.c_int, [vp, vp, i32, i32]),
         "sf_nn_append_received_f32_device": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_append_local_f16_device": (C.c_int, [vp, vp, i32, i32]),
+        "sf_nn_append_received_f16_device": (C.c_int, [vp, vp, i32, i32]),
         "sf_nn_sizes": (C.c_int, [vp, P(i32), P(i32)]),
         "sf_nn_mark_local_used": (C.c_int, [vp, i32]),
         "sf_nn_mark_other_used": (C.c_int, [vp, i32]),
@@ -110,7 +112,8 @@ def load():
 EXPORTED = [
     "sf_abi_version", "sf_default_params", "sf_create", "sf_destroy", "sf_last_error", "sf_get_params",
     "sf_set_stream", "sf_synchronize", "sf_nn_append_local", "sf_nn_append_received",
-    "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_sizes",
+    "sf_nn_append_local_f32_device", "sf_nn_append_received_f32_device", "sf_nn_append_local_f16_device",
+    "sf_nn_append_received_f16_device", "sf_nn_sizes",
     "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
     "sf_nn_set_precision",
     "sf_set_option",
@@ -186,6 +189,13 @@ class SeparatorFinder:
 
     def nn_append_received_device(self, dptr, n, dim):
         self._check(self._L.sf_nn_append_received_f32_device(self._h, C.c_void_p(dptr), n, dim))
+
+    def nn_append_local_f16_device(self, dptr, n, dim):
+        """n x dim IEEE binary16 descriptors in device memory (converted exactly to the fp32 database rows)."""
+        self._check(self._L.sf_nn_append_local_f16_device(self._h, C.c_void_p(dptr), n, dim))
+
+    def nn_append_received_f16_device(self, dptr, n, dim):
+        self._check(self._L.sf_nn_append_received_f16_device(self._h, C.c_void_p(dptr), n, dim))
 
     def nn_sizes(self):
         a, b = C.c_int32(), C.c_int32()
