@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--estimator", choices=("3d3d", "pnp"), default="3d3d",
                     help="motion estimator of both registration passes: 3d3d = RANSAC 3D->3D (north_star, "
                          "myRegistrationVis.cpp:1113-1152), pnp = RANSAC 3D->2D (:1055-1112, rtabmap's default)")
+    ap.add_argument("--netvlad-f16", action="store_true",
+                    help="NetVLAD descriptors handed over in fp16 (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined-extra", action="store_true",
                     help="skip the informational two-stream pipelined measurement")
@@ -257,8 +259,13 @@ def main():
         else:
             slot_b = first
     ta, tb = up(nv_a), up(nv_b)
-    f.nn_append_received_device(ta.data_ptr(), n_kf, dim)    # robot A's descriptors, as received by B
-    f.nn_append_local_device(tb.data_ptr(), n_kf, dim)       # robot B's own descriptors
+    if args.netvlad_f16:      # BASELINE configs[4]: NetVLAD shipped in fp16 (exactly representable in the fp32 database)
+        ta, tb = ta.to(torch.float16), tb.to(torch.float16)
+        nn_append_received, nn_append_local = "nn_append_received_f16_device", "nn_append_local_f16_device"
+    else:
+        nn_append_received, nn_append_local = "nn_append_received_device", "nn_append_local_device"
+    getattr(f, nn_append_received)(ta.data_ptr(), n_kf, dim)    # robot A's descriptors, as received by B
+    getattr(f, nn_append_local)(tb.data_ptr(), n_kf, dim)       # robot B's own descriptors
     torch.cuda.synchronize()
 
     d_res = torch.empty((n_kf, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -425,8 +432,8 @@ def main():
     piped = None
     if world == 1 and args.nn_precision == 1 and not args.no_pipelined_extra and not args.no_extras:
         f_nn = lib.SeparatorFinder(p, device=dev_index)          # own non-blocking stream
-        f_nn.nn_append_received_device(ta.data_ptr(), n_kf, dim)
-        f_nn.nn_append_local_device(tb.data_ptr(), n_kf, dim)
+        getattr(f_nn, nn_append_received)(ta.data_ptr(), n_kf, dim)
+        getattr(f_nn, nn_append_local)(tb.data_ptr(), n_kf, dim)
         f_nn.synchronize()
 
         def launch_verify(m):

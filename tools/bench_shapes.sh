@@ -9,5 +9,6 @@ PY
 }
 run cfg3 --keyframes 20000 --features 1000 --iterations 2000 --steps 5 --warmup 2 &&
 run b512 --desc-bytes 64 &&
+run cfg5 --desc-bytes 64 --netvlad-f16 &&
 run k40 --keyframes 40000 --steps 8 --warmup 2 &&
 run k125 --keyframes 125000 --steps 4 --warmup 1
