@@ -539,6 +539,26 @@ def test_find_matches_and_verify_when_the_speculation_overflows():
         assert res["success"].sum() > n_l // 4
 
 
+@pytest.mark.parametrize("name,k,cols,iters", [("configs[1]", 500, 32, 500), ("configs[2]", 1000, 32, 2000),
+                                                ("configs[4]", 500, 64, 500)])
+@pytest.mark.parametrize("est", [0, 1])
+def test_baseline_config_shapes_against_the_oracle(oracle, name, k, cols, iters, est):
+    """The per-pair shapes of BASELINE.json's configs (features per keyframe, descriptor width, RANSAC iterations)
+    on a handful of pairs each, both estimators: the GPU result equals the oracle's byte for byte."""
+    from multi_robot_slam_separators_amd import lib
+    A, B, is_true, _ = synth.make_pairs(1000 + k + cols + est, 6, k=k, cols=cols, true_frac=0.5)
+    p = synth.camera_params()
+    p.iterations = iters
+    p.max_features = k
+    p.estimation_type = est
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    ref = oracle.estimate_transform_batch(p, A, B, oracle.num_threads())
+    for i in range(len(A)):
+        assert got[i].tobytes() == ref[i].tobytes(), (name, est, i)
+    assert got["success"][is_true].all()
+
+
 def test_execution_options_on_a_live_handle():
     """sf_set_option switches matcher / fusion / two-stream execution between calls of ONE handle; every
     combination returns the same bytes; an unknown option is SF_EINVAL."""
