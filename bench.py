@@ -394,34 +394,42 @@ def main():
     total_pairs = float(npairs.item())
 
     # ---- the same step with the fp32-ranking NN stage, for reference (untimed by the driver) -------
+    # (the comparison runs below are informational: none of them may take the headline line down)
     alt = None
     if args.nn_precision == 1 and not args.no_extras:
-        f.nn_set_precision(0)
-        step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_alt = 0
-        for _ in range(3):
-            n_alt += step()
-        torch.cuda.synchronize()
-        alt = n_alt / (time.perf_counter() - t1)
-        alt_m = state["last"][0]
+        try:
+            f.nn_set_precision(0)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            for _ in range(3):
+                n_alt += step()
+            torch.cuda.synchronize()
+            alt = n_alt / (time.perf_counter() - t1)
+            alt_m = state["last"][0]
+        except Exception as e:
+            print("bench: fp32-ranking comparison run failed: %r" % (e,), file=sys.stderr)
+            alt = None
         f.nn_set_precision(1)
         step()
 
     # ---- the same step with the VALU matcher (xor + popcount; north_star's literal kernel mix), untimed ----
     alt_valu = None
     if os.environ.get("SF_MATCH_MFMA", "1") != "0" and not args.no_extras:
-        f.set_option(_abi.SF_OPT_MATCH_MFMA, 0)
-        step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_alt = 0
-        for _ in range(5):
-            n_alt += step()
-        torch.cuda.synchronize()
-        alt_valu = n_alt / (time.perf_counter() - t1)
-        alt_valu_m = state["last"]
+        try:
+            f.set_option(_abi.SF_OPT_MATCH_MFMA, 0)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            for _ in range(5):
+                n_alt += step()
+            torch.cuda.synchronize()
+            alt_valu = n_alt / (time.perf_counter() - t1)
+        except Exception as e:
+            print("bench: VALU-matcher comparison run failed: %r" % (e,), file=sys.stderr)
+            alt_valu = None
         f.set_option(_abi.SF_OPT_MATCH_MFMA, 1)
         step()
 
