@@ -162,6 +162,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     }
   }
   __syncthreads();
+  SF_TRACE_MARK(P, pair, 8);
 
   int n_finite = 0, n_proj = 0;
   for (int base = 0; base < Kf; base += NT) {
@@ -245,6 +246,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   __syncthreads();
   n_finite = misc[0];
   n_proj = misc[1];
+  SF_TRACE_MARK(P, pair, 9);
 
   // id-ordered compaction
   uint32_t* out = corr + (size_t)pair * kcap;
@@ -314,6 +316,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
       list[pos] = pair;
     }
   }
+  SF_TRACE_MARK(P, pair, 10);
   return survivor;
 }
 

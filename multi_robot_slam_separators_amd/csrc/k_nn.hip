@@ -442,6 +442,18 @@ __global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* m
 
 static int nn_reserve(sf_context* c, NNDb& db, int n_total, int ld) {
   const int cap = std::max(128, (n_total + 127) & ~127);
+  if (ld != db.ld) {
+    // the row pitch changed (sf_nn_reset, then a database of another dimension): the old buffers were sized and
+    // zero-padded for the old pitch.  Only an EMPTY database can change its pitch.
+    if (db.n != 0) return sf_fail(c, SF_EINVAL, "NetVLAD row pitch changed on a non-empty database");
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+    if (db.rows.p) (void)hipFree(db.rows.p);
+    if (db.norms.p) (void)hipFree(db.norms.p);
+    db.rows = Buf(); db.norms = Buf();
+    db.cap = 0;
+    db.ld = ld;
+    db.h_n = -1;
+  }
   if (cap <= db.cap) return SF_OK;
   int newcap = std::max(cap, ((db.cap * 2) + 127) & ~127);
   const size_t old_rows = (size_t)db.cap * ld * 4, old_norms = (size_t)db.cap * 4;
@@ -453,6 +465,28 @@ static int nn_reserve(sf_context* c, NNDb& db, int n_total, int ld) {
   SF_HIP(c, hipMemsetAsync((char*)db.norms.p + old_norms, 0, (size_t)newcap * 4 - old_norms, c->stream));
   db.cap = newcap;
   return SF_OK;
+}
+
+// staging of the per-tick host append: pinned host + device bounce buffers owned by the handle (grow-only).  The
+// caller's rows are copied into the pinned block before the call returns (the pointer is only borrowed), the H2D
+// copy and the cast kernel are asynchronous; the next append waits for `nn_stage_done` before it overwrites the
+// block -- by then (one tick later, find_separators.py:17) the copy has long finished.
+static int nn_stage_reserve(sf_context* c, size_t bytes) {
+  if (c->nn_stage_busy) {
+    SF_HIP(c, hipEventSynchronize(c->nn_stage_done));
+    c->nn_stage_busy = false;
+  }
+  if (!c->nn_stage_done) SF_HIP(c, hipEventCreateWithFlags(&c->nn_stage_done, hipEventDisableTiming));
+  if (bytes > c->nn_stage_pinned_bytes) {
+    if (c->nn_stage_pinned) (void)hipHostFree(c->nn_stage_pinned);
+    c->nn_stage_pinned = nullptr;
+    c->nn_stage_pinned_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 16);
+    if (hipHostMalloc(&c->nn_stage_pinned, want, hipHostMallocDefault) != hipSuccess)
+      return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", want);
+    c->nn_stage_pinned_bytes = want;
+  }
+  return sf_buf_reserve(c, c->nn_stage_dev, std::max<size_t>(bytes, (size_t)1 << 16));
 }
 
 // src_kind 0: host float64 rows ; 1: device float32 rows
@@ -470,15 +504,15 @@ int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int s
   float* dst = (float*)db.rows.p + (size_t)db.n * ld;
   float* nrm = (float*)db.norms.p + db.n;
   if (src_kind == 0) {
-    Buf tmp;
-    if ((rc = sf_buf_reserve(c, tmp, (size_t)n * dim * 8)) != SF_OK) return rc;
-    hipError_t e = hipMemcpyAsync(tmp.p, src, (size_t)n * dim * 8, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_nn_cast_rows, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const double*)tmp.p, dst, nrm, n, dim, ld);
-      e = hipStreamSynchronize(c->stream);
-    }
-    (void)hipFree(tmp.p);
-    if (e != hipSuccess) return sf_fail(c, SF_EHIP, "NN append -> %s", hipGetErrorString(e));
+    const size_t bytes = (size_t)n * dim * 8;
+    if ((rc = nn_stage_reserve(c, bytes)) != SF_OK) return rc;
+    memcpy(c->nn_stage_pinned, src, bytes);
+    SF_HIP(c, hipMemcpyAsync(c->nn_stage_dev.p, c->nn_stage_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_nn_cast_rows, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const double*)c->nn_stage_dev.p, dst,
+                       nrm, n, dim, ld);
+    SF_HIP(c, hipGetLastError());
+    SF_HIP(c, hipEventRecord(c->nn_stage_done, c->stream));
+    c->nn_stage_busy = true;
   } else if (src_kind == 2) {
     hipLaunchKernelGGL(k_nn_copy_rows_f16, dim3((n + 3) / 4), dim3(256), 0, c->stream, (const _Float16*)src, dst, nrm, n, dim, ld);
     SF_HIP(c, hipGetLastError());

@@ -200,7 +200,7 @@ template <int NW = 4>
 __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                             const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                             const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
-                                            const DeviceParams& P, unsigned char* smem_raw) {
+                                            const DeviceParams& P, unsigned char* smem_raw, int trace_base = 2) {
   constexpr int NT = 64 * NW;
   // NW < 4: the live wavefronts are (pair & 3), (pair & 3) + 1, ... mod 4 (k_verify_fused), numbered from 0 here
   const int tid = NW == 4 ? (int)threadIdx.x
@@ -265,6 +265,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     __syncthreads();
   }
 
+  SF_TRACE_MARK(P, pair, trace_base + 0);
   PassState ps;
 #pragma unroll
   for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
@@ -305,6 +306,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   }
 
   if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  SF_TRACE_MARK(P, pair, trace_base + 1);
 
   // ---- hypotheses: one lane each -----------------------------------------------------------------
   const double thr = P.inlier_thr;
@@ -394,6 +396,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     if (L.misc[1]) break;
   }
   if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation
+  SF_TRACE_MARK(P, pair, trace_base + 2);
   const int best_it = L.misc[0];
   if (best_it < 0) {
     if (tid == 0) pass[pair] = ps;
@@ -411,6 +414,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   int n_last = n_inl;
 
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  SF_TRACE_MARK(P, pair, trace_base + 3);
 
   // ---- refine loop (copy of pcl::SampleConsensus::refineModel inside rtabmap) ----------------------
   if (P.refine_iterations > 0) {
@@ -458,6 +462,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   }
 
   if (P.dbg_stop == 5) { if (tid == 0) pass[pair] = ps; return; }
+  SF_TRACE_MARK(P, pair, trace_base + 4);
   if (n_inl >= 3) {
     const double variance = variance_of<NW>(L, m, n_last, tid);
     ps.var = variance;
@@ -484,6 +489,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     }
   }
   if (tid == 0) pass[pair] = ps;
+  SF_TRACE_MARK(P, pair, trace_base + 5);
 }
 
 __global__ void __launch_bounds__(SF_BLOCK, 4)

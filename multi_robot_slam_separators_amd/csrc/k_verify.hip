@@ -40,10 +40,12 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
                uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = blockIdx.x;
+  SF_TRACE_MARK(P, pair, 0);
   // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
   const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
                                                    pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
   __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
+  SF_TRACE_MARK(P, pair, 1);
   if constexpr (CW < 4) {
     // the wavefronts that stay rotate with the pair, so that the chains of a CU spread over its SIMDs
     if ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) >= (unsigned)CW) return;
@@ -61,9 +63,10 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
                                        nullptr, P, reinterpret_cast<int*>(smem_raw));
   __syncthreads();
   if (est2) {
-    ransac_body<CW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    ransac_body<CW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 11);
     __syncthreads();
   }
+  SF_TRACE_MARK(P, pair, 17);
   if ((CW == 4 ? threadIdx.x : ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u))) == 0)
     finalize_one(pair, pass1, pass2, guided_flag, out);
 }

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -354,7 +356,7 @@ static int store_add_host(sf_context* c, Store& st, const sf_features* f, int* o
   if (rc != SF_OK) return rc;
   const int rows = f->rows;
   int cols = f->cols;
-  if (rows == 0 && cols == 0) cols = st.slots > 0 ? 32 : std::max(1, c->params.desc_bytes);
+  if (rows == 0 && cols == 0) cols = st.slots > 0 ? (st.w == 8 ? 32 : 64) : std::max(1, c->params.desc_bytes);
   if ((rc = store_reserve(c, st, st.slots + 1, rows, cols)) != SF_OK) return rc;
   if (st.slots > 0 || rows > 0) {
     // all keyframes of one store share the descriptor width class
@@ -382,22 +384,6 @@ static int store_add_host(sf_context* c, Store& st, const sf_features* f, int* o
   return SF_OK;
 }
 
-struct PinnedBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
-static int pinned_reserve(sf_context* c, PinnedBuf& b, size_t bytes) {
-  if (bytes <= b.bytes) return SF_OK;
-  if (b.p) (void)hipHostFree(b.p);
-  b.p = nullptr;
-  b.bytes = 0;
-  size_t want = bytes + bytes / 2;
-  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
-  if (e != hipSuccess) return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) -> %s", want, hipGetErrorString(e));
-  b.bytes = want;
-  return SF_OK;
-}
-
 // n host keyframes -> consecutive slots.  Features are packed into ONE pinned staging buffer in
 // chunks of a few MB: worker threads pack chunk k+1 while the H2D copy of chunk k is in flight, then
 // ONE ragged ingest launch converts everything (no per-keyframe synchronisation).  Small batches
@@ -411,6 +397,83 @@ static void pack_keyframe(uint8_t* hp, const IngestEntry& e, const sf_features* 
   PackedKp* k = reinterpret_cast<PackedKp*>(hp + e.kp_off);
   const sf_keypoint* src = f->kpts;
   for (int i = 0; i < (int)f->rows; ++i) { k[i].x = src[i].x; k[i].y = src[i].y; k[i].octave = src[i].octave; }
+}
+
+
+// Packing workers of the host-buffer batch ingest: started once per handle (first large batch), parked on a
+// condition variable between batches, joined by sf_destroy.  A batch is cut into chunks; worker t packs the
+// keyframes lo + t, lo + t + workers, ... of every chunk in turn and bumps done[k]; the calling thread ships
+// chunk k to the device as soon as every worker has passed it.
+struct IngestPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_start, cv_idle;
+  uint64_t generation = 0;
+  int running = 0;
+  bool quit = false;
+  // the job of the current generation
+  uint8_t* hp = nullptr;
+  const IngestEntry* tab = nullptr;
+  const sf_features* const* feats = nullptr;
+  const std::pair<size_t, int>* chunks = nullptr;
+  int n_chunks = 0;
+  std::vector<std::atomic<int>> done;
+  std::vector<IngestEntry> tab_storage;
+  std::vector<std::pair<size_t, int>> chunk_storage;
+
+  explicit IngestPool(int workers) : done(0) {
+    for (int t = 0; t < workers; ++t) threads.emplace_back([this, t]() { work(t); });
+  }
+  ~IngestPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv_start.notify_all();
+    for (auto& th : threads) th.join();
+  }
+  void work(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_start.wait(lk, [&] { return quit || generation != seen; });
+        if (quit) return;
+        seen = generation;
+      }
+      const int nw = (int)threads.size();
+      int lo = 0;
+      for (int k = 0; k < n_chunks; ++k) {
+        const int hi = chunks[k].second;
+        for (int i = lo + t; i < hi; i += nw) pack_keyframe(hp, tab[i], feats[i]);
+        done[k].fetch_add(1, std::memory_order_release);
+        lo = hi;
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--running == 0) cv_idle.notify_all();
+      }
+    }
+  }
+  void start() {
+    if ((int)done.size() < n_chunks) done = std::vector<std::atomic<int>>(n_chunks);
+    for (int k = 0; k < n_chunks; ++k) done[k].store(0, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      running = (int)threads.size();
+      ++generation;
+    }
+    cv_start.notify_all();
+  }
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_idle.wait(lk, [&] { return running == 0; });
+  }
+};
+
+void sf_ingest_pool_destroy(sf_context* c) {
+  delete c->ingest_pool;
+  c->ingest_pool = nullptr;
 }
 
 static int store_add_host_batch(sf_context* c, Store& st, const sf_features* const* feats, int n, int* first_slot) {
@@ -430,8 +493,11 @@ static int store_add_host_batch(sf_context* c, Store& st, const sf_features* con
   if ((rc = store_reserve(c, st, st.slots + n, max_rows, cols)) != SF_OK) return rc;
 
   // layout: [table][keyframe 0: desc | xyz | kp][keyframe 1 ...], chunk boundaries every ~4 MB
-  static thread_local std::vector<IngestEntry> tab;
-  static thread_local std::vector<std::pair<size_t, int>> chunks;   // (end offset, end keyframe)
+  // (table / chunk scratch lives in the pool object when there is one, else on this call's stack vectors)
+  std::vector<IngestEntry> tab_local;
+  std::vector<std::pair<size_t, int>> chunks_local;   // (end offset, end keyframe)
+  std::vector<IngestEntry>& tab = c->ingest_pool ? c->ingest_pool->tab_storage : tab_local;
+  std::vector<std::pair<size_t, int>>& chunks = c->ingest_pool ? c->ingest_pool->chunk_storage : chunks_local;
   tab.resize(n);
   chunks.clear();
   const size_t tb = pad16((size_t)n * sizeof(IngestEntry));
@@ -447,10 +513,18 @@ static int store_add_host_batch(sf_context* c, Store& st, const sf_features* con
     if (off - chunk_start >= chunk_bytes || i == n - 1) { chunks.push_back({off, i + 1}); chunk_start = off; }
   }
   const size_t total = off;
-  static thread_local PinnedBuf pin;   // host staging (process lifetime)
-  if ((rc = pinned_reserve(c, pin, total)) != SF_OK) return rc;
+  // pinned host staging owned by the handle (released by sf_destroy)
+  if (total > c->ingest_pinned_bytes) {
+    if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
+    c->ingest_pinned = nullptr;
+    c->ingest_pinned_bytes = 0;
+    const size_t want = total + total / 2;
+    hipError_t e = hipHostMalloc(&c->ingest_pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) -> %s", want, hipGetErrorString(e));
+    c->ingest_pinned_bytes = want;
+  }
   if ((rc = sf_buf_reserve(c, c->stage_desc, total)) != SF_OK) return rc;
-  uint8_t* hp = (uint8_t*)pin.p;
+  uint8_t* hp = (uint8_t*)c->ingest_pinned;
   uint8_t* dp = (uint8_t*)c->stage_desc.p;
   memcpy(hp, tab.data(), (size_t)n * sizeof(IngestEntry));
 
@@ -462,32 +536,28 @@ static int store_add_host_batch(sf_context* c, Store& st, const sf_features* con
     for (int i = 0; i < n; ++i) pack_keyframe(hp, tab[i], feats[i]);
     herr = hipMemcpyAsync(dp, hp, total, hipMemcpyHostToDevice, c->stream);
   } else {
-    // done[k] counts the workers that finished their share of chunk k
-    std::vector<std::atomic<int>> done(n_chunks);
-    for (auto& d : done) d.store(0, std::memory_order_relaxed);
-    const IngestEntry* tabp = tab.data();
-    const std::pair<size_t, int>* chp = chunks.data();
-    std::vector<std::thread> pool;
-    pool.reserve(workers);
-    for (int t = 0; t < workers; ++t) {
-      pool.emplace_back([=, &done]() {
-        int lo = 0;
-        for (int k = 0; k < n_chunks; ++k) {
-          const int hi = chp[k].second;
-          for (int i = lo + t; i < hi; i += workers) pack_keyframe(hp, tabp[i], feats[i]);
-          done[k].fetch_add(1, std::memory_order_release);
-          lo = hi;
-        }
-      });
+    if (!c->ingest_pool) {
+      // first large batch of this handle: start the workers, and move the table / chunk lists into the pool
+      c->ingest_pool = new IngestPool(workers);
+      c->ingest_pool->tab_storage.swap(tab_local);
+      c->ingest_pool->chunk_storage.swap(chunks_local);
     }
+    IngestPool& pool = *c->ingest_pool;
+    pool.hp = hp;
+    pool.tab = pool.tab_storage.data();
+    pool.feats = feats;
+    pool.chunks = pool.chunk_storage.data();
+    pool.n_chunks = n_chunks;
+    pool.start();
+    const int nw = (int)pool.threads.size();
     size_t sent = 0;
     for (int k = 0; k < n_chunks; ++k) {
-      while (done[k].load(std::memory_order_acquire) < workers) std::this_thread::yield();
-      const size_t end = chunks[k].first;
+      while (pool.done[k].load(std::memory_order_acquire) < nw) std::this_thread::yield();
+      const size_t end = pool.chunk_storage[k].first;
       if (herr == hipSuccess) herr = hipMemcpyAsync(dp + sent, hp + sent, end - sent, hipMemcpyHostToDevice, c->stream);
       sent = end;
     }
-    for (auto& th : pool) th.join();
+    pool.wait_idle();
   }
   if (herr != hipSuccess) return sf_fail(c, SF_EHIP, "staging H2D copy -> %s", hipGetErrorString(herr));
   hipLaunchKernelGGL(k_ingest_ragged, dim3(n), dim3(SF_BLOCK), 0, c->stream, (uint32_t*)st.desc.p, (float*)st.xyz.p,
@@ -640,8 +710,13 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
-                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
   for (Buf* b : bufs) buf_free(*b);
+  sf_ingest_pool_destroy(c);
+  if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
+  if (c->nn_stage_pinned) (void)hipHostFree(c->nn_stage_pinned);
+  if (c->nn_stage_done) (void)hipEventDestroy(c->nn_stage_done);
+  buf_free(c->nn_stage_dev);
   if (c->nn_pinned) (void)hipHostFree(c->nn_pinned);
   if (c->pairs_pinned) (void)hipHostFree(c->pairs_pinned);
   if (c->count_pinned) (void)hipHostFree(c->count_pinned);
@@ -658,6 +733,16 @@ extern "C" void sf_destroy(sf_handle c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+
+#ifdef SF_CHAIN_TRACE
+// diagnostic build only: phase timestamps of the last verification ([n][32] uint64, 100 MHz ticks)
+extern "C" int sf_debug_chain_trace(sf_handle c, unsigned long long* out, int32_t n) {
+  if (!c || !out || n < 0 || n > c->ws_pairs) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  SF_HIP(c, hipMemcpy(out, c->trace.p, (size_t)n * 32 * 8, hipMemcpyDeviceToHost));
+  return SF_OK;
+}
+#endif
 
 extern "C" const char* sf_last_error(sf_handle c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
@@ -730,6 +815,11 @@ static int ws_reserve(sf_context* c, int n, int kcap) {
   if ((rc = sf_buf_reserve(c, c->list1, np * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->list3, np * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->flags, np)) != SF_OK) return rc;
+#ifdef SF_CHAIN_TRACE
+  if ((rc = sf_buf_reserve(c, c->trace, np * 32 * 8)) != SF_OK) return rc;
+  SF_HIP(c, hipMemsetAsync(c->trace.p, 0, np * 32 * 8, c->stream));
+  c->dparams.dbg_trace = (unsigned long long*)c->trace.p;
+#endif
   c->ws_pairs = n;
   c->ws_kcap = kcap;
   return SF_OK;
@@ -1228,10 +1318,15 @@ extern "C" int sf_nn_ignore_pair(sf_handle c, int32_t il, int32_t io) {
 extern "C" int sf_nn_reset(sf_handle c) {
   if (!c) return SF_EINVAL;
   SF_HIP(c, hipStreamSynchronize(c->stream));
-  c->nn_local.n = 0;
-  c->nn_recv.n = 0;
-  c->nn_local.h_n = -1;
-  c->nn_recv.h_n = -1;
+  // the row buffers are sized, pitched and zero-padded for the old dimension: release them, the next append
+  // re-allocates for its own (nn_reserve); the fp16 copies and cached filter coefficients go with them
+  for (NNDb* db : {&c->nn_local, &c->nn_recv}) {
+    buf_free(db->rows); buf_free(db->norms); buf_free(db->rows_h); buf_free(db->norms_k);
+    db->n = 0; db->cap = 0; db->ld = 0; db->h_n = -1; db->h_ld = 0; db->h_kprefix = 0;
+  }
+  c->nn_coef_level = -1;
+  c->nn_level = 0;
+  c->nn_level_cooldown = 32;
   c->nn_dim = 0;
   c->mask_local.clear();
   c->mask_other.clear();

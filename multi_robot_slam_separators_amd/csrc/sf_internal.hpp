@@ -67,7 +67,19 @@ struct DeviceParams {
   float pnp_thr2f;            // (float)(pnp_reproj_error^2)
   float pnp_reproj_error;
   int32_t pnp_refine_iterations;
+  unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][32] timestamps; else null
 };
+
+// Phase timestamps of the fused kernel's chain (diagnostic build -DSF_CHAIN_TRACE, libsepfinder_trace.so; the product
+// build compiles these to nothing): thread 0 of the pair's workgroup stores the 100 MHz wall clock.
+#ifdef SF_CHAIN_TRACE
+#define SF_TRACE_MARK(P, pair, slot)                                                              \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && (P).dbg_trace) (P).dbg_trace[(size_t)(pair) * 32 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define SF_TRACE_MARK(P, pair, slot) do { } while (0)
+#endif
 
 struct Buf {
   void* p = nullptr;
@@ -84,6 +96,7 @@ struct NNDb {
   Buf norms;       // float32 [cap]
   Buf rows_h;      // fp16 [cap][dim] (nn_precision == 1)
   int n = 0, cap = 0;
+  int ld = 0;      // row pitch (floats) `rows` was allocated and zero-padded for; a change re-allocates (nn_reserve)
   Buf norms_k;     // float32 [cap] squared norm of the first h_kprefix elements (filter stage)
   int h_n = -1, h_ld = 0, h_kprefix = 0;   // rows / pitch / prefix covered by the fp16 copy
   float h_scale = 1.f;      // power-of-two scale applied before the fp16 conversion
@@ -106,6 +119,18 @@ struct sf_context {
   Store store;        // persistent keyframes
   Store scratch;      // staging slots for host-buffer calls
   Buf stage_desc, stage_xyz, stage_kp;   // H2D bounce buffers of the host-buffer ingest path
+  // host-buffer batch ingest (store_add_host_batch): pinned staging, table scratch and the packing workers all
+  // belong to the handle and end with it (sf_destroy)
+  void* ingest_pinned = nullptr;
+  size_t ingest_pinned_bytes = 0;
+  struct IngestPool* ingest_pool = nullptr;
+  // per-tick NetVLAD append from host float64 rows (sf_nn_append): grow-only pinned + device staging, re-used once
+  // the previous append's copy has left it (nn_stage_done), so the path neither allocates nor synchronises
+  void* nn_stage_pinned = nullptr;
+  size_t nn_stage_pinned_bytes = 0;
+  Buf nn_stage_dev;
+  hipEvent_t nn_stage_done = nullptr;
+  bool nn_stage_busy = false;
 
   // verification workspace (sized for `ws_pairs` pairs)
   int ws_pairs = 0, ws_kcap = 0;
@@ -117,6 +142,7 @@ struct sf_context {
   Buf counters;                 // int32[8]
   Buf results;                  // sf_result[n]
   Buf flags;                    // uint8[n] pass2_guided
+  Buf trace;                    // SF_CHAIN_TRACE builds: uint64[n][32] phase timestamps of the fused kernel
 
   // NN stage
   NNDb nn_local, nn_recv;

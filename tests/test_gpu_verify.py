@@ -653,3 +653,44 @@ def test_verify_matches_and_compaction_entry_points(finder):
         m_bad = m.copy(); m_bad["idx_other"][0] = 10_000
         finder.verify_matches_device(m_bad, sa, sb, d_res.data_ptr())
     finder.store_clear()
+
+
+def test_empty_keyframe_on_a_512_bit_store(oracle):
+    """Featureless frames exist in the reference (no corners -> rows = cols = 0).  On a store of 64-byte
+    descriptors the per-tick sf_store_add_keyframe used to default such a frame to the 32-byte width class and
+    reject it; both ingest paths must accept it and verify it as the oracle does."""
+    from multi_robot_slam_separators_amd import lib
+    rng = np.random.default_rng(77)
+    p = synth.camera_params()
+    p.desc_bytes = 64
+    a = synth.make_keyframe(rng, 120, cols=64)
+    empty = _abi.FeatureArrays(np.zeros((0, 0), np.uint8), np.zeros((0, 3), np.float32),
+                               np.zeros(0, _abi.KEYPOINT_DTYPE))
+    with lib.SeparatorFinder(p) as f:
+        s0 = f.store_add_keyframe(a)
+        s1 = f.store_add_keyframe(empty)       # per-tick path (one keyframe per call)
+        s2 = f.store_add_keyframe(a)
+        got = f.verify_pairs([s0, s1, s0], [s1, s0, s2])
+        assert got[2]["success"] == 1
+        for g, (x, y) in zip(got, [(a, empty), (empty, a), (a, a)]):
+            assert_result_parity(g, oracle.estimate_transform(p, x, y))
+        got_b = f.estimate_transform_batch([a, empty], [empty, a])   # batch path
+        assert got_b[0].tobytes() == got[0].tobytes() and got_b[1].tobytes() == got[1].tobytes()
+
+
+def test_host_batch_ingest_reuses_its_pool():
+    """Several large host-buffer batches through one handle (the packing workers and the pinned staging belong to the
+    handle and are re-used), interleaved with small ones; results must not depend on the batch they travelled in."""
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = 100
+    A, B, is_true, _ = synth.make_pairs(4242, 160, k=500, cols=32, true_frac=0.3)
+    with lib.SeparatorFinder(p) as f:
+        ref = f.estimate_transform_batch(A, B)          # > 4 MB of staged features: the worker pool starts
+        again = f.estimate_transform_batch(A, B)        # ... and is re-used
+        small = f.estimate_transform_batch(A[:3], B[:3])   # inline packing on the calling thread
+        rev = f.estimate_transform_batch(A[::-1], B[::-1])
+    assert ref.tobytes() == again.tobytes()
+    assert small.tobytes() == ref[:3].tobytes()
+    assert rev[::-1].tobytes() == ref.tobytes()
+    assert ref["success"][is_true].all()

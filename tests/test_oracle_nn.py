@@ -1,16 +1,36 @@
-"""Pins the oracle's NN stage against the golden vectors produced by scipy.cdist + numpy.argsort
-driven through data_handler.py:168-205 (oracle/gen_golden.py)."""
+"""Pins the oracle's NN stage against golden vectors produced by EXECUTING the reference's own functions
+(data_handler.py:166-209 find_matches, :297-328 find_matches_service, :373-408 the mask bookkeeping of
+receive_separators_service) on seeded inputs in the build container (oracle/gen_golden.py, oracle/ref_exec.py)."""
 import glob
 import os
 
 import numpy as np
 import pytest
 
+import ref_session
+
 CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nn_*.npz")))
 
 
 def test_golden_present():
-    assert len(CASES) >= 9
+    assert len(CASES) >= 11
+    assert len(ref_session.SESSIONS) >= 3
+
+
+@pytest.mark.parametrize("path", ref_session.SESSIONS, ids=[os.path.basename(p)[:-4] for p in ref_session.SESSIONS])
+def test_oracle_replays_the_reference_sessions(path):
+    """Multi-tick sessions recorded from the reference's find_matches_service + receive_separators_service: the
+    oracle behind the raw backend calls, and behind this repository's DataHandler mirror, returns the reference's
+    matches, keyframe ids and mask state at every tick."""
+    from multi_robot_slam_separators_amd import _abi
+    from oracle_backend import OracleBackend
+    g = np.load(path)
+    p = _abi.default_params()
+    p.netvlad_distance = float(g["netvlad_distance"])
+    p.netvlad_max_matches_nb = int(g["max_matches_nb"])
+    p.netvlad_dimensions = int(g["dim"])
+    ref_session.replay_backend(g, OracleBackend(p))
+    ref_session.replay_mirror(g, OracleBackend(p))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
