@@ -175,23 +175,34 @@ k_nn_argmin(const float* __restrict__ A, const float* __restrict__ B, const floa
       const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
       const float nai = na[row];
       const int ip0 = ign_ptr[row], ip1 = ign_ptr[row + 1];
-      unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
+      // best and second-best key of this row over the strip's 64 columns (k_nn_select re-evaluates both in
+      // float64 when they are closer than the error of this fp32 expansion)
+      unsigned long long best = 0xFFFFFFFFFFFFFFFFull, second = 0xFFFFFFFFFFFFFFFFull;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         float d2 = (nai + nbj[j]) - 2.f * acc[i][j][r];
-        d2 = d2 > 0.f ? d2 : 0.f;   // also maps -0 and tiny negative cancellation to +0
+        // -0 and tiny negative cancellation -> +0; NaN (a non-finite input) -> +inf: cdist reports NaN there
+        // and numpy's argsort puts NaN last, so such a column can never be a row minimum
+        d2 = d2 > 0.f ? d2 : (d2 == d2 ? 0.f : __int_as_float(0x7F800000));
         for (int e = ip0; e < ip1; ++e)
           if (ign_col[e] == colj[j]) d2 = __int_as_float(0x7F800000);
         const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)colj[j];
+        second = key < best ? best : (key < second ? key : second);
         best = key < best ? key : best;
       }
-      // min across the 32 lanes that hold this row (same lane>>5)
+      // merge across the 32 lanes that hold this row (same lane>>5): the two smallest of the union
 #pragma unroll
       for (int off = 16; off >= 1; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off);
-        best = o < best ? o : best;
+        const unsigned long long ob = __shfl_xor(best, off), os = __shfl_xor(second, off);
+        const unsigned long long hi = ob < best ? best : ob;         // the larger of the two bests
+        const unsigned long long lo2 = os < second ? os : second;    // the smaller of the two seconds
+        best = ob < best ? ob : best;
+        second = hi < lo2 ? hi : lo2;
       }
-      if (l31 == 0) part[(size_t)strip * n_l_pad + row] = best;
+      if (l31 == 0) {
+        part[((size_t)strip * n_l_pad + row) * 2] = best;
+        part[((size_t)strip * n_l_pad + row) * 2 + 1] = second;
+      }
     }
   }
 }
@@ -218,33 +229,79 @@ __device__ __forceinline__ double nn_exact_sq_dist(const float* __restrict__ a, 
   return s;
 }
 
-// one wavefront per local row: reduce strips, re-evaluate in float64, apply row mask
+// One wavefront per local row: reduce the strips' keys, re-evaluate in float64, apply the row mask.
+//
+// The keys rank columns on the fp32 expansion |a|^2 + |b|^2 - 2 a.b, whose error is up to
+// E = (ld + 8) 2^-24 (|a|^2 + max_j |b_j|^2) (ld-term fp32 dot product + the rounding of norms and sums), so a
+// column whose true distance is the smallest may carry a key up to 2 E above the smallest key.  Every column
+// that can be the true minimum is therefore re-evaluated exactly (float64, cdist's direct form) and the smallest
+// exact distance wins, ties to the lowest column like a stable arg-min: a strip's best key when it lies within
+// the band, and ALL 64 columns of a strip whose SECOND key lies within it (a third could hide behind it).
+// With well-separated rows this is one evaluation per row, as before.
 __global__ void __launch_bounds__(256)
 k_nn_select(const unsigned long long* __restrict__ part, int n_strips, int n_l, int n_l_pad,
             const float* __restrict__ A, const float* __restrict__ B, int dim, int ld,
-            const uint8_t* __restrict__ mask_local, double* __restrict__ out_dist, int* __restrict__ out_idx) {
+            const uint8_t* __restrict__ mask_local, const float* __restrict__ na, const float* __restrict__ nb_eff,
+            const unsigned* __restrict__ nb_max_bits, const int* __restrict__ ign_ptr,
+            const int* __restrict__ ign_col, int n_r, double* __restrict__ out_dist, int* __restrict__ out_idx) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_l) return;
   unsigned long long best = 0xFFFFFFFFFFFFFFFFull;
   for (int s = lane; s < n_strips; s += 64) {
-    const unsigned long long k = part[(size_t)s * n_l_pad + row];
+    const unsigned long long k = part[((size_t)s * n_l_pad + row) * 2];
     best = k < best ? k : best;
   }
   for (int off = 32; off >= 1; off >>= 1) {
     const unsigned long long o = __shfl_xor(best, off);
     best = o < best ? o : best;
   }
-  const int j = (int)(best & 0xFFFFFFFFu);
-  const bool finite = ((unsigned)(best >> 32) < 0x7F800000u) && !mask_local[row];
-  double s = 0.0;
+  const unsigned best_bits = (unsigned)(best >> 32);
+  const bool finite = (best_bits < 0x7F800000u) && !mask_local[row];
+  double bd = (double)INFINITY;
+  int bj = (int)(best & 0xFFFFFFFFu);
   if (finite) {
-    s = nn_exact_sq_dist(A + (size_t)row * ld, B + (size_t)j * ld, ld, lane);
+    const float E = (float)(ld + 8) * 5.9604645e-08f * (na[row] + __uint_as_float(*nb_max_bits));
+    const float bound = __uint_as_float(best_bits) + 2.f * E;    // keys above it cannot be the true minimum
+    const float* a = A + (size_t)row * ld;
+    const int ip0 = ign_ptr[row], ip1 = ign_ptr[row + 1];
+    bj = 0x7FFFFFFF;
+    auto consider = [&](int j) {   // wave-uniform j
+      const double d = nn_exact_sq_dist(a, B + (size_t)j * ld, ld, lane);
+      if (d < bd || (d == bd && j < bj)) { bd = d; bj = j; }
+    };
+    for (int s0 = 0; s0 < n_strips; s0 += 64) {
+      const int s = s0 + lane;
+      unsigned long long k1 = 0xFFFFFFFFFFFFFFFFull, k2 = 0xFFFFFFFFFFFFFFFFull;
+      if (s < n_strips) {
+        k1 = part[((size_t)s * n_l_pad + row) * 2];
+        k2 = part[((size_t)s * n_l_pad + row) * 2 + 1];
+      }
+      const bool in1 = (unsigned)(k1 >> 32) < 0x7F800000u && __uint_as_float((unsigned)(k1 >> 32)) <= bound;
+      const bool in2 = (unsigned)(k2 >> 32) < 0x7F800000u && __uint_as_float((unsigned)(k2 >> 32)) <= bound;
+      unsigned long long m1 = __ballot(in1 && !in2), m2 = __ballot(in2);
+      while (m1) {                                   // strips with ONE column in the band
+        const int l = __ffsll((long long)m1) - 1;
+        m1 &= m1 - 1;
+        consider((int)(__shfl(k1, l) & 0xFFFFFFFFu));
+      }
+      while (m2) {                                   // strips with two (or possibly more): all 64 columns
+        const int l = __ffsll((long long)m2) - 1;
+        m2 &= m2 - 1;
+        const int c0 = (s0 + l) * 64;
+        for (int j = c0; j < c0 + 64 && j < n_r; ++j) {
+          bool skip = !(nb_eff[j] < __int_as_float(0x7F800000));       // masked column
+          for (int e = ip0; e < ip1 && !skip; ++e) skip = ign_col[e] == j;   // ignored pair
+          if (!skip) consider(j);
+        }
+      }
+    }
   }
   if (lane == 0) {
-    out_dist[row] = finite ? sqrt(s) : (double)INFINITY;
+    const bool got = finite && bj != 0x7FFFFFFF;
+    out_dist[row] = got ? sqrt(bd) : (double)INFINITY;
     // an all-inf row has no meaningful arg-min (numpy returns an unspecified index there)
-    out_idx[row] = ((unsigned)(best >> 32) < 0x7F800000u) ? j : 0;
+    out_idx[row] = (best_bits < 0x7F800000u) ? (got ? bj : (int)(best & 0xFFFFFFFFu)) : 0;
   }
 }
 
@@ -432,10 +489,19 @@ k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, 
   }
 }
 
-__global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad) {
+// nb_eff[j] = |b_j|^2, +inf for masked / padding columns; *nb_max_bits = the largest finite one (bit pattern; the
+// error band of k_nn_select).  The caller zeroes *nb_max_bits.
+__global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad,
+                                unsigned* nb_max_bits) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_r_pad) return;
-  nb_eff[j] = (j < n_r && !mask_other[j]) ? nb[j] : __int_as_float(0x7F800000);
+  float v = 0.f;
+  if (j < n_r_pad) {
+    const bool live = j < n_r && !mask_other[j];
+    nb_eff[j] = live ? nb[j] : __int_as_float(0x7F800000);
+    if (live && nb[j] < __int_as_float(0x7F800000)) v = nb[j];     // (false for NaN)
+  }
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(nb_max_bits, __float_as_uint(v));
 }
 
 }  // namespace
@@ -838,7 +904,10 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   c->last_row_cand.clear();
   c->nn_coef_level = -1;   // the exact path re-uses the coefficient buffer for its partial minima
   // workspace: partial minima, effective column norms, per-row results
-  const size_t part_bytes = (size_t)n_strips * n_l_pad * 8;
+  const size_t part_bytes = (size_t)n_strips * n_l_pad * 16;   // best + second-best key per (strip, row)
+  if ((rc = sf_buf_reserve(c, c->nn_scalar, 64)) != SF_OK) return rc;
+  unsigned* nb_max_bits = (unsigned*)((char*)c->nn_scalar.p + 16);
+  SF_HIP(c, hipMemsetAsync(nb_max_bits, 0, 4, c->stream));
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, part_bytes + (size_t)n_r_pad * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->nn_exact, (size_t)n_l * 12)) != SF_OK) return rc;
   unsigned long long* part = (unsigned long long*)c->nn_rowmin.p;
@@ -847,7 +916,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   int* d_idx = (int*)((char*)c->nn_exact.p + (size_t)n_l * 8);
 
   hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
-                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad);
+                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad, nb_max_bits);
   sf_prof_begin(c, SF_K_NN);
   hipLaunchKernelGGL(k_nn_argmin, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                      (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p,
@@ -857,7 +926,8 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   sf_prof_begin(c, SF_K_NN_SELECT);
   hipLaunchKernelGGL(k_nn_select, dim3((n_l + 3) / 4), dim3(256), 0, c->stream, part, n_strips, n_l, n_l_pad,
                      (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld,
-                     (const uint8_t*)c->d_mask_local.p, d_dist, d_idx);
+                     (const uint8_t*)c->d_mask_local.p, (const float*)c->nn_local.norms.p, nb_eff, nb_max_bits,
+                     (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_r, d_dist, d_idx);
   sf_prof_end(c, SF_K_NN_SELECT);
   SF_HIP(c, hipGetLastError());
 
