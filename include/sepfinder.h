@@ -253,7 +253,8 @@ int  sf_compact_accepted_device_async(sf_handle h, const sf_result* d_results, i
                                       uint8_t* d_flags, int32_t* d_n_accepted);
 /* Correspondences found by the two matching passes of the LAST verify call for pair `i`
    (tests / diagnostics): pairs (from_feature, to_feature), ascending from_feature.  Calls with more
-   than 131072 pairs are processed in chunks; `pair` then indexes the LAST chunk.                 */
+   than 131072 pairs are processed in chunks; `pair` then indexes the LAST chunk.  Needs SF_OPT_DEBUG_CORR
+   set BEFORE that verify call (SF_EINVAL otherwise) when the fused kernel ran it.                  */
 int  sf_debug_correspondences(sf_handle h, int32_t pair, int32_t pass, uint16_t* from_idx,
                               uint16_t* to_idx, int32_t cap, int32_t* n_out);
 
@@ -312,8 +313,10 @@ enum {
   SF_OPT_MATCH_MFMA = 0,  /* 1 (default): Hamming table on the fp4 matrix cores; 0: xor + popcount on the VALU   */
   SF_OPT_FUSED = 1,       /* 1 (default): one fused launch per chunk (3D-3D estimator); 0: the stage kernels     */
   SF_OPT_OVERLAP = 2,     /* 1: batches >= 4096 pairs as two halves on two streams; 0 (default): one stream     */
-  SF_OPT_CHAIN_WAVES = 3  /* fused kernel: 4 (default) = the whole workgroup runs a surviving pair's motion-
-                             estimation chain; 1 / 2 = that many wavefronts do, the others end after matching  */
+  SF_OPT_CHAIN_WAVES = 3, /* round 1's narrower motion-estimation chains (measured slower, removed): accepted, no effect */
+  SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
+                             to the global workspace, which sf_debug_correspondences reads (default 0: they never
+                             leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */
 };
 int  sf_set_option(sf_handle h, int32_t option, int32_t value);
 

@@ -23,23 +23,18 @@ namespace {
 
 // Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
-// NW = 4: the 256-thread workgroup; NW = 1: one wavefront alone (single-wavefront chains, k_verify.hip); the
-// stage is integer work with index-ordered outputs, so only the strides and the cross-wave offsets change.
-template <int W, int NW = 4>
-__device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
-                                            const int32_t* __restrict__ pair_to, const PassState* __restrict__ pass1,
-                                            PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
-                                            uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
-                                            int32_t* __restrict__ list, int32_t* __restrict__ counter,
-                                            const DeviceParams& P, int* smem) {
-  constexpr int NT = 64 * NW;
-  // NW < 4: the live wavefronts are (pair & 3), (pair & 3) + 1, ... mod 4 (k_verify_fused), numbered from 0 here
-  const int tid = NW == 4 ? (int)threadIdx.x
-                          : (int)((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u));
+// `out` / hdr_out / pass2_out / guided_flag_out: the pair's pass-2 correspondence list, header, state and flag
+// (global arrays in the stage kernel, LDS in the fused kernel).
+template <int W>
+__device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int sF, int sT, const PassState& pass1,
+                                            PassState& pass2_out, uint8_t& guided_flag_out, uint32_t* out,
+                                            CorrHeader& hdr_out, int32_t* __restrict__ list,
+                                            int32_t* __restrict__ counter, const DeviceParams& P, int* smem) {
+  constexpr int NW = 4, NT = 64 * NW;
+  const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const int sF = pair_from[pair], sT = pair_to[pair];
-  const PassState p1 = pass1[pair];
+  const PassState p1 = pass1;
   const bool bad_slot = (unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots;
   const int4 mF = bad_slot ? make_int4(0, 0, 0, 0) : st.meta[sF];
   const int4 mT = bad_slot ? make_int4(0, 0, 0, 0) : st.meta[sT];
@@ -52,10 +47,10 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   const bool eligible = !p1.is_null && !ident && P.guess_win > 0 && mF.y > 0 && P.calibrated && Kf > 0 && Kt > 0;
   if (!eligible) {
     if (tid == 0) {
-      pass2[pair] = p1;
-      guided_flag[pair] = 0;
+      pass2_out = p1;
+      guided_flag_out = 0;
       CorrHeader h = {0, 0, 0, 0};
-      hdr[pair] = h;
+      hdr_out = h;
     }
     return false;
   }
@@ -249,7 +244,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
   SF_TRACE_MARK(P, pair, 9);
 
   // id-ordered compaction
-  uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
   for (int base = 0; base < Kf; base += NT) {
     const int i = base + tid;
@@ -300,8 +294,8 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     h.words_from = words_from;
     h.words_to = words_to;
     h.words_to_2d = words_to_2d;
-    hdr[pair] = h;
-    guided_flag[pair] = 1;
+    hdr_out = h;
+    guided_flag_out = 1;
     PassState ps;
 #pragma unroll
     for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
@@ -310,7 +304,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, const
     ps.inliers = 0;
     ps.matches = (motion && !survivor) ? misc[2] : 0;
     ps.pad = 0;
-    pass2[pair] = ps;
+    pass2_out = ps;
     if (survivor && list) {
       int pos = atomicAdd(counter, 1);
       list[pos] = pair;
@@ -327,14 +321,15 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
          uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr, int32_t* __restrict__ list,
          int32_t* __restrict__ counter, DeviceParams P) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
-  guided_body<W, 4>(st, (int)blockIdx.x, pair_from, pair_to, pass1, pass2, guided_flag, corr, hdr, list, counter, P, smem);
+  const int pair = (int)blockIdx.x;
+  guided_body<W>(st, pair, pair_from[pair], pair_to[pair], pass1[pair], pass2[pair], guided_flag[pair],
+                 corr + (size_t)pair * st.kcap, hdr[pair], list, counter, P, smem);
 }
 
 // ---- result assembly: myRegistration.cpp:279-295 covariance clamp + MsgConversion.cpp:61-81 ------
-__device__ __forceinline__ void finalize_one(int i, const PassState* __restrict__ pass1,
-                                             const PassState* __restrict__ pass2,
-                                             const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
-  const PassState a = pass1[i], b = pass2[i];
+__device__ __forceinline__ void finalize_one(const PassState& pass1, const PassState& pass2, uint8_t guided_flag,
+                                             sf_result& out) {
+  const PassState a = pass1, b = pass2;
   sf_result r;
 #pragma unroll
   for (int k = 0; k < 3; ++k) r.position[k] = 0.0;
@@ -353,7 +348,7 @@ __device__ __forceinline__ void finalize_one(int i, const PassState* __restrict_
   r.matches_pass1 = a.matches;
   r.success = b.is_null ? 0 : 1;
   r.pass1_success = a.is_null ? 0 : 1;
-  r.pass2_guided = guided_flag[i];
+  r.pass2_guided = guided_flag;
 #pragma unroll
   for (int k = 0; k < 5; ++k) r.pad[k] = 0;
   if (!b.is_null) {
@@ -399,7 +394,7 @@ __device__ __forceinline__ void finalize_one(int i, const PassState* __restrict_
     if (w < 0.0) { x = -x; y = -y; z = -z; w = -w; }
     r.orientation[0] = x; r.orientation[1] = y; r.orientation[2] = z; r.orientation[3] = w;
   }
-  out[i] = r;
+  out = r;
 }
 
 __global__ void __launch_bounds__(SF_BLOCK)
@@ -407,7 +402,7 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
            const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out) {
   const int i = blockIdx.x * SF_BLOCK + threadIdx.x;
   if (i >= n) return;
-  finalize_one(i, pass1, pass2, guided_flag, out);
+  finalize_one(pass1[i], pass2[i], guided_flag[i], out[i]);
 }
 
 }  // namespace

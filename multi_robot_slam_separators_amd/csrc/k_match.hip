@@ -451,26 +451,26 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 // Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
 // LDS.  Returns whether the pair goes on to motion estimation (block-uniform).  With list == nullptr
 // the pair is not appended to a work list (fused pipeline, k_verify.hip).
+// `out` = the pair's correspondence list (kcap entries; global in the stage kernels, LDS -- it may alias the
+// staged "from" block, which is dead by the time the list is written -- in the fused kernel); hdr_out / pass_out
+// = the pair's header and pass-1 state (same two homes).
 template <int W, int NQ, int NT, int MF_NTL = 2>
-__device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
-                                              const int32_t* __restrict__ pair_to, float nndr, int min_inliers, int est,
-                                              uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
-                                              PassState* __restrict__ pass, int32_t* __restrict__ list,
-                                              int32_t* __restrict__ counter, int* smem) {
+__device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int sF, int sT, float nndr, int min_inliers,
+                                              int est, uint32_t* out, CorrHeader& hdr_out, PassState& pass_out,
+                                              int32_t* __restrict__ list, int32_t* __restrict__ counter, int* smem) {
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const int sF = pair_from[pair], sT = pair_to[pair];
   if ((unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots) {
     if (tid == 0) {
       CorrHeader h = {0, 0, 0, 0};
-      hdr[pair] = h;
+      hdr_out = h;
       PassState ps;
 #pragma unroll
       for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
       ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
-      pass[pair] = ps;
+      pass_out = ps;
     }
     return false;
   }
@@ -589,7 +589,6 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, con
   if (lane == 0 && rejected) atomicAdd(&misc[0], rejected);
   __syncthreads();
 
-  uint32_t* out = corr + (size_t)pair * kcap;
   int running = 0;
   for (int base = 0; base < Kf; base += NT) {
     const int f = base + tid;
@@ -640,7 +639,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, con
     h.words_from = words_from;
     h.words_to = words_to;
     h.words_to_2d = unique_to;
-    hdr[pair] = h;
+    hdr_out = h;
     PassState ps;
 #pragma unroll
     for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
@@ -649,7 +648,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, con
     ps.inliers = 0;
     ps.matches = (motion && !survivor) ? misc[2] : 0;
     ps.pad = 0;
-    pass[pair] = ps;
+    pass_out = ps;
     if (survivor && list) {
       int pos = atomicAdd(counter, 1);
       list[pos] = pair;
@@ -664,8 +663,9 @@ k_match_global_v2(StoreView st, const int32_t* __restrict__ pair_from, const int
                   float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                   PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
-  match_v2_body<W, NQ, NT>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
-                           counter, smem);
+  const int pair = (int)blockIdx.x;
+  match_v2_body<W, NQ, NT>(st, pair, pair_from[pair], pair_to[pair], nndr, min_inliers, est, corr + (size_t)pair * st.kcap,
+                           hdr[pair], pass[pair], list, counter, smem);
 }
 
 // the matrix-core variant as a stage kernel: 4 column tiles per scan at 2 workgroups per CU (<= 256
@@ -678,8 +678,9 @@ k_match_global_mf(StoreView st, const int32_t* __restrict__ pair_from, const int
                   float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
                   PassState* __restrict__ pass, int32_t* __restrict__ list, int32_t* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
-  match_v2_body<W, 0, NT, 4>(st, (int)blockIdx.x, pair_from, pair_to, nndr, min_inliers, est, corr, hdr, pass, list,
-                             counter, smem);
+  const int pair = (int)blockIdx.x;
+  match_v2_body<W, 0, NT, 4>(st, pair, pair_from[pair], pair_to[pair], nndr, min_inliers, est,
+                             corr + (size_t)pair * st.kcap, hdr[pair], pass[pair], list, counter, smem);
 }
 
 template <int W, int NQ, int NT>

@@ -273,10 +273,7 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
   const int max_it = P.iterations > 0 ? P.iterations : 0;
-#ifdef SF_PNP_FLAG_TOP
-  // experiment build only (csrc `make flagtop`): the flag read where round 1's failing fused-PnP build read it
-  const bool to_has_3d_top = st.meta[sT].y > 0;
-#endif
+  const bool to_has_3d = st.meta[sT].y > 0;   // the "to" frame carries 3D points (selects the covariance form)
 
   PnpLds L;
   {
@@ -556,14 +553,7 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
   ps.is_null = allz ? 1 : 0;
 
   // ---- covariance [upstream estimateMotion3DTo2D] ---------------------------------------------------------
-  // (the "to" frame's 3D flag is read HERE, not kept from the top of the function: in an experimental build
-  //  that inlined this body into a larger kernel a wave-uniform bool carried across these ~250 lines came
-  //  back wrong after the compiler's SGPR spilling; long-lived uniform predicates are re-derived at their use)
-#ifdef SF_PNP_FLAG_TOP
-  if (to_has_3d_top) {
-#else
-  if (st.meta[sT].y > 0) {
-#endif
+  if (to_has_3d) {
     const int m4 = (m + 3) & ~3;
     int cnt = 0;
     for (int i = tid; i < m4; i += SF_BLOCK) {

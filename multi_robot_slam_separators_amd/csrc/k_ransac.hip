@@ -6,20 +6,24 @@
 // transformFromXYZCorrespondences; PCL RandomSampleConsensus + SampleConsensusModelRegistration +
 // the refineModel loop], for the correspondences produced by k_match / k_guided.
 //
-// CDNA4 mapping:
+// CDNA4 mapping (round 2: the chain of a surviving pair is the latency tail of the fused kernel, so every phase
+// is laid out for few dependent steps and few issued instructions -- results are unchanged, bit for bit):
 //   * the finite, non-zero correspondences are gathered once into LDS as float4 pairs;
-//   * hypotheses in rounds of 64, one LANE each: wavefront 0 does the stateless keyed sampling, PCL's
-//     sample-distance test and the closed-form 3-point rigid fit in fp64 (Horn quaternion) and
-//     parks the 64 models in LDS; then all four wavefronts count inliers, each over a quarter of the
-//     points, with LDS BROADCAST reads (every lane reads the same address -> one LDS cycle, no bank
-//     conflicts) -- 12 fma + compare per point.  With the usual inlier ratios PCL's adaptive rule
-//     stops inside the first round, so a round of 64 (not 256) quarters the wasted fits and the
-//     point split quarters the counting time;
-//   * PCL's sequential adaptive-termination rule is applied afterwards to the per-hypothesis
-//     counts, which reproduces the sequential algorithm's choice exactly;
-//   * refinement: block-wide fp64 moment reductions in a FIXED order (strided partials, xor
-//     butterfly inside each wavefront via DPP shuffles, four wave sums folded left to right), so
-//     the result is reproducible bit for bit; inlier sets live in LDS byte masks.
+//   * hypotheses in rounds, one LANE each: ONE wavefront samples (stateless keyed sampler, PCL's sample-distance
+//     test) and fits (closed-form 3-point rigid fit in fp64, Horn quaternion) and parks the models in LDS; then
+//     all four wavefronts count inliers, each over a quarter of the points.  The first round has 16 hypotheses
+//     (PCL's adaptive rule stops after a handful of iterations when the correspondences are good), counted by
+//     four lanes per hypothesis; later rounds have 64.  Point loads are issued four at a time so the counting
+//     loop is not one LDS round trip per point;
+//   * PCL's sequential adaptive-termination rule is replayed over a round's counts by a wavefront SCAN (prefix
+//     maximum = the best count after every iteration, the bound k after every iteration evaluated by all lanes at
+//     once, first lane whose top-of-loop test fails = where the sequential loop stops): the same decisions as the
+//     sequential replay, one logarithm deep instead of one per improvement;
+//   * refinement: block-wide fp64 moment reductions in a FIXED order (sfd::canon_reduce); the rigid fit of the
+//     reduced moments is solved by ONE wavefront and broadcast through LDS (the other three wait at the barrier
+//     instead of issuing the same ~500 fp64 instructions); selection, membership change and the 3-sigma threshold
+//     test share one pass and one block reduction; the exact median of the residuals (rank counting) is only
+//     evaluated when the threshold actually shrinks, and once for the covariance.
 // Compiled with -ffp-contract=off (canonical arithmetic, see sf_device_math.hpp).
 #include "sf_device_math.hpp"
 #include "sf_internal.hpp"
@@ -32,32 +36,30 @@ struct RansacLds {
   float* d2;        // [kcap] squared residuals of the last selectWithinDistance
   uint8_t* mask_a;  // [kcap]
   uint8_t* mask_b;  // [kcap]
-  int* counts;      // [iterations + 2]
   double* red;      // [4][16]
+  unsigned long long* sums;   // [4] packed per-wavefront counters of a selection
   int* misc;        // [16]
   float* hyp;       // [12][64] models of the current round of hypotheses
   int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
   float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the scan)
+  float* bc;        // [12] model being refined (broadcast from the solving wavefront)
 };
 
-template <int N>
-__device__ __forceinline__ void block_sum_vec(double (&v)[N], double* red, int tid) {
-  sfd::block_sum_canon<N, 16>(v, red, tid);
-}
-
-template <int NW>
-__device__ __forceinline__ int block_sum_int(int v, int* misc, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  __syncthreads();
-  if constexpr (NW == 1) return v;   // one wavefront: the barrier above only orders its LDS traffic
-  if (lane == 0) misc[8 + wave] = v;
-  __syncthreads();
-  int t = 0;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) t += misc[8 + w];
-  return t;
+__device__ __forceinline__ RansacLds ransac_carve(unsigned char* p, int kcap) {
+  RansacLds L;
+  L.src = (float4*)p; p += (size_t)kcap * 16;
+  L.dst = (float4*)p; p += (size_t)kcap * 16;
+  L.red = (double*)p; p += 64 * 8;
+  L.sums = (unsigned long long*)p; p += 4 * 8;
+  L.d2 = (float*)p; p += (size_t)kcap * 4;
+  L.misc = (int*)p; p += 16 * 4;
+  L.mask_a = p; p += kcap;
+  L.mask_b = p; p += kcap;
+  L.hyp = (float*)p; p += 12 * 64 * 4;
+  L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
+  L.best = (float*)p; p += 16 * 4;
+  L.bc = (float*)p;
+  return L;
 }
 
 // PCL isSampleGood on the source cloud + keyed sampler; returns false when max_checks attempts fail
@@ -106,13 +108,12 @@ __device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32
   sfd::rigid_from_moments(S, mp, mq, ga, gb, coef);
 }
 
-// optimizeModelCoefficients over the members of `mask` (block-order reductions)
-template <int NW>
-__device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask, int n_in, float (&coef)[12],
-                                  int tid) {
+// optimizeModelCoefficients over the members of `mask` (block-order reductions); the fit of the reduced moments is
+// solved by wavefront 0 and left in L.bc (visible to the workgroup after the caller's next barrier)
+__device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask, int n_in, int tid) {
   const double inv_n = 1.0 / (double)n_in;
   double s6[6];
-  sfd::canon_reduce<6, 16, NW>(m, tid, L.red, s6, [&](int i, double (&a)[6]) {
+  sfd::canon_reduce<6, 16, 4>(m, tid, L.red, s6, [&](int i, double (&a)[6]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
       a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
@@ -122,7 +123,7 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
   double mp[3] = {s6[0] * inv_n, s6[1] * inv_n, s6[2] * inv_n};
   double mq[3] = {s6[3] * inv_n, s6[4] * inv_n, s6[5] * inv_n};
   double s9[11];   // S (9), ga, gb
-  sfd::canon_reduce<11, 16, NW>(m, tid, L.red, s9, [&](int i, double (&acc)[11]) {
+  sfd::canon_reduce<11, 16, 4>(m, tid, L.red, s9, [&](int i, double (&acc)[11]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
       const double a[3] = {(double)p.x - mp[0], (double)p.y - mp[1], (double)p.z - mp[2]};
@@ -135,47 +136,77 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
       acc[10] += (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
     }
   });
-  double S[3][3];
+  if (tid < 64) {
+    double S[3][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) S[j][k] = s9[3 * j + k];
-  sfd::rigid_from_moments(S, mp, mq, s9[9], s9[10], coef);
+      for (int k = 0; k < 3; ++k) S[j][k] = s9[3 * j + k];
+    float coef[12];
+    sfd::rigid_from_moments(S, mp, mq, s9[9], s9[10], coef);
+    if (tid < 12) {
+      float v = coef[0];
+#pragma unroll
+      for (int k = 1; k < 12; ++k) v = (tid == k) ? coef[k] : v;
+      L.bc[tid] = v;
+    }
+  }
 }
 
-// selectWithinDistance: membership mask, member count, and the members' squared residuals in
-// L.d2 (non-members and the padding up to a multiple of 4 hold +inf, so order statistics over the
-// selected set can scan the array without consulting the mask).
-template <int NW>
-__device__ inline int select_within(const RansacLds& L, int m, const float (&coef)[12], double thr2,
-                                    uint8_t* mask, int tid) {
-  int n = 0;
+// Result of one selectWithinDistance pass (reduced together, 13 bits per field, K <= 4096):
+//   n    members (squared residual < thr2)
+//   low  members whose residual keeps the 3-sigma rule BELOW the inlier threshold, i.e. for which
+//        !(thr < sigma * sqrt(2.1981 * d2)) -- the rule's operations are monotone in d2, so these are the `low`
+//        smallest members and the median (rank n >> 1) is one of them iff n >> 1 < low
+//   diff elements whose membership differs from `prev`
+struct SelCounts { int n, low, diff; };
+
+// selectWithinDistance under the model at `cf` (LDS): membership mask, the members' squared residuals in L.d2
+// (non-members and the padding up to a multiple of 4 hold +inf, so order statistics over the selected set can
+// scan the array without consulting the mask), and the three counts above in ONE block reduction.
+__device__ inline SelCounts select_within(const RansacLds& L, int m, const float* cf, double thr2, uint8_t* mask,
+                                          const uint8_t* prev, double sigma, double thr, int tid) {
+  float coef[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) coef[k] = cf[k];
+  unsigned long long acc = 0;
   const int m4 = (m + 3) & ~3;
-  for (int i = tid; i < m4; i += 64 * NW) {
-    bool in = false;
+  for (int i = tid; i < m4; i += SF_BLOCK) {
     float r2 = __int_as_float(0x7F800000);
     if (i < m) {
       float4 p = L.src[i], q = L.dst[i];
       const float v = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
-      in = (double)v < thr2;
+      const bool in = (double)v < thr2;
       r2 = in ? v : r2;
+      const bool was = prev ? prev[i] != 0 : false;
       mask[i] = in ? 1 : 0;
+      const bool low = in && !(thr < sigma * sqrt(2.1981 * (double)v));
+      acc += (in ? 1ull : 0ull) + (low ? (1ull << 13) : 0ull) + ((was != in) ? (1ull << 26) : 0ull);
     }
     L.d2[i] = r2;
-    n += in ? 1 : 0;
   }
-  return block_sum_int<NW>(n, L.misc, tid);
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  __syncthreads();
+  if (lane == 0) L.sums[wave] = acc;
+  __syncthreads();
+  const unsigned long long t = ((L.sums[0] + L.sums[1]) + L.sums[2]) + L.sums[3];
+  SelCounts c;
+  c.n = (int)(t & 0x1FFFull);
+  c.low = (int)((t >> 13) & 0x1FFFull);
+  c.diff = (int)((t >> 26) & 0x1FFFull);
+  return c;
 }
 
 // 2.1981 * median (element n>>1 in sorted order) of the members' squared residuals
 // [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting
 // over the +inf-padded residual array (4 values per LDS read, broadcast).
-template <int NW>
 __device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) {
   const int med = n >> 1;
   const int m4 = (m + 3) & ~3;
   __syncthreads();
-  for (int i = tid; i < m; i += 64 * NW) {
+  for (int i = tid; i < m; i += SF_BLOCK) {
     const float v = L.d2[i];
     if (v < __int_as_float(0x7F800000)) {   // member
       int lt = 0, eq = 0;
@@ -193,41 +224,123 @@ __device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) 
   return 2.1981 * medv;
 }
 
-// Body of one RANSAC pass for ONE pair (the calling workgroup); smem_raw is the workgroup's dynamic LDS.
-// NW = 4: the whole 256-thread workgroup; NW = 1: ONE wavefront runs the pass alone (the other three of the
-// workgroup have ended, k_verify.hip) -- same canonical arithmetic (sfd::canon_reduce), same integers.
-template <int NW = 4>
-__device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
-                                            const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
-                                            const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
-                                            const DeviceParams& P, unsigned char* smem_raw, int trace_base = 2) {
-  constexpr int NT = 64 * NW;
-  // NW < 4: the live wavefronts are (pair & 3), (pair & 3) + 1, ... mod 4 (k_verify_fused), numbered from 0 here
-  const int tid = NW == 4 ? (int)threadIdx.x
-                          : (int)((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u));
+// Inlier counts of a round of R hypotheses (R = 16: four lanes per hypothesis, R = 64: one) over this wavefront's
+// quarter [i0, i1) of the points; point loads are issued four at a time (same address in the lanes of a group:
+// LDS broadcast).  Returns this lane's partial count.
+template <int R>
+__device__ __forceinline__ int count_round(const RansacLds& L, const int* hv, int i0, int i1, int lane, float thr2f) {
+  constexpr int G = 64 / R;
+  const int h = lane & (R - 1), g = lane / R;
+  int cnt = 0;
+  if (hv[h]) {
+    float coef[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) coef[k] = L.hyp[k * 64 + h];
+    int i = i0 + g;
+#pragma unroll 1
+    for (; i + 3 * G < i1; i += 4 * G) {
+      float4 p[4], q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { p[u] = L.src[i + u * G]; q[u] = L.dst[i + u * G]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float r2 = sfd::residual2(coef, p[u].x, p[u].y, p[u].z, q[u].x, q[u].y, q[u].z);
+        cnt += (r2 <= thr2f) ? 1 : 0;
+      }
+    }
+#pragma unroll 1
+    for (; i < i1; i += G) {
+      const float4 p = L.src[i], q = L.dst[i];
+      const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+      cnt += (r2 <= thr2f) ? 1 : 0;
+    }
+  }
+  return cnt;
+}
+
+// State of PCL's sequential loop between rounds (wave-uniform in the solving wavefront)
+struct ScanState {
+  int best;      // best inlier count so far (-1: none)
+  int best_it;   // its iteration
+  int it;        // iterations processed (PCL's iterations_)
+  double k;      // adaptive bound
+};
+
+// Advance PCL's loop [upstream pcl::RandomSampleConsensus::computeModel] over the R counts of one round, held one
+// per lane (c = count of iteration base + lane, -1 when getSamples failed; `present` = lane < R and the
+// iteration is <= max_it).  Sequentially the loop tests at the top of iteration `it`:  (adaptive && !(it < k)) ->
+// stop; it > max_it -> stop; count < 0 -> stop; then updates best / k on a STRICT improvement and increments it.
+// k is a function of the best count alone, so the value it has after iteration j is f(max(best, c_0 .. c_j)): every
+// lane evaluates f on its inclusive prefix maximum, the top-of-loop test of lane j uses lane j-1's value, and the
+// first lane whose test fails is where the sequential loop stops.  Returns true when the loop has terminated.
+__device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, int base, int R, int lane, int c,
+                                             bool present, int max_it, bool adaptive, double inv_m,
+                                             double log_probability) {
+  int x = present ? c : -1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off);
+    if (lane >= off) x = max(x, y);
+  }
+  x = max(x, S.best);                                   // inclusive prefix maximum incl. the earlier rounds
+  double kj = 1.0;                                      // (no best yet: k keeps its initial value)
+  if (x >= 0) {
+    const double w = (double)x * inv_m;
+    double pno = 1.0 - (w * w) * w;
+    if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
+    if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
+    kj = log_probability / sfd::canon_log(pno);
+  }
+  double kprev = __shfl_up(kj, 1);
+  if (lane == 0) kprev = S.k;
+  const int it = base + lane;
+  const bool top_ok = present && (!adaptive || (double)it < kprev) && c >= 0;
+  const unsigned long long fail = ~__ballot(top_ok);
+  const int n_proc = fail ? (__ffsll((long long)fail) - 1) : 64;
+  if (n_proc > 0) {
+    const int nb = __shfl(x, n_proc - 1);
+    const double nk = __shfl(kj, n_proc - 1);
+    if (nb > S.best) {
+      const unsigned long long at = __ballot(present && c == nb && lane < n_proc);
+      const int lb = __ffsll((long long)at) - 1;        // first iteration that reached the final best
+      S.best = nb;
+      S.best_it = base + lb;
+      if (lane < 12) L.best[lane] = L.hyp[lane * 64 + lb];   // keep the winning model
+    }
+    S.k = nk;
+  }
+  S.it = base + n_proc;
+  return n_proc < R || base + R > max_it;
+}
+
+// The "no transform" state of a pass (identity covariance scale, `matches` correspondences seen): built where it is
+// written, so that no copy of it stays live in registers across the pass.
+__device__ __forceinline__ void write_null_pass(PassState& out, int matches) {
+  PassState ps;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+  ps.var = 1.0; ps.var_ang = 1.0;
+  ps.is_null = 1;
+  ps.inliers = 0;
+  ps.matches = matches;
+  ps.pad = 0;
+  out = ps;
+}
+
+// Body of one RANSAC pass for ONE pair (the calling 256-thread workgroup).  `cl` = the pair's n_corr
+// correspondences (from | to << 16, ascending "from"; LDS in the fused kernel, global in the stage kernel);
+// `lds` = this stage's region of the workgroup's dynamic LDS (sf_ransac_lds_bytes).  The result is written to
+// `out` by thread 0.
+__device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int sF, int sT, const uint32_t* cl, int n_corr,
+                                            PassState& out, const DeviceParams& P, unsigned char* lds,
+                                            int trace_base = 2) {
+  constexpr int NT = SF_BLOCK;
+  const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const int sF = pair_from[pair], sT = pair_to[pair];
-
-  RansacLds L;
-  {
-    unsigned char* p = smem_raw;
-    L.src = (float4*)p; p += (size_t)kcap * 16;
-    L.dst = (float4*)p; p += (size_t)kcap * 16;
-    L.red = (double*)p; p += 64 * 8;
-    L.d2 = (float*)p; p += (size_t)kcap * 4;
-    L.counts = (int*)p; p += (size_t)((P.iterations + 2 + 3) & ~3) * 4;
-    L.misc = (int*)p; p += 16 * 4;
-    L.mask_a = p; p += kcap;
-    L.mask_b = p; p += kcap;
-    L.hyp = (float*)p; p += 12 * 64 * 4;
-    L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
-    L.best = (float*)p;
-  }
+  const RansacLds L = ransac_carve(lds, kcap);
 
   // ---- util3d::findCorrespondences: finite, non-zero, id-ordered ---------------------------------
-  const int n_corr = hdr[pair].n_corr;
-  const uint32_t* cl = corr + (size_t)pair * kcap;
   const float* xF = st.xyz + (size_t)sF * kcap * 3;
   const float* xT = st.xyz + (size_t)sT * kcap * 3;
   if (tid < 16) L.misc[tid] = 0;
@@ -252,7 +365,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
+    for (int w = 0; w < 4; ++w) {
       int c = L.misc[4 + w];
       if (w < wave) woff += c;
       total += c;
@@ -266,71 +379,65 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
   }
 
   SF_TRACE_MARK(P, pair, trace_base + 0);
-  PassState ps;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-  ps.var = 1.0; ps.var_ang = 1.0;
-  ps.is_null = 1;
-  ps.inliers = 0;
-  ps.matches = m;
-  ps.pad = 0;
   if (m < P.min_inliers || m < 3) {
-    if (tid == 0) pass[pair] = ps;
+    if (tid == 0) write_null_pass(out, m);
     return;
   }
 
+  // the wavefront that samples, fits and replays rotates with the pair, so that the workgroups sharing a CU do
+  // not all put this serial fp64 section on the same SIMD
+  const int fit_wave = pair & 3;
+
   // ---- computeSampleDistanceThreshold (PCA of the source cloud) ----------------------------------
   const double inv_m = 1.0 / (double)m;
-  double mean[3];
+  double sdt = 0.0;     // only the solving wavefront needs (and computes) it
   {
+    double mean[3];
     double s3[3];
-    sfd::canon_reduce<3, 16, NW>(m, tid, L.red, s3, [&](int i, double (&a)[3]) {
+    sfd::canon_reduce<3, 16, 4>(m, tid, L.red, s3, [&](int i, double (&a)[3]) {
       float4 p = L.src[i];
       a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
     });
     mean[0] = s3[0] * inv_m; mean[1] = s3[1] * inv_m; mean[2] = s3[2] * inv_m;
-  }
-  double sdt;
-  {
     double c6[6];  // xx xy xz yy yz zz
-    sfd::canon_reduce<6, 16, NW>(m, tid, L.red, c6, [&](int i, double (&a)[6]) {
+    sfd::canon_reduce<6, 16, 4>(m, tid, L.red, c6, [&](int i, double (&a)[6]) {
       float4 p = L.src[i];
       const double a0 = (double)p.x - mean[0], a1 = (double)p.y - mean[1], a2 = (double)p.z - mean[2];
       a[0] += a0 * a0; a[1] += a0 * a1; a[2] += a0 * a2;
       a[3] += a1 * a1; a[4] += a1 * a2; a[5] += a2 * a2;
     });
-    double ev[3];
-    sfd::sym3_eigenvalues(c6[0] * inv_m, c6[1] * inv_m, c6[2] * inv_m, c6[3] * inv_m, c6[4] * inv_m, c6[5] * inv_m, ev);
-    sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
-    sdt = sdt * sdt;
+    if (wave == fit_wave) {
+      double ev[3];
+      sfd::sym3_eigenvalues(c6[0] * inv_m, c6[1] * inv_m, c6[2] * inv_m, c6[3] * inv_m, c6[4] * inv_m, c6[5] * inv_m, ev);
+      sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
+      sdt = sdt * sdt;
+    }
   }
 
-  if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  if (P.dbg_stop == 1) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation (SF_RANSAC_STOP)
   SF_TRACE_MARK(P, pair, trace_base + 1);
 
-  // ---- hypotheses: one lane each -----------------------------------------------------------------
-  const double thr = P.inlier_thr;
-  const double thr2 = thr * thr;
-  float thr2f = (float)thr2;                       // largest float strictly below thr2
-  if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
+  // ---- hypotheses: one lane each, rounds of 16 then 64 ----------------------------------------------
+  // (values only needed behind this loop -- thr, thr2, sigma -- are formed there, and the replay's constants inside
+  //  the replay: the fit in the middle of the loop wants every register it can get)
+  float thr2f;                                     // largest float strictly below thr^2
+  {
+    const double thr2 = P.inlier_thr * P.inlier_thr;
+    thr2f = (float)thr2;
+    if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
+  }
   const int max_it = P.iterations;
-  // Hypotheses are evaluated in rounds of 64 (one lane each); after every round thread 0 advances
-  // PCL's sequential loop (adaptive k) over the counts available so far.  Once that loop has
-  // terminated the remaining rounds are skipped: their counts would never be read.
-  double k_adapt = 1.0;                                  // thread 0 only
-  const double log_probability = sfd::canon_log(1.0 - 0.99);
-  int sc_best = -1, sc_best_it = -1, sc_it = 0;          // thread 0 only
-  const int slice = (m + NW - 1) / NW;                   // points counted by each wavefront
+  ScanState S;                                             // meaningful in the solving wavefront only
+  S.best = -1; S.best_it = -1; S.it = 0; S.k = 1.0;
+  const int slice = (m + 3) / 4;                           // points counted by each wavefront
   const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
   int* hv = L.hyp_cnt + 4 * 64;
-  // the wavefront that samples and fits rotates with the pair, so that the workgroups sharing a CU do
-  // not all put this serial fp64 section on the same SIMD
-  const int fit_wave = NW == 4 ? (pair & 3) : 0;   // (NW < 4: the live wavefronts already rotate with the pair)
-  for (int base = 0; base <= max_it; base += 64) {
+  int R = 16;
+  for (int base = 0; base <= max_it; base += R, R = 64) {   // (the increment uses the R of the round just finished)
     const int it = base + lane;
     if (wave == fit_wave) {
       int valid = 0;
-      if (it <= max_it) {
+      if (lane < R && it <= max_it) {
         uint32_t s0, s1, s2;
         if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
           float coef[12];
@@ -343,77 +450,54 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
       hv[lane] = valid;
     }
     __syncthreads();
-    {
-      int cnt = 0;
-      if (hv[lane]) {
-        float coef[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) coef[k] = L.hyp[k * 64 + lane];
-        for (int i = i0; i < i1; ++i) {
-          const float4 p = L.src[i], q = L.dst[i];  // same address in every lane: LDS broadcast
-          const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
-          cnt += (r2 <= thr2f) ? 1 : 0;
-        }
-      }
-      L.hyp_cnt[wave * 64 + lane] = cnt;
-    }
+    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 18 : 21);   // first round: models parked
+    L.hyp_cnt[wave * 64 + lane] = R == 16 ? count_round<16>(L, hv, i0, i1, lane, thr2f)
+                                          : count_round<64>(L, hv, i0, i1, lane, thr2f);
     __syncthreads();
-    if (wave == fit_wave && it <= max_it)
-    {
+    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 19 : 22);   // ... inliers counted
+    if (wave == fit_wave) {
       int tot = 0;
+      if (R == 16) {
+        const int h = lane & 15;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) tot += L.hyp_cnt[w * 64 + lane];
-      L.counts[it] = hv[lane] ? tot : -1;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      const int lim = min(max_it, base + 63);  // last iteration whose count exists
-      bool stop = false;
-      while (true) {
-        if (P.adaptive_stop && !((double)sc_it < k_adapt)) { stop = true; break; }
-        if (sc_it > max_it) { stop = true; break; }
-        if (sc_it > lim) break;                           // needs the next round
-        const int c = L.counts[sc_it];
-        if (c < 0) { stop = true; break; }                // getSamples failed -> PCL breaks out
-        if (c > sc_best) {
-          sc_best = c;
-          sc_best_it = sc_it;
+        for (int w = 0; w < 4; ++w)
 #pragma unroll
-          for (int k = 0; k < 12; ++k) L.best[k] = L.hyp[k * 64 + (sc_it - base)];   // keep the winning model
-          const double w = (double)sc_best * inv_m;
-          double pno = 1.0 - (w * w) * w;
-          if (pno < 2.220446049250313e-16) pno = 2.220446049250313e-16;
-          if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
-          k_adapt = log_probability / sfd::canon_log(pno);
-        }
-        ++sc_it;
-        if (sc_it > max_it) { stop = true; break; }
+          for (int g = 0; g < 4; ++g) tot += L.hyp_cnt[w * 64 + g * 16 + h];
+      } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += L.hyp_cnt[w * 64 + lane];
       }
-      L.misc[0] = sc_best_it;
-      L.misc[1] = stop ? 1 : 0;
+      const bool present = lane < R && it <= max_it;
+      const int c = (present && hv[lane]) ? tot : -1;
+      const bool stop = replay_round(L, S, base, R, lane, c, present, max_it, P.adaptive_stop != 0, 1.0 / (double)m,
+                                     sfd::canon_log(1.0 - 0.99));
+      if (lane == 0) {
+        L.misc[0] = S.best_it;
+        L.misc[1] = stop ? 1 : 0;
+      }
     }
     __syncthreads();
+    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 20 : 23);   // ... PCL's loop replayed
     if (L.misc[1]) break;
   }
-  if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation
+  if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation
   SF_TRACE_MARK(P, pair, trace_base + 2);
   const int best_it = L.misc[0];
   if (best_it < 0) {
-    if (tid == 0) pass[pair] = ps;
+    if (tid == 0) write_null_pass(out, m);
     return;
   }
 
-  if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
-
   // ---- winning model (parked in LDS by the scan) --------------------------------------------------
-  float coef[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) coef[k] = L.best[k];
-  uint8_t* inl = L.mask_a;
-  int n_inl = select_within<NW>(L, m, coef, thr2, inl, tid);
+  const double thr = P.inlier_thr;
+  const double thr2 = thr * thr;
+  const double sigma = P.refine_sigma;
+  SelCounts sc = select_within(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid);
+  int n_inl = sc.n;
   int n_last = n_inl;
+  const float* model = L.best;
 
-  if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  if (P.dbg_stop == 4) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation (SF_RANSAC_STOP)
   SF_TRACE_MARK(P, pair, trace_base + 3);
 
   // ---- refine loop (copy of pcl::SampleConsensus::refineModel inside rtabmap) ----------------------
@@ -425,25 +509,32 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
     uint8_t* neu = L.mask_b;
     int n_prev = n_inl, n_new = 0;
     for (int i = tid; i < m; i += NT) neu[i] = 0;
+    if (tid < 12) L.bc[tid] = L.best[tid];            // new_model_coefficients = model_coefficients
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;  // last four pushed sizes (z1 newest)
-    float newc[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) newc[i] = coef[i];
     do {
-      if (n_prev >= 3) fit_masked<NW>(L, m, prev, n_prev, newc, tid);
+      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, tid);
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
-      __syncthreads();
-      n_new = select_within<NW>(L, m, newc, error_threshold * error_threshold, neu, tid);
+      __syncthreads();                                // L.bc (and the cleared `neu`) visible
+      // membership changes are counted against `prev`, the set selected one round ago, while `neu` (the set of
+      // two rounds ago) is overwritten
+      sc = select_within(L, m, L.bc, error_threshold * error_threshold, neu, prev, sigma, thr, tid);
+      n_new = sc.n;
       n_last = n_new;
       if (n_new == 0) {
         ++refine_iterations;
         if (refine_iterations >= P.refine_iterations) break;
         continue;
       }
-      const double variance = variance_of<NW>(L, m, n_new, tid);
-      const double sthr = P.refine_sigma * sqrt(variance);
-      error_threshold = thr < sthr ? thr : sthr;
+      // error_threshold = min(thr, sigma * sqrt(variance)), variance = 2.1981 * median: the median is only needed
+      // when it is one of the `low` members (see SelCounts)
+      if ((n_new >> 1) < sc.low) {
+        const double variance = variance_of(L, m, n_new, tid);
+        const double sthr = sigma * sqrt(variance);
+        error_threshold = thr < sthr ? thr : sthr;
+      } else {
+        error_threshold = thr;
+      }
       inlier_changed = false;
       { uint8_t* t = prev; prev = neu; neu = t; int tn = n_prev; n_prev = n_new; n_new = tn; }
       if (n_new != n_prev) {
@@ -451,44 +542,50 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, const
         inlier_changed = true;
         continue;
       }
-      int diff = 0;
-      for (int i = tid; i < m; i += NT) diff |= (prev[i] != neu[i]) ? 1 : 0;
-      inlier_changed = block_sum_int<NW>(diff, L.misc, tid) != 0;
+      inlier_changed = sc.diff != 0;
     } while (inlier_changed && ++refine_iterations < P.refine_iterations);
-    inl = neu;
     n_inl = n_new;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) coef[i] = newc[i];
+    model = L.bc;
   }
 
-  if (P.dbg_stop == 5) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 5) { if (tid == 0) write_null_pass(out, m); return; }
   SF_TRACE_MARK(P, pair, trace_base + 4);
   if (n_inl >= 3) {
-    const double variance = variance_of<NW>(L, m, n_last, tid);
-    ps.var = variance;
-    ps.var_ang = variance;
-    ps.inliers = n_inl;
-    if (n_inl >= P.min_inliers) {
-      double R[9], t[3];
+    const double variance = variance_of(L, m, n_last, tid);
+    if (tid == 0) {
+      PassState ps;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
+      ps.is_null = 1;
+      ps.matches = m;
+      ps.pad = 0;
+      ps.var = variance;
+      ps.var_ang = variance;
+      ps.inliers = n_inl;
+      if (n_inl >= P.min_inliers) {
+        double R9[9], t[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) R[3 * i + j] = (double)coef[4 * i + j];
-        t[i] = (double)coef[4 * i + 3];
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) R9[3 * i + j] = (double)model[4 * i + j];
+          t[i] = (double)model[4 * i + 3];
+        }
+        bool allz = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) ps.T[4 * i + j] = (float)R9[3 * j + i];
+          ps.T[4 * i + 3] = (float)(-((R9[i] * t[0] + R9[3 + i] * t[1]) + R9[6 + i] * t[2]));
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) allz = allz && (ps.T[i] == 0.f);
+        ps.is_null = allz ? 1 : 0;
       }
-      bool allz = true;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) ps.T[4 * i + j] = (float)R[3 * j + i];
-        ps.T[4 * i + 3] = (float)(-((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]));
-      }
-#pragma unroll
-      for (int i = 0; i < 12; ++i) allz = allz && (ps.T[i] == 0.f);
-      ps.is_null = allz ? 1 : 0;
+      out = ps;
     }
+  } else if (tid == 0) {
+    write_null_pass(out, m);
   }
-  if (tid == 0) pass[pair] = ps;
   SF_TRACE_MARK(P, pair, trace_base + 5);
 }
 
@@ -499,14 +596,17 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
          PassState* __restrict__ pass, DeviceParams P) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  ransac_body<4>(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
+  const int pair = list[blockIdx.x];
+  ransac_body(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr, pass[pair], P,
+              smem_raw);
 }
 
 }  // namespace
 
 size_t sf_ransac_lds_bytes(int kcap, int iterations) {
-  return (size_t)kcap * 32 + 64 * 8 + (size_t)kcap * 4 + (size_t)((iterations + 2 + 3) & ~3) * 4 + 16 * 4 +
-         (size_t)kcap * 2 + 12 * 64 * 4 + 5 * 64 * 4 + 16 * 4;
+  (void)iterations;   // (round 1 kept one count per iteration in LDS; a round's counts now live in lanes)
+  return (size_t)kcap * 32 + 64 * 8 + 4 * 8 + (size_t)kcap * 4 + 16 * 4 + (size_t)kcap * 2 + 12 * 64 * 4 + 5 * 64 * 4 +
+         16 * 4 + 16 * 4;
 }
 
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {

@@ -1,18 +1,21 @@
 // k_verify.hip -- the verification kernels as ONE translation unit, plus the fused per-pair pipeline.
 //
-// The three stage files are included (not linked) so that their per-pair bodies can be inlined into
+// The stage files are included (not linked) so that their per-pair bodies can be inlined into
 // k_verify_fused: one 256-thread workgroup takes a candidate pair through the whole of
 // StereoCamGeometricTools::estimateTransformation (stereoCamGeometricTools.cpp:122-178) --
 // global matching, RANSAC, guess-guided matching, RANSAC again, result assembly -- without leaving the
 // CU.  Why fuse: the motion-estimation stages are short dependent fp64 chains that occupy a few
-// hundred workgroups for ~0.1 ms each and leave the issue ports idle, while matching is bound by
-// instruction issue (matrix pipe + VALU top-2 scan; measured insensitive to 2 / 3 / 4 resident workgroups
-// per CU).  In the fused kernel the 20 % of pairs that survive matching run their RANSAC chain while the
-// other workgroups of the same CU are still matching.  Since matching moved to the matrix cores the two
-// halves weigh about the same and the fused launch takes as long as the five stage launches (DESIGN.md
-// section 5); it still is one launch instead of five for small batches.  The stage kernels remain for the
-// PnP estimator (k_pnp: 177 VGPRs, 3 workgroups per CU) and as the A/B reference (SF_FUSED=0): both paths
-// run the same bodies and produce identical bytes.
+// hundred workgroups for tens of microseconds each and leave the issue ports idle, while matching is bound by
+// instruction issue (matrix pipe + VALU top-2 scan).  In the fused kernel the 20 % of pairs that survive
+// matching run their chain while the other workgroups of the same CU are still matching.
+//
+// Round 2: everything a pair's stages hand to each other -- the correspondence lists, their headers, the pass
+// states, the guided flag -- stays in the workgroup's LDS; the only global write of a pair is its sf_result
+// (368 B).  Round 1 round-tripped all of it through HBM between stages of the SAME workgroup (a write, a
+// vmcnt(0) wait, a barrier and a dependent read per hand-over, 60 MB of writes per 10 000-pair launch).
+// SF_OPT_DEBUG_CORR (sf_debug_correspondences, tests) additionally copies lists and headers to the global
+// workspace.  The stage kernels remain for the PnP estimator (k_pnp: ~170 VGPRs, 3 workgroups per CU) and as
+// the A/B reference (SF_FUSED=0): both paths run the same bodies and produce identical bytes.
 // Compiled with -ffp-contract=off (canonical arithmetic of the RANSAC / guided bodies).
 #include "k_match.hip"
 #include "k_ransac.hip"
@@ -21,134 +24,102 @@
 
 namespace {
 
-// CW = wavefronts that run the motion-estimation chain of a surviving pair.  4 (default): the whole
-// workgroup, as the stage kernels do.  1 or 2 (SF_CHAIN_WAVES / SF_OPT_CHAIN_WAVES): after matching the other
-// wavefronts END and one or two carry the pair through RANSAC / guided matching / RANSAC
-// (ransac_body<CW>, guided_body<W, CW>: same canonical sums, same integers, byte-identical results; the
-// barriers inside the chain only see the live wavefronts).  The idea: a chain holds four wavefront slots and
-// 4 x 128 VGPRs for ~100 us while using a fraction of one SIMD, and a CU whose four workgroup slots fill up
-// with chains stops matching; ended wavefronts give slots and registers back.  Measured per 10 000 pairs:
-// CW = 1 0.75 ms, CW = 2 0.68, CW = 4 0.59-0.61 -- a chain is more arithmetic than it looks (inlier counts
-// of 64 hypotheses, rank counting for the median, the replayed 256-lane sums: ~200 us on one wavefront
-// against ~106 on four), and the workgroup's LDS (26-30 KB, held until its last wavefront ends) caps a CU at
-// five chains whatever their width.  Kept as options and as second implementations the tests compare against.
-template <int W, int NQ, int CW>
+// Tail of the fused kernel's dynamic LDS: what the stages of one pair hand to each other.
+struct FusedTail {
+  PassState pass1, pass2;
+  CorrHeader hdr1, hdr2;
+  uint8_t guided_flag;
+};
+
+template <int W, int NQ>
 __global__ void __launch_bounds__(SF_BLOCK, 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
                uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
-               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
+               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int tail_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
+  uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);          // [kcap] the current pass's correspondence list
+  unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;        // RANSAC / guided working set behind it
   SF_TRACE_MARK(P, pair, 0);
   // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
-  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, 0, corr1, hdr1,
-                                                   pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
-  __syncthreads();   // hdr1 / pass1 / corr1 of this pair are visible to the whole workgroup
+  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, sF, sT, P.nndr, P.min_inliers, 0, cl, T.hdr1, T.pass1,
+                                                   nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
+  __syncthreads();   // list / header / pass-1 defaults visible to the whole workgroup
   SF_TRACE_MARK(P, pair, 1);
-  if constexpr (CW < 4) {
-    // the wavefronts that stay rotate with the pair, so that the chains of a CU spread over its SIMDs
-    if ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) >= (unsigned)CW) return;
+  if (P.dbg_corr) {
+    const int n = T.hdr1.n_corr;
+    for (int i = tid; i < n; i += SF_BLOCK) corr1[(size_t)pair * kcap + i] = cl[i];
+    if (tid == 0) hdr1[pair] = T.hdr1;
   }
   // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
   // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
   // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
   __builtin_amdgcn_s_setprio(3);
   if (est1) {
-    ransac_body<CW>(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    ransac_body(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2);
     __syncthreads();
   }
   // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
-  const bool est2 = guided_body<W, CW>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr,
-                                       nullptr, P, reinterpret_cast<int*>(smem_raw));
+  const bool est2 = guided_body<W>(st, pair, sF, sT, T.pass1, T.pass2, T.guided_flag, cl, T.hdr2, nullptr, nullptr, P,
+                                   reinterpret_cast<int*>(chain_lds));
   __syncthreads();
+  if (P.dbg_corr) {
+    const int n = T.hdr2.n_corr;
+    for (int i = tid; i < n; i += SF_BLOCK) corr2[(size_t)pair * kcap + i] = cl[i];
+    if (tid == 0) hdr2[pair] = T.hdr2;
+  }
   if (est2) {
-    ransac_body<CW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 11);
+    ransac_body(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11);
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);
-  if ((CW == 4 ? threadIdx.x : ((((threadIdx.x >> 6) - (unsigned)(pair & 3)) & 3u) * 64u + (threadIdx.x & 63u))) == 0)
-    finalize_one(pair, pass1, pass2, guided_flag, out);
-}
-
-// The same pipeline with the PnP estimator (estimation_type = 1, myRegistrationVis.cpp:1055-1112), opt-in
-// (SF_FUSED_PNP=1): k_pnp needs ~170 VGPRs, so three workgroups per CU, and a surviving pair's PnP chain is
-// ~200 us (66 + 30 + 107) -- twice the 3D-3D one on fewer slots.  Measured three times, last with the matrix-core
-// matcher: 0.95 ms per 10 000 pairs fused against 0.81 for the four stage launches.  Byte-identical either way
-// (test_fused_pipeline_equals_stage_kernels[1]).
-template <int W, int NQ>
-__global__ void __launch_bounds__(SF_BLOCK, 3)
-k_verify_fused_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-                   uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
-                   uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
-                   uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int pair = blockIdx.x;
-  const int est = P.calibrated ? 1 : 2;     // gate selector of the matching body (sf_est_mode)
-  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, pair_from, pair_to, P.nndr, P.min_inliers, est, corr1, hdr1,
-                                                   pass1, nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
-  __syncthreads();
-  __builtin_amdgcn_s_setprio(3);
-  if (est1) {
-    pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
-    __syncthreads();
+  if (tid == 0) {
+    if (P.dbg_corr) { pass1[pair] = T.pass1; pass2[pair] = T.pass2; guided_flag[pair] = T.guided_flag; }
+    finalize_one(T.pass1, T.pass2, T.guided_flag, out[pair]);
   }
-  const bool est2 = guided_body<W, 4>(st, pair, pair_from, pair_to, pass1, pass2, guided_flag, corr2, hdr2, nullptr,
-                                      nullptr, P, reinterpret_cast<int*>(smem_raw));
-  __syncthreads();
-  if (est2) {
-    pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) finalize_one(pair, pass1, pass2, guided_flag, out);
 }
 
 template <int W, int NQ>
-int launch_fused_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
-                     size_t lds) {
-  bool& attr_set = c->fused_pnp_attr[W == 16][NQ == 0];
-  if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused_pnp<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_verify_fused_pnp<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                     (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
-                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
-  return SF_OK;
-}
-
-template <int W, int NQ, int CW>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
-                 size_t lds) {
-  bool& attr_set = c->fused_attr[W == 16][NQ == 0][CW == 4 ? 0 : CW];   // one flag per instantiation
+                 size_t lds, int tail_off) {
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0];   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_verify_fused<W, NQ, CW>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_verify_fused<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
-                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams);
+                     (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams,
+                     tail_off);
   return SF_OK;
+}
+
+// offset of the FusedTail = the largest stage's working set (the chain stages sit behind the kcap-entry list)
+size_t fused_tail_offset(const sf_context* c, const StoreView& st) {
+  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  const size_t guided = (size_t)st.kcap * 4 + sf_guided_lds_bytes(st.kcap, nc);
+  const size_t ransac = (size_t)st.kcap * 4 + sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  return (std::max(match, std::max(guided, ransac)) + 15) & ~(size_t)15;
 }
 
 }  // namespace
 
-// Dynamic LDS of the fused kernel = the largest stage; 0 when the fused pipeline does not apply
-// (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
+// Dynamic LDS of the fused kernel = the largest stage + the hand-over tail; 0 when the fused pipeline does not
+// apply (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
-  if (!c->fused || c->dparams.estimation_type > 1) return 0;
-  if (c->dparams.estimation_type == 1 && !c->fused_pnp) return 0;
-  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  if (!c->fused || c->dparams.estimation_type != 0) return 0;
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
-  const size_t guided = sf_guided_lds_bytes(st.kcap, nc);
-  const size_t ransac = c->dparams.estimation_type == 1 ? sf_pnp_lds_bytes(st.kcap, c->dparams.iterations)
-                                                        : sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
   if (match > 64 * 1024 || c->match_variant != 0) return 0;
-  const size_t lds = std::max(match, std::max(guided, ransac));
+  const size_t lds = fused_tail_offset(c, st) + ((sizeof(FusedTail) + 15) & ~(size_t)15);
   return lds <= 160 * 1024 ? lds : 0;
 }
 
@@ -157,29 +128,14 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   if (n <= 0) return SF_OK;
   const size_t lds = sf_fused_lds_bytes(c, st);
   if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
+  const int tail_off = (int)fused_tail_offset(c, st);
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
   const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
-  if (c->dparams.estimation_type == 1) {
-    if (mf) rc = st.w == 8 ? launch_fused_pnp<8, 0>(c, st, d_from, d_to, n, d_out, lds)
-                           : launch_fused_pnp<16, 0>(c, st, d_from, d_to, n, d_out, lds);
-    else rc = st.w == 8 ? launch_fused_pnp<8, 2>(c, st, d_from, d_to, n, d_out, lds)
-                        : launch_fused_pnp<16, 2>(c, st, d_from, d_to, n, d_out, lds);
-    sf_prof_end(c, SF_K_FUSED);
-    if (rc != SF_OK) return rc;
-    SF_HIP(c, hipGetLastError());
-    return SF_OK;
-  }
-#define SF_FUSED_CASE(W_, NQ_)                                                                    \
-  rc = c->chain_waves == 1   ? launch_fused<W_, NQ_, 1>(c, st, d_from, d_to, n, d_out, lds)        \
-       : c->chain_waves == 2 ? launch_fused<W_, NQ_, 2>(c, st, d_from, d_to, n, d_out, lds)        \
-                             : launch_fused<W_, NQ_, 4>(c, st, d_from, d_to, n, d_out, lds)
-  if (mf) {
-    if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0);
-  } else {
-    if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2);
-  }
-#undef SF_FUSED_CASE
+  if (mf) rc = st.w == 8 ? launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+                         : launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off);
+  else rc = st.w == 8 ? launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+                      : launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off);
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());

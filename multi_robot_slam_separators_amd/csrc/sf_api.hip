@@ -678,8 +678,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
   if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
-  if (const char* v = getenv("SF_FUSED_PNP")) c->fused_pnp = atoi(v) != 0;     // 1: fused kernel for the PnP estimator
-  if (const char* v = getenv("SF_CHAIN_WAVES")) c->chain_waves = (atoi(v) == 1 || atoi(v) == 2) ? atoi(v) : 4;   // 1 / 2: chains on fewer wavefronts
+  if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
   if (const char* v = getenv("SF_OVERLAP_MIN")) c->overlap_min_pairs = std::max(2, atoi(v));
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
@@ -803,11 +802,15 @@ extern "C" int sf_store_clear(sf_handle c) {
 }
 
 // ---- verification pipeline ------------------------------------------------------------------------
-static int ws_reserve(sf_context* c, int n, int kcap) {
+// lists: the correspondence lists live in HBM (stage kernels, or the fused kernel with SF_OPT_DEBUG_CORR); the fused
+// kernel otherwise keeps them in LDS and the two kcap-entry arrays per pair are not needed
+static int ws_reserve(sf_context* c, int n, int kcap, bool lists) {
   int rc;
   const size_t np = (size_t)n;
-  if ((rc = sf_buf_reserve(c, c->corr1, np * kcap * 4)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->corr2, np * kcap * 4)) != SF_OK) return rc;
+  if (lists) {
+    if ((rc = sf_buf_reserve(c, c->corr1, np * kcap * 4)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->corr2, np * kcap * 4)) != SF_OK) return rc;
+  }
   if ((rc = sf_buf_reserve(c, c->hdr1, np * sizeof(CorrHeader))) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->hdr2, np * sizeof(CorrHeader))) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->pass1, np * sizeof(PassState))) != SF_OK) return rc;
@@ -832,9 +835,13 @@ static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the wo
 static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t* d_from, const int32_t* d_to, int m,
                            sf_result* d_out, bool allow_fused) {
   int rc;
-  if (allow_fused && sf_fused_lds_bytes(ctx, view) != 0)
+  ctx->dparams.dbg_corr = ctx->debug_corr ? 1 : 0;
+  if (allow_fused && sf_fused_lds_bytes(ctx, view) != 0) {
     // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
+    ctx->last_lists_valid = ctx->debug_corr;
     return sf_launch_verify_fused(ctx, view, d_from, d_to, m, d_out);
+  }
+  ctx->last_lists_valid = true;
   SF_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));   // work-list counters of the stage kernels
   if ((rc = sf_launch_match_global(ctx, view, d_from, d_to, m)) != SF_OK) return rc;
   const bool pnp = ctx->dparams.estimation_type == 1;
@@ -869,8 +876,7 @@ static int ensure_twin(sf_context* c) {
   t->match_variant = c->match_variant;
   t->match_mfma = c->match_mfma;
   t->fused = c->fused;
-  t->fused_pnp = c->fused_pnp;
-  t->chain_waves = c->chain_waves;
+  t->debug_corr = c->debug_corr;
   t->prof = c->prof;
   return SF_OK;
 }
@@ -897,8 +903,8 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     sf_context* t = c->twin;
     const int span = std::min(n, 2 * SF_CHUNK);          // pairs per round: one chunk per stream
     const int half0 = (std::min(span, n) + 1) / 2;
-    if ((rc = ws_reserve(c, std::min(half0, SF_CHUNK), st.kcap)) != SF_OK) return rc;
-    if ((rc = ws_reserve(t, std::min(half0, SF_CHUNK), st.kcap)) != SF_OK) { c->err = t->err; return rc; }
+    if ((rc = ws_reserve(c, std::min(half0, SF_CHUNK), st.kcap, true)) != SF_OK) return rc;
+    if ((rc = ws_reserve(t, std::min(half0, SF_CHUNK), st.kcap, true)) != SF_OK) { c->err = t->err; return rc; }
     SF_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     SF_HIP(c, hipStreamWaitEvent(t->stream, c->ev_fork, 0));
     c->ws_split = 0;
@@ -917,7 +923,8 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     SF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return SF_OK;
   }
-  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap)) != SF_OK) return rc;
+  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap, c->debug_corr || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
+    return rc;
   c->ws_split = 0;
   for (int off = 0; off < n; off += SF_CHUNK) {
     const int m = std::min(SF_CHUNK, n - off);
@@ -1168,6 +1175,9 @@ extern "C" int sf_debug_correspondences(sf_handle c, int32_t pair, int32_t pass,
     c = c->twin;
   }
   if (pair >= c->ws_pairs) return SF_EINVAL;
+  if (!c->last_lists_valid)
+    return sf_fail(c, SF_EINVAL, "the fused kernel keeps correspondence lists in LDS: set SF_OPT_DEBUG_CORR (or "
+                                 "SF_DEBUG_CORR=1) before the verification call");
   CorrHeader h;
   const Buf& hb = pass == 1 ? c->hdr1 : c->hdr2;
   const Buf& cb = pass == 1 ? c->corr1 : c->corr2;
@@ -1249,7 +1259,8 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
     case SF_OPT_MATCH_MFMA: c->match_mfma = value != 0; return SF_OK;
     case SF_OPT_FUSED: c->fused = value != 0; return SF_OK;
     case SF_OPT_OVERLAP: c->overlap = value != 0; return SF_OK;
-    case SF_OPT_CHAIN_WAVES: c->chain_waves = (value == 1 || value == 2) ? value : 4; return SF_OK;
+    case SF_OPT_CHAIN_WAVES: return SF_OK;   // (round 1's narrower chains are gone: accepted, no effect)
+    case SF_OPT_DEBUG_CORR: c->debug_corr = value != 0; return SF_OK;
     default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
   }
 }

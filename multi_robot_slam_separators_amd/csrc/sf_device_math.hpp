@@ -149,6 +149,30 @@ __device__ inline void sym3_eigenvalues(double c00, double c01, double c02, doub
   ev[0] = l1; ev[1] = l2; ev[2] = l3;
 }
 
+// Eigenvector of the largest eigenvalue of the symmetric 4x4 matrix given by its upper triangle (cyclic Jacobi; the
+// first maximum of the diagonal wins ties): the fallback of rigid_from_moments for an exactly vanishing adjugate.
+// (Tried out of line -- __attribute__((noinline)) -- to keep its two 4x4 double matrices off the callers' register
+// budget: the call's save area made the kernels' scratch larger, 184 against 116 bytes per lane, not smaller.)
+__device__ inline double4 jacobi_dominant4(double n00, double n01, double n02, double n03, double n11,
+                                                             double n12, double n13, double n22, double n23,
+                                                             double n33) {
+  double Nm[4][4] = {{n00, n01, n02, n03}, {n01, n11, n12, n13}, {n02, n12, n22, n23}, {n03, n13, n23, n33}};
+  double V[4][4];
+  jacobi<4>(Nm, V);
+  double bv = Nm[0][0];
+  double w = V[0][0], qx = V[1][0], qy = V[2][0], qz = V[3][0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool gt = Nm[i][i] > bv;
+    bv = gt ? Nm[i][i] : bv;
+    w = gt ? V[0][i] : w;
+    qx = gt ? V[1][i] : qx;
+    qy = gt ? V[2][i] : qy;
+    qz = gt ? V[3][i] : qz;
+  }
+  return make_double4(w, qx, qy, qz);
+}
+
 // Rotation and translation from the cross-covariance S[j][k] = sum a_j b_k of the demeaned
 // source/target, their means and spreads ga = sum |a|^2, gb = sum |b|^2 (Horn's quaternion
 // method).  The dominant eigenpair of the 4x4 matrix N comes from Newton's iteration on the
@@ -217,19 +241,10 @@ __device__ inline void rigid_from_moments(const double (&S)[3][3], const double 
   if (fabs(a33) > best) { best = fabs(a33); w = a03; qx = a13; qy = a23; qz = a33; }
   double nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   if (!(best > 0.0) || !(nrm2 > 0.0) || !isfinite(nrm2)) {
-    double V[4][4];
-    jacobi<4>(Nm, V);
-    double bv = Nm[0][0];
-    w = V[0][0]; qx = V[1][0]; qy = V[2][0]; qz = V[3][0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-      const bool gt = Nm[i][i] > bv;
-      bv = gt ? Nm[i][i] : bv;
-      w = gt ? V[0][i] : w;
-      qx = gt ? V[1][i] : qx;
-      qy = gt ? V[2][i] : qy;
-      qz = gt ? V[3][i] : qz;
-    }
+    // vanishing adjugate (an exactly degenerate configuration): full eigen-decomposition
+    const double4 qf = jacobi_dominant4(Nm[0][0], Nm[0][1], Nm[0][2], Nm[0][3], Nm[1][1], Nm[1][2], Nm[1][3], Nm[2][2],
+                                        Nm[2][3], Nm[3][3]);
+    w = qf.x; qx = qf.y; qy = qf.z; qz = qf.w;
     nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   }
   const double inv = 1.0 / sqrt(nrm2);

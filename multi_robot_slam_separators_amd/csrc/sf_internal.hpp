@@ -67,6 +67,8 @@ struct DeviceParams {
   float pnp_thr2f;            // (float)(pnp_reproj_error^2)
   float pnp_reproj_error;
   int32_t pnp_refine_iterations;
+  int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
+                              // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
   unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][32] timestamps; else null
 };
 
@@ -170,11 +172,9 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
-  bool fused_pnp_attr[2][2] = {};
-  bool fused_pnp = false;   // SF_FUSED_PNP=1: fused kernel for the PnP estimator too (slower than its stage kernels)
-  bool fused_attr[2][2][3] = {};   // [W == 16][matrix-core matcher][single-wavefront chains]: LDS attribute set
-  int chain_waves = 4;      // wavefronts that run a surviving pair's motion-estimation chain in the fused kernel
-                            // (4: the whole workgroup; 1: three of the four end after matching; SF_CHAIN_WAVES)
+  bool fused_attr[2][2] = {};   // [W == 16][matrix-core matcher]: LDS attribute set
+  bool debug_corr = false;      // SF_OPT_DEBUG_CORR: the fused kernel also writes lists / headers / states to HBM
+  bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
   bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies

@@ -69,7 +69,10 @@ def test_fuzz_pairs_against_oracle(oracle, seed):
         A.append(corrupt(rng, a))
         B.append(corrupt(rng, b))
     with lib.SeparatorFinder(p) as f:
+        plain = f.estimate_transform_batch(A, B)       # product path: lists never leave the workgroup's LDS
+        f.set_option(_abi.SF_OPT_DEBUG_CORR, 1)         # ... and with the lists copied out for inspection
         got = f.estimate_transform_batch(A, B)
+        assert got.tobytes() == plain.tobytes()
         corr = [(f.debug_correspondences(i, 1), f.debug_correspondences(i, 2)) for i in range(len(A))]
     n_success = 0
     for i in range(len(A)):

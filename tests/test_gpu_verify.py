@@ -20,6 +20,9 @@ def finder():
     p = synth.camera_params()
     p.iterations = 500
     f = lib.SeparatorFinder(p)
+    # the tests that inspect correspondence lists (sf_debug_correspondences) need them copied out of LDS; that the
+    # option changes no result byte is checked by test_debug_option_changes_no_result and the fuzz test
+    f.set_option(_abi.SF_OPT_DEBUG_CORR, 1)
     yield f
     f.close()
 
@@ -342,7 +345,7 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch, est):
         p.iterations = 300
         p.estimation_type = est
         out = {}
-        monkeypatch.setenv("SF_FUSED_PNP", "1")       # (the fused PnP kernel is opt-in)
+        monkeypatch.setenv("SF_DEBUG_CORR", "1")      # (the fused kernel keeps the lists in LDS otherwise)
         for fused in ("1", "0"):
             monkeypatch.setenv("SF_FUSED", fused)
             with lib.SeparatorFinder(p) as f:
@@ -351,7 +354,8 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch, est):
                 corr = [f.debug_correspondences(i, w) for i in range(len(AA)) for w in (1, 2)]
                 prof = f.prof_get()
             out[fused] = (res, corr, prof)
-        assert out["1"][2]["k_verify_fused"][0] >= 1 and out["1"][2]["k_match_global"][0] == 0
+        if est == 0:      # (the PnP estimator always runs the stage kernels)
+            assert out["1"][2]["k_verify_fused"][0] >= 1 and out["1"][2]["k_match_global"][0] == 0
         assert out["0"][2]["k_verify_fused"][0] == 0 and out["0"][2]["k_match_global"][0] >= 1
         assert out["1"][0].tobytes() == out["0"][0].tobytes()
         for c1, c0 in zip(out["1"][1], out["0"][1]):
@@ -393,6 +397,7 @@ def test_matrix_core_matcher_equals_valu_matcher(monkeypatch, fused):
         for mf in ("1", "0"):
             monkeypatch.setenv("SF_MATCH_MFMA", mf)
             monkeypatch.setenv("SF_FUSED", fused)
+            monkeypatch.setenv("SF_DEBUG_CORR", "1")
             with lib.SeparatorFinder(p) as f:
                 res = f.estimate_transform_batch(A, B)
                 corr = [f.debug_correspondences(i, w) for i in range(len(A)) for w in (1, 2)]
@@ -417,6 +422,7 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     for mode in ("single", "two"):
         monkeypatch.setenv("SF_OVERLAP", "1" if mode == "two" else "0")
         monkeypatch.setenv("SF_OVERLAP_MIN", "2")
+        monkeypatch.setenv("SF_DEBUG_CORR", "1")
         with lib.SeparatorFinder(p) as f:
             f.prof_enable(True)
             res = [f.estimate_transform_batch(A[:n], B[:n]) for n in (37, 5, 36)]
@@ -569,16 +575,21 @@ def test_execution_options_on_a_live_handle():
     with lib.SeparatorFinder(p) as f:
         base = f.estimate_transform_batch(A, B)
         assert base["success"][is_true].all()
-        for mfma, fused, chain in ((0, 0, 4), (0, 1, 4), (1, 0, 4), (1, 1, 4), (1, 1, 1), (0, 1, 1), (1, 1, 2)):
-            if True:
-                f.set_option(_abi.SF_OPT_MATCH_MFMA, mfma)
-                f.set_option(_abi.SF_OPT_FUSED, fused)
-                f.set_option(_abi.SF_OPT_CHAIN_WAVES, chain)   # 1: single-wavefront motion-estimation chains
-                f.prof_reset(); f.prof_enable(True)
-                got = f.estimate_transform_batch(A, B)
-                prof = f.prof_get()
-                assert got.tobytes() == base.tobytes(), (mfma, fused, chain)
-                assert (prof["k_verify_fused"][0] > 0) == bool(fused)
+        for mfma, fused, dbg in ((0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1), (1, 0, 1)):
+            f.set_option(_abi.SF_OPT_MATCH_MFMA, mfma)
+            f.set_option(_abi.SF_OPT_FUSED, fused)
+            f.set_option(_abi.SF_OPT_DEBUG_CORR, dbg)     # 1: correspondence lists also copied to the workspace
+            f.set_option(_abi.SF_OPT_CHAIN_WAVES, 1)      # (round 1's option: accepted, no effect)
+            f.prof_reset(); f.prof_enable(True)
+            got = f.estimate_transform_batch(A, B)
+            prof = f.prof_get()
+            assert got.tobytes() == base.tobytes(), (mfma, fused, dbg)
+            assert (prof["k_verify_fused"][0] > 0) == bool(fused)
+            if fused and not dbg:       # the lists stayed in LDS: asking for them is an error, not garbage
+                with pytest.raises(lib.SepfinderError):
+                    f.debug_correspondences(0, 1)
+            else:
+                assert len(f.debug_correspondences(0, 1)[0]) >= 0
         with pytest.raises(Exception):
             f.set_option(99, 1)
 

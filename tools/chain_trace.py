@@ -28,6 +28,8 @@ PHASES = [
     ("guided bucket", 7, 8), ("guided search", 8, 9), ("guided compact", 9, 10),
     ("r2 gather", 10, 11), ("r2 pca", 11, 12), ("r2 hypotheses", 12, 13), ("r2 select", 13, 14),
     ("r2 refine", 14, 15), ("r2 variance+out", 15, 16), ("finalize", 16, 17),
+    ("r1 round0 fit", 3, 18), ("r1 round0 count", 18, 19), ("r1 round0 replay", 19, 20),
+    ("r2 round0 fit", 12, 21), ("r2 round0 count", 21, 22), ("r2 round0 replay", 22, 23),
     ("CHAIN (1 -> 17)", 1, 17), ("WHOLE (0 -> 17)", 0, 17),
 ]
 
