@@ -21,6 +21,10 @@
 
 namespace {
 
+// recorded (from, to) combinations per thread of the candidate-parallel search (list = GUIDED_CPT * 256 entries); a
+// frame with more takes the per-lane loop
+#define GUIDED_CPT 8
+
 // Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
 // `out` / hdr_out / pass2_out / guided_flag_out: the pair's pass-2 correspondence list, header, state and flag
@@ -63,7 +67,15 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   int* cell_fill = cell_start + NC + 1;   // [NC]
   // [kcap] the "to" keypoints grouped by cell as {x, y, octave bits, index bits}: the window test never leaves
   // LDS and takes ONE 16-byte read per entry
-  float4* item4 = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(cell_fill + NC) + 15) & ~(uintptr_t)15);
+  // (the 16-byte alignment is done on the int INDEX: rounding the pointer through uintptr_t, as round 1 did, hid the
+  //  LDS address space from the compiler and turned every access behind it -- the window tests' entry reads, the
+  //  key atomics -- into FLAT instructions)
+  float4* item4 = reinterpret_cast<float4*>(smem + ((2 * kcap + 16 + 2 * NC + 1 + 3) & ~3));
+  float2* proj = reinterpret_cast<float2*>(item4 + kcap);        // [kcap] projection of each "from" point (NaN: not searched)
+  uint32_t* oilast = reinterpret_cast<uint32_t*>(proj + kcap);   // [kcap] candidates of the point << 16 | highest one
+  uint32_t* key1 = oilast + kcap;                                // [kcap] best (Hamming << 16 | to) of the point
+  uint32_t* key2 = key1 + kcap;                                  // [kcap] second best
+  uint32_t* cand = key2 + kcap;                                  // [GUIDED_CPT * 256] recorded combinations (from << 16 | to)
   for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;
   for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
@@ -113,12 +125,47 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   // border cells instead made every search near a border walk through all of them (synthetic frames whose
   // features fill a wider field of view than the image put a third of their keypoints there).
   const float x_hi = P.wlim + reach, y_hi = P.hlim + reach;
-  for (int t = tid; t < Kt; t += NT) {
-    const float4 k = kT[t];
+  // All of this stage's streaming loads are issued up front, two per lane and array: the "to" keypoints (staged raw
+  // in LDS for the second bucketing pass -- the region is the search's scratch, unused until then) and the first
+  // 512 "from" points with their octaves (kept in registers until the search).  Round 1 re-read the keypoints from
+  // HBM for the fill pass and loaded the "from" points inside the search loop.
+  float4* raw = reinterpret_cast<float4*>(proj);        // [kcap] (aliases proj / oilast / key1 / key2 / cand)
+  float pre_x[2], pre_y[2], pre_z[2];
+  int pre_o[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = tid + j * NT;
+    pre_x[j] = pre_y[j] = pre_z[j] = 0.f;
+    pre_o[j] = 0;
+    if (i < Kf) {
+      pre_x[j] = xF[3 * i]; pre_y[j] = xF[3 * i + 1]; pre_z[j] = xF[3 * i + 2];
+      pre_o[j] = __float_as_int(kF[i].z);
+    }
+  }
+  auto cell_of = [&](const float4& k) -> int {
     if (isfinite(k.x) && isfinite(k.y) && k.x >= -reach && k.x < x_hi && k.y >= -reach && k.y < y_hi) {
       const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
       const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
-      atomicAdd(&cell_start[cy * P.grid_gx + cx + 1], 1);
+      return cy * P.grid_gx + cx;
+    }
+    return -1;
+  };
+  for (int base = 0; base < Kt; base += 2 * NT) {
+    float4 k2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = base + tid + j * NT;
+      k2[j] = make_float4(__int_as_float(0x7FC00000), 0.f, 0.f, 0.f);
+      if (t < Kt) k2[j] = kT[t];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int t = base + tid + j * NT;
+      if (t < Kt) {
+        raw[t] = k2[j];
+        const int cidx = cell_of(k2[j]);
+        if (cidx >= 0) atomicAdd(&cell_start[cidx + 1], 1);
+      }
     }
   }
   __syncthreads();
@@ -147,11 +194,9 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   }
   __syncthreads();
   for (int t = tid; t < Kt; t += NT) {
-    const float4 k = kT[t];
-    if (isfinite(k.x) && isfinite(k.y) && k.x >= -reach && k.x < x_hi && k.y >= -reach && k.y < y_hi) {
-      const int cx = min(max((int)floorf(fminf(fmaxf(k.x * inv_cell, -1.f), 1e6f)), 0), gxm);
-      const int cy = min(max((int)floorf(fminf(fmaxf(k.y * inv_cell, -1.f), 1e6f)), 0), gym);
-      const int cidx = cy * P.grid_gx + cx;
+    const float4 k = raw[t];
+    const int cidx = cell_of(k);
+    if (cidx >= 0) {
       const int pos = cell_start[cidx] + atomicAdd(&cell_fill[cidx], 1);
       item4[pos] = make_float4(k.x, k.y, k.z, __int_as_float(t));
     }
@@ -159,13 +204,33 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   __syncthreads();
   SF_TRACE_MARK(P, pair, 8);
 
+  // ---- search.  Two formulations of the same integers:
+  //  * candidate-parallel (default): every lane projects its "from" point and walks the 3x3 cells around the
+  //    projection, but only RECORDS the (from, to) combinations that pass the window and octave tests; the
+  //    Hamming distances of all recorded combinations are then evaluated one combination per lane -- the two
+  //    descriptor loads of every combination are in flight together, instead of one dependent HBM round trip per
+  //    combination inside a divergent per-lane loop -- and folded into per-point best / second-best keys with LDS
+  //    atomics;
+  //  * sequential per lane (the round-1 loop): when a frame has more combinations than the list holds
+  //    (GUIDED_CPT per thread), e.g. all keypoints piled on one spot.
   int n_finite = 0, n_proj = 0;
+  const int cand_cap = GUIDED_CPT * NT;
+  // pass A: projections, per-point candidate count / highest candidate (:751-764 needs it), candidate list
   for (int base = 0; base < Kf; base += NT) {
     const int i = base + tid;
     bool inimg = false;
     float u = 0.f, v = 0.f;
+    const int rnd = base / NT;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int octf = 0;
+    if (rnd < 2) {               // (the first 512 points were loaded up front; larger frames load here)
+      x = rnd == 0 ? pre_x[0] : pre_x[1]; y = rnd == 0 ? pre_y[0] : pre_y[1]; z = rnd == 0 ? pre_z[0] : pre_z[1];
+      octf = rnd == 0 ? pre_o[0] : pre_o[1];
+    } else if (i < Kf) {
+      x = xF[3 * i]; y = xF[3 * i + 1]; z = xF[3 * i + 2];
+      octf = __float_as_int(kF[i].z);
+    }
     if (i < Kf) {
-      const float x = xF[3 * i], y = xF[3 * i + 1], z = xF[3 * i + 2];
       if (sfd::finite3(x, y, z)) {
         ++n_finite;
         const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
@@ -179,8 +244,140 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
                 (zf > 0.f);
       }
     }
-    if (inimg) {
+    // Window / octave tests of this lane's point against the 3x3 cells around its projection.  Combinations that
+    // pass are parked in four registers and handed to the workgroup's list in bulk: one slot allocation per
+    // WAVEFRONT and round (prefix sum of the per-lane counts + one LDS atomic by a single lane), plus a per-lane
+    // flush for the few points with more than four.
+    int oi = 0, last = -1, nb = 0;
+    uint32_t hb0 = 0, hb1 = 0, hb2 = 0, hb3 = 0;
+    if (base == 0) SF_TRACE_MARK(P, pair, 28);   // (thread 0's own timeline: first round projected)
+    if (i < Kf && inimg) {
       ++n_proj;
+      const int cx0 = min(max((int)floorf((u - reach) * inv_cell), 0), gxm);
+      const int cx1 = min(max((int)floorf((u + reach) * inv_cell), 0), gxm);
+      const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
+      const int cy1 = min(max((int)floorf((v + reach) * inv_cell), 0), gym);
+      for (int cy = cy0; cy <= cy1; ++cy) {
+        // cells cx0..cx1 of one grid row are contiguous in the CSR; entries are read FOUR at a time (the loop is
+        // one LDS round trip per trip, and a wavefront runs as many trips as its busiest lane)
+        const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
+        for (int e = e0; e < e1; e += 4) {
+          float4 it4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) it4[q] = item4[min(e + q, e1 - 1)];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 it = it4[q];
+            const float dx = u - it.x, dy = v - it.y;
+            const float d2 = dx * dx + dy * dy;
+            if (e + q < e1 && d2 < r2lim && __float_as_int(it.z) == octf) {
+              const int t = __float_as_int(it.w);
+              if (nb == 4) {                     // (rare) more than four for one point: flush this lane's four
+                const int slot = atomicAdd(&misc[3], 4);
+                if (slot + 4 <= cand_cap) {
+                  cand[slot] = hb0; cand[slot + 1] = hb1; cand[slot + 2] = hb2; cand[slot + 3] = hb3;
+                }
+                nb = 0;
+              }
+              const uint32_t rec = ((uint32_t)i << 16) | (uint32_t)t;
+              hb0 = nb == 0 ? rec : hb0; hb1 = nb == 1 ? rec : hb1; hb2 = nb == 2 ? rec : hb2; hb3 = nb == 3 ? rec : hb3;
+              ++nb;
+              ++oi;
+              if (last < 0 || t > last) last = t;
+            }
+          }
+        }
+      }
+    }
+    if (base == 0) SF_TRACE_MARK(P, pair, 29);   // ... its cells scanned
+    {
+      // bulk hand-over of the parked combinations of this wavefront
+      int incl = nb;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const int wtot = __shfl(incl, 63);
+      int wbase = 0;
+      if (wtot > 0) {
+        if (lane == 0) wbase = atomicAdd(&misc[3], wtot);
+        wbase = __shfl(wbase, 0);
+        const int s0 = wbase + incl - nb;
+        if (s0 + nb <= cand_cap) {
+          if (nb > 0) cand[s0] = hb0;
+          if (nb > 1) cand[s0 + 1] = hb1;
+          if (nb > 2) cand[s0 + 2] = hb2;
+          if (nb > 3) cand[s0 + 3] = hb3;
+        }
+      }
+    }
+    if (base == 0) SF_TRACE_MARK(P, pair, 30);   // ... combinations handed over
+    if (i < Kf) {
+      proj[i] = make_float2(inimg ? u : __int_as_float(0x7FC00000), v);   // NaN u = "not searched"
+      oilast[i] = ((uint32_t)min(oi, 0xFFFF) << 16) | (uint32_t)(last & 0xFFFF);
+      key1[i] = 0xFFFFFFFFu;
+      key2[i] = 0xFFFFFFFFu;
+    }
+  }
+  __syncthreads();
+  SF_TRACE_MARK(P, pair, 24);     // projections + candidate recording done
+  const int n_cand = misc[3];
+#ifdef SF_CHAIN_TRACE
+  if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * 32 + 27] = (unsigned long long)n_cand;
+#endif
+  if (n_cand <= cand_cap) {
+    // pass B: one combination per lane (<= GUIDED_CPT per thread, kept in registers between the two atomic passes)
+    uint32_t ck[GUIDED_CPT], ci[GUIDED_CPT];
+#pragma unroll
+    for (int j = 0; j < GUIDED_CPT; ++j) {
+      const int c = tid + j * NT;
+      ck[j] = 0xFFFFFFFFu;
+      ci[j] = 0;
+      if (c < n_cand) {
+        const uint32_t it = cand[c];
+        const uint32_t i = it >> 16, t = it & 0xFFFFu;
+        const uint4* pf = reinterpret_cast<const uint4*>(dF + (size_t)i * W);
+        const uint4* pt = reinterpret_cast<const uint4*>(dT + (size_t)t * W);
+        uint32_t d = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < W / 4; ++q4) {
+          const uint4 a = pf[q4], b = pt[q4];
+          d += __popc(a.x ^ b.x) + __popc(a.y ^ b.y) + __popc(a.z ^ b.z) + __popc(a.w ^ b.w);
+        }
+        ck[j] = (d << 16) | t;
+        ci[j] = i;
+        atomicMin(&key1[i], ck[j]);
+      }
+    }
+    __syncthreads();
+    SF_TRACE_MARK(P, pair, 25);   // Hamming distances + best keys
+#pragma unroll
+    for (int j = 0; j < GUIDED_CPT; ++j)
+      if (ck[j] != 0xFFFFFFFFu && ck[j] != key1[ci[j]]) atomicMin(&key2[ci[j]], ck[j]);   // keys of a point are distinct
+    __syncthreads();
+    SF_TRACE_MARK(P, pair, 26);   // second-best keys
+    for (int i = tid; i < Kf; i += NT) {
+      const uint32_t ol = oilast[i];
+      const int oi = (int)(ol >> 16);
+      int m = -1;
+      if (oi >= 2) {
+        const uint32_t b0 = key1[i], b1 = key2[i];
+        if ((float)(b0 >> 16) < P.nndr * (float)(b1 >> 16)) m = (int)(b0 & 0xFFFFu);  // :744
+      } else if (oi == 1) {
+        m = (int)(ol & 0xFFFFu);                                                     // :751-764
+      }
+      if (m >= 0) {
+        matched[i] = m;
+        atomicMin(&claim[m], i);                                                      // :776-787
+      }
+    }
+  } else {
+    // more combinations than the list holds: the per-lane loop (same tests, same keys)
+    for (int i = tid; i < Kf; i += NT) {
+      const float2 pr = proj[i];
+      if (!(pr.x == pr.x)) continue;
+      const float u = pr.x, v = pr.y;
       const int octf = __float_as_int(kF[i].z);
       uint32_t q[W];
       {
@@ -198,7 +395,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
       const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
       const int cy1 = min(max((int)floorf((v + reach) * inv_cell), 0), gym);
       for (int cy = cy0; cy <= cy1; ++cy) {
-        // cells cx0..cx1 of one grid row are contiguous in the CSR
         const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
         for (int e = e0; e < e1; ++e) {
           const float4 it = item4[e];
@@ -408,7 +604,9 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 }  // namespace
 
 size_t sf_guided_lds_bytes(int kcap, int n_cells) {
-  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3) * sizeof(int);   // (+3: 16-byte alignment of the item block)
+  // claim, matched, misc, cell_start, cell_fill, (+3: 16-byte alignment of the item block) item4, then the search's
+  // projections (2), candidate summaries, best / second-best keys (3) and the combination list
+  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3 + 5 * kcap + GUIDED_CPT * SF_BLOCK) * sizeof(int);
 }
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {

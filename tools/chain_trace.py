@@ -30,6 +30,8 @@ PHASES = [
     ("r2 refine", 14, 15), ("r2 variance+out", 15, 16), ("finalize", 16, 17),
     ("r1 round0 fit", 3, 18), ("r1 round0 count", 18, 19), ("r1 round0 replay", 19, 20),
     ("r2 round0 fit", 12, 21), ("r2 round0 count", 21, 22), ("r2 round0 replay", 22, 23),
+    ("guided A0 project", 8, 28), ("guided A0 scan", 28, 29), ("guided A0 handover", 29, 30), ("guided A1 (round 2)", 30, 24),
+    ("guided A record", 8, 24), ("guided B hamming", 24, 25), ("guided B second", 25, 26), ("guided C decide", 26, 9),
     ("CHAIN (1 -> 17)", 1, 17), ("WHOLE (0 -> 17)", 0, 17),
 ]
 
@@ -85,6 +87,8 @@ def run(n, k, cols, iters, true_frac, label):
     t0 = us[:, 0].min()
     print("   kernel span from stamps: %.1f us; match-only pairs: mean %.1f us" % (
         us[:, 17].max() - t0, float(np.mean((us[:, 1] - us[:, 0])[~full]))))
+    ncand = tr[full, 27].astype(np.int64)
+    print("   guided candidates per pair: mean %.0f  p90 %.0f  max %d" % (ncand.mean(), np.percentile(ncand, 90), ncand.max()))
     for name, a, b in PHASES:
         d = (us[:, b] - us[:, a])[full]
         print("   %-18s mean %7.2f  median %7.2f  p90 %7.2f us" % (name, d.mean(), np.median(d), np.percentile(d, 90)))
