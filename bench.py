@@ -12,7 +12,20 @@ One STEP = one full inter-robot matching pass at BASELINE.json configs[1]:
      with N > 1 ranks the accepted records are first all-gathered over RCCL (ragged, two-phase).
 `value` = candidate pairs verified per second over the whole step, all ranks.  Inputs (both
 robots' NetVLAD databases and keyframe feature stores) are resident in HBM before the timed
-region.  Weak scaling: every rank owns an independent robot pair of the same size.
+region.
+
+N > 1 (`python bench.py --gpus N` starts the N ranks itself when WORLD_SIZE is unset; under torchrun the
+environment's WORLD_SIZE must equal --gpus):
+  --partition robot-pairs (default, "weak"): every rank owns an independent robot pair of the same size and the
+      accepted separators are all-gathered (one RCCL collective per step);
+  --partition 8e ("strong"): SURVEY.md section 8(e) as written -- ONE robot pair's step cut over the ranks: local NN
+      rows in contiguous blocks against the replicated received database, all-gather of the per-row minima, the
+      walk replicated, candidate p to rank p mod G over a replicated keyframe store, flags + accepted records
+      all-gathered and interleaved back into candidate order (multi_robot_slam_separators_amd/sharded.py; the same
+      orchestration is run by gloo ranks in tests/test_sharded_step.py).  --robots R flattens R(R-1)/2 robot pairs
+      into one candidate list first (BASELINE configs[4]: 5 robots).
+  --workload cfg4: BASELINE configs[3], verification only: --pairs candidate pairs (default 1 000 000) of the
+      configs[1] shape round-robin over the ranks, accepted separators all-gathered.
 """
 import argparse
 import json
@@ -162,6 +175,266 @@ def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
     }
 
 
+def upload_store(f, feats, dev, n_kf, k, cols):
+    """Both robots' keyframes of one robot pair into the handle's device store; returns (slot_a, slot_b)."""
+    import torch
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        if x.dtype.fields:
+            x = x.view(np.uint8)
+        return torch.from_numpy(x).to(dev)
+    CH = 2048
+    first = {}
+    for which in ("a", "b"):
+        fs0 = None
+        for s in range(0, n_kf, CH):
+            e = min(n_kf, s + CH)
+            td_, tx, tk = up(feats["desc_" + which][s:e]), up(feats["xyz_" + which][s:e]), up(feats["kp_" + which][s:e])
+            fs = f.store_add_keyframes_device(e - s, k, cols, td_.data_ptr(), tx.data_ptr(), tk.data_ptr())
+            torch.cuda.synchronize()
+            fs0 = fs if fs0 is None else fs0
+        first[which] = fs0
+    return first["a"], first["b"]
+
+
+class GpuShardBackend:
+    """multi_robot_slam_separators_amd.sharded backend on one GPU: the handle holds THIS rank's block of local
+    NetVLAD rows, the whole received database and the whole (replicated) keyframe store of one robot pair."""
+
+    def __init__(self, f, lo, n_received, slot_a, slot_b, n_local_total, dev):
+        import torch
+        from multi_robot_slam_separators_amd import _abi
+        self.f, self.lo, self.n_r, self.slot_a, self.slot_b, self.dev = f, lo, n_received, slot_a, slot_b, dev
+        self.RB = _abi.RESULT_DTYPE.itemsize
+        self.d_res = torch.empty((max(n_local_total, 1), self.RB), dtype=torch.uint8, device=dev)
+        self.n_total = n_local_total
+
+    def row_minima(self, lo, hi):
+        if hi <= lo:
+            return np.zeros(0), np.zeros(0, np.int32)
+        self.f.nn_find_matches(cap=hi - lo)             # NN kernels of this block (its own walk is not used)
+        return self.f.nn_last_row_minima()
+
+    def walk(self, d, a):
+        return self.f.nn_walk(d, a, self.n_r, cap=self.n_total)
+
+    def verify(self, matches):
+        import torch
+        n = len(matches)
+        if n == 0:
+            return self.d_res[:0]
+        self.f.verify_matches_device(np.ascontiguousarray(matches), self.slot_a, self.slot_b, self.d_res.data_ptr())
+        torch.cuda.synchronize()
+        return self.d_res[:n]
+
+
+def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
+    """the step(s) of R(R-1)/2 robot pairs cut over the ranks (strong scaling).  Prints its own
+    JSON line (rank 0)."""
+    import torch
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import _abi, dist, lib, sharded, synth
+    n_kf, k, cols, dim = args.keyframes, args.features, args.desc_bytes, args.dim
+    n_rp = args.robots * (args.robots - 1) // 2
+    p = synth.camera_params()
+    p.iterations = args.iterations
+    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.nn_precision = args.nn_precision
+    p.max_features = k
+    p.desc_bytes = cols
+    p.store_capacity = 2 * n_kf
+    lo, hi = sharded.row_blocks(n_kf, world)[rank]
+    steps, truths = [], []
+    for rp in range(n_rp):
+        feats, nv_a, nv_b, _ = generate_inputs(12345 + rp, n_kf, k, cols, dim, args.true_frac)   # SAME on every rank
+        f = lib.SeparatorFinder(p, device=dev_index)
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        slot_a, slot_b = upload_store(f, feats, dev, n_kf, k, cols)        # replicated store
+        ta = torch.from_numpy(nv_a).to(dev)
+        tb = torch.from_numpy(np.ascontiguousarray(nv_b[lo:hi])).to(dev)
+        if args.netvlad_f16:
+            ta, tb = ta.to(torch.float16), tb.to(torch.float16)
+            f.nn_append_received_f16_device(ta.data_ptr(), n_kf, dim)
+            if hi > lo:
+                f.nn_append_local_f16_device(tb.data_ptr(), hi - lo, dim)
+        else:
+            f.nn_append_received_device(ta.data_ptr(), n_kf, dim)
+            if hi > lo:
+                f.nn_append_local_device(tb.data_ptr(), hi - lo, dim)
+        torch.cuda.synchronize()
+        be = GpuShardBackend(f, lo, n_kf, slot_a, slot_b, n_kf, dev)
+        steps.append(sharded.ShardedStep(be, rank, world, n_kf, coll_dev, accept_cap=n_kf // (4 * world) + 256))
+        truths.append(feats["is_true"])
+        del feats
+
+    def step():
+        out = [st.step() for st in steps]          # one robot pair after the other: each is cut over all the ranks
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if dist_on:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_pairs = 0
+    for _ in range(args.steps):
+        last = step()
+        n_pairs += sum(len(m) for m, _, _ in last)
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    if dist_on:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # the node's output = the single-GPU output: every candidate's decision equals the ground truth on every rank
+    correct = total = accepted = 0
+    for (m, flags, acc), truth in zip(last, truths):
+        want = truth[m["idx_local"]] & (m["idx_local"] == m["idx_other"])
+        correct += int((flags.numpy() == want).sum())
+        total += len(m)
+        accepted += int(acc.shape[0])
+        rec = np.frombuffer(acc.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+        assert bool(rec["success"].all()) and len(rec) == int(flags.sum())
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": n_pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8+f32+f64" if args.nn_precision == 0 else "u8+f16+f32+f64", "data": "synthetic",
+            "config": {"workload": "SURVEY 8(e) partition: %d robots = %d robot pair(s) x %d keyframes, %d-D %s NetVLAD, "
+                                   "%d x %d-bit ORB, <= %d RANSAC hypotheses (PCL adaptive stop, p = 0.99); local NN rows in "
+                                   "%d contiguous blocks + all-gather of row minima + replicated walk; candidate p -> rank "
+                                   "p mod %d over a replicated store; flags + accepted records all-gathered and interleaved"
+                                   % (args.robots, n_rp, n_kf, dim, "fp16" if args.netvlad_f16 else "fp32", k, cols * 8,
+                                      args.iterations, world, world),
+                       "pairs_per_step": n_pairs / args.steps, "parallelism": "section 8(e): row-sharded NN, pairs p mod G"},
+            "check": {"decisions_matching_ground_truth": correct, "of": total, "accepted_last_step": accepted},
+        }))
+    for st in steps:
+        st.b.f.close()
+
+
+def run_cfg4(args, rank, world, dev, dev_index, coll_dev, dist_on):
+    """BASELINE configs[3]: --pairs candidate pairs of the configs[1] shape round-robin over the ranks, verification
+    only; the accepted separators are all-gathered (dist.RecordExchange).  The pairs re-use a replicated store of
+    --keyframes keyframes per robot (pair p = keyframe p mod N of robot A against the same of robot B)."""
+    import torch
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import _abi, dist, lib, synth
+    n_kf, k, cols = args.keyframes, args.features, args.desc_bytes
+    p = synth.camera_params()
+    p.iterations = args.iterations
+    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    p.max_features = k
+    p.desc_bytes = cols
+    p.store_capacity = 2 * n_kf
+    feats = synth.make_store_batch(12345, n_kf, k=k, cols=cols, true_frac=args.true_frac)     # replicated
+    f = lib.SeparatorFinder(p, device=dev_index)
+    f.set_stream(torch.cuda.current_stream().cuda_stream)
+    slot_a, slot_b = upload_store(f, feats, dev, n_kf, k, cols)
+    mine = dist.shard_pairs(args.pairs, rank, world)                  # p mod G
+    d_from = torch.from_numpy((slot_a + mine % n_kf).astype(np.int32)).to(dev)
+    d_to = torch.from_numpy((slot_b + mine % n_kf).astype(np.int32)).to(dev)
+    n = len(mine)
+    RB = _abi.RESULT_DTYPE.itemsize
+    d_res = torch.empty((n, RB), dtype=torch.uint8, device=dev)
+    exch = dist.RecordExchange(RB, n, n // 4 + 1024, coll_dev) if dist_on else None
+    d_acc = torch.empty((n, RB), dtype=torch.uint8, device=dev)
+    d_flags = torch.empty(n, dtype=torch.bool, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    h_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def step():
+        f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+        if exch is not None and coll_dev.type == "cuda":
+            f.compact_accepted_device_async(d_res.data_ptr(), n, exch.payload.data_ptr(), d_flags.data_ptr(), exch.count_ptr)
+            exch.exchange(None)
+            h_cnt.copy_(exch.send[0, :4].view(torch.int32), non_blocking=True)
+        elif exch is not None:
+            n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
+            exch.payload[:n_acc].copy_(d_acc[:n_acc])
+            exch.exchange(n_acc)
+            h_cnt[0] = n_acc
+        else:
+            f.compact_accepted_device_async(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr(), d_cnt.data_ptr())
+            h_cnt.copy_(d_cnt, non_blocking=True)
+        torch.cuda.synchronize()
+        return int(h_cnt[0])
+
+    for _ in range(args.warmup):
+        step()
+    f.prof_reset()
+    f.prof_enable(True)
+    if dist_on:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_acc = step()
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = f.prof_get()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    if dist_on:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    elapsed = float(t.item())
+    truth = feats["is_true"][mine % n_kf]
+    ok = bool((d_flags.cpu().numpy() == truth).all())
+    gathered = sum(exch.counts()) if exch is not None else n_acc
+    if rank == 0:
+        nm, tm = prof.get("k_verify_fused", (0, 0.0))
+        bpp = bytes_per_pair(k, cols)
+        launch_ms = tm / max(nm, 1)
+        ppl = n * args.steps / max(nm, 1)
+        ach = ppl * bpp / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        print(json.dumps({
+            "metric": METRIC, "value": args.pairs * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8+f32+f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d candidate pairs (%d x %d-bit ORB per keyframe, <= %d RANSAC "
+                                   "hypotheses with PCL's adaptive stop, both passes, %.0f %% true) round-robin over %d rank(s), "
+                                   "verification only, replicated store of 2 x %d keyframes, accepted separators "
+                                   "all-gathered" % (args.pairs, k, cols * 8, args.iterations, 100 * args.true_frac, world, n_kf),
+                       "pairs_per_step_per_gpu": n, "parallelism": "pairs p mod G"},
+            "roofline": {"kernel": "k_verify_fused", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_pair": bpp, "pairs_per_launch": ppl,
+                         "avg_launch_ms": launch_ms},
+            "check": {"decisions_matching_ground_truth_rank0": ok, "accepted_rank0": n_acc,
+                      "accepted_separators_gathered_per_step": gathered},
+        }))
+    f.close()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: one child process per GPU with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rank 0's stdout (the JSON line) passed through.  The parent has not
+    imported torch or touched HIP."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +462,27 @@ def main():
                          "pipelined) -- what the profiling rounds use, so that every launch they see is a timed one")
     ap.add_argument("--cpu-sample-pairs", type=int, default=10000)
     ap.add_argument("--cpu-sample-rows", type=int, default=1024)
+    ap.add_argument("--partition", choices=("robot-pairs", "8e"), default="robot-pairs",
+                    help="N > 1: robot-pairs = one independent robot pair per rank (weak scaling); 8e = one robot "
+                         "pair's step cut over the ranks as SURVEY.md section 8(e) writes it (strong scaling)")
+    ap.add_argument("--robots", type=int, default=2,
+                    help="--partition 8e: robots in the topology; their R(R-1)/2 robot pairs are flattened into one "
+                         "candidate list before the round-robin (BASELINE configs[4]: 5)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
+                    help="cfg2 = NN + verification step (configs[1], the metric's configuration); cfg4 = "
+                         "configs[3]: --pairs candidate pairs round-robin over the ranks, verification only")
+    ap.add_argument("--pairs", type=int, default=1000000, help="--workload cfg4: candidate pairs per step (all ranks)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (a process that has
+    # initialised HIP must never exec or fork GPU work; this parent only waits for its children) ----------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s: start it as `python -m "
+                         "torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d "
+                         "...` or let `python bench.py --gpus %d` start the ranks itself"
+                         % (args.gpus, os.environ["WORLD_SIZE"], args.gpus, args.gpus, args.gpus))
 
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with RCCL's streams in the process
     # the library's second stream would share a queue with its first and lose the overlap it exists for
@@ -222,6 +515,12 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from multi_robot_slam_separators_amd import _abi, dist, lib, synth
+
+    if args.workload == "cfg4" or args.partition == "8e":
+        (run_cfg4 if args.workload == "cfg4" else run_partition_8e)(args, rank, world, dev, dev_index, coll_dev, dist_on)
+        if dist_on:
+            td.destroy_process_group()
+        return
 
     n_kf, k, cols, dim = args.keyframes, args.features, args.desc_bytes, args.dim
     p = synth.camera_params()
@@ -375,8 +674,11 @@ def main():
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
-        step()
+        ts = time.perf_counter()
+        step()                      # (ends with the step's one synchronisation)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if dist_on:
         td.barrier()
@@ -413,6 +715,56 @@ def main():
             alt = None
         f.nn_set_precision(1)
         step()
+
+    # ---- the same step with the prefix ladder of the NN filter forced to the FULL descriptor length (the cost on a
+    # data set whose prefixes are uninformative; the timed steps contract `filter_dims` dimensions), untimed ----
+    alt_full = None
+    if args.nn_precision == 1 and not args.no_extras:
+        try:
+            f.set_option(_abi.SF_OPT_NN_FULL_FILTER, 1)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            for _ in range(5):
+                n_alt += step()
+            torch.cuda.synchronize()
+            alt_full = {"value": n_alt / (time.perf_counter() - t1) * world, "contracted_dims": f.nn_last_filter_dims()}
+        except Exception as e:
+            print("bench: full-length filter comparison run failed: %r" % (e,), file=sys.stderr)
+        f.set_option(_abi.SF_OPT_NN_FULL_FILTER, 0)
+        step()
+
+    # ---- the same step with EXACTLY iterations + 1 hypotheses per pass (ransac_adaptive_stop = 0), untimed: a second
+    # handle with the same stores and databases (parameters are fixed at sf_create) ----
+    alt_fixed = None
+    if not args.no_extras:
+        try:
+            q = _abi.copy_params(p)
+            q.ransac_adaptive_stop = 0
+            f2 = lib.SeparatorFinder(q, device=dev_index)
+            f2.set_stream(torch.cuda.current_stream().cuda_stream)
+            sa2, sb2 = upload_store(f2, feats, dev, n_kf, k, cols)
+            getattr(f2, nn_append_received)(ta.data_ptr(), n_kf, dim)
+            getattr(f2, nn_append_local)(tb.data_ptr(), n_kf, dim)
+            torch.cuda.synchronize()
+
+            def step_fixed():
+                m2 = f2.find_matches_and_verify_device(sa2, sb2, d_res.data_ptr(), cap=n_kf)
+                n_acc2 = f2.compact_accepted_device(d_res.data_ptr(), len(m2), d_acc.data_ptr(), d_flags.data_ptr())
+                return len(m2), n_acc2
+            step_fixed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            for _ in range(5):
+                n_alt += step_fixed()[0]
+            torch.cuda.synchronize()
+            alt_fixed = {"value": n_alt / (time.perf_counter() - t1) * world, "accepted_last_step": step_fixed()[1],
+                         "hypotheses_per_pass": args.iterations + 1}
+            f2.close()
+        except Exception as e:
+            print("bench: fixed-iteration comparison run failed: %r" % (e,), file=sys.stderr)
 
     # ---- the same step with the VALU matcher (xor + popcount; north_star's literal kernel mix), untimed ----
     alt_valu = None
@@ -485,6 +837,38 @@ def main():
         except Exception as e:   # informational only: never let it take the headline line down
             piped = {"error": repr(e)}
         f_nn.close()
+    # ---- NN stage alone on SURVEY 8(d)'s generator (5 % planted revisits at distance ~0.05, 95 % independent rows),
+    # untimed: queries/s and the matrix-core rate of whatever prefix level the filter settles on ----
+    nn_only = None
+    if world == 1 and not args.no_extras:
+        try:
+            loc, oth, planted = synth.make_netvlad(777, n_kf, n_kf, dim, planted_frac=0.05)
+            f.nn_reset()
+            tl, to = torch.from_numpy(loc).to(dev), torch.from_numpy(oth).to(dev)
+            f.nn_append_local_device(tl.data_ptr(), n_kf, dim)
+            f.nn_append_received_device(to.data_ptr(), n_kf, dim)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                mm = f.nn_find_matches(cap=n_kf)
+            f.prof_reset(); f.prof_enable(True)
+            t1 = time.perf_counter()
+            reps = 20
+            for _ in range(reps):
+                mm = f.nn_find_matches(cap=n_kf)
+            dtn = time.perf_counter() - t1
+            prn = f.prof_get()
+            f.prof_enable(False)
+            kd = f.nn_last_filter_dims() or dim
+            kern = "k_nn_filter_f16" if args.nn_precision == 1 else "k_nn_argmin"
+            kms = prn[kern][1] / max(prn[kern][0], 1)
+            nn_only = {"generator": "5 %% planted revisits (distance ~0.05), 95 %% independent unit rows; %d x %d x %d" % (n_kf, n_kf, dim),
+                       "queries_per_s": n_kf * reps / dtn, "ms_per_query_block": dtn / reps * 1e3,
+                       "matches_found": int(len(mm)), "planted": int((planted >= 0).sum()),
+                       "contracted_dims": kd, "kernel": kern, "kernel_ms": kms,
+                       "kernel_tflops": 2.0 * n_kf * n_kf * kd / (kms * 1e-3) / 1e12 if kms > 0 else 0.0}
+            del tl, to
+        except Exception as e:
+            print("bench: NN-only run failed: %r" % (e,), file=sys.stderr)
     del ta, tb
 
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
@@ -540,11 +924,16 @@ def main():
             "dtype": "u8+f32+f64" if args.nn_precision == 0 else "u8+f16+f32+f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: 1xMI355X per rank, 2 robots x %d keyframes, %d-D fp32 NetVLAD, "
-                            "%d x %d-bit ORB per keyframe, %d RANSAC iterations (%s), both registration passes, "
-                            "%.0f %% true revisits" % (n_kf, dim, k, cols * 8, args.iterations,
-                                                       "3D-3D" if args.estimator == "3d3d" else "PnP",
-                                                       100 * args.true_frac),
+                "workload": "BASELINE configs[1]: 1xMI355X per rank, 2 robots x %d keyframes, %d-D %s NetVLAD, "
+                            "%d x %d-bit ORB per keyframe, <= %d RANSAC hypotheses per pass with PCL's adaptive stop "
+                            "(p = 0.99; it ends inside the first 16-hypothesis round on these correspondences -- the "
+                            "fixed-count figure is value_fixed_iterations) (%s), both registration passes, %.0f %% true "
+                            "revisits, every row has a perceptual alias under netvlad_distance (all %d rows become "
+                            "candidates); NN filter contracted %s of %d dimensions (adaptive prefix ladder -- the "
+                            "full-length figure is value_full_length_filter)" % (
+                                n_kf, dim, "fp16" if args.netvlad_f16 else "fp32", k, cols * 8, args.iterations,
+                                "3D-3D" if args.estimator == "3d3d" else "PnP", 100 * args.true_frac, n_kf,
+                                (filter_dims or dim) if args.nn_precision == 1 else dim, dim),
                 "pairs_per_step_per_gpu": pairs_per_step,
                 "parallelism": "pairs sharded by robot pair, 1 rank per GPU" if world > 1 else "single GPU",
             },
@@ -552,6 +941,7 @@ def main():
                 "kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": (pmc or {}).get("bytes"),
+                "traffic_measured_in_this_run": False,
                 "traffic_source": pmc,
                 "compute": compute_note(dom, k, cols, pairs_per_launch, match_ms),
                 "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": match_ms,
@@ -567,7 +957,17 @@ def main():
                       "accepted_separators_gathered_per_step": state.get("gathered", 0),
                       "gathered_records_all_accepted": all_ok},
             "input_generation_s": t_gen,
+            "step_ms_spread": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
+                               "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
         }
+        if alt_fixed is not None:
+            out["value_fixed_iterations"] = alt_fixed["value"]
+            out["fixed_iterations"] = alt_fixed
+        if alt_full is not None:
+            out["value_full_length_filter"] = alt_full["value"]
+            out["full_length_filter"] = alt_full
+        if nn_only is not None:
+            out["nn_only_survey_8d_generator"] = nn_only
         if piped is not None:
             out["pipelined_two_streams"] = piped
         if alt_valu is not None:

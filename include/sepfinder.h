@@ -204,6 +204,13 @@ int  sf_nn_set_precision(sf_handle h, int32_t nn_precision);
 int  sf_nn_find_matches(sf_handle h, sf_match* out, int32_t cap, int32_t* n_out);
 /* Per-row minima of the last find_matches call (diagnostics / tests): n_local entries.      */
 int  sf_nn_last_row_minima(sf_handle h, double* dist, int32_t* idx, int32_t cap);
+/* The sequential tail of DataHandler.find_matches (data_handler.py:191-205: rows sorted by their minimum, the
+   walk with its "idx_other already taken" and break rules) on caller-provided per-row minima -- host work only.
+   For a node that shards the LOCAL rows of one query over its GPUs: every rank searches its
+   block (sf_nn_find_matches + sf_nn_last_row_minima), the minima are all-gathered, and every rank runs this
+   identical walk.  row_min: n_local float64 (+inf = no candidate under the threshold), row_arg: column of each. */
+int  sf_nn_walk(sf_handle h, const double* row_min, const int32_t* row_arg, int32_t n_local, int32_t n_received,
+                sf_match* out, int32_t cap, int32_t* n_out);
 /* Descriptor dimensions the fp16 filter contracted in the last find_matches call (0: exact path). */
 int  sf_nn_last_filter_dims(sf_handle h, int32_t* dims);
 
@@ -314,6 +321,9 @@ enum {
   SF_OPT_FUSED = 1,       /* 1 (default): one fused launch per chunk (3D-3D estimator); 0: the stage kernels     */
   SF_OPT_OVERLAP = 2,     /* 1: batches >= 4096 pairs as two halves on two streams; 0 (default): one stream     */
   SF_OPT_CHAIN_WAVES = 3, /* round 1's narrower motion-estimation chains (measured slower, removed): accepted, no effect */
+  SF_OPT_NN_FULL_FILTER = 5, /* 1: the fp16 NN filter (nn_precision = 1) always contracts the FULL descriptor length
+                             instead of climbing its adaptive prefix ladder (128 / 512 / full): the cost of a data set
+                             whose prefixes are uninformative; matches are identical either way                        */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never
                              leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */

@@ -250,6 +250,9 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     // flush for the few points with more than four.
     int oi = 0, last = -1, nb = 0;
     uint32_t hb0 = 0, hb1 = 0, hb2 = 0, hb3 = 0;
+#ifdef SF_CHAIN_TRACE
+    int dbg_trips = 0, dbg_entries = 0;
+#endif
     if (base == 0) SF_TRACE_MARK(P, pair, 28);   // (thread 0's own timeline: first round projected)
     if (i < Kf && inimg) {
       ++n_proj;
@@ -262,6 +265,9 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
         // one LDS round trip per trip, and a wavefront runs as many trips as its busiest lane)
         const int e0 = cell_start[cy * P.grid_gx + cx0], e1 = cell_start[cy * P.grid_gx + cx1 + 1];
         for (int e = e0; e < e1; e += 4) {
+#ifdef SF_CHAIN_TRACE
+          ++dbg_trips; dbg_entries += min(4, e1 - e);
+#endif
           float4 it4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) it4[q] = item4[min(e + q, e1 - 1)];
@@ -289,6 +295,13 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
         }
       }
     }
+#ifdef SF_CHAIN_TRACE
+    if (base == 0 && wave == 0 && P.dbg_trace) {
+      int mx = dbg_trips, sm = dbg_entries;
+      for (int off = 32; off >= 1; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); sm += __shfl_xor(sm, off); }
+      if (lane == 0) P.dbg_trace[(size_t)pair * 32 + 31] = ((unsigned long long)mx << 32) | (unsigned)sm;
+    }
+#endif
     if (base == 0) SF_TRACE_MARK(P, pair, 29);   // ... its cells scanned
     {
       // bulk hand-over of the parked combinations of this wavefront

@@ -679,7 +679,9 @@ static int nn_run_filter(sf_context* c, int* done) {
   if (512 * 4 <= dim) levels[n_levels++] = 512;
   levels[n_levels++] = kfull;
   int level = std::min(std::max(c->nn_level, 0), n_levels - 1);
-  if (level > 0 && c->nn_level_cooldown == 0) {   // now and then re-try the cheaper level
+  if (c->nn_force_full) {
+    level = n_levels - 1;      // SF_OPT_NN_FULL_FILTER: no prefix level (the worst case of the adaptive ladder)
+  } else if (level > 0 && c->nn_level_cooldown == 0) {   // now and then re-try the cheaper level
     --level;
     c->nn_level_cooldown = 32;
   } else if (c->nn_level_cooldown > 0) {
@@ -828,7 +830,7 @@ static int nn_run_filter(sf_context* c, int* done) {
       }
     }
     if (ok) {
-      c->nn_level = level;
+      if (!c->nn_force_full) c->nn_level = level;
       c->nn_last_kdims = kdims;
     }
   }
@@ -860,6 +862,81 @@ static int nn_run_filter(sf_context* c, int* done) {
   // a candidate admitted only by the error band may still be >= the threshold: that is fine, the
   // walk compares the exact float64 value
   *done = 1;
+  return SF_OK;
+}
+
+// data_handler.py:191-205 on explicit per-row minima: argsort of the row minima, then the sequential walk.  Host
+// only (no GPU work): sf_nn_run ends with it, and sf_nn_walk exposes it for the row-sharded NN stage of a multi-GPU
+// node, where every rank runs the identical walk on the all-gathered minima.
+int sf_nn_walk_host(sf_context* c, const double* rm, const int32_t* row_arg, int n_l, int n_r, double thr_d,
+                    int max_matches_nb, sf_match* out, int cap, int* n_out) {
+  // data_handler.py:191-205: argsort of the row minima, then the sequential walk.
+  // Only rows whose minimum is under the threshold can be accepted, and they sort in front of all
+  // others; once they are exhausted the reference's loop can only `continue` or `break`.  So the
+  // sort is restricted to those rows: LSD radix sort on the float64 bit patterns (non-negative
+  // doubles order like unsigned integers; the sort is stable, so ties keep the lowest row first).
+  NnTrace tr2;
+  std::vector<uint64_t>& keys = c->nn_sort_keys;
+  std::vector<int32_t>& rows = c->nn_sort_rows;
+  keys.clear();
+  rows.clear();
+  for (int i = 0; i < n_l; ++i) {
+    if (rm[i] < thr_d) {
+      uint64_t b;
+      const double v = rm[i] == 0.0 ? 0.0 : rm[i];   // -0.0 -> +0.0
+      memcpy(&b, &v, 8);
+      keys.push_back(b);
+      rows.push_back(i);
+    }
+  }
+  const size_t nu = keys.size();
+  if (nu > 1) {
+    // LSD radix sort, 11-bit digits (6 passes cover 64 bits); all digit histograms come from ONE read
+    // of the keys, and a pass whose digit is identical in every key is skipped
+    constexpr int DIG = 11, NB = 1 << DIG, NP = (64 + DIG - 1) / DIG;
+    std::vector<uint64_t>& k2 = c->nn_sort_keys2;
+    std::vector<int32_t>& r2 = c->nn_sort_rows2;
+    k2.resize(nu);
+    r2.resize(nu);
+    std::vector<uint32_t>& hist = c->nn_sort_hist;
+    hist.assign((size_t)NP * NB, 0u);
+    for (size_t i = 0; i < nu; ++i) {
+      const uint64_t k = keys[i];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hist[(size_t)p * NB + ((k >> (p * DIG)) & (NB - 1))]++;
+    }
+    for (int p = 0; p < NP; ++p) {
+      uint32_t* h = hist.data() + (size_t)p * NB;
+      const int shift = p * DIG;
+      if (h[(keys[0] >> shift) & (NB - 1)] == nu) continue;   // this digit is identical in every key
+      uint32_t run = 0;
+      for (int b2 = 0; b2 < NB; ++b2) { const uint32_t cnt = h[b2]; h[b2] = run; run += cnt; }
+      for (size_t i = 0; i < nu; ++i) {
+        const uint32_t pos = h[(keys[i] >> shift) & (NB - 1)]++;
+        k2[pos] = keys[i];
+        r2[pos] = rows[i];
+      }
+      keys.swap(k2);
+      rows.swap(r2);
+    }
+  }
+  tr2.mark("host sort", (long long)nu);
+  const int lim = std::min(n_l, max_matches_nb);
+  int n = 0;
+  std::vector<uint8_t>& taken = c->nn_taken;
+  taken.assign(n_r, 0);
+  for (int s = 0; s < lim && s < (int)nu; ++s) {
+    const int il = rows[s], io = row_arg[il];
+    if (io < 0 || io >= n_r) continue;   // (caller-provided minima: never index outside the column range)
+    if (taken[io]) continue;                                  // :199-200 (slot still consumed)
+    // rm[il] < netvlad_distance holds for every row kept above (:202-203)
+    if (n < cap) { out[n].idx_local = il; out[n].idx_other = io; out[n].distance = rm[il]; }
+    taken[io] = 1;
+    ++n;
+    if (n >= cap) break;
+  }
+  *n_out = std::min(n, cap);
+  tr2.mark("host walk", n);
   return SF_OK;
 }
 
@@ -938,73 +1015,7 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
   SF_HIP(c, hipStreamSynchronize(c->stream));
   }
 
-  // data_handler.py:191-205: argsort of the row minima, then the sequential walk.
-  // Only rows whose minimum is under the threshold can be accepted, and they sort in front of all
-  // others; once they are exhausted the reference's loop can only `continue` or `break`.  So the
-  // sort is restricted to those rows: LSD radix sort on the float64 bit patterns (non-negative
-  // doubles order like unsigned integers; the sort is stable, so ties keep the lowest row first).
-  NnTrace tr2;
-  const std::vector<double>& rm = c->last_row_min;
-  const double thr_d = c->params.netvlad_distance;
-  std::vector<uint64_t>& keys = c->nn_sort_keys;
-  std::vector<int32_t>& rows = c->nn_sort_rows;
-  keys.clear();
-  rows.clear();
-  for (int i = 0; i < n_l; ++i) {
-    if (rm[i] < thr_d) {
-      uint64_t b;
-      const double v = rm[i] == 0.0 ? 0.0 : rm[i];   // -0.0 -> +0.0
-      memcpy(&b, &v, 8);
-      keys.push_back(b);
-      rows.push_back(i);
-    }
-  }
-  const size_t nu = keys.size();
-  if (nu > 1) {
-    // LSD radix sort, 11-bit digits (6 passes cover 64 bits); all digit histograms come from ONE read
-    // of the keys, and a pass whose digit is identical in every key is skipped
-    constexpr int DIG = 11, NB = 1 << DIG, NP = (64 + DIG - 1) / DIG;
-    std::vector<uint64_t>& k2 = c->nn_sort_keys2;
-    std::vector<int32_t>& r2 = c->nn_sort_rows2;
-    k2.resize(nu);
-    r2.resize(nu);
-    std::vector<uint32_t>& hist = c->nn_sort_hist;
-    hist.assign((size_t)NP * NB, 0u);
-    for (size_t i = 0; i < nu; ++i) {
-      const uint64_t k = keys[i];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) hist[(size_t)p * NB + ((k >> (p * DIG)) & (NB - 1))]++;
-    }
-    for (int p = 0; p < NP; ++p) {
-      uint32_t* h = hist.data() + (size_t)p * NB;
-      const int shift = p * DIG;
-      if (h[(keys[0] >> shift) & (NB - 1)] == nu) continue;   // this digit is identical in every key
-      uint32_t run = 0;
-      for (int b2 = 0; b2 < NB; ++b2) { const uint32_t cnt = h[b2]; h[b2] = run; run += cnt; }
-      for (size_t i = 0; i < nu; ++i) {
-        const uint32_t pos = h[(keys[i] >> shift) & (NB - 1)]++;
-        k2[pos] = keys[i];
-        r2[pos] = rows[i];
-      }
-      keys.swap(k2);
-      rows.swap(r2);
-    }
-  }
-  tr2.mark("host sort", (long long)nu);
-  const int lim = std::min(n_l, c->params.netvlad_max_matches_nb);
-  int n = 0;
-  std::vector<uint8_t>& taken = c->nn_taken;
-  taken.assign(n_r, 0);
-  for (int s = 0; s < lim && s < (int)nu; ++s) {
-    const int il = rows[s], io = c->last_row_arg[il];
-    if (taken[io]) continue;                                  // :199-200 (slot still consumed)
-    // rm[il] < netvlad_distance holds for every row kept above (:202-203)
-    if (n < cap) { out[n].idx_local = il; out[n].idx_other = io; out[n].distance = rm[il]; }
-    taken[io] = 1;
-    ++n;
-    if (n >= cap) break;
-  }
-  *n_out = std::min(n, cap);
-  tr2.mark("host walk", n);
-  return SF_OK;
+  return sf_nn_walk_host(c, c->last_row_min.data(), c->last_row_arg.data(), n_l, n_r, c->params.netvlad_distance,
+                         c->params.netvlad_max_matches_nb, out, cap, n_out);
 }
+

@@ -1261,6 +1261,7 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
     case SF_OPT_OVERLAP: c->overlap = value != 0; return SF_OK;
     case SF_OPT_CHAIN_WAVES: return SF_OK;   // (round 1's narrower chains are gone: accepted, no effect)
     case SF_OPT_DEBUG_CORR: c->debug_corr = value != 0; return SF_OK;
+    case SF_OPT_NN_FULL_FILTER: c->nn_force_full = value != 0; c->nn_coef_level = -1; return SF_OK;
     default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
   }
 }
@@ -1360,6 +1361,16 @@ extern "C" int sf_nn_find_matches(sf_handle c, sf_match* out, int32_t cap, int32
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
   return sf_nn_run(c, out, cap, n_out);
+}
+
+extern "C" int sf_nn_walk(sf_handle c, const double* row_min, const int32_t* row_arg, int32_t n_local, int32_t n_received,
+                          sf_match* out, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out || n_local < 0 || n_received < 0 || cap < 0 || (cap > 0 && !out) || (n_local > 0 && (!row_min || !row_arg)))
+    return SF_EINVAL;
+  *n_out = 0;
+  if (n_local == 0 || n_received == 0) return SF_OK;
+  return sf_nn_walk_host(c, row_min, row_arg, n_local, n_received, c->params.netvlad_distance,
+                         c->params.netvlad_max_matches_nb, out, cap, n_out);
 }
 
 extern "C" int sf_nn_last_filter_dims(sf_handle c, int32_t* dims) {

@@ -158,6 +158,7 @@ struct sf_context {
   Buf nn_cand;       // filter path: counter + candidate (row, col) pairs + exact distances
   Buf nn_scalar;     // small reduction scratch
   int nn_level = 0, nn_level_cooldown = 32, nn_last_kdims = 0;   // adaptive prefix ladder of the filter
+  bool nn_force_full = false;   // SF_OPT_NN_FULL_FILTER: always contract the full descriptor length
   int nn_coef_level = -1, nn_coef_nl = 0, nn_coef_nr = 0;         // what the cached filter coefficients were built for
   double nn_coef_thr = 0.0;
   float nn_coef_scale = 0.f;
@@ -267,6 +268,8 @@ int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, 
                      const uint8_t* d_desc, const float* d_xyz, const sf_keypoint* d_kp);
 // NN stage
 int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out);
+int sf_nn_walk_host(sf_context* c, const double* row_min, const int32_t* row_arg, int n_l, int n_r, double thr,
+                    int max_matches_nb, sf_match* out, int cap, int* n_out);
 // Speculation hook (sf_api.hip), called by the NN filter right behind the refinement launch of a prefix level:
 // builds the candidate pair list on the device and queues the verification of every candidate.
 int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count);

@@ -76,6 +76,7 @@ def load():
         "sf_nn_find_matches": (C.c_int, [vp, vp, i32, P(i32)]),
         "sf_nn_last_row_minima": (C.c_int, [vp, vp, vp, i32]),
         "sf_nn_last_filter_dims": (C.c_int, [vp, P(i32)]),
+        "sf_nn_walk": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, P(i32)]),
         "sf_store_add_keyframe": (C.c_int, [vp, P(_abi.Features), P(i32)]),
         "sf_store_add_keyframes_device": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, P(i32)]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
@@ -117,7 +118,7 @@ EXPORTED = [
     "sf_nn_mark_local_used", "sf_nn_mark_other_used", "sf_nn_ignore_pair", "sf_nn_reset",
     "sf_nn_set_precision",
     "sf_set_option",
-    "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_store_add_keyframe",
+    "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async",
@@ -229,6 +230,18 @@ class SeparatorFinder:
         out = np.zeros(max(cap, 1), dtype=_abi.MATCH_DTYPE)
         n = C.c_int32()
         self._check(self._L.sf_nn_find_matches(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value]
+
+    def nn_walk(self, row_min, row_arg, n_received, cap=None):
+        """data_handler.py:191-205 on caller-provided per-row minima (host work; row-sharded NN of a multi-GPU node)."""
+        d = np.ascontiguousarray(row_min, dtype=np.float64)
+        a = np.ascontiguousarray(row_arg, dtype=np.int32)
+        if cap is None:
+            cap = max(1, min(max(d.size, 1), self.params.netvlad_max_matches_nb))
+        out = np.zeros(max(cap, 1), dtype=_abi.MATCH_DTYPE)
+        n = C.c_int32()
+        self._check(self._L.sf_nn_walk(self._h, _ptr(d), _ptr(a), d.size, int(n_received), out.ctypes.data, cap,
+                                       C.byref(n)))
         return out[: n.value]
 
     def nn_last_filter_dims(self):

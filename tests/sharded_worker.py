@@ -1,0 +1,87 @@
+"""Worker of tests/test_sharded_step.py: one gloo rank running multi_robot_slam_separators_amd.sharded.ShardedStep
+(the section 8(e) partition the multi-GPU bench uses) with the CPU ORACLE as the compute backend -- the tests may use
+the oracle; the orchestration (row blocks, all-gather of minima, replicated walk, p mod G, flag + record exchange,
+interleave) is the product's.  usage: sharded_worker.py RANK WORLD PORT OUT_PREFIX"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleShardBackend:
+    def __init__(self, params, local, received, feats_other, feats_local):
+        self.p, self.local, self.received = params, local, received
+        self.fo, self.fl = feats_other, feats_local
+
+    def row_minima(self, lo, hi):
+        from oracle import pyoracle
+        if hi <= lo:
+            return np.zeros(0), np.zeros(0, np.int32)
+        _, d, a = pyoracle.find_matches(self.local[lo:hi], self.received, (), (), (), self.p.netvlad_distance,
+                                        self.p.netvlad_max_matches_nb)
+        return np.asarray(d, dtype=np.float64), np.asarray(a, dtype=np.int32)
+
+    def walk(self, d, a):
+        from multi_robot_slam_separators_amd import _abi, dist
+        pairs = dist.walk_matches(d, a, self.p.netvlad_distance, self.p.netvlad_max_matches_nb)
+        m = np.zeros(len(pairs), dtype=_abi.MATCH_DTYPE)
+        for k, (il, io) in enumerate(pairs):
+            m[k] = (il, io, d[il])
+        return m
+
+    def verify(self, matches):
+        import torch
+        from multi_robot_slam_separators_amd import _abi
+        from oracle import pyoracle
+        if len(matches) == 0:
+            return torch.zeros((0, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8)
+        A = [self.fo[int(r["idx_other"])] for r in matches]      # "from" = the querying robot's frame
+        B = [self.fl[int(r["idx_local"])] for r in matches]      # "to"   = the computing robot's frame
+        res = pyoracle.estimate_transform_batch(self.p, A, B, 1)
+        return torch.from_numpy(np.frombuffer(res.tobytes(), dtype=np.uint8).reshape(len(matches), -1).copy())
+
+
+def make_problem(seed=4711, n=36):
+    from multi_robot_slam_separators_amd import synth
+    p = synth.camera_params()
+    p.iterations = 100
+    p.netvlad_dimensions = 64
+    p.netvlad_max_matches_nb = n
+    A, B, is_true, _ = synth.make_pairs(seed, n, k=120, cols=32, true_frac=0.5)
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(n, 64)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a + rng.normal(size=(n, 64)) * (0.04 / 8.0)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b[5] = rng.normal(size=64) / 8.0           # a local row without a neighbour under the threshold
+    b[7] = b[6]                                  # two local rows nearest to the same received row (slot consumed)
+    return p, b.astype(np.float32).astype(np.float64), a.astype(np.float32).astype(np.float64), A, B
+
+
+def main():
+    rank, world, port, prefix = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    import torch
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import sharded
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = port
+        td.init_process_group("gloo", rank=rank, world_size=world)
+    p, local, received, A, B = make_problem()
+    st = sharded.ShardedStep(OracleShardBackend(p, local, received, A, B), rank, world, len(local), "cpu",
+                             accept_cap=3)      # small capacity: the overflow path of the record exchange runs too
+    m, flags, acc = st.step()
+    np.save(prefix + "_m_%d.npy" % rank, m)
+    np.save(prefix + "_flags_%d.npy" % rank, flags.numpy())
+    np.save(prefix + "_acc_%d.npy" % rank, acc.cpu().numpy())
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+    print("rank %d ok: %d candidates, %d accepted" % (rank, len(m), int(flags.sum())))
+
+
+if __name__ == "__main__":
+    main()

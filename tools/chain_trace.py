@@ -89,6 +89,9 @@ def run(n, k, cols, iters, true_frac, label):
         us[:, 17].max() - t0, float(np.mean((us[:, 1] - us[:, 0])[~full]))))
     ncand = tr[full, 27].astype(np.int64)
     print("   guided candidates per pair: mean %.0f  p90 %.0f  max %d" % (ncand.mean(), np.percentile(ncand, 90), ncand.max()))
+    dbg = tr[full, 31]
+    print("   guided scan, wavefront 0 / round 0: busiest lane's trips mean %.1f max %d; entries read by its 64 lanes mean %.0f" % (
+        (dbg >> 32).mean(), int((dbg >> 32).max()), (dbg & 0xFFFFFFFF).mean()))
     for name, a, b in PHASES:
         d = (us[:, b] - us[:, a])[full]
         print("   %-18s mean %7.2f  median %7.2f  p90 %7.2f us" % (name, d.mean(), np.median(d), np.percentile(d, 90)))
