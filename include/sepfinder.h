@@ -280,9 +280,16 @@ int  sf_comm_unique_id(uint8_t* out, int32_t cap);          /* rank 0 creates, t
 int  sf_comm_init(sf_handle h, const uint8_t* unique_id, int32_t rank, int32_t world);
 int  sf_comm_destroy(sf_handle h);
 /* d_local: n_local records in device memory.  d_all: world * cap_per_rank records in device memory,
-   rank r's records at d_all + r * cap_per_rank; counts (host): world entries.  Synchronous.          */
+   rank r's records at d_all + r * cap_per_rank; counts (host): world entries.  Synchronous; one collective (the
+   count travels in a header slot of the block).                                                       */
 int  sf_allgather_separators(sf_handle h, const sf_separator* d_local, int32_t n_local,
                              sf_separator* d_all, int32_t cap_per_rank, int32_t* counts);
+/* The same exchange with no host in it: d_send = cap_per_rank + 1 record slots, slot 0 a header whose first int32
+   is this rank's count STAMPED ON THE DEVICE (e.g. by sf_compact_accepted_device_async writing its count there),
+   slots 1.. the records; d_all = world such blocks (block r = rank r).  ONE collective, asynchronous on the handle's
+   stream; the caller reads the counts out of the gathered headers behind its own synchronisation.            */
+int  sf_allgather_separators_device(sf_handle h, const sf_separator* d_send, sf_separator* d_all,
+                                    int32_t cap_per_rank);
 
 /* sf_nn_find_matches followed by sf_verify_matches_device of what it returned, as ONE call (the loop body of
    find_separators.py:59-133 when both robots' keyframes live in this handle): `out` / `*n_out` as

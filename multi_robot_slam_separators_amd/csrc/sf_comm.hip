@@ -94,32 +94,51 @@ extern "C" int sf_comm_destroy(sf_handle c) {
   return SF_OK;
 }
 
-// d_local: n_local records in device memory; d_all: world * cap_per_rank records in device memory
-// (rank r's records start at r * cap_per_rank); counts: world entries on the host.
+// ONE collective, no host involvement: every rank contributes cap_per_rank + 1 record slots -- slot 0 is a header whose
+// first int32 is the rank's record count, stamped ON THE DEVICE by whoever produced the records (e.g. a compaction
+// kernel writing its count there), slots 1.. are the records -- and receives world such blocks.  Asynchronous on the
+// handle's stream: the caller reads the world counts out of the gathered headers behind its own synchronisation.
+// This is the form the torch-side exchange of bench.py uses (dist.RecordExchange); a sub-millisecond step cannot
+// afford the count round trip of a two-phase exchange.
+extern "C" int sf_allgather_separators_device(sf_handle c, const sf_separator* d_send, sf_separator* d_all,
+                                              int32_t cap_per_rank) {
+  if (!c || !d_send || !d_all || cap_per_rank < 1) return SF_EINVAL;
+  if (!c->comm) return sf_fail(c, SF_EINVAL, "sf_comm_init has not been called");
+  RcclApi* a = rccl();
+  SF_HIP(c, hipSetDevice(c->device));
+  const ncclResult_t r = a->AllGather(d_send, d_all, (size_t)(cap_per_rank + 1) * sizeof(sf_separator), ncclUint8,
+                                      (ncclComm_t)c->comm, c->stream);
+  if (r != ncclSuccess) return fail_rccl(c, "ncclAllGather(records)", r);
+  return SF_OK;
+}
+
+// Host-count convenience form (synchronous): d_local: n_local records in device memory; d_all: world * cap_per_rank
+// records in device memory (rank r's records start at r * cap_per_rank); counts: world entries on the host.  Also ONE
+// collective: the count travels in the header slot of the block (uploaded with the records' staging copy), the
+// gathered blocks are unpacked into the caller's layout with one pitched copy.
 extern "C" int sf_allgather_separators(sf_handle c, const sf_separator* d_local, int32_t n_local,
                                        sf_separator* d_all, int32_t cap_per_rank, int32_t* counts) {
   if (!c || n_local < 0 || cap_per_rank < 1 || !d_all || !counts || (n_local > 0 && !d_local)) return SF_EINVAL;
   if (!c->comm) return sf_fail(c, SF_EINVAL, "sf_comm_init has not been called");
   if (n_local > cap_per_rank) return sf_fail(c, SF_ERANGE, "%d local records exceed the per-rank capacity %d", n_local, cap_per_rank);
-  RcclApi* a = rccl();
   SF_HIP(c, hipSetDevice(c->device));
   const int world = c->comm_world;
+  const size_t rec = sizeof(sf_separator), blk = (size_t)(cap_per_rank + 1) * rec;
   int rc;
-  // phase 1: counts
-  if ((rc = sf_buf_reserve(c, c->comm_scratch, (size_t)(world + 1) * 4 + (size_t)cap_per_rank * sizeof(sf_separator))) != SF_OK) return rc;
-  int32_t* d_counts = (int32_t*)c->comm_scratch.p;
-  int32_t* d_mine = d_counts + world;
-  SF_HIP(c, hipMemcpyAsync(d_mine, &n_local, 4, hipMemcpyHostToDevice, c->stream));
-  ncclResult_t r = a->AllGather(d_mine, d_counts, 1, ncclInt32, (ncclComm_t)c->comm, c->stream);
-  if (r != ncclSuccess) return fail_rccl(c, "ncclAllGather(counts)", r);
-  // phase 2: payload, padded to the fixed per-rank capacity (records are 360 B: sent as bytes)
-  sf_separator* d_send = (sf_separator*)((char*)c->comm_scratch.p + (size_t)(world + 1) * 4);
-  SF_HIP(c, hipMemsetAsync(d_send, 0, (size_t)cap_per_rank * sizeof(sf_separator), c->stream));
+  if ((rc = sf_buf_reserve(c, c->comm_scratch, blk * (size_t)(world + 1))) != SF_OK) return rc;
+  char* d_send = (char*)c->comm_scratch.p;
+  char* d_recv = d_send + blk;
+  SF_HIP(c, hipMemsetAsync(d_send, 0, blk, c->stream));
+  c->comm_count_host = n_local;       // (pageable source of a 4-byte copy: staged by the runtime before it returns)
+  SF_HIP(c, hipMemcpyAsync(d_send, &c->comm_count_host, 4, hipMemcpyHostToDevice, c->stream));
   if (n_local)
-    SF_HIP(c, hipMemcpyAsync(d_send, d_local, (size_t)n_local * sizeof(sf_separator), hipMemcpyDeviceToDevice, c->stream));
-  r = a->AllGather(d_send, d_all, (size_t)cap_per_rank * sizeof(sf_separator), ncclUint8, (ncclComm_t)c->comm, c->stream);
-  if (r != ncclSuccess) return fail_rccl(c, "ncclAllGather(records)", r);
-  SF_HIP(c, hipMemcpyAsync(counts, d_counts, (size_t)world * 4, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipMemcpyAsync(d_send + rec, d_local, (size_t)n_local * rec, hipMemcpyDeviceToDevice, c->stream));
+  if ((rc = sf_allgather_separators_device(c, (const sf_separator*)d_send, (sf_separator*)d_recv, cap_per_rank)) != SF_OK)
+    return rc;
+  // unpack: records of rank r (block r, slots 1..) -> d_all + r * cap_per_rank; headers -> counts
+  SF_HIP(c, hipMemcpy2DAsync(d_all, (size_t)cap_per_rank * rec, d_recv + rec, blk, (size_t)cap_per_rank * rec, world,
+                             hipMemcpyDeviceToDevice, c->stream));
+  SF_HIP(c, hipMemcpy2DAsync(counts, 4, d_recv, blk, 4, world, hipMemcpyDeviceToHost, c->stream));
   SF_HIP(c, hipStreamSynchronize(c->stream));
   return SF_OK;
 }

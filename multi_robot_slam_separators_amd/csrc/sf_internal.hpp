@@ -191,6 +191,7 @@ struct sf_context {
   // multi-GPU exchange (sf_comm.hip)
   void* comm = nullptr;    // ncclComm_t
   int comm_rank = 0, comm_world = 1;
+  int32_t comm_count_host = 0;
   Buf comm_scratch;
 
   // Two-stream verification of large batches (sf_api.hip, verify_device): the second half of a batch runs

@@ -95,6 +95,7 @@ def load():
         "sf_comm_init": (C.c_int, [vp, vp, i32, i32]),
         "sf_comm_destroy": (C.c_int, [vp]),
         "sf_allgather_separators": (C.c_int, [vp, vp, i32, vp, i32, vp]),
+        "sf_allgather_separators_device": (C.c_int, [vp, vp, vp, i32]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_reset": (C.c_int, [vp]),
         "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
@@ -123,7 +124,7 @@ EXPORTED = [
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
-    "sf_allgather_separators", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
+    "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
 
@@ -360,6 +361,10 @@ class SeparatorFinder:
         return counts
 
     # -- measurement ------------------------------------------------------------------------------
+    def allgather_separators_device(self, d_send, d_all, cap_per_rank):
+        """One-collective exchange on device buffers with a device-stamped count (see include/sepfinder.h)."""
+        self._check(self._L.sf_allgather_separators_device(self._h, C.c_void_p(d_send), C.c_void_p(d_all), cap_per_rank))
+
     def prof_enable(self, on=True):
         self._check(self._L.sf_prof_enable(self._h, int(on)))
 

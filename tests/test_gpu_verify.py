@@ -253,6 +253,17 @@ def test_rccl_allgather_separators_single_rank(finder):
         assert back.tobytes() == acc.tobytes()
         with pytest.raises(lib.SepfinderError):
             finder.allgather_separators(d_local.data_ptr(), cap + 1, d_all.data_ptr(), cap, 1)
+        # the no-host form: header slot with a device-stamped count in front of the records, one collective
+        RB = _abi.SEPARATOR_DTYPE.itemsize
+        d_send = torch.zeros((cap + 1, RB), dtype=torch.uint8, device="cuda")
+        d_send[1: 1 + len(acc)] = d_local
+        d_send[0, :4].view(torch.int32).fill_(len(acc))          # stamped on the device
+        d_blk = torch.zeros((cap + 1, RB), dtype=torch.uint8, device="cuda")
+        finder.set_stream(torch.cuda.current_stream().cuda_stream)
+        finder.allgather_separators_device(d_send.data_ptr(), d_blk.data_ptr(), cap)
+        torch.cuda.synchronize()
+        assert int(d_blk[0, :4].view(torch.int32).item()) == len(acc)
+        assert d_blk[1: 1 + len(acc)].cpu().numpy().tobytes() == acc.tobytes()
     finally:
         finder.comm_destroy()
 
