@@ -105,7 +105,16 @@ typedef struct sf_params {
   int32_t pnp_flags;               /* 0    Vis/PnPFlags: only 0 (cv::SOLVEPNP_ITERATIVE)      */
   int32_t pnp_refine_iterations;   /* 0    Vis/PnPRefineIterations (rtabmap util3d::solvePnPRansac
                                            re-solve / re-select rounds, 3-sigma threshold)        */
-  int32_t reserved[5];
+  /* Two-view bundle adjustment after each pass's motion estimate (myRegistrationVis.cpp:1192-1370; rtabmap
+     Vis/BundleAdjustment, upstream default 1 when built with g2o): the inliers' 3D points (from-frame) and the pose of
+     the "to" camera are refined against both frames' keypoints, the "from" pose fixed, Huber kernel; words whose
+     reprojection stays beyond the kernel width are removed from the inliers (sbaOutliers, :1314-1330) and the
+     min_inliers test is repeated (:1331-1336).                                                              */
+  int32_t bundle_adjustment;       /* 0 (default here; north_star's path) = off, 1 = on (needs a calibrated camera) */
+  int32_t ba_iterations;           /* 20   Optimizer/Iterations                                             */
+  float   ba_robust_kernel_delta;  /* 8.0  g2o/RobustKernelDelta (pixels)                                   */
+  float   ba_pixel_variance;       /* 1.0  g2o/PixelVariance                                                */
+  float   stereo_baseline;         /* metres; > 0 adds the stereo (disparity) residual of points with depth  */
 } sf_params;
 
 /* ---- wire layouts ------------------------------------------------------------------------ */

@@ -49,7 +49,11 @@ class Params(C.Structure):
         ("pnp_reproj_error", C.c_float),
         ("pnp_flags", C.c_int32),
         ("pnp_refine_iterations", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("bundle_adjustment", C.c_int32),
+        ("ba_iterations", C.c_int32),
+        ("ba_robust_kernel_delta", C.c_float),
+        ("ba_pixel_variance", C.c_float),
+        ("stereo_baseline", C.c_float),
     ]
 
 
@@ -172,6 +176,11 @@ def default_params() -> Params:
     p.pnp_reproj_error = 2.0
     p.pnp_flags = 0
     p.pnp_refine_iterations = 0
+    p.bundle_adjustment = 0
+    p.ba_iterations = 20
+    p.ba_robust_kernel_delta = 8.0
+    p.ba_pixel_variance = 1.0
+    p.stereo_baseline = 0.0
     return p
 
 

@@ -599,6 +599,11 @@ extern "C" void sf_default_params(sf_params* p) {
   p->pnp_reproj_error = 2.0f;        // Vis/PnPReprojError
   p->pnp_flags = 0;                  // Vis/PnPFlags (cv::SOLVEPNP_ITERATIVE)
   p->pnp_refine_iterations = 0;      // Vis/PnPRefineIterations
+  p->bundle_adjustment = 0;          // Vis/BundleAdjustment (rtabmap: 1 with g2o; off here: north_star's path has none)
+  p->ba_iterations = 20;             // Optimizer/Iterations
+  p->ba_robust_kernel_delta = 8.f;   // g2o/RobustKernelDelta
+  p->ba_pixel_variance = 1.f;        // g2o/PixelVariance
+  p->stereo_baseline = 0.f;
 }
 
 static int fill_device_params(sf_context* c) {

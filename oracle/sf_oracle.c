@@ -916,15 +916,27 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
                          : (n_words_from >= p->min_inliers && n_words_to >= p->min_inliers);
     if (gate) {
       sfo_motion mo;
+      uint8_t* imask = (uint8_t*)calloc((size_t)(*nc > 0 ? *nc : 1), 1);
+      if (!imask) return SF_ENOMEM;
       rc = p->estimation_type == 1
-               ? sfo_estimate_motion_3d2d(p, from->xyz, to->kpts, to->n3d > 0 ? to->xyz : NULL, cf, ct, *nc, &mo, NULL)
-               : sfo_estimate_motion_3d3d(p, from->xyz, to->xyz, cf, ct, *nc, &mo, NULL);
-      if (rc != SF_OK) return rc;
+               ? sfo_estimate_motion_3d2d(p, from->xyz, to->kpts, to->n3d > 0 ? to->xyz : NULL, cf, ct, *nc, &mo, imask)
+               : sfo_estimate_motion_3d3d(p, from->xyz, to->xyz, cf, ct, *nc, &mo, imask);
+      if (rc != SF_OK) { free(imask); return rc; }
       out->cov_diag = mo.variance;
       out->cov_diag_ang = mo.variance_ang;
       out->inliers = mo.inliers;
       out->matches = mo.matches;
       if (!mo.is_null) { memcpy(out->transform, mo.transform, sizeof(out->transform)); out->is_null = 0; }
+      /* :1192-1197 bundle adjustment of the forward transform (the covariance keeps the motion estimate's value) */
+      if (p->bundle_adjustment > 0 && !mo.is_null && mo.inliers > 0 && n_words_from > 0 && n_words_to_2d > 0) {
+        int n_inl = mo.inliers, null2 = 0;
+        rc = sfo_bundle_adjust(p, from->xyz, from->kpts, to->n3d > 0 ? to->xyz : NULL, to->kpts, cf, ct, imask, *nc,
+                               out->transform, &n_inl, &null2, NULL);
+        if (rc != SF_OK) { free(imask); return rc; }
+        out->inliers = n_inl;
+        out->is_null = null2;
+      }
+      free(imask);
     }
   }
   return SF_OK;
@@ -968,6 +980,11 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if ((rc = sfo_validate(to)) != SF_OK) return rc;
   if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
   if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations < 0)) return SF_EINVAL;
+  if (p->bundle_adjustment != 0 &&
+      (p->bundle_adjustment != 1 || !(p->image_width > 0 && p->image_height > 0 && p->fx > 0.0 && p->fy > 0.0) ||
+       p->ba_iterations < 0 || !(p->ba_pixel_variance > 0.0f) || !(p->ba_robust_kernel_delta > 0.0f) ||
+       !(p->stereo_baseline >= 0.0f)))
+    return SF_EINVAL;   /* :1230 UASSERT(stereoCameraModelTo.isValidForProjection()) */
   memset(out, 0, sizeof(*out));
   int cap = from->rows > to->rows ? from->rows : to->rows;
   if (cap < 1) cap = 1;

@@ -79,6 +79,12 @@ typedef struct sfo_motion {
   int    refine_rounds;
 } sfo_motion;
 
+/* Two-view bundle adjustment of one pass (myRegistrationVis.cpp:1192-1370; sf_oracle_ba.c).  mask: the motion
+ * estimate's inliers over the pass's correspondences.  T in/out (p_from = T p_to); *n_inliers in/out; *is_null out. */
+int sfo_bundle_adjust(const sf_params* p, const float* xyz_from, const sf_keypoint* kp_from, const float* xyz_to,
+                      const sf_keypoint* kp_to, const uint16_t* corr_from, const uint16_t* corr_to,
+                      const uint8_t* mask, int n_corr, float T[12], int* n_inliers, int* is_null, uint8_t* mask_out);
+
 int sfo_estimate_motion_3d3d(const sf_params* p,
                              const float* xyz_from, const float* xyz_to,
                              const uint16_t* corr_from, const uint16_t* corr_to, int n_corr,

@@ -312,7 +312,7 @@ static int sfo_pnp_hypothesis(const sfo_pnp_problem* pb, uint64_t seed, uint32_t
   return 1;
 }
 
-static void sfo_quat_to_R(const double q[4], double R[9]) {
+void sfo_quat_to_R(const double q[4], double R[9]) {
   const double w = q[0], x = q[1], y = q[2], z = q[3];
   const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
   const double wx = w * x, wy = w * y, wz = w * z;
@@ -322,7 +322,7 @@ static void sfo_quat_to_R(const double q[4], double R[9]) {
 }
 
 /* Shepperd's rotation-matrix -> unit quaternion (w, x, y, z) */
-static void sfo_R_to_quat(const double R[9], double q[4]) {
+void sfo_R_to_quat(const double R[9], double q[4]) {
   const double tr = (R[0] + R[4]) + R[8];
   double w, x, y, z;
   if (tr > 0.0) {
@@ -391,7 +391,7 @@ static void sfo_pnp_normal_eq(const sfo_pnp_problem* pb, const uint8_t* mask, co
 }
 
 /* solve (H with diagonal scaled by 1 + lambda) d = -g by Cholesky; 0 when not positive definite */
-static int sfo_pnp_solve6(const double ne[SFO_PNP_NSUM], double lambda, double d[6]) {
+int sfo_pnp_solve6(const double ne[SFO_PNP_NSUM], double lambda, double d[6]) {
   double A[6][6], Lm[6][6];
   int o = 0;
   for (int j = 0; j < 6; ++j)
