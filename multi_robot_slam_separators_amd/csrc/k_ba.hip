@@ -1,0 +1,453 @@
+#pragma once
+// k_ba.hip -- two-view bundle adjustment of one pass's motion estimate, for one candidate pair per 256-thread
+// workgroup (included by k_verify.hip; runs inside the RANSAC / PnP workgroup right behind the estimate, while its
+// inlier mask and compacted correspondences are still in LDS).
+//
+// Replaces myRegistrationVis.cpp:1192-1370 of the reference: Optimizer::optimizeBA [upstream rtabmap OptimizerG2O on
+// g2o's sba types, un-vendored] on two poses (the "from" pose fixed at identity) and the inlier words' 3D points, mono
+// or stereo reprojection residuals against both frames' keypoints, Huber kernel, Levenberg-Marquardt; words whose
+// reprojection stays outside the kernel leave the inliers (:1314-1330), fewer than min_inliers left -> null
+// (:1331-1336).  The algorithm and its operation order are those of oracle/sf_oracle_ba.c;
+// results are compared bit for bit.
+//
+// CDNA4 mapping: one LANE per inlier word (stride 256).  A word's two edges give its 3x3 point block, its 6x3 coupling
+// to the pose and its share of the 6x6 pose block, all in registers; the point is eliminated in the lane (Schur
+// complement, 3x3 inverse by cofactors) and only the 28 reduced sums (21 + 6 + cost) cross lanes, through the
+// canonical block reduction (sfd::block_sum_canon_to_lds: totals land in LDS, every lane then solves the same 6x6
+// system).  The back-substitution recomputes the word's blocks instead of keeping 27 doubles per word alive.
+// ~60 fp64 values are live per lane, so the kernels that include this body are built for 2 workgroups per CU.
+#include "sf_device_math.hpp"
+#include "sf_internal.hpp"
+#include "sf_pnp_math.hpp"
+
+namespace {
+
+#define BA_NSUM 28
+
+struct BaLds {
+  double* X;      // [kcap][3] current points (world = "from" base frame)
+  double* Xc;     // [kcap][3] candidate points
+  float* o1;      // [kcap][3] camera-1 observation: u - cx, v - cy, depth (<= 0: mono)
+  float* o2;      // [kcap][3] camera-2 observation
+  double* red;    // [4][32]
+  double* ne_a;   // [32]
+  double* ne_b;   // [32]
+  int* misc;      // [16]
+};
+
+struct BaCam {
+  double fx, fy, b, info, delta;
+  double R1[9], t1[3];
+};
+
+// one edge: residual rows (2 mono, 3 stereo) and their Jacobians wrt the camera-frame point; 0 = behind the camera
+__device__ __forceinline__ int ba_edge(const BaCam& cam, const double (&P)[3], const float* o, double (&r)[3],
+                                       double (&J)[3][3]) {
+  if (!(P[2] > 0.0)) return 0;
+  const double iz = 1.0 / P[2];
+  const double xn = P[0] * iz, yn = P[1] * iz;
+  const double a0 = cam.fx * iz, a2 = -(a0 * xn);
+  const double b1 = cam.fy * iz, b2 = -(b1 * yn);
+  r[0] = cam.fx * xn - (double)o[0];
+  r[1] = cam.fy * yn - (double)o[1];
+  J[0][0] = a0; J[0][1] = 0.0; J[0][2] = a2;
+  J[1][0] = 0.0; J[1][1] = b1; J[1][2] = b2;
+  if (cam.b > 0.0 && o[2] > 0.0f) {
+    const double fb = cam.fx * cam.b;
+    r[2] = (cam.fx * xn - fb * iz) - ((double)o[0] - fb / (double)o[2]);
+    J[2][0] = a0; J[2][1] = 0.0; J[2][2] = a2 + (fb * iz) * iz;
+    return 3;
+  }
+  return 2;
+}
+
+__device__ __forceinline__ double ba_huber(double chi2, double delta, double& w) {
+  const double e = sqrt(chi2);
+  if (e <= delta) { w = 1.0; return chi2; }
+  w = delta / e;
+  return 2.0 * delta * e - delta * delta;
+}
+
+struct BaBlocks {
+  double A[6], bp[3], C[18], H[21], bc[6], cost;
+  bool ok;
+};
+
+__device__ inline void ba_point_blocks(const BaCam& cam, const double* Xp, const float* o1, const float* o2,
+                                       const double (&R2)[9], const double (&t2)[3], BaBlocks& B) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) B.A[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) B.bp[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 18; ++k) B.C[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) B.H[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) B.bc[k] = 0.0;
+  B.cost = 0.0;
+  B.ok = true;
+  const double X[3] = {Xp[0], Xp[1], Xp[2]};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = c == 0 ? cam.R1[k] : R2[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = c == 0 ? cam.t1[k] : t2[k];
+    const float* o = c == 0 ? o1 : o2;
+    const double Y[3] = {(R[0] * X[0] + R[1] * X[1]) + R[2] * X[2], (R[3] * X[0] + R[4] * X[1]) + R[5] * X[2],
+                         (R[6] * X[0] + R[7] * X[1]) + R[8] * X[2]};
+    const double P[3] = {Y[0] + t[0], Y[1] + t[1], Y[2] + t[2]};
+    double r[3], J[3][3];
+    const int rows = ba_edge(cam, P, o, r, J);
+    if (rows == 0) { B.cost += 1e30; B.ok = false; continue; }
+    double chi2 = r[0] * r[0] + r[1] * r[1];
+    if (rows == 3) chi2 = chi2 + r[2] * r[2];
+    chi2 = chi2 * cam.info;
+    double w;
+    B.cost += ba_huber(chi2, cam.delta, w);
+    w = w * cam.info;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < rows) {
+        const double j0 = J[k][0], j1 = J[k][1], j2 = J[k][2];
+        const double JX[3] = {(j0 * R[0] + j1 * R[3]) + j2 * R[6], (j0 * R[1] + j1 * R[4]) + j2 * R[7],
+                              (j0 * R[2] + j1 * R[5]) + j2 * R[8]};
+        const double wr = w * r[k];
+        B.A[0] += w * (JX[0] * JX[0]); B.A[1] += w * (JX[0] * JX[1]); B.A[2] += w * (JX[0] * JX[2]);
+        B.A[3] += w * (JX[1] * JX[1]); B.A[4] += w * (JX[1] * JX[2]); B.A[5] += w * (JX[2] * JX[2]);
+        B.bp[0] += JX[0] * wr; B.bp[1] += JX[1] * wr; B.bp[2] += JX[2] * wr;
+        if (c == 1) {
+          const double Jc[6] = {j2 * Y[1] - j1 * Y[2], j0 * Y[2] - j2 * Y[0], j1 * Y[0] - j0 * Y[1], j0, j1, j2};
+          int o_ = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int cc = a; cc < 6; ++cc) { B.H[o_] += w * (Jc[a] * Jc[cc]); ++o_; }
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            B.bc[a] += Jc[a] * wr;
+            B.C[3 * a] += w * (Jc[a] * JX[0]); B.C[3 * a + 1] += w * (Jc[a] * JX[1]); B.C[3 * a + 2] += w * (Jc[a] * JX[2]);
+          }
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool ba_inv3(const double (&A)[6], double lambda, double (&Ai)[6]) {
+  const double s = 1.0 + lambda;
+  const double a = A[0] * s, b = A[1], c = A[2], d = A[3] * s, e = A[4], f = A[5] * s;
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = (a * c00 + b * c01) + c * c02;
+  if (!(det > 0.0) || !isfinite(det)) return false;
+  const double id = 1.0 / det;
+  Ai[0] = c00 * id; Ai[1] = c01 * id; Ai[2] = c02 * id;
+  Ai[3] = (a * f - c * c) * id; Ai[4] = (b * c - a * e) * id; Ai[5] = (a * d - b * b) * id;
+  return true;
+}
+
+__device__ __forceinline__ void ba_sym3_mul(const double (&Ai)[6], const double* v, double* out) {
+  out[0] = (Ai[0] * v[0] + Ai[1] * v[1]) + Ai[2] * v[2];
+  out[1] = (Ai[1] * v[0] + Ai[3] * v[1]) + Ai[4] * v[2];
+  out[2] = (Ai[2] * v[0] + Ai[4] * v[1]) + Ai[5] * v[2];
+}
+
+// Schur-reduced normal equations at (q, t, points Xs): totals in `out` (LDS, [28])
+__device__ inline void ba_normal_eq(const BaLds& L, const BaCam& cam, int m, const double* Xs, const double (&q)[4],
+                                    const double (&t)[3], double lambda, double* out, int tid) {
+  double R2[9];
+  sfd::quat_to_R(q, R2);
+  double ne[BA_NSUM];
+#pragma unroll
+  for (int k = 0; k < BA_NSUM; ++k) ne[k] = 0.0;
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    BaBlocks B;
+    ba_point_blocks(cam, Xs + 3 * i, L.o1 + 3 * i, L.o2 + 3 * i, R2, t, B);
+    double term[BA_NSUM];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) term[k] = B.H[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) term[21 + k] = B.bc[k];
+    term[27] = B.cost;
+    double Ai[6];
+    if (B.ok && ba_inv3(B.A, lambda, Ai)) {
+      double CA[18];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) ba_sym3_mul(Ai, B.C + 3 * a, CA + 3 * a);
+      int o_ = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) {
+          term[o_] = term[o_] - ((CA[3 * a] * B.C[3 * c] + CA[3 * a + 1] * B.C[3 * c + 1]) + CA[3 * a + 2] * B.C[3 * c + 2]);
+          ++o_;
+        }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        term[21 + a] = term[21 + a] - ((CA[3 * a] * B.bp[0] + CA[3 * a + 1] * B.bp[1]) + CA[3 * a + 2] * B.bp[2]);
+    }
+#pragma unroll
+    for (int k = 0; k < BA_NSUM; ++k) ne[k] += term[k];
+  }
+  sfd::block_sum_canon_to_lds<BA_NSUM, 32>(ne, L.red, out, tid);
+}
+
+// candidate points Xc = X - A'^-1 (bp + C^T dc) at the current state
+__device__ inline void ba_backsub(const BaLds& L, const BaCam& cam, int m, const double (&q)[4], const double (&t)[3],
+                                  double lambda, const double (&dc)[6], int tid) {
+  double R2[9];
+  sfd::quat_to_R(q, R2);
+  for (int i = tid; i < m; i += SF_BLOCK) {
+    BaBlocks B;
+    ba_point_blocks(cam, L.X + 3 * i, L.o1 + 3 * i, L.o2 + 3 * i, R2, t, B);
+    double Ai[6];
+    double dx[3] = {0.0, 0.0, 0.0};
+    if (B.ok && ba_inv3(B.A, lambda, Ai)) {
+      double v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double sacc = B.bp[c];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) sacc = sacc + B.C[3 * a + c] * dc[a];
+        v[c] = sacc;
+      }
+      ba_sym3_mul(Ai, v, dx);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.Xc[3 * i + c] = L.X[3 * i + c] - dx[c];
+  }
+}
+
+__device__ __forceinline__ BaLds ba_carve(unsigned char* p, int kcap) {
+  BaLds L;
+  L.X = (double*)p; p += (size_t)kcap * 24;
+  L.Xc = (double*)p; p += (size_t)kcap * 24;
+  L.red = (double*)p; p += 128 * 8;
+  L.ne_a = (double*)p; p += 32 * 8;
+  L.ne_b = (double*)p; p += 32 * 8;
+  L.o1 = (float*)p; p += (size_t)kcap * 12;
+  L.o2 = (float*)p; p += (size_t)kcap * 12;
+  L.misc = (int*)p;
+  return L;
+}
+
+// Bundle adjustment of one pass.  pts[i] / cidx[i] / inl[i] (LDS, i < m): the estimate's compacted correspondences --
+// the "from" 3D point, the packed (from | to << 16) feature indices, the inlier flag.  `ps` (the pass state the
+// estimate just wrote; thread 0's view is authoritative): T, inliers and is_null are updated in place.
+__device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, const float4* pts, const uint32_t* cidx,
+                                        const uint8_t* inl, int m, PassState& ps, const DeviceParams& P,
+                                        unsigned char* lds) {
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const BaLds L = ba_carve(lds, kcap);
+  __syncthreads();                       // the estimate's result (ps) is visible
+  const PassState p0 = ps;
+  // :1192-1197 gate (the words3From / wordsTo conditions hold whenever the estimate ran)
+  if (p0.is_null || p0.inliers <= 0) return;
+
+  BaCam cam;
+  cam.fx = P.fx; cam.fy = P.fy; cam.b = (double)P.stereo_baseline;
+  cam.info = 1.0 / (double)P.ba_pixel_variance;
+  cam.delta = (double)P.ba_robust_kernel_delta;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cam.R1[3 * i + j] = (double)P.L[4 * j + i];
+    cam.t1[i] = -(((double)P.L[i] * (double)P.L[3] + (double)P.L[4 + i] * (double)P.L[7]) + (double)P.L[8 + i] * (double)P.L[11]);
+  }
+
+  // ---- the inlier words, in correspondence order -----------------------------------------------------------------------
+  const float4* kF = st.kp + (size_t)sF * kcap;
+  const float4* kT = st.kp + (size_t)sT * kcap;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const bool to3d = st.meta[sT].y > 0;
+  const float cxf = (float)P.cx, cyf = (float)P.cy;
+  if (tid < 16) L.misc[tid] = 0;
+  __syncthreads();
+  int n = 0;
+  for (int base = 0; base < m; base += SF_BLOCK) {
+    const int i = base + tid;
+    const bool in = i < m && inl[i] != 0;
+    const unsigned long long bal = __ballot(in);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = L.misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (in) {
+      const int k = n + woff + before;
+      const float4 a = pts[i];
+      const uint32_t c = cidx[i];
+      const float4 k1 = kF[c & 0xFFFFu], k2 = kT[c >> 16];
+      L.X[3 * k] = (double)a.x; L.X[3 * k + 1] = (double)a.y; L.X[3 * k + 2] = (double)a.z;
+      const float d1 = (float)(((cam.R1[6] * (double)a.x + cam.R1[7] * (double)a.y) + cam.R1[8] * (double)a.z) + cam.t1[2]);
+      L.o1[3 * k] = k1.x - cxf; L.o1[3 * k + 1] = k1.y - cyf; L.o1[3 * k + 2] = d1;
+      float d2 = 0.0f;
+      if (to3d) {
+        const float* bq = xT + 3 * (size_t)(c >> 16);
+        const float bx = bq[0], by = bq[1], bz = bq[2];
+        if (sfd::finite3(bx, by, bz))
+          d2 = (float)(((cam.R1[6] * (double)bx + cam.R1[7] * (double)by) + cam.R1[8] * (double)bz) + cam.t1[2]);
+      }
+      L.o2[3 * k] = k2.x - cxf; L.o2[3 * k + 1] = k2.y - cyf; L.o2[3 * k + 2] = d2;
+    }
+    n += total;
+    __syncthreads();
+  }
+  if (n == 0) return;
+
+  // camera 2: M = (T L)^-1 from float matrices (rtabmap::Transform), then double
+  double q[4], t[3];
+  {
+    float TL[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        TL[4 * i + j] = (p0.T[4 * i] * P.L[j] + p0.T[4 * i + 1] * P.L[4 + j]) + p0.T[4 * i + 2] * P.L[8 + j];
+      TL[4 * i + 3] = ((p0.T[4 * i] * P.L[3] + p0.T[4 * i + 1] * P.L[7]) + p0.T[4 * i + 2] * P.L[11]) + p0.T[4 * i + 3];
+    }
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = (double)TL[4 * j + i];
+      t[i] = -(((double)TL[i] * (double)TL[3] + (double)TL[4 + i] * (double)TL[7]) + (double)TL[8 + i] * (double)TL[11]);
+    }
+    sfd::R_to_quat(R, q);
+  }
+
+  // ---- Levenberg-Marquardt on the Schur complement (every lane runs the same scalar control flow) -----------------------
+  double* cur = L.ne_a;
+  double* cnd = L.ne_b;
+  double lambda = 1e-3;
+  ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+  for (int iter = 0; iter < P.ba_iterations; ++iter) {
+    double d[6];
+    if (!sfd::solve6(cur, lambda, d)) {
+      lambda = lambda * 10.0;
+      if (lambda > 1e12) break;
+      ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+      continue;
+    }
+    const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
+    const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
+    const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
+    double qc[4], tc[3];
+    qc[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
+    qc[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
+    qc[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
+    qc[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
+    const double qn = 1.0 / sqrt(((qc[0] * qc[0] + qc[1] * qc[1]) + qc[2] * qc[2]) + qc[3] * qc[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
+    ba_backsub(L, cam, n, q, t, lambda, d, tid);
+    const double lambda_acc = lambda * 0.1 < 1e-16 ? 1e-16 : lambda * 0.1;
+    __syncthreads();                                   // candidate points written
+    ba_normal_eq(L, cam, n, L.Xc, qc, tc, lambda_acc, cnd, tid);
+    const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
+    const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
+    if (cnd[27] < cur[27]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = qc[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[i] = tc[i];
+      for (int i = tid; i < 3 * n; i += SF_BLOCK) L.X[i] = L.Xc[i];
+      double* sw = cur; cur = cnd; cnd = sw;
+      lambda = lambda_acc;
+      __syncthreads();
+    } else {
+      lambda = lambda * 10.0;
+      if (lambda > 1e12) break;
+      ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+    }
+    if (dd <= 1.4e-14 * tt) break;
+  }
+
+  // ---- outliers: a word any of whose edges ends with chi2 > delta^2 ------------------------------------------------------
+  double R2[9];
+  sfd::quat_to_R(q, R2);
+  const double lim = cam.delta * cam.delta;
+  int n_out = 0;
+  for (int i = tid; i < n; i += SF_BLOCK) {
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double R[9], tt[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = c == 0 ? cam.R1[k] : R2[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tt[k] = c == 0 ? cam.t1[k] : t[k];
+      const double* Xi = L.X + 3 * i;
+      const double Pc[3] = {((R[0] * Xi[0] + R[1] * Xi[1]) + R[2] * Xi[2]) + tt[0],
+                            ((R[3] * Xi[0] + R[4] * Xi[1]) + R[5] * Xi[2]) + tt[1],
+                            ((R[6] * Xi[0] + R[7] * Xi[1]) + R[8] * Xi[2]) + tt[2]};
+      double r[3], J[3][3];
+      const int rows = ba_edge(cam, Pc, (c == 0 ? L.o1 : L.o2) + 3 * i, r, J);
+      if (rows == 0) { bad = true; continue; }
+      double chi2 = r[0] * r[0] + r[1] * r[1];
+      if (rows == 3) chi2 = chi2 + r[2] * r[2];
+      chi2 = chi2 * cam.info;
+      if (chi2 > lim) bad = true;
+    }
+    n_out += bad ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) n_out += __shfl_xor(n_out, off);
+  __syncthreads();
+  if (lane == 0) L.misc[8 + wave] = n_out;
+  __syncthreads();
+  n_out = ((L.misc[8] + L.misc[9]) + L.misc[10]) + L.misc[11];
+
+  if (tid == 0) {
+    PassState o = p0;
+    o.inliers = n - n_out;
+    if (o.inliers < P.min_inliers) {
+      o.is_null = 1;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o.T[i] = 0.f;
+    } else {
+      double Rd[9];
+      sfd::quat_to_R(q, Rd);
+      float Rf[9], tf[3], MR[9], Mt[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rf[i] = (float)Rd[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tf[i] = (float)t[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          MR[3 * i + j] = (P.L[4 * i] * Rf[j] + P.L[4 * i + 1] * Rf[3 + j]) + P.L[4 * i + 2] * Rf[6 + j];
+        Mt[i] = ((P.L[4 * i] * tf[0] + P.L[4 * i + 1] * tf[1]) + P.L[4 * i + 2] * tf[2]) + P.L[4 * i + 3];
+      }
+      bool allz = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.T[4 * i + j] = MR[3 * j + i];
+        o.T[4 * i + 3] = -((MR[i] * Mt[0] + MR[3 + i] * Mt[1]) + MR[6 + i] * Mt[2]);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) allz = allz && (o.T[i] == 0.f);
+      o.is_null = allz ? 1 : 0;
+    }
+    ps = o;
+  }
+}
+
+}  // namespace
+
+size_t sf_ba_lds_bytes(int kcap) {
+  return (size_t)kcap * (24 + 24 + 12 + 12) + 128 * 8 + 2 * 32 * 8 + 16 * 4;
+}

@@ -29,10 +29,17 @@
 #include "sf_device_math.hpp"
 #include "sf_internal.hpp"
 #include "sf_pnp_math.hpp"
+#include "k_ba.hip"
 
 namespace {
 
 #define PNP_NSUM 28
+
+__host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations) {
+  const int it = iterations > 0 ? iterations : 0;
+  return (size_t)kcap * (16 + 24 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
+         5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
+}
 
 struct PnpLds {
   float4* obj;      // [kcap] world ("from" base frame) point
@@ -263,8 +270,18 @@ __device__ inline float rank_value(const float* arr, int m, int rank, double* sl
   return (float)*slot;
 }
 
+// What a finished pass leaves in LDS for the bundle adjustment (k_ba.hip): the compacted "from" points, the packed
+// feature indices, the final inlier mask.  ran = false: the pass ended early (no estimate to refine).
+struct PnpTail {
+  const float4* obj;
+  const uint32_t* cidx;
+  const uint8_t* inl;
+  int m;
+  bool ran;
+};
+
 // Body of one PnP pass for ONE pair (the calling 256-thread workgroup); smem_raw is the workgroup's dynamic LDS.
-__device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
+__device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                          const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                          const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
                                          const DeviceParams& P, unsigned char* smem_raw) {
@@ -272,6 +289,7 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
+  const PnpTail none = {nullptr, nullptr, nullptr, 0, false};
   const int max_it = P.iterations > 0 ? P.iterations : 0;
   const bool to_has_3d = st.meta[sT].y > 0;   // the "to" frame carries 3D points (selects the covariance form)
 
@@ -359,10 +377,10 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
   ps.pad = 0;
   if (m < P.min_inliers || m < 4) {
     if (tid == 0) pass[pair] = ps;
-    return;
+    return none;
   }
 
-  if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return none; }   // diagnostic truncation (SF_RANSAC_STOP)
   PnpCam cam;
   cam.fx = P.fx; cam.fy = P.fy;
   cam.fxf = (float)P.fx; cam.fyf = (float)P.fy;
@@ -427,11 +445,11 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
     }
     __syncthreads();
   }
-  if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return none; }
   const int best_it = L.misc[0];
   if (best_it < 0) {   // solvePnPRansac returned false: no inliers
     if (tid == 0) pass[pair] = ps;
-    return;
+    return none;
   }
 
   // ---- winning model (parked in LDS by the replay) and its inlier mask ---------------------------------
@@ -446,7 +464,7 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
   }
   n_inl = block_sum_i(n_inl, L.misc, tid);   // also orders the mask writes before the reads below
 
-  if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return none; }
   // ---- final solve on the inliers: Levenberg-Marquardt, at most 20 evaluations ------------------------
   double q[4], t[3];
   {
@@ -516,11 +534,11 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
     n_inl = n_new;
   }
 
-  if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return; }
+  if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return none; }
   ps.inliers = n_inl;
   if (n_inl < P.min_inliers) {
     if (tid == 0) pass[pair] = ps;
-    return;
+    return none;
   }
 
   // ---- transform = (localTransform * pnp).inverse()  (rtabmap::Transform is float) ----------------------
@@ -593,42 +611,53 @@ __device__ __forceinline__ void pnp_body(const StoreView& st, int pair, const in
     ps.var_ang = v;
   }
   if (tid == 0) pass[pair] = ps;
+  return PnpTail{L.obj, L.cidx, inl, m, true};
 }
 
-__global__ void __launch_bounds__(SF_BLOCK, 3)
+template <bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
 k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
       PassState* __restrict__ pass, DeviceParams P) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  pnp_body(st, list[blockIdx.x], pair_from, pair_to, corr, hdr, pass, P, smem_raw);
+  const int pair = list[blockIdx.x];
+  const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr, hdr, pass, P, smem_raw);
+  if constexpr (BA) {
+    // myRegistrationVis.cpp:1192-1370: two-view bundle adjustment of this pass's estimate
+    if (P.bundle_adjustment && tail.ran)
+      ba_body(st, pair_from[pair], pair_to[pair], tail.obj, tail.cidx, tail.inl, tail.m, pass[pair], P,
+              smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15));
+  }
 }
 
 }  // namespace
 
-size_t sf_pnp_lds_bytes(int kcap, int iterations) {
-  const int it = iterations > 0 ? iterations : 0;
-  return (size_t)kcap * (16 + 24 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
-         5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
-}
+size_t sf_pnp_lds_bytes(int kcap, int iterations) { return sf_pnp_lds_bytes_dev(kcap, iterations); }
 
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
-  const size_t lds = sf_pnp_lds_bytes(st.kcap, c->dparams.iterations);
+  const bool ba = c->dparams.bundle_adjustment != 0;
+  const size_t lds = ((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "PnP workgroup needs %zu B of LDS (> 160 KiB)", lds);
-  if (!c->pnp_attr_set) {   // per handle = per device
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->pnp_attr_set = true;
+  bool& attr = ba ? c->pnp_ba_attr_set : c->pnp_attr_set;
+  if (!attr) {   // per handle = per device
+    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
-  hipLaunchKernelGGL(k_pnp, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                     (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
-                     (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
-                     (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
-                     (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
+                       (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
+                       (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
+                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  };
+  if (ba) launch(k_pnp<true>); else launch(k_pnp<false>);
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
   return SF_OK;

@@ -27,6 +27,7 @@
 // Compiled with -ffp-contract=off (canonical arithmetic, see sf_device_math.hpp).
 #include "sf_device_math.hpp"
 #include "sf_internal.hpp"
+#include "k_ba.hip"
 
 namespace {
 
@@ -43,6 +44,7 @@ struct RansacLds {
   int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
   float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the scan)
   float* bc;        // [12] model being refined (broadcast from the solving wavefront)
+  uint32_t* cidx;   // [kcap] packed (from | to << 16) feature indices of the gathered correspondences (bundle adjustment)
 };
 
 __device__ __forceinline__ RansacLds ransac_carve(unsigned char* p, int kcap) {
@@ -58,7 +60,8 @@ __device__ __forceinline__ RansacLds ransac_carve(unsigned char* p, int kcap) {
   L.hyp = (float*)p; p += 12 * 64 * 4;
   L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
   L.best = (float*)p; p += 16 * 4;
-  L.bc = (float*)p;
+  L.bc = (float*)p; p += 16 * 4;
+  L.cidx = (uint32_t*)p;
   return L;
 }
 
@@ -313,6 +316,11 @@ __device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, i
   return n_proc < R || base + R > max_it;
 }
 
+__host__ __device__ inline size_t sf_ransac_lds_bytes_dev(int kcap) {
+  return (size_t)kcap * 32 + 64 * 8 + 4 * 8 + (size_t)kcap * 4 + 16 * 4 + (size_t)kcap * 2 + 12 * 64 * 4 + 5 * 64 * 4 +
+         16 * 4 + 16 * 4 + (size_t)kcap * 4;
+}
+
 // The "no transform" state of a pass (identity covariance scale, `matches` correspondences seen): built where it is
 // written, so that no copy of it stays live in registers across the pass.
 __device__ __forceinline__ void write_null_pass(PassState& out, int matches) {
@@ -331,6 +339,7 @@ __device__ __forceinline__ void write_null_pass(PassState& out, int matches) {
 // correspondences (from | to << 16, ascending "from"; LDS in the fused kernel, global in the stage kernel);
 // `lds` = this stage's region of the workgroup's dynamic LDS (sf_ransac_lds_bytes).  The result is written to
 // `out` by thread 0.
+template <bool BA = false>
 __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int sF, int sT, const uint32_t* cl, int n_corr,
                                             PassState& out, const DeviceParams& P, unsigned char* lds,
                                             int trace_base = 2) {
@@ -373,6 +382,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     if (ok) {
       L.src[m + woff + before] = make_float4(ax, ay, az, 0.f);
       L.dst[m + woff + before] = make_float4(bx, by, bz, 0.f);
+      L.cidx[m + woff + before] = cl[i];
     }
     m += total;
     __syncthreads();
@@ -494,6 +504,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   const double sigma = P.refine_sigma;
   SelCounts sc = select_within(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid);
   int n_inl = sc.n;
+  const uint8_t* inl = L.mask_a;     // the final inlier set (std::swap(inliers_, new_inliers) below)
   int n_last = n_inl;
   const float* model = L.best;
 
@@ -544,6 +555,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       }
       inlier_changed = sc.diff != 0;
     } while (inlier_changed && ++refine_iterations < P.refine_iterations);
+    inl = neu;
     n_inl = n_new;
     model = L.bc;
   }
@@ -586,10 +598,16 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   } else if (tid == 0) {
     write_null_pass(out, m);
   }
+  if constexpr (BA) {
+    // :1192-1370 two-view bundle adjustment of this pass's estimate (its working set sits behind this stage's)
+    if (P.bundle_adjustment)
+      ba_body(st, sF, sT, L.src, L.cidx, inl, m, out, P, lds + ((sf_ransac_lds_bytes_dev(kcap) + 15) & ~(size_t)15));
+  }
   SF_TRACE_MARK(P, pair, trace_base + 5);
 }
 
-__global__ void __launch_bounds__(SF_BLOCK, 4)
+template <bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
 k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
          const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
          const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
@@ -597,34 +615,39 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = list[blockIdx.x];
-  ransac_body(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr, pass[pair], P,
-              smem_raw);
+  ransac_body<BA>(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr, pass[pair],
+                  P, smem_raw);
 }
 
 }  // namespace
 
 size_t sf_ransac_lds_bytes(int kcap, int iterations) {
   (void)iterations;   // (round 1 kept one count per iteration in LDS; a round's counts now live in lanes)
-  return (size_t)kcap * 32 + 64 * 8 + 4 * 8 + (size_t)kcap * 4 + 16 * 4 + (size_t)kcap * 2 + 12 * 64 * 4 + 5 * 64 * 4 +
-         16 * 4 + 16 * 4;
+  return sf_ransac_lds_bytes_dev(kcap);
 }
 
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
-  const size_t lds = sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  const bool ba = c->dparams.bundle_adjustment != 0;
+  const size_t lds = ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
-  if (!c->ransac_attr_set) {   // per handle = per device
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->ransac_attr_set = true;
+  bool& attr = ba ? c->ransac_ba_attr_set : c->ransac_attr_set;
+  if (!attr) {   // per handle = per device
+    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
-  hipLaunchKernelGGL(k_ransac, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                     (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
-                     (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
-                     (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
-                     (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                       (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
+                       (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
+                       (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
+                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+  };
+  if (ba) launch(k_ransac<true>); else launch(k_ransac<false>);
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
   return SF_OK;

@@ -31,8 +31,8 @@ struct FusedTail {
   uint8_t guided_flag;
 };
 
-template <int W, int NQ>
-__global__ void __launch_bounds__(SF_BLOCK, 4)
+template <int W, int NQ, bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
                uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
@@ -61,7 +61,7 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
   __builtin_amdgcn_s_setprio(3);
   if (est1) {
-    ransac_body(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2);
+    ransac_body<BA>(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2);
     __syncthreads();
   }
   // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
@@ -74,7 +74,7 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     if (tid == 0) hdr2[pair] = T.hdr2;
   }
   if (est2) {
-    ransac_body(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11);
+    ransac_body<BA>(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11);
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);
@@ -84,16 +84,16 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   }
 }
 
-template <int W, int NQ>
+template <int W, int NQ, bool BA>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds, int tail_off) {
-  bool& attr_set = c->fused_attr[W == 16][NQ == 0];   // one flag per instantiation
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0][BA];   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, BA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_verify_fused<W, NQ>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_verify_fused<W, NQ, BA>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
                      (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams,
                      tail_off);
@@ -105,7 +105,8 @@ size_t fused_tail_offset(const sf_context* c, const StoreView& st) {
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
   const size_t guided = (size_t)st.kcap * 4 + sf_guided_lds_bytes(st.kcap, nc);
-  const size_t ransac = (size_t)st.kcap * 4 + sf_ransac_lds_bytes(st.kcap, c->dparams.iterations);
+  const size_t ransac = (size_t)st.kcap * 4 + ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
+                        (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0);
   return (std::max(match, std::max(guided, ransac)) + 15) & ~(size_t)15;
 }
 
@@ -132,10 +133,13 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
   const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
-  if (mf) rc = st.w == 8 ? launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off)
-                         : launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off);
-  else rc = st.w == 8 ? launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off)
-                      : launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off);
+  const bool ba = c->dparams.bundle_adjustment != 0;   // (own instantiation: 2 workgroups per CU, ~60 live fp64 values)
+#define SF_FUSED_CASE(W_, NQ_)                                                               \
+  rc = ba ? launch_fused<W_, NQ_, true>(c, st, d_from, d_to, n, d_out, lds, tail_off)         \
+          : launch_fused<W_, NQ_, false>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+  if (mf) { if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0); }
+  else { if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2); }
+#undef SF_FUSED_CASE
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());

@@ -621,6 +621,13 @@ static int fill_device_params(sf_context* c) {
   if (p.iterations > 30000) return sf_fail(c, SF_ERANGE, "iterations > 30000");
   if (p.max_sample_checks < 1) return sf_fail(c, SF_EINVAL, "max_sample_checks must be >= 1");
   if (p.netvlad_max_matches_nb < 0) return sf_fail(c, SF_EINVAL, "netvlad_max_matches_nb < 0");
+  if (p.bundle_adjustment != 0) {
+    if (p.bundle_adjustment != 1) return sf_fail(c, SF_EINVAL, "bundle_adjustment %d not implemented (0 = off, 1 = on)", p.bundle_adjustment);
+    if (!(p.image_width > 0 && p.image_height > 0 && p.fx > 0.0 && p.fy > 0.0))
+      return sf_fail(c, SF_EINVAL, "bundle adjustment needs a calibrated camera (myRegistrationVis.cpp:1230 UASSERT)");
+    if (p.ba_iterations < 0 || !(p.ba_pixel_variance > 0.f) || !(p.ba_robust_kernel_delta > 0.f) || !(p.stereo_baseline >= 0.f))
+      return sf_fail(c, SF_EINVAL, "bundle adjustment: ba_iterations >= 0, ba_pixel_variance > 0, ba_robust_kernel_delta > 0, stereo_baseline >= 0");
+  }
   DeviceParams& d = c->dparams;
   memset(&d, 0, sizeof(d));
   d.nndr = p.nndr;
@@ -641,6 +648,11 @@ static int fill_device_params(sf_context* c) {
   d.estimation_type = p.estimation_type;
   d.pnp_reproj_error = p.pnp_reproj_error;
   d.pnp_refine_iterations = p.pnp_refine_iterations;
+  d.bundle_adjustment = p.bundle_adjustment;
+  d.ba_iterations = p.ba_iterations;
+  d.ba_robust_kernel_delta = p.ba_robust_kernel_delta;
+  d.ba_pixel_variance = p.ba_pixel_variance;
+  d.stereo_baseline = p.stereo_baseline;
   {
     const double thr = (double)p.pnp_reproj_error;
     d.pnp_thr2f = (float)(thr * thr);     // OpenCV: float t = (float)(thresh*thresh); err <= t

@@ -67,6 +67,9 @@ struct DeviceParams {
   float pnp_thr2f;            // (float)(pnp_reproj_error^2)
   float pnp_reproj_error;
   int32_t pnp_refine_iterations;
+  int32_t bundle_adjustment;  // two-view BA after each pass's estimate (k_ba.hip)
+  int32_t ba_iterations;
+  float ba_robust_kernel_delta, ba_pixel_variance, stereo_baseline;
   int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
                               // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
   unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][32] timestamps; else null
@@ -173,7 +176,8 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
-  bool fused_attr[2][2] = {};   // [W == 16][matrix-core matcher]: LDS attribute set
+  bool fused_attr[2][2][2] = {};   // [W == 16][matrix-core matcher][bundle adjustment]: LDS attribute set
+  bool ransac_ba_attr_set = false, pnp_ba_attr_set = false;
   bool debug_corr = false;      // SF_OPT_DEBUG_CORR: the fused kernel also writes lists / headers / states to HBM
   bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
@@ -260,6 +264,7 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out);
 size_t sf_ransac_lds_bytes(int kcap, int iterations);
+size_t sf_ba_lds_bytes(int kcap);
 size_t sf_pnp_lds_bytes(int kcap, int iterations);
 size_t sf_guided_lds_bytes(int kcap, int n_cells);
 // Assemble sf_result records.
