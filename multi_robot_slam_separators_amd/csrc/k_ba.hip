@@ -7,8 +7,8 @@
 // g2o's sba types, un-vendored] on two poses (the "from" pose fixed at identity) and the inlier words' 3D points, mono
 // or stereo reprojection residuals against both frames' keypoints, Huber kernel, Levenberg-Marquardt; words whose
 // reprojection stays outside the kernel leave the inliers (:1314-1330), fewer than min_inliers left -> null
-// (:1331-1336).  The algorithm and its operation order are those of oracle/sf_oracle_ba.c;
-// results are compared bit for bit.
+// (:1331-1336).  The algorithm and its operation order are fixed in DESIGN.md sections 3 and 4 (the test suite holds a
+// CPU restatement of the same specification and compares results bit for bit).
 //
 // CDNA4 mapping: one LANE per inlier word (stride 256).  A word's two edges give its 3x3 point block, its 6x3 coupling
 // to the pose and its share of the 6x6 pose block, all in registers; the point is eliminated in the lane (Schur
