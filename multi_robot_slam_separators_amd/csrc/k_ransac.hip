@@ -269,6 +269,21 @@ struct ScanState {
   double k;      // adaptive bound
 };
 
+// __shfl_up with the source lane derived from the CALLER's lane number: the library form derives it from the hardware
+// lane id, which is loop invariant -- the six source addresses of the scan below were hoisted in front of the
+// hypothesis loop and spilled around the fit.
+__device__ __forceinline__ int shfl_up_from(int v, int off, int lane) {
+  const int src = lane >= off ? lane - off : lane;
+  return __builtin_amdgcn_ds_bpermute(src << 2, v);
+}
+__device__ __forceinline__ double shfl_up_from(double v, int off, int lane) {
+  const int src = lane >= off ? lane - off : lane;
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b & 0xFFFFFFFFll));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
 // Advance PCL's loop [upstream pcl::RandomSampleConsensus::computeModel] over the R counts of one round, held one
 // per lane (c = count of iteration base + lane, -1 when getSamples failed; `present` = lane < R and the
 // iteration is <= max_it).  Sequentially the loop tests at the top of iteration `it`:  (adaptive && !(it < k)) ->
@@ -282,7 +297,7 @@ __device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, i
   int x = present ? c : -1;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    const int y = __shfl_up(x, off);
+    const int y = shfl_up_from(x, off, lane);
     if (lane >= off) x = max(x, y);
   }
   x = max(x, S.best);                                   // inclusive prefix maximum incl. the earlier rounds
@@ -294,15 +309,18 @@ __device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, i
     if (pno > 1.0 - 2.220446049250313e-16) pno = 1.0 - 2.220446049250313e-16;
     kj = log_probability / sfd::canon_log(pno);
   }
-  double kprev = __shfl_up(kj, 1);
+  double kprev = shfl_up_from(kj, 1, lane);
   if (lane == 0) kprev = S.k;
   const int it = base + lane;
   const bool top_ok = present && (!adaptive || (double)it < kprev) && c >= 0;
   const unsigned long long fail = ~__ballot(top_ok);
   const int n_proc = fail ? (__ffsll((long long)fail) - 1) : 64;
   if (n_proc > 0) {
-    const int nb = __shfl(x, n_proc - 1);
-    const double nk = __shfl(kj, n_proc - 1);
+    const int nb = __builtin_amdgcn_readlane(x, n_proc - 1);          // n_proc comes from a ballot: wave uniform
+    const long long kb = __double_as_longlong(kj);
+    const double nk = __longlong_as_double(
+        ((long long)__builtin_amdgcn_readlane((int)(kb >> 32), n_proc - 1) << 32) |
+        (unsigned)__builtin_amdgcn_readlane((int)(kb & 0xFFFFFFFFll), n_proc - 1));
     if (nb > S.best) {
       const unsigned long long at = __ballot(present && c == nb && lane < n_proc);
       const int lb = __ffsll((long long)at) - 1;        // first iteration that reached the final best
@@ -400,7 +418,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
 
   // ---- computeSampleDistanceThreshold (PCA of the source cloud) ----------------------------------
   const double inv_m = 1.0 / (double)m;
-  double sdt = 0.0;     // only the solving wavefront needs (and computes) it
+  double sdt = 0.0;     // only the solving wavefront needs (and computes) it; kept in LDS from here on
   {
     double mean[3];
     double s3[3];
@@ -421,6 +439,17 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       sfd::sym3_eigenvalues(c6[0] * inv_m, c6[1] * inv_m, c6[2] * inv_m, c6[3] * inv_m, c6[4] * inv_m, c6[5] * inv_m, ev);
       sdt = ((sqrt(ev[0]) + sqrt(ev[1])) + sqrt(ev[2])) / 3.0;
       sdt = sdt * sdt;
+      // the threshold and the state of PCL's loop are parked in LDS between rounds (L.sums is free until the first
+      // selection): they are only touched by the solving wavefront, a few times per round, and would otherwise
+      // occupy registers across the fit
+      if (lane == 0) {
+        double* st = reinterpret_cast<double*>(L.sums);
+        st[0] = sdt;       // sample-distance threshold
+        st[1] = 1.0;       // ScanState.k
+        L.misc[12] = -1;   // ScanState.best
+        L.misc[13] = -1;   // ScanState.best_it
+        L.misc[14] = 0;    // ScanState.it
+      }
     }
   }
 
@@ -430,58 +459,74 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   // ---- hypotheses: one lane each, rounds of 16 then 64 ----------------------------------------------
   // (values only needed behind this loop -- thr, thr2, sigma -- are formed there, and the replay's constants inside
   //  the replay: the fit in the middle of the loop wants every register it can get)
-  float thr2f;                                     // largest float strictly below thr^2
-  {
-    const double thr2 = P.inlier_thr * P.inlier_thr;
-    thr2f = (float)thr2;
-    if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
-  }
   const int max_it = P.iterations;
-  ScanState S;                                             // meaningful in the solving wavefront only
-  S.best = -1; S.best_it = -1; S.it = 0; S.k = 1.0;
-  const int slice = (m + 3) / 4;                           // points counted by each wavefront
-  const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
   int* hv = L.hyp_cnt + 4 * 64;
   int R = 16;
   for (int base = 0; base <= max_it; base += R, R = 64) {   // (the increment uses the R of the round just finished)
-    const int it = base + lane;
-    if (wave == fit_wave) {
+    // The lane / wavefront numbers of a round go through an empty asm: everything derived from them (LDS addresses,
+    // the point slice) is then computed INSIDE the round instead of being hoisted in front of the loop and kept alive
+    // across the fit, where the register allocator had to spill it (96-128 bytes of scratch per lane, and spill
+    // stores are HBM writes: 125 MB per 10 000-pair launch).
+    int lane_r = lane, wave_r = wave;
+    asm volatile("" : "+v"(lane_r), "+v"(wave_r));
+    const int it = base + lane_r;
+    if (wave_r == fit_wave) {
       int valid = 0;
-      if (lane < R && it <= max_it) {
+      if (lane_r < R && it <= max_it) {
         uint32_t s0, s1, s2;
-        if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, sdt, s0, s1, s2)) {
+        if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, reinterpret_cast<const double*>(L.sums)[0],
+                        s0, s1, s2)) {
           float coef[12];
           fit3(L, s0, s1, s2, coef);
+          int lane_s = lane;                       // (addresses of the stores below: derived behind the fit)
+          asm volatile("" : "+v"(lane_s));
 #pragma unroll
-          for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane] = coef[k];
+          for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane_s] = coef[k];
           valid = 1;
         }
       }
-      hv[lane] = valid;
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      hv[lane_s] = valid;
     }
     __syncthreads();
     if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 18 : 21);   // first round: models parked
-    L.hyp_cnt[wave * 64 + lane] = R == 16 ? count_round<16>(L, hv, i0, i1, lane, thr2f)
-                                          : count_round<64>(L, hv, i0, i1, lane, thr2f);
+    {
+      int lane_c = lane, wave_c = wave;
+      asm volatile("" : "+v"(lane_c), "+v"(wave_c));
+      const double thr2 = P.inlier_thr * P.inlier_thr;
+      float thr2f = (float)thr2;                             // largest float strictly below thr^2
+      if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
+      const int slice = (m + 3) / 4;                           // points counted by each wavefront
+      const int i0 = min(m, wave_c * slice), i1 = min(m, i0 + slice);
+      L.hyp_cnt[wave_c * 64 + lane_c] = R == 16 ? count_round<16>(L, hv, i0, i1, lane_c, thr2f)
+                                                : count_round<64>(L, hv, i0, i1, lane_c, thr2f);
+    }
     __syncthreads();
     if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 19 : 22);   // ... inliers counted
-    if (wave == fit_wave) {
+    if (wave_r == fit_wave) {
+      asm volatile("" : "+v"(lane_r));
       int tot = 0;
       if (R == 16) {
-        const int h = lane & 15;
+        const int h = lane_r & 15;
 #pragma unroll
         for (int w = 0; w < 4; ++w)
 #pragma unroll
           for (int g = 0; g < 4; ++g) tot += L.hyp_cnt[w * 64 + g * 16 + h];
       } else {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot += L.hyp_cnt[w * 64 + lane];
+        for (int w = 0; w < 4; ++w) tot += L.hyp_cnt[w * 64 + lane_r];
       }
-      const bool present = lane < R && it <= max_it;
-      const int c = (present && hv[lane]) ? tot : -1;
-      const bool stop = replay_round(L, S, base, R, lane, c, present, max_it, P.adaptive_stop != 0, 1.0 / (double)m,
+      const bool present = lane_r < R && it <= max_it;
+      const int c = (present && hv[lane_r]) ? tot : -1;
+      ScanState S;
+      S.best = L.misc[12]; S.best_it = L.misc[13]; S.it = L.misc[14];
+      S.k = reinterpret_cast<const double*>(L.sums)[1];
+      const bool stop = replay_round(L, S, base, R, lane_r, c, present, max_it, P.adaptive_stop != 0, 1.0 / (double)m,
                                      sfd::canon_log(1.0 - 0.99));
-      if (lane == 0) {
+      if (lane_r == 0) {
+        L.misc[12] = S.best; L.misc[13] = S.best_it; L.misc[14] = S.it;
+        reinterpret_cast<double*>(L.sums)[1] = S.k;
         L.misc[0] = S.best_it;
         L.misc[1] = stop ? 1 : 0;
       }
@@ -490,11 +535,15 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 20 : 23);   // ... PCL's loop replayed
     if (L.misc[1]) break;
   }
-  if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation
+  // (same for everything behind the loop: addresses are re-derived from a laundered thread index instead of
+  //  being shared with -- and kept alive since -- the gather in front of it)
+  int tid_b = tid;
+  asm volatile("" : "+v"(tid_b));
+  if (P.dbg_stop == 2 || P.dbg_stop == 3) { if (tid_b == 0) write_null_pass(out, m); return; }   // diagnostic truncation
   SF_TRACE_MARK(P, pair, trace_base + 2);
   const int best_it = L.misc[0];
   if (best_it < 0) {
-    if (tid == 0) write_null_pass(out, m);
+    if (tid_b == 0) write_null_pass(out, m);
     return;
   }
 
@@ -502,13 +551,13 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   const double thr = P.inlier_thr;
   const double thr2 = thr * thr;
   const double sigma = P.refine_sigma;
-  SelCounts sc = select_within(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid);
+  SelCounts sc = select_within(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid_b);
   int n_inl = sc.n;
   const uint8_t* inl = L.mask_a;     // the final inlier set (std::swap(inliers_, new_inliers) below)
   int n_last = n_inl;
   const float* model = L.best;
 
-  if (P.dbg_stop == 4) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation (SF_RANSAC_STOP)
+  if (P.dbg_stop == 4) { if (tid_b == 0) write_null_pass(out, m); return; }   // diagnostic truncation (SF_RANSAC_STOP)
   SF_TRACE_MARK(P, pair, trace_base + 3);
 
   // ---- refine loop (copy of pcl::SampleConsensus::refineModel inside rtabmap) ----------------------
@@ -519,17 +568,17 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     uint8_t* prev = L.mask_a;
     uint8_t* neu = L.mask_b;
     int n_prev = n_inl, n_new = 0;
-    for (int i = tid; i < m; i += NT) neu[i] = 0;
-    if (tid < 12) L.bc[tid] = L.best[tid];            // new_model_coefficients = model_coefficients
+    for (int i = tid_b; i < m; i += NT) neu[i] = 0;
+    if (tid_b < 12) L.bc[tid_b] = L.best[tid_b];            // new_model_coefficients = model_coefficients
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;  // last four pushed sizes (z1 newest)
     do {
-      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, tid);
+      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, tid_b);
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
       __syncthreads();                                // L.bc (and the cleared `neu`) visible
       // membership changes are counted against `prev`, the set selected one round ago, while `neu` (the set of
       // two rounds ago) is overwritten
-      sc = select_within(L, m, L.bc, error_threshold * error_threshold, neu, prev, sigma, thr, tid);
+      sc = select_within(L, m, L.bc, error_threshold * error_threshold, neu, prev, sigma, thr, tid_b);
       n_new = sc.n;
       n_last = n_new;
       if (n_new == 0) {
@@ -540,7 +589,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       // error_threshold = min(thr, sigma * sqrt(variance)), variance = 2.1981 * median: the median is only needed
       // when it is one of the `low` members (see SelCounts)
       if ((n_new >> 1) < sc.low) {
-        const double variance = variance_of(L, m, n_new, tid);
+        const double variance = variance_of(L, m, n_new, tid_b);
         const double sthr = sigma * sqrt(variance);
         error_threshold = thr < sthr ? thr : sthr;
       } else {
@@ -560,11 +609,11 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     model = L.bc;
   }
 
-  if (P.dbg_stop == 5) { if (tid == 0) write_null_pass(out, m); return; }
+  if (P.dbg_stop == 5) { if (tid_b == 0) write_null_pass(out, m); return; }
   SF_TRACE_MARK(P, pair, trace_base + 4);
   if (n_inl >= 3) {
-    const double variance = variance_of(L, m, n_last, tid);
-    if (tid == 0) {
+    const double variance = variance_of(L, m, n_last, tid_b);
+    if (tid_b == 0) {
       PassState ps;
 #pragma unroll
       for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
@@ -595,7 +644,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       }
       out = ps;
     }
-  } else if (tid == 0) {
+  } else if (tid_b == 0) {
     write_null_pass(out, m);
   }
   if constexpr (BA) {

@@ -149,36 +149,12 @@ __device__ inline void sym3_eigenvalues(double c00, double c01, double c02, doub
   ev[0] = l1; ev[1] = l2; ev[2] = l3;
 }
 
-// Eigenvector of the largest eigenvalue of the symmetric 4x4 matrix given by its upper triangle (cyclic Jacobi; the
-// first maximum of the diagonal wins ties): the fallback of rigid_from_moments for an exactly vanishing adjugate.
-// (Tried out of line -- __attribute__((noinline)) -- to keep its two 4x4 double matrices off the callers' register
-// budget: the call's save area made the kernels' scratch larger, 184 against 116 bytes per lane, not smaller.)
-__device__ inline double4 jacobi_dominant4(double n00, double n01, double n02, double n03, double n11,
-                                                             double n12, double n13, double n22, double n23,
-                                                             double n33) {
-  double Nm[4][4] = {{n00, n01, n02, n03}, {n01, n11, n12, n13}, {n02, n12, n22, n23}, {n03, n13, n23, n33}};
-  double V[4][4];
-  jacobi<4>(Nm, V);
-  double bv = Nm[0][0];
-  double w = V[0][0], qx = V[1][0], qy = V[2][0], qz = V[3][0];
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    const bool gt = Nm[i][i] > bv;
-    bv = gt ? Nm[i][i] : bv;
-    w = gt ? V[0][i] : w;
-    qx = gt ? V[1][i] : qx;
-    qy = gt ? V[2][i] : qy;
-    qz = gt ? V[3][i] : qz;
-  }
-  return make_double4(w, qx, qy, qz);
-}
-
 // Rotation and translation from the cross-covariance S[j][k] = sum a_j b_k of the demeaned
 // source/target, their means and spreads ga = sum |a|^2, gb = sum |b|^2 (Horn's quaternion
 // method).  The dominant eigenpair of the 4x4 matrix N comes from Newton's iteration on the
 // characteristic quartic, started at the upper bound (ga+gb)/2 (monotone convergence to the largest
 // root), and the best-conditioned column of adj(N - lambda I): ~0.5 kflop and a dozen divisions
-// instead of a full Jacobi eigen-decomposition (3 div + 2 sqrt per rotation).  Jacobi remains the
+// instead of a full Jacobi eigen-decomposition (3 div + 2 sqrt per rotation).  A power iteration is the
 // fallback for a vanishing adjugate.  Output as the float coefficients PCL stores.
 __device__ inline void rigid_from_moments(const double (&S)[3][3], const double (&mp)[3],
                                           const double (&mq)[3], double ga, double gb, float (&coef)[12]) {
@@ -241,10 +217,25 @@ __device__ inline void rigid_from_moments(const double (&S)[3][3], const double 
   if (fabs(a33) > best) { best = fabs(a33); w = a03; qx = a13; qy = a23; qz = a33; }
   double nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   if (!(best > 0.0) || !(nrm2 > 0.0) || !isfinite(nrm2)) {
-    // vanishing adjugate (an exactly degenerate configuration): full eigen-decomposition
-    const double4 qf = jacobi_dominant4(Nm[0][0], Nm[0][1], Nm[0][2], Nm[0][3], Nm[1][1], Nm[1][2], Nm[1][3], Nm[2][2],
-                                        Nm[2][3], Nm[3][3]);
-    w = qf.x; qx = qf.y; qy = qf.z; qz = qf.w;
+    // vanishing adjugate (an exactly degenerate configuration: the largest eigenvalue is repeated, or N = 0): a vector
+    // of its eigenspace by 64 steps of the power iteration on N + shift I (positive semi-definite with
+    // shift = (ga + gb) / 2 >= |eigenvalues|), from a fixed start.  Round 1 ran a cyclic Jacobi here: its two 4x4
+    // double matrices raised the 3-point fit from 72 to 110 VGPRs and were what pushed k_ransac / k_verify_fused into
+    // scratch (116-128 bytes per lane, 125 MB of spill writes per 10 000-pair launch) although this branch is
+    // practically never taken.  Any unit vector of the eigenspace is a valid answer.
+    const double shift = 0.5 * (ga + gb);
+    double v0 = 1.0, v1 = 0.5, v2 = 0.25, v3 = 0.125;
+    for (int it = 0; it < 64; ++it) {
+      const double u0 = (((Nm[0][0] + shift) * v0 + Nm[0][1] * v1) + Nm[0][2] * v2) + Nm[0][3] * v3;
+      const double u1 = ((Nm[0][1] * v0 + (Nm[1][1] + shift) * v1) + Nm[1][2] * v2) + Nm[1][3] * v3;
+      const double u2 = ((Nm[0][2] * v0 + Nm[1][2] * v1) + (Nm[2][2] + shift) * v2) + Nm[2][3] * v3;
+      const double u3 = ((Nm[0][3] * v0 + Nm[1][3] * v1) + Nm[2][3] * v2) + (Nm[3][3] + shift) * v3;
+      const double n2 = ((u0 * u0 + u1 * u1) + u2 * u2) + u3 * u3;
+      if (!(n2 > 0.0) || !isfinite(n2)) break;
+      const double in = 1.0 / sqrt(n2);
+      v0 = u0 * in; v1 = u1 * in; v2 = u2 * in; v3 = u3 * in;
+    }
+    w = v0; qx = v1; qy = v2; qz = v3;
     nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   }
   const double inv = 1.0 / sqrt(nrm2);

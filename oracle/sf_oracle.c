@@ -320,11 +320,25 @@ static void sfo_rigid_from_moments(const double S[3][3], const double mp[3], con
   if (fabs(a33) > best) { best = fabs(a33); w = a03; qx = a13; qy = a23; qz = a33; }
   double nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   if (!(best > 0.0) || !(nrm2 > 0.0) || !isfinite(nrm2)) {
-    /* degenerate: full symmetric eigen-decomposition */
-    sfo_jacobi(4, N, V);
-    int bi = 0;
-    for (int i = 1; i < 4; ++i) if (N[i][i] > N[bi][bi]) bi = i;
-    w = V[0][bi]; qx = V[1][bi]; qy = V[2][bi]; qz = V[3][bi];
+    /* vanishing adjugate (an exactly degenerate configuration: the largest eigenvalue is repeated, or N = 0): a
+     * vector of its eigenspace by 64 steps of the power iteration on N + shift I (positive semi-definite with
+     * shift = (ga + gb) / 2 >= |eigenvalues|), from a fixed start.  Round 1 ran a cyclic Jacobi here; its two 4x4
+     * matrices were what pushed the GPU kernels into scratch on the HOT path, although this branch is practically
+     * never taken -- any unit vector of the eigenspace is a valid answer, and this one needs 14 doubles. */
+    (void)V;
+    const double shift = 0.5 * (ga + gb);
+    double v0 = 1.0, v1 = 0.5, v2 = 0.25, v3 = 0.125;
+    for (int it = 0; it < 64; ++it) {
+      const double u0 = (((N[0][0] + shift) * v0 + N[0][1] * v1) + N[0][2] * v2) + N[0][3] * v3;
+      const double u1 = ((N[0][1] * v0 + (N[1][1] + shift) * v1) + N[1][2] * v2) + N[1][3] * v3;
+      const double u2 = ((N[0][2] * v0 + N[1][2] * v1) + (N[2][2] + shift) * v2) + N[2][3] * v3;
+      const double u3 = ((N[0][3] * v0 + N[1][3] * v1) + N[2][3] * v2) + (N[3][3] + shift) * v3;
+      const double n2 = ((u0 * u0 + u1 * u1) + u2 * u2) + u3 * u3;
+      if (!(n2 > 0.0) || !isfinite(n2)) break;
+      const double in = 1.0 / sqrt(n2);
+      v0 = u0 * in; v1 = u1 * in; v2 = u2 * in; v3 = u3 * in;
+    }
+    w = v0; qx = v1; qy = v2; qz = v3;
     nrm2 = ((w * w + qx * qx) + qy * qy) + qz * qz;
   }
   const double inv = 1.0 / sqrt(nrm2);
