@@ -7,11 +7,16 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 B="python bench.py --steps 6 --warmup 2 --no-extras --no-cpu-baseline $*"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B > $out/stats.log 2>&1
+# the stats pass times enough launches that its averages can be held against bench.py's own (HIP-event) figures
+BS="python bench.py --steps 60 --warmup 20 --no-extras --no-cpu-baseline $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $BS > $out/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $B > $out/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $B > $out/write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/sq -- $B > $out/sq.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sqw -- $B > $out/sqw.log 2>&1
 python tools/summarize_prof.py $tag $out/stats $out/fetch $out/write > $out/summary.txt
 python tools/pmc_kernel.py $out/sq > $out/sq.txt
-cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv $out/
+python tools/sq_json.py $tag k_verify_fused $out/sq $out/sqw
+cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv profiles/${tag}_sq_*.json $out/
+grep "^{" $out/stats.log > $out/${tag}_bench_stdout.log
 tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_global_mf" $out/sq.txt

@@ -23,6 +23,17 @@ for f in glob.glob(os.path.join(stats, "**", "*_kernel_stats.csv"), recursive=Tr
     for r in csv.DictReader(open(f)):
         out["kernels"].append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
                                "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])})
+# per-launch durations from the kernel trace: median and the mean without the first quarter (warm-up launches)
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(stats, "**", "*_kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+for k in out["kernels"]:
+    d = [x[1] for x in sorted(dur.get(k["kernel"], []))]
+    if d:
+        k["median_us"] = sorted(d)[len(d) // 2] / 1e3
+        tail = d[len(d) // 4:]
+        k["avg_after_warmup_us"] = sum(tail) / len(tail) / 1e3
 if len(sys.argv) >= 5:
     fe, wr = pmc(sys.argv[3]), pmc(sys.argv[4])
     out["pmc_per_launch"] = {}
@@ -32,6 +43,7 @@ if len(sys.argv) >= 5:
         out["pmc_per_launch"][k]["launches"] = n
 json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
 for k in out["kernels"]:
-    print("%-22s calls %3d avg %10.1f us  %5.1f %%" % (k["kernel"], k["calls"], k["avg_us"], k["pct"]))
+    print("%-22s calls %3d avg %10.1f us  %5.1f %%  median %8.1f us  after warm-up %8.1f us" % (
+        k["kernel"], k["calls"], k["avg_us"], k["pct"], k.get("median_us", 0.0), k.get("avg_after_warmup_us", 0.0)))
 for k, v in out.get("pmc_per_launch", {}).items():
     print(k, v)
