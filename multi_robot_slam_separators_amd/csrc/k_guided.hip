@@ -299,7 +299,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     if (base == 0 && wave == 0 && P.dbg_trace) {
       int mx = dbg_trips, sm = dbg_entries;
       for (int off = 32; off >= 1; off >>= 1) { mx = max(mx, __shfl_xor(mx, off)); sm += __shfl_xor(sm, off); }
-      if (lane == 0) P.dbg_trace[(size_t)pair * 32 + 31] = ((unsigned long long)mx << 32) | (unsigned)sm;
+      if (lane == 0) P.dbg_trace[(size_t)pair * SF_TRACE_SLOTS + 31] = ((unsigned long long)mx << 32) | (unsigned)sm;
     }
 #endif
     if (base == 0) SF_TRACE_MARK(P, pair, 29);   // ... its cells scanned
@@ -337,7 +337,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   SF_TRACE_MARK(P, pair, 24);     // projections + candidate recording done
   const int n_cand = misc[3];
 #ifdef SF_CHAIN_TRACE
-  if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * 32 + 27] = (unsigned long long)n_cand;
+  if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * SF_TRACE_SLOTS + 27] = (unsigned long long)n_cand;
 #endif
   if (n_cand <= cand_cap) {
     // pass B: one combination per lane (<= GUIDED_CPT per thread, kept in registers between the two atomic passes)

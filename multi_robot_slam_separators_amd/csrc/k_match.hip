@@ -457,7 +457,8 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 template <int W, int NQ, int NT, int MF_NTL = 2>
 __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int sF, int sT, float nndr, int min_inliers,
                                               int est, uint32_t* out, CorrHeader& hdr_out, PassState& pass_out,
-                                              int32_t* __restrict__ list, int32_t* __restrict__ counter, int* smem) {
+                                              int32_t* __restrict__ list, int32_t* __restrict__ counter, int* smem,
+                                              unsigned long long* trace_row = nullptr) {
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -492,6 +493,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
   for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
   if (tid < 16) misc[tid] = 0;
   __syncthreads();
+  SF_TRACE_ROW_MARK(trace_row, 32);   // "from" rows staged
 
   int rejected = 0;
   if constexpr (NQ == 0) {
@@ -587,7 +589,9 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
   }
   for (int off = 32; off >= 1; off >>= 1) rejected += __shfl_xor(rejected, off);
   if (lane == 0 && rejected) atomicAdd(&misc[0], rejected);
+  SF_TRACE_ROW_MARK(trace_row, 33);   // wavefront 0 done with its scans
   __syncthreads();
+  SF_TRACE_ROW_MARK(trace_row, 34);   // all wavefronts done
 
   int running = 0;
   for (int base = 0; base < Kf; base += NT) {
@@ -609,6 +613,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
     __syncthreads();
   }
   const int n_corr = running;
+  SF_TRACE_ROW_MARK(trace_row, 35);   // list compacted
 
   const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
   const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;

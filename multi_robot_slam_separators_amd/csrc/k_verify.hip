@@ -31,31 +31,15 @@ struct FusedTail {
   uint8_t guided_flag;
 };
 
-template <int W, int NQ, bool BA>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
-k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
-               uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
-               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int tail_off) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int pair = blockIdx.x;
+// Everything after the pass-1 correspondence list of a pair: RANSAC, guess-guided matching, RANSAC, result.
+template <int W, bool BA>
+__device__ __forceinline__ void chain_after_match(const StoreView& st, int pair, int sF, int sT, bool est1, FusedTail& T,
+                                                  uint32_t* cl, unsigned char* chain_lds, uint32_t* __restrict__ corr2,
+                                                  CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass1,
+                                                  PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
+                                                  sf_result* __restrict__ out, const DeviceParams& P) {
   const int tid = threadIdx.x;
   const int kcap = st.kcap;
-  const int sF = pair_from[pair], sT = pair_to[pair];
-  FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
-  uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);          // [kcap] the current pass's correspondence list
-  unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;        // RANSAC / guided working set behind it
-  SF_TRACE_MARK(P, pair, 0);
-  // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
-  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, sF, sT, P.nndr, P.min_inliers, 0, cl, T.hdr1, T.pass1,
-                                                   nullptr, nullptr, reinterpret_cast<int*>(smem_raw));
-  __syncthreads();   // list / header / pass-1 defaults visible to the whole workgroup
-  SF_TRACE_MARK(P, pair, 1);
-  if (P.dbg_corr) {
-    const int n = T.hdr1.n_corr;
-    for (int i = tid; i < n; i += SF_BLOCK) corr1[(size_t)pair * kcap + i] = cl[i];
-    if (tid == 0) hdr1[pair] = T.hdr1;
-  }
   // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
   // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
   // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
@@ -85,6 +69,88 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 }
 
 template <int W, int NQ, bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
+k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+               uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
+               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int tail_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
+  uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);          // [kcap] the current pass's correspondence list
+  unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;        // RANSAC / guided working set behind it
+  SF_TRACE_MARK(P, pair, 0);
+  // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
+  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, sF, sT, P.nndr, P.min_inliers, 0, cl, T.hdr1, T.pass1,
+                                                   nullptr, nullptr, reinterpret_cast<int*>(smem_raw),
+                                                   P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
+  __syncthreads();   // list / header / pass-1 defaults visible to the whole workgroup
+  SF_TRACE_MARK(P, pair, 1);
+  if (P.dbg_corr) {
+    const int n = T.hdr1.n_corr;
+    for (int i = tid; i < n; i += SF_BLOCK) corr1[(size_t)pair * kcap + i] = cl[i];
+    if (tid == 0) hdr1[pair] = T.hdr1;
+  }
+  chain_after_match<W, BA>(st, pair, sF, sT, est1, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P);
+}
+
+// ---- the split pipeline: ONE matching launch over all pairs, ONE chain launch over the survivors -------------
+// The fused kernel holds a latency-bound chain (~55 us alone, ~73 us beside matching workgroups) in a quarter of a
+// CU's slots while the matching of the other pairs (issue-bound, 7 us of a CU per pair whatever the occupancy)
+// queues behind it, and the chains born from the last matches run on an emptying chip.  Split, the matching of all
+// pairs runs at its issue bound with 4 "to" tiles resident per wavefront (2 workgroups per CU), the survivors'
+// lists / headers take one trip through HBM (~2 KB per survivor) and their chains run four to a CU with nothing
+// else on it.  Same bodies, same bytes.
+template <int W>
+__global__ void __launch_bounds__(SF_BLOCK, 2)
+k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+              uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+              CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
+              int32_t* __restrict__ list, int32_t* __restrict__ counter, sf_result* __restrict__ out, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) int smem_i[];
+  const int pair = blockIdx.x;
+  const bool survivor = match_v2_body<W, 0, SF_BLOCK, 4>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
+                                                         0, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
+                                                         list, counter, smem_i);
+  if (!survivor && threadIdx.x == 0) {
+    // no motion estimate: guided matching is not eligible (its pass state is pass 1's), the result is final
+    const PassState p = pass1[pair];
+    if (P.dbg_corr) {
+      const CorrHeader h = {0, 0, 0, 0};
+      hdr2[pair] = h; pass2[pair] = p; guided_flag[pair] = 0;
+    }
+    finalize_one(p, p, 0, out[pair]);
+  }
+}
+
+template <int W, bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
+k_chain(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+        const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+        uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
+        uint8_t* __restrict__ guided_flag, const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+        sf_result* __restrict__ out, DeviceParams P, int tail_off) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x >= *counter) return;           // (the grid is sized for every pair surviving)
+  const int pair = list[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
+  uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);
+  unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;
+  const CorrHeader h1 = hdr1[pair];
+  if (tid == 0) { T.hdr1 = h1; T.pass1 = pass1[pair]; }
+  for (int i = tid; i < h1.n_corr; i += SF_BLOCK) cl[i] = corr1[(size_t)pair * kcap + i];
+  __syncthreads();
+  SF_TRACE_MARK(P, pair, 1);
+  chain_after_match<W, BA>(st, pair, sF, sT, true, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P);
+}
+
+template <int W, int NQ, bool BA>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds, int tail_off) {
   bool& attr_set = c->fused_attr[W == 16][NQ == 0][BA];   // one flag per instantiation
@@ -101,9 +167,9 @@ int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32
 }
 
 // offset of the FusedTail = the largest stage's working set (the chain stages sit behind the kcap-entry list)
-size_t fused_tail_offset(const sf_context* c, const StoreView& st) {
+size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_match = true) {
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  const size_t match = with_match ? (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int) : 0;
   const size_t guided = (size_t)st.kcap * 4 + sf_guided_lds_bytes(st.kcap, nc);
   const size_t ransac = (size_t)st.kcap * 4 + ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
                         (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0);
@@ -140,6 +206,67 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   if (mf) { if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0); }
   else { if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2); }
 #undef SF_FUSED_CASE
+  sf_prof_end(c, SF_K_FUSED);
+  if (rc != SF_OK) return rc;
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
+// The split pipeline (k_match_split + k_chain); applies where the fused kernel does.
+bool sf_split_applicable(const sf_context* c, const StoreView& st) {
+  return sf_fused_lds_bytes(c, st) != 0 && c->match_mfma && st.kcap <= MF_MAX_ROWS;
+}
+
+namespace {
+template <int W, bool BA>
+int launch_chain(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
+                 size_t lds, int tail_off) {
+  bool& attr_set = c->chain_attr[W == 16][BA];
+  if (lds > 64 * 1024 && !attr_set) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain<W, BA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int32_t* counters = (int32_t*)c->counters.p;
+  hipLaunchKernelGGL((k_chain<W, BA>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,
+                     (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                     (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams, tail_off);
+  return SF_OK;
+}
+}  // namespace
+
+int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
+                           sf_result* d_out) {
+  if (n <= 0) return SF_OK;
+  if (!sf_split_applicable(c, st)) return sf_fail(c, SF_EINVAL, "split verification pipeline not applicable");
+  SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+  const size_t lds_m = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  sf_prof_begin(c, SF_K_MATCH);
+  if (lds_m > 64 * 1024 && !c->split_match_attr[st.w == 16]) {
+    if (st.w == 8)
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_match_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_match_split<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->split_match_attr[st.w == 16] = true;
+  }
+#define SF_SPLIT_MATCH(W_)                                                                                         \
+  hipLaunchKernelGGL((k_match_split<W_>), dim3(n), dim3(SF_BLOCK), lds_m, c->stream, st, d_from, d_to,             \
+                     (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p, \
+                     (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams)
+  if (st.w == 8) SF_SPLIT_MATCH(8); else SF_SPLIT_MATCH(16);
+#undef SF_SPLIT_MATCH
+  sf_prof_end(c, SF_K_MATCH);
+  SF_HIP(c, hipGetLastError());
+  const int tail_off = (int)fused_tail_offset(c, st, false);
+  const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);
+  const bool ba = c->dparams.bundle_adjustment != 0;
+  int rc;
+  sf_prof_begin(c, SF_K_FUSED);
+  if (st.w == 8) rc = ba ? launch_chain<8, true>(c, st, d_from, d_to, n, d_out, lds_c, tail_off)
+                         : launch_chain<8, false>(c, st, d_from, d_to, n, d_out, lds_c, tail_off);
+  else rc = ba ? launch_chain<16, true>(c, st, d_from, d_to, n, d_out, lds_c, tail_off)
+               : launch_chain<16, false>(c, st, d_from, d_to, n, d_out, lds_c, tail_off);
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());

@@ -693,7 +693,10 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   }
   c->own_stream = true;
   if (const char* v = getenv("SF_MATCH_VARIANT")) c->match_variant = atoi(v);
-  if (const char* v = getenv("SF_FUSED")) c->fused = atoi(v) != 0;   // 0: stage kernels (A/B reference)
+  if (const char* v = getenv("SF_FUSED")) {   // 0: stage kernels (A/B reference), 1: fused kernel, 2: split pipeline
+    c->fused = atoi(v) != 0;
+    c->split = atoi(v) == 2;
+  }
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
@@ -755,7 +758,7 @@ extern "C" void sf_destroy(sf_handle c) {
 extern "C" int sf_debug_chain_trace(sf_handle c, unsigned long long* out, int32_t n) {
   if (!c || !out || n < 0 || n > c->ws_pairs) return SF_EINVAL;
   SF_HIP(c, hipStreamSynchronize(c->stream));
-  SF_HIP(c, hipMemcpy(out, c->trace.p, (size_t)n * 32 * 8, hipMemcpyDeviceToHost));
+  SF_HIP(c, hipMemcpy(out, c->trace.p, (size_t)n * SF_TRACE_SLOTS * 8, hipMemcpyDeviceToHost));
   return SF_OK;
 }
 #endif
@@ -836,8 +839,8 @@ static int ws_reserve(sf_context* c, int n, int kcap, bool lists) {
   if ((rc = sf_buf_reserve(c, c->list3, np * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->flags, np)) != SF_OK) return rc;
 #ifdef SF_CHAIN_TRACE
-  if ((rc = sf_buf_reserve(c, c->trace, np * 32 * 8)) != SF_OK) return rc;
-  SF_HIP(c, hipMemsetAsync(c->trace.p, 0, np * 32 * 8, c->stream));
+  if ((rc = sf_buf_reserve(c, c->trace, np * SF_TRACE_SLOTS * 8)) != SF_OK) return rc;
+  SF_HIP(c, hipMemsetAsync(c->trace.p, 0, np * SF_TRACE_SLOTS * 8, c->stream));
   c->dparams.dbg_trace = (unsigned long long*)c->trace.p;
 #endif
   c->ws_pairs = n;
@@ -853,6 +856,10 @@ static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t
                            sf_result* d_out, bool allow_fused) {
   int rc;
   ctx->dparams.dbg_corr = ctx->debug_corr ? 1 : 0;
+  if (allow_fused && ctx->split && sf_split_applicable(ctx, view)) {
+    ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
+    return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
+  }
   if (allow_fused && sf_fused_lds_bytes(ctx, view) != 0) {
     // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
     ctx->last_lists_valid = ctx->debug_corr;
@@ -893,6 +900,7 @@ static int ensure_twin(sf_context* c) {
   t->match_variant = c->match_variant;
   t->match_mfma = c->match_mfma;
   t->fused = c->fused;
+  t->split = c->split;
   t->debug_corr = c->debug_corr;
   t->prof = c->prof;
   return SF_OK;
@@ -940,7 +948,8 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     SF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return SF_OK;
   }
-  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap, c->debug_corr || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
+  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap,
+                       c->debug_corr || c->split || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
     return rc;
   c->ws_split = 0;
   for (int off = 0; off < n; off += SF_CHUNK) {

@@ -72,18 +72,23 @@ struct DeviceParams {
   float ba_robust_kernel_delta, ba_pixel_variance, stereo_baseline;
   int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
                               // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
-  unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][32] timestamps; else null
+  unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][SF_TRACE_SLOTS] timestamps; else null
 };
 
 // Phase timestamps of the fused kernel's chain (diagnostic build -DSF_CHAIN_TRACE, libsepfinder_trace.so; the product
 // build compiles these to nothing): thread 0 of the pair's workgroup stores the 100 MHz wall clock.
 #ifdef SF_CHAIN_TRACE
+#define SF_TRACE_SLOTS 48
 #define SF_TRACE_MARK(P, pair, slot)                                                              \
   do {                                                                                            \
-    if (threadIdx.x == 0 && (P).dbg_trace) (P).dbg_trace[(size_t)(pair) * 32 + (slot)] = wall_clock64(); \
+    if (threadIdx.x == 0 && (P).dbg_trace) (P).dbg_trace[(size_t)(pair) * SF_TRACE_SLOTS + (slot)] = wall_clock64(); \
   } while (0)
+// (the same with the pair's row pointer, for bodies that do not see the parameter block)
+#define SF_TRACE_ROW_MARK(row, slot) do { if (threadIdx.x == 0 && (row)) (row)[slot] = wall_clock64(); } while (0)
 #else
+#define SF_TRACE_SLOTS 48
 #define SF_TRACE_MARK(P, pair, slot) do { } while (0)
+#define SF_TRACE_ROW_MARK(row, slot) do { } while (0)
 #endif
 
 struct Buf {
@@ -181,6 +186,9 @@ struct sf_context {
   bool debug_corr = false;      // SF_OPT_DEBUG_CORR: the fused kernel also writes lists / headers / states to HBM
   bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
+  bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
+  bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
+  bool split_match_attr[2] = {};   // k_match_split [W == 16]
   bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
@@ -261,6 +269,9 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
 // Fused per-pair pipeline (k_verify.hip): match -> RANSAC -> guided -> RANSAC -> result in one launch.
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
+bool sf_split_applicable(const sf_context* c, const StoreView& st);
+int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
+                           sf_result* d_out);
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out);
 size_t sf_ransac_lds_bytes(int kcap, int iterations);

@@ -1,7 +1,7 @@
 """Phase timestamps of k_verify_fused's per-pair pipeline (diagnostic build libsepfinder_trace.so, csrc `make trace`).
 
 Loads the trace build through SEPFINDER_LIB, verifies n pairs of the bench shape (20 % true revisits) in one
-launch, reads the [pair][32] wall-clock stamps thread 0 of every workgroup left, and prints, for the pairs that
+launch, reads the [pair][48] wall-clock stamps thread 0 of every workgroup left, and prints, for the pairs that
 ran the whole chain, the mean / median / p90 duration of every phase -- under load (the 10 000-pair launch) and
 uncontended (a launch with fewer surviving pairs than CUs).  Also the launch's wall time from HIP events.
 
@@ -23,6 +23,8 @@ from multi_robot_slam_separators_amd import _abi, lib, synth  # noqa: E402
 
 PHASES = [
     ("match", 0, 1),
+    ("match stage rows", 0, 32), ("match scan (wave 0)", 32, 33), ("match scan (wait others)", 33, 34),
+    ("match compact", 34, 35), ("match header", 35, 1),
     ("r1 gather", 1, 2), ("r1 pca", 2, 3), ("r1 hypotheses", 3, 4), ("r1 select", 4, 5), ("r1 refine", 5, 6),
     ("r1 variance+out", 6, 7),
     ("guided bucket", 7, 8), ("guided search", 8, 9), ("guided compact", 9, 10),
@@ -76,7 +78,7 @@ def run(n, k, cols, iters, true_frac, label):
     L = lib.load()
     L.sf_debug_chain_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
     L.sf_debug_chain_trace.restype = ctypes.c_int
-    tr = np.zeros((n, 32), np.uint64)
+    tr = np.zeros((n, 48), np.uint64)
     rc = L.sf_debug_chain_trace(f._h, tr.ctypes.data, n)
     assert rc == 0, rc
     res = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
