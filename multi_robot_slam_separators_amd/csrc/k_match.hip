@@ -298,8 +298,10 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
 // ------------------------------------------------------------------------------------------------
 // Variant 3 ("fp4 matrix cores", NQ == 0): the K_from x K_to Hamming table as a matrix product.
 // With every descriptor bit b mapped to the fp4 (E2M1) value 1 - 2b, the dot product of two rows is
-// (bits - 2 * hamming): +-1 products are exact in fp4 and their sums (|.| <= 512) are exact in the f32
-// accumulator, so the distances are the integers the VALU variants compute.  v_mfma_f32_32x32x64_f8f6f4
+// (bits - 2 * hamming); the coding actually used (fp4_spread_from / fp4_spread_to below) gives the same number
+// minus a constant of the "to" row for 4 instead of 7 VALU ops per streamed dword.  The products are exact in
+// fp4 and their sums (|.| <= 1024) are exact in the f32 accumulator, so the distances are the integers the VALU
+// variants compute.  v_mfma_f32_32x32x64_f8f6f4
 // does 32 x 32 x 64 of them per instruction (tools/ubench/mfma_fp4_hamming.hip pins operand layout and
 // exactness on the device); the order of the 64 bits inside one instruction is irrelevant as long as
 // both operands use the same one, so a lane simply spreads the raw dwords it loaded.
@@ -314,17 +316,38 @@ typedef float mf_v16f __attribute__((ext_vector_type(16)));
 constexpr float MF_FR = 1.f / 2048.f;        // index fraction (kcap <= 2048 rows on this path)
 constexpr int MF_MAX_ROWS = 2048;
 
-// 32 descriptor bits -> 32 fp4 values (4 dwords of nibbles): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2).
-// m88 / c22 hold 0x88888888 / 0x22222222 in VGPRs the compiler cannot see through (knn2_mfma), so that
-// ((x << k) & m88) | c22 becomes shift + v_and_or_b32 (7 VALU ops per dword); with literal constants a
-// VOP3 cannot encode them on gfx9 and the expression costs 11.  No asm on this path: the results are MFMA
+// 32 descriptor bits -> 32 fp4 (E2M1) values, 4 dwords of nibbles.  The streamed operand (the "from" rows, spread
+// once per tile by every wavefront) must be cheap, so its bits stay where they are: dword k of the result keeps
+// the bits at nibble position 3 - k of the raw dword,
+//   position 3: sign bit of 1.0          -> +1 / -1          (x & 0x8888.. | 0x2222..)
+//   position 2: exponent bit, code 0100  ->  0 / 2.0         (x & 0x4444..)
+//   position 1: exponent bit, code 0010  ->  0 / 1.0         (x & 0x2222..)
+//   position 0: mantissa bit, code 0001  ->  0 / 0.5         (x & 0x1111..)
+// 4 VALU ops per raw dword (the all-sign form ((x << k) & 0x8888..) | 0x2222.. costs 7).  With t = +1 / -1 for a
+// bit 0 / 1, an element of the last three classes is a = d (1 - tx), d = 1, 1/2, 1/4; the resident operand (the
+// "to" rows, spread once per pass) answers with b = -ty / d = -+1, -+2, -+4 (codes 0x2, 0x4, 0x6 under the sign),
+// so a b = tx ty - ty, and the sign class contributes tx ty directly:
+//   dot = (bits - 2 hamming) - sum_{classes 2,1,0} ty = (bits - 2 hamming) - (3 bits / 4 - 2 popc(y & 0x7777..)).
+// The second term is a constant of the "to" row: it shifts every score of a column alike (best / second best and
+// the tie rule are untouched) and is taken out when the distances are decoded.  Products and sums are exact.
+// m88 / c22 hold 0x88888888 / 0x22222222 in VGPRs the compiler cannot see through (knn2_mfma): a VOP3 cannot
+// encode a literal on gfx9, so v_and_or_b32 needs them in registers.  No asm on this path: the results are MFMA
 // operands and the hazard recogniser must see the instructions that write them.
-__device__ __forceinline__ mf_v8i fp4_spread(uint32_t x, uint32_t m88, uint32_t c22) {
+__device__ __forceinline__ mf_v8i fp4_spread_from(uint32_t x, uint32_t m88, uint32_t c22) {
   mf_v8i o = {0, 0, 0, 0, 0, 0, 0, 0};
-  o[0] = (int)(((x << 3) & m88) | c22);
-  o[1] = (int)(((x << 2) & m88) | c22);
-  o[2] = (int)(((x << 1) & m88) | c22);
-  o[3] = (int)((x & m88) | c22);
+  o[0] = (int)((x & m88) | c22);
+  o[1] = (int)(x & 0x44444444u);
+  o[2] = (int)(x & 0x22222222u);
+  o[3] = (int)(x & 0x11111111u);
+  return o;
+}
+__device__ __forceinline__ mf_v8i fp4_spread_to(uint32_t y, uint32_t m88, uint32_t c22) {
+  mf_v8i o = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t n = ~y;
+  o[0] = (int)((y & m88) | c22);
+  o[1] = (int)(((n << 1) & m88) | c22);
+  o[2] = (int)(((n << 2) & m88) | 0x44444444u);
+  o[3] = (int)(((n << 3) & m88) | 0x66666666u);
   return o;
 }
 
@@ -388,7 +411,7 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
   }
   mf_v8i Af[KS];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) Af[k] = fp4_spread(raw[k], m88, c22);
+  for (int k = 0; k < KS; ++k) Af[k] = fp4_spread_from(raw[k], m88, c22);
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     // the scores kept so far move with the origin (the first row of the current tile)
@@ -417,6 +440,7 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
   asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
   asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
   mf_v8i Bf[NTL][KS];
+  int tsum[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     const int t = tile[j] * 32 + r;
@@ -424,8 +448,14 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 #pragma unroll
     for (int k = 0; k < KS; ++k) raw[k] = 0;
     if (t < Kt) load_raw<KS>(dT + (size_t)t * W + KS * h, raw);
+    int p = 0;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) Bf[j][k] = fp4_spread(raw[k], m88, c22);
+    for (int k = 0; k < KS; ++k) {
+      Bf[j][k] = fp4_spread_to(raw[k], m88, c22);
+      p += __popc(raw[k] & 0x77777777u);
+    }
+    p += __shfl_xor(p, 32);                 // both halves of the row
+    tsum[j] = 24 * W - 2 * p;               // the column's constant (see fp4_spread_from)
   }
   float cin[16], b[NTL], s[NTL];
 #pragma unroll
@@ -443,8 +473,8 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
     const float ns = fmaxf(fminf(b[j], ob), fmaxf(s[j], os)) - org;
     const float dot1 = 2.f * ceilf(nb * 0.5f), dot2 = 2.f * ceilf(ns * 0.5f);
     idx[j] = (int)((dot1 - nb) * 2048.f);
-    d1[j] = (uint32_t)((32 * W - (int)dot1) >> 1);
-    d2[j] = ns == -INFINITY ? 0xFFFFu : (uint32_t)((32 * W - (int)dot2) >> 1);
+    d1[j] = (uint32_t)((32 * W - tsum[j] - (int)dot1) >> 1);
+    d2[j] = ns == -INFINITY ? 0xFFFFu : (uint32_t)((32 * W - tsum[j] - (int)dot2) >> 1);
   }
 }
 

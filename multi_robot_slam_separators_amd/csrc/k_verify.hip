@@ -105,7 +105,7 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 // lists / headers take one trip through HBM (~2 KB per survivor) and their chains run four to a CU with nothing
 // else on it.  Same bodies, same bytes.
 template <int W>
-__global__ void __launch_bounds__(SF_BLOCK, 2)
+__global__ void __launch_bounds__(SF_BLOCK, 3)
 k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
               CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
