@@ -233,6 +233,35 @@ int  sf_store_add_keyframes_device(sf_handle h, int32_t n, int32_t rows, int32_t
 int  sf_store_size(sf_handle h, int32_t* n_slots);
 int  sf_store_clear(sf_handle h);
 
+/* ---- features of one stereo keyframe -------------------------------- */
+/* replaces: RegistrationVis::getFeaturesImpl (myRegistrationVis.cpp:343-436: descriptors for the given keypoints,
+   3D keypoints of the stereo pair, removal of keypoints without a finite 3D point) as called by
+   StereoCamGeometricTools::getFeaturesAndDescriptor (stereoCamGeometricTools.cpp:100-120), writing the keyframe
+   straight into the device-resident store.  Corner detection and the right-image position of every corner
+   (rtabmap: GFTT + pyramidal LK) stay upstream of this call.                                      */
+typedef struct sf_stereo_camera {
+  float fx, fy, cx, cy;        /* left camera (StereoCameraModel::left())                                  */
+  float cx_right;              /* right camera cx (0: unknown, no principal-point correction)              */
+  float baseline;              /* metres, > 0                                                              */
+  float local_transform[12];   /* base <- camera optical frame, row-major 3x4 (CameraModel::localTransform) */
+  float min_depth, max_depth;  /* Vis/MinDepth, Vis/MaxDepth; both 0 (the reference's defaults) keeps the
+                                  keypoints whose 3D point is NaN                                          */
+} sf_stereo_camera;
+/* BRIEF test locations: [8 * bytes][4] int8 {x1, y1, x2, y2}, each within +-24 (the 48 px patch); bytes = 16, 32
+   or 64.  A fresh handle holds a seeded Gaussian set (NOT OpenCV's table, which is not in the reference tree):
+   install OpenCV's generated_<bytes>.i values here for descriptors identical to the reference build's.       */
+int  sf_brief_set_pattern(sf_handle h, const int8_t* tests, int32_t bytes);
+int  sf_brief_get_pattern(sf_handle h, int8_t* tests, int32_t cap_bytes, int32_t* bytes);
+/* d_left: 8-bit image on the device (height rows of `pitch` bytes); d_kpts: n corners; d_right_x: their x in the
+   right image (NULL: no 3D); d_status: per-corner validity of d_right_x (NULL: all valid).  Appends ONE keyframe
+   to the store; *out_slot = its slot, *out_rows = features kept (the call synchronises the stream to read it;
+   pass NULL to stay asynchronous).  Optional copies for the wire (GetFeatsAndDesc response), device pointers
+   sized for n rows, any may be NULL: d_desc_out [n][bytes], d_xyz_out [n][3], d_kpts_out [n].               */
+int  sf_extract_keyframe_device(sf_handle h, const uint8_t* d_left, int32_t width, int32_t height, int32_t pitch,
+                                const sf_keypoint* d_kpts, const float* d_right_x, const uint8_t* d_status,
+                                int32_t n, const sf_stereo_camera* cam, int32_t* out_slot, int32_t* out_rows,
+                                uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out);
+
 /* ---- geometric verification (stereoCamGeometricTools.cpp:122-178) ---------------------------- */
 /* One estimate_transformation service call on host buffers.                                  */
 int  sf_estimate_transform(sf_handle h, const sf_features* from, const sf_features* to,

@@ -76,6 +76,26 @@ KEYPOINT_DTYPE = np.dtype(
 assert KEYPOINT_DTYPE.itemsize == C.sizeof(Keypoint) == 28
 
 
+class StereoCamera(C.Structure):
+    """sf_stereo_camera (include/sepfinder.h): the stereo model of sf_extract_keyframe_device."""
+    _fields_ = [
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("cx_right", C.c_float), ("baseline", C.c_float),
+        ("local_transform", C.c_float * 12),
+        ("min_depth", C.c_float), ("max_depth", C.c_float),
+    ]
+
+
+def stereo_camera(fx, fy, cx, cy, baseline, cx_right=0.0, local_transform=None, min_depth=0.0, max_depth=0.0):
+    cam = StereoCamera()
+    cam.fx, cam.fy, cam.cx, cam.cy, cam.cx_right, cam.baseline = fx, fy, cx, cy, cx_right, baseline
+    lt = np.eye(4, dtype=np.float32)[:3] if local_transform is None else np.asarray(local_transform, np.float32).reshape(3, 4)
+    for i, v in enumerate(lt.ravel()):
+        cam.local_transform[i] = float(v)
+    cam.min_depth, cam.max_depth = min_depth, max_depth
+    return cam
+
+
 class Features(C.Structure):
     _fields_ = [
         ("desc", C.c_void_p),

@@ -729,7 +729,8 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
-                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp};
+                 &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
+                 &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests};
   for (Buf* b : bufs) buf_free(*b);
   sf_ingest_pool_destroy(c);
   if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
@@ -805,6 +806,78 @@ extern "C" int sf_store_add_keyframes_device(sf_handle c, int32_t n, int32_t row
   if ((rc = sf_launch_ingest(c, c->store, c->store.slots, n, rows, cols, d_desc, d_xyz, d_kp)) != SF_OK) return rc;
   if (out_first_slot) *out_first_slot = c->store.slots;
   c->store.slots += n;
+  return SF_OK;
+}
+
+// ---- feature extraction (kernels in k_extract.hip) ----------------------------------
+static int brief_upload(sf_context* c) {
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->brief_tests, sizeof c->brief_host)) != SF_OK) return rc;
+  SF_HIP(c, hipMemcpyAsync(c->brief_tests.p, c->brief_host, (size_t)c->brief_bytes * 32, hipMemcpyHostToDevice, c->stream));
+  SF_HIP(c, hipStreamSynchronize(c->stream));   // (the host table may change right after the call returns)
+  return SF_OK;
+}
+
+extern "C" int sf_brief_set_pattern(sf_handle c, const int8_t* tests, int32_t bytes) {
+  if (!c || !tests) return SF_EINVAL;
+  if (bytes != 16 && bytes != 32 && bytes != 64) return sf_fail(c, SF_ERANGE, "BRIEF descriptors are 16, 32 or 64 bytes, not %d", bytes);
+  for (int t = 0; t < bytes * 32; ++t)
+    if (tests[t] < -24 || tests[t] > 24) return sf_fail(c, SF_ERANGE, "BRIEF test offset %d outside the 48 px patch", (int)tests[t]);
+  SF_HIP(c, hipSetDevice(c->device));
+  memcpy(c->brief_host, tests, (size_t)bytes * 32);
+  c->brief_bytes = bytes;
+  return brief_upload(c);
+}
+
+static int brief_ensure(sf_context* c) {
+  if (c->brief_bytes) return SF_OK;
+  const int want = c->params.desc_bytes;
+  c->brief_bytes = (want == 16 || want == 64) ? want : 32;
+  sf_brief_default_pattern(c->brief_host, c->brief_bytes);
+  return brief_upload(c);
+}
+
+extern "C" int sf_brief_get_pattern(sf_handle c, int8_t* tests, int32_t cap_bytes, int32_t* bytes) {
+  if (!c || !bytes) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc = brief_ensure(c);
+  if (rc != SF_OK) return rc;
+  *bytes = c->brief_bytes;
+  if (tests) {
+    if (cap_bytes < c->brief_bytes) return sf_fail(c, SF_ERANGE, "pattern buffer holds %d of %d descriptor bytes", cap_bytes, c->brief_bytes);
+    memcpy(tests, c->brief_host, (size_t)c->brief_bytes * 32);
+  }
+  return SF_OK;
+}
+
+extern "C" int sf_extract_keyframe_device(sf_handle c, const uint8_t* d_left, int32_t width, int32_t height,
+                                          int32_t pitch, const sf_keypoint* d_kpts, const float* d_right_x,
+                                          const uint8_t* d_status, int32_t n, const sf_stereo_camera* cam,
+                                          int32_t* out_slot, int32_t* out_rows, uint8_t* d_desc_out,
+                                          float* d_xyz_out, sf_keypoint* d_kpts_out) {
+  if (!c || !cam || n < 0) return SF_EINVAL;
+  if (!d_left || width < 1 || height < 1 || pitch < width) return sf_fail(c, SF_EINVAL, "left image missing or malformed (%d x %d, pitch %d)", width, height, pitch);
+  if (n > 0 && !d_kpts) return sf_fail(c, SF_EINVAL, "keypoints missing");
+  if (n > SF_MAX_FEATURES) return sf_fail(c, SF_ERANGE, "%d corners > int16 limit of KeyPointVec.size", n);
+  if ((long long)(width + 1) * (height + 1) * 255 > 0x7FFFFFFFll) return sf_fail(c, SF_ERANGE, "image too large for a 32-bit integral image");
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc = brief_ensure(c);
+  if (rc != SF_OK) return rc;
+  if ((rc = store_reserve(c, c->store, c->store.slots + 1, n, c->brief_bytes)) != SF_OK) return rc;
+  if (out_rows && (rc = sf_buf_reserve(c, c->ex_rows, 16)) != SF_OK) return rc;
+  Store& st = c->store;
+  const int slot = st.slots;
+  if ((rc = sf_launch_extract(c, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam, c->brief_bytes,
+                              (const int8_t*)c->brief_tests.p, (uint32_t*)st.desc.p, (float*)st.xyz.p, (float4*)st.kp.p,
+                              (int4*)st.meta.p, st.kcap, st.w, slot, d_desc_out, d_xyz_out, d_kpts_out,
+                              out_rows ? (int32_t*)c->ex_rows.p : nullptr)) != SF_OK)
+    return rc;
+  st.slots += 1;
+  if (out_slot) *out_slot = slot;
+  if (out_rows) {
+    SF_HIP(c, hipMemcpyAsync(out_rows, c->ex_rows.p, 4, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+  }
   return SF_OK;
 }
 

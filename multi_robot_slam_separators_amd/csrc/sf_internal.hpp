@@ -152,6 +152,10 @@ struct sf_context {
   Buf counters;                 // int32[8]
   Buf results;                  // sf_result[n]
   Buf flags;                    // uint8[n] pass2_guided
+  // feature extraction (k_extract.hip): integral image, per-corner scratch, the BRIEF test table
+  Buf ex_integral, ex_desc, ex_xyz, ex_keep, ex_rows, brief_tests;
+  int brief_bytes = 0;                 // 0: table not uploaded yet
+  int8_t brief_host[64 * 8 * 4] = {};
   Buf trace;                    // SF_CHAIN_TRACE builds: uint64[n][32] phase timestamps of the fused kernel
 
   // NN stage
@@ -278,6 +282,12 @@ size_t sf_ransac_lds_bytes(int kcap, int iterations);
 size_t sf_ba_lds_bytes(int kcap);
 size_t sf_pnp_lds_bytes(int kcap, int iterations);
 size_t sf_guided_lds_bytes(int kcap, int n_cells);
+void sf_brief_default_pattern(int8_t* tests, int bytes);
+int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int height, int pitch, const sf_keypoint* d_kpts,
+                      const float* d_right_x, const uint8_t* d_status, int n, const sf_stereo_camera* cam, int bytes,
+                      const int8_t* d_tests, uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap,
+                      int w_dwords, int slot, uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out,
+                      int32_t* d_rows_out);
 // Assemble sf_result records.
 int sf_launch_finalize(sf_context* c, int n, sf_result* d_out);
 // Ingest kernels

@@ -79,6 +79,10 @@ def load():
         "sf_nn_walk": (C.c_int, [vp, vp, vp, i32, i32, vp, i32, P(i32)]),
         "sf_store_add_keyframe": (C.c_int, [vp, P(_abi.Features), P(i32)]),
         "sf_store_add_keyframes_device": (C.c_int, [vp, i32, i32, i32, vp, vp, vp, P(i32)]),
+        "sf_brief_set_pattern": (C.c_int, [vp, vp, i32]),
+        "sf_brief_get_pattern": (C.c_int, [vp, vp, i32, P(i32)]),
+        "sf_extract_keyframe_device": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i32, P(_abi.StereoCamera),
+                                                 P(i32), P(i32), vp, vp, vp]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
         "sf_store_clear": (C.c_int, [vp]),
         "sf_estimate_transform": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), vp]),
@@ -120,7 +124,8 @@ EXPORTED = [
     "sf_nn_set_precision",
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
-    "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear", "sf_estimate_transform",
+    "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -270,6 +275,28 @@ class SeparatorFinder:
                                                           C.c_void_p(d_xyz), C.c_void_p(d_kp),
                                                           C.byref(first)))
         return first.value
+
+    # -- feature extraction ------------------------------------------------
+    def brief_set_pattern(self, tests):
+        """tests: int8 [8 * bytes, 4] = (x1, y1, x2, y2) per descriptor bit."""
+        t = np.ascontiguousarray(tests, dtype=np.int8).reshape(-1, 4)
+        self._check(self._L.sf_brief_set_pattern(self._h, C.c_void_p(t.ctypes.data), t.shape[0] // 8))
+
+    def brief_get_pattern(self):
+        n = C.c_int32()
+        buf = np.zeros((64 * 8, 4), np.int8)
+        self._check(self._L.sf_brief_get_pattern(self._h, C.c_void_p(buf.ctypes.data), 64, C.byref(n)))
+        return buf[:8 * n.value].copy()
+
+    def extract_keyframe_device(self, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam,
+                                d_desc_out=None, d_xyz_out=None, d_kpts_out=None, want_rows=True):
+        """Device pointers (ints).  Returns (slot, rows kept or None)."""
+        slot, rows = C.c_int32(), C.c_int32()
+        self._check(self._L.sf_extract_keyframe_device(
+            self._h, C.c_void_p(d_left), width, height, pitch, C.c_void_p(d_kpts), C.c_void_p(d_right_x),
+            C.c_void_p(d_status), n, C.byref(cam), C.byref(slot), C.byref(rows) if want_rows else None,
+            C.c_void_p(d_desc_out), C.c_void_p(d_xyz_out), C.c_void_p(d_kpts_out)))
+        return slot.value, (rows.value if want_rows else None)
 
     def store_size(self):
         n = C.c_int32()

@@ -20,7 +20,8 @@ def build(force=False):
     """Compile oracle/libsf_oracle.so with gcc (Makefile in this directory)."""
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in
-                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle.h", "sf_oracle_internal.h"))
+                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle_ba.c", "sf_oracle_extract.c", "sf_oracle.h",
+                                           "sf_oracle_internal.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -74,6 +75,10 @@ def lib():
         L.sfo_sample_triplet.restype = None
         L.sfo_sample_triplet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.sfo_num_threads.restype = C.c_int
+        L.sfo_extract_keyframe.restype = C.c_int
+        L.sfo_extract_keyframe.argtypes = [
+            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+            P(_abi.StereoCamera), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
         L.sfo_estimate_motion_3d2d.restype = C.c_int
         L.sfo_estimate_motion_3d2d.argtypes = [
             P(_abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -278,3 +283,30 @@ def sample_triplet(seed, it, attempt, m):
 
 def num_threads():
     return lib().sfo_num_threads()
+
+
+def extract_keyframe(image, kpts, right_x, status, cam, tests):
+    """sfo_extract_keyframe: image uint8 [h, w] (C-contiguous rows, pitch = stride), kpts KEYPOINT_DTYPE [n],
+    right_x float32 [n] or None, status uint8 [n] or None, tests int8 [8 * bytes, 4].
+    Returns (desc [rows, bytes] u8, xyz [rows, 3] f32, kpts [rows])."""
+    L = lib()
+    image = np.asarray(image, np.uint8)
+    assert image.ndim == 2 and image.strides[1] == 1
+    kpts = np.ascontiguousarray(kpts, dtype=_abi.KEYPOINT_DTYPE)
+    n = kpts.shape[0]
+    tests = np.ascontiguousarray(tests, np.int8).reshape(-1, 4)
+    nbytes = tests.shape[0] // 8
+    rx = None if right_x is None else np.ascontiguousarray(right_x, np.float32)
+    stt = None if status is None else np.ascontiguousarray(status, np.uint8)
+    desc = np.zeros((max(n, 1), nbytes), np.uint8)
+    xyz = np.zeros((max(n, 1), 3), np.float32)
+    kout = np.zeros(max(n, 1), _abi.KEYPOINT_DTYPE)
+    rows = C.c_int32()
+    rc = L.sfo_extract_keyframe(image.ctypes.data, image.shape[1], image.shape[0], image.strides[0],
+                                kpts.ctypes.data if n else None, None if rx is None else rx.ctypes.data,
+                                None if stt is None else stt.ctypes.data, n, C.byref(cam), tests.ctypes.data, nbytes,
+                                desc.ctypes.data, xyz.ctypes.data, kout.ctypes.data, C.byref(rows))
+    if rc != 0:
+        raise RuntimeError("sfo_extract_keyframe failed: %d" % rc)
+    r = rows.value
+    return desc[:r].copy(), xyz[:r].copy(), kout[:r].copy()

@@ -167,52 +167,6 @@ void sfo_sample_triplet(uint64_t seed, uint32_t iteration, uint32_t attempt, uin
   out[0] = i0; out[1] = i1; out[2] = i2;
 }
 
-/* Cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 4), rows of a/v have
- * stride 4.  Eigenvalues on the diagonal of a, eigenvectors in the columns of v. */
-static void sfo_jacobi(int n, double a[4][4], double v[4][4]) {
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 50; ++sweep) {
-    double sm = 0.0;
-    for (int p = 0; p < n - 1; ++p) for (int q = p + 1; q < n; ++q) sm += fabs(a[p][q]);
-    if (sm == 0.0) break;
-    for (int p = 0; p < n - 1; ++p) {
-      for (int q = p + 1; q < n; ++q) {
-        double apq = a[p][q];
-        double g = 100.0 * fabs(apq);
-        double app = fabs(a[p][p]), aqq = fabs(a[q][q]);
-        if (sweep > 3 && app + g == app && aqq + g == aqq) { a[p][q] = 0.0; a[q][p] = 0.0; continue; }
-        if (apq == 0.0) continue;
-        double h = a[q][q] - a[p][p];
-        double t;
-        if (fabs(h) + g == fabs(h)) {
-          t = apq / h;
-        } else {
-          double theta = 0.5 * h / apq;
-          t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-          if (theta < 0.0) t = -t;
-        }
-        double c = 1.0 / sqrt(1.0 + t * t);
-        double s = t * c;
-        for (int k = 0; k < n; ++k) {
-          double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        a[p][q] = 0.0; a[q][p] = 0.0;
-        for (int k = 0; k < n; ++k) {
-          double vkp = v[k][p], vkq = v[k][q];
-          v[k][p] = c * vkp - s * vkq;
-          v[k][q] = s * vkp + c * vkq;
-        }
-      }
-    }
-  }
-}
 
 static double sfo_det3(double a, double b, double c, double d, double e, double f, double g, double h,
                        double i) {

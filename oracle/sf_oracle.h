@@ -125,6 +125,13 @@ int    sfo_quartic_roots(const double c[5], double r[4]);
 int    sfo_p3p(const double P[3][3], const double f[3][3], double R[4][9], double t[4][3]);
 double sfo_canon_atan2(double y, double x);
 
+/* SURVEY section 8 row f3 (sf_oracle_extract.c): features of one stereo keyframe for given corners.  tests:
+ * [8 * bytes][4] int8 {x1, y1, x2, y2}; outputs sized for n rows; *rows_out = rows kept.                          */
+int sfo_extract_keyframe(const uint8_t* image, int32_t width, int32_t height, int32_t pitch, const sf_keypoint* kpts,
+                         const float* right_x, const uint8_t* status, int32_t n, const sf_stereo_camera* cam,
+                         const int8_t* tests, int32_t bytes, uint8_t* desc_out, float* xyz_out, sf_keypoint* kp_out,
+                         int32_t* rows_out);
+
 #ifdef __cplusplus
 }
 #endif
