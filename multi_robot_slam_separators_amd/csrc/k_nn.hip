@@ -345,22 +345,38 @@ __global__ void __launch_bounds__(256) k_nn_to_f16(const float* __restrict__ row
 // with A_i = (na_i (1-delta) - thr2) s/2,  B_j = nb_j (1-delta) s/2,  C_i = eps s sqrt(na_i),  D_j = sqrt(nb_j)
 // (delta = 2e-6 also covers the rounding of this rearrangement).  Masked / padding rows and columns get
 // A = +inf (resp. B = +inf) and C = D = 0, so they can never be candidates.
+// C_i and D_j are rounded UP to fp16-representable values (a larger error allowance keeps the filter a superset):
+// the resident-panel kernel feeds them to the matrix cores as one more contraction step.  Their product is
+// eps (s_a |a|)(s_b |b|); the scaled norms reach sqrt(k) 2^15, so the split is C = 64 eps s_a |a| (<= 2.4e4 at
+// k = 128) and D = s_b |b| / 64 (<= 5.8e3): both inside fp16's range whatever the data.  delta = 2e-6 plus
+// (k + 8) 2^-24 for the fp32 additions that now also carry -A_i (k_nn_filter_f16_k128 starts its accumulators there).
+__device__ __forceinline__ float nn_up_to_f16(float x) {   // x >= 0
+  _Float16 hv = (_Float16)x;
+  if ((float)hv < x) {
+    unsigned short b;
+    __builtin_memcpy(&b, &hv, 2);
+    ++b;                                   // next fp16 up (0x7BFF + 1 = +inf)
+    __builtin_memcpy(&hv, &b, 2);
+  }
+  return (float)hv;
+}
 __global__ void k_nn_filter_row_coef(float2* rowc, const float* na, const uint8_t* mask_local, int n_l, int n_l_pad,
-                                     float half_s, float thr2, float eps_s) {
+                                     float half_s, float thr2, float eps_sa64, float delta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_l_pad) return;
   const bool ok = i < n_l && !mask_local[i];
   const float n = ok ? na[i] : 0.f;
-  rowc[i] = ok ? make_float2((n * (1.f - 2e-6f) - thr2) * half_s, eps_s * sqrtf(n))
+  rowc[i] = ok ? make_float2((n * (1.f - delta) - thr2) * half_s, nn_up_to_f16(eps_sa64 * sqrtf(n)))
                : make_float2(__int_as_float(0x7F800000), 0.f);
 }
 __global__ void k_nn_filter_col_coef(float2* colc, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad,
-                                     float half_s) {
+                                     float half_s, float sb_64, float delta) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_r_pad) return;
   const bool ok = j < n_r && !mask_other[j];
   const float n = ok ? nb[j] : 0.f;
-  colc[j] = ok ? make_float2(n * (1.f - 2e-6f) * half_s, sqrtf(n)) : make_float2(__int_as_float(0x7F800000), 0.f);
+  colc[j] = ok ? make_float2(n * (1.f - delta) * half_s, nn_up_to_f16(sb_64 * sqrtf(n)))
+               : make_float2(__int_as_float(0x7F800000), 0.f);
 }
 
 // A16: local rows [n_l_pad][ld] fp16 (x scale_a), B16: received rows [n_r_pad][ld] fp16 (x scale_b).
@@ -470,6 +486,163 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
         }
       }
     }
+  }
+}
+
+// ---- the same filter for a 128-dimension contraction, with the row panel resident ----------------------------
+// k_nn_filter_f16 at k = 128 spent its time outside the matrix cores: every 128 x 128 tile paid the global-load
+// latency of both operand panels (two barriers per 64-dimension step, nothing to overlap it with) and ~10 VALU
+// instructions per pair of outputs in the compare epilogue (profiles/r02b: 73 us for 25.6 GFLOP).  Here
+//   * a workgroup keeps ONE 128-row panel of the local descriptors in LDS (32 KB) and walks a strip of column
+//     tiles: the received panel of tile t + 1 is in flight (registers) while tile t is contracted, one LDS buffer,
+//     two barriers per TILE;
+//   * the inequality  acc > (A_i + B_j) - C_i D_j  is folded into the contraction: the accumulators START at -A_i
+//     (the MFMA's C operand, free), C_i D_j is a ninth contraction step (C_i and D_j are fp16-representable by
+//     construction, their product is exact), and what is left per output is  acc' > B_j;
+//   * that compare is done on the MAXIMUM of each lane's 16 outputs of a 32 x 32 block (v_max3), one compare and a
+//     ballot per block; only blocks with a hit look at their 16 outputs one by one;
+//   * hits go to a list in LDS and the workgroup takes its slots of the global candidate list with ONE atomic at the
+//     end of its strip: one returning atomic per hit on the single global counter serialises in L2 at ~3 ns each,
+//     which -- not the contraction -- was what both this kernel and k_nn_filter_f16 took 73 us for at ~25 000 hits.
+// Per 64 x 64 wavefront tile: 36 MFMAs (1152 matrix-pipe cycles) against ~150 other instructions.
+constexpr int NN_KP = 68;                 // LDS row pitch in dwords: 64 dwords (128 halfs) + 4
+constexpr int NN_K128_HITS = 1024;        // candidates a workgroup collects in LDS before it takes global slots
+constexpr int NN_K128_LDS = 2 * NN_BM * NN_KP * 4 + NN_K128_HITS * 8 + 16;
+
+__global__ void __launch_bounds__(256, 2)
+k_nn_filter_f16_k128(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float2* __restrict__ rowc,
+                     const float2* __restrict__ colc, int gx, int gy, int tiles_per_strip,
+                     uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
+  extern __shared__ __attribute__((aligned(16))) float nn_lds[];
+  float* sA = nn_lds;                         // [128][NN_KP]
+  float* sB = nn_lds + NN_BM * NN_KP;         // [128][NN_KP]
+  uint2* s_hits = reinterpret_cast<uint2*>(nn_lds + 2 * NN_BM * NN_KP);   // [NN_K128_HITS]
+  unsigned* s_nhits = reinterpret_cast<unsigned*>(s_hits + NN_K128_HITS);  // [0] count, [1] global base
+  const int tid = threadIdx.x;
+  if (tid == 0) s_nhits[0] = 0;               // (visible after the first barrier of the tile loop)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int strips = (gx + tiles_per_strip - 1) / tiles_per_strip;
+  const int tile_y = blockIdx.x / strips, strip = blockIdx.x - tile_y * strips;   // (gy row panels) x strips
+  const int t_first = strip * tiles_per_strip;
+  const int t_last = min(gx, t_first + tiles_per_strip);
+  const int row0 = tile_y * NN_BM;
+  const float4* Ag = reinterpret_cast<const float4*>(A) + (size_t)row0 * 16;   // 16 float4 per 128-half row
+
+  // the column panel of the first tile is requested first, then the row panel (written to LDS straight away)
+  // (named registers, not an array: hipcc demotes a float4[8] carried around the tile loop to scratch)
+  float4 rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+#define SF_K128_LOAD(Bg)                                                                              \
+  rb0 = (Bg)[tid]; rb1 = (Bg)[tid + 256]; rb2 = (Bg)[tid + 512]; rb3 = (Bg)[tid + 768];               \
+  rb4 = (Bg)[tid + 1024]; rb5 = (Bg)[tid + 1280]; rb6 = (Bg)[tid + 1536]; rb7 = (Bg)[tid + 1792]
+#define SF_K128_STORE(u, v)                                                                           \
+  *reinterpret_cast<float4*>(&sB[((tid + 256 * (u)) >> 4) * NN_KP + ((tid + 256 * (u)) & 15) * 4]) = (v)
+  {
+    const float4* Bg = reinterpret_cast<const float4*>(B) + (size_t)t_first * NN_BN * 16;
+    SF_K128_LOAD(Bg);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int ch = tid + 256 * u;
+    *reinterpret_cast<float4*>(&sA[(ch >> 4) * NN_KP + (ch & 15) * 4]) = Ag[ch];
+  }
+  // accumulator start values -A_i and the row half of the ninth step, for this lane's rows
+  f32x16 cinit[2];
+  half8 a_ext[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[i][r] = -rowc[row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h].x;
+    const float ci = rowc[row0 + 64 * wr + 32 * i + l31].y;
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    a_ext[i] = z;
+    if (h == 0) a_ext[i][0] = (_Float16)ci;      // k = 0 of the extra step lives in lanes 0..31
+  }
+
+  for (int t = t_first; t < t_last; ++t) {
+    const int col0 = t * NN_BN;
+    __syncthreads();                              // the previous tile's reads of sB are complete
+    SF_K128_STORE(0, rb0); SF_K128_STORE(1, rb1); SF_K128_STORE(2, rb2); SF_K128_STORE(3, rb3);
+    SF_K128_STORE(4, rb4); SF_K128_STORE(5, rb5); SF_K128_STORE(6, rb6); SF_K128_STORE(7, rb7);
+    __syncthreads();
+    if (t + 1 < t_last) {
+      const float4* Bg = reinterpret_cast<const float4*>(B) + (size_t)(t + 1) * NN_BN * 16;
+      SF_K128_LOAD(Bg);
+    }
+    float bj[2];
+    half8 b_ext[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float2 cj = colc[col0 + 64 * wc + 32 * j + l31];
+      bj[j] = cj.x;
+      const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      b_ext[j] = z;
+      if (h == 0) b_ext[j][0] = (_Float16)cj.y;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {   // 16 halfs of K per MFMA: lane holds k = 16 q + 8 h + 0..7
+      half8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const half8*>(&sA[(64 * wr + 32 * i + l31) * NN_KP + 8 * q + 4 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const half8*>(&sB[(64 * wc + 32 * j + l31) * NN_KP + 8 * q + 4 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], q == 0 ? cinit[i] : acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_ext[i], b_ext[j], acc[i][j], 0, 0, 0);
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x16& v = acc[i][j];
+        // the block test runs on the BIT PATTERNS as signed integers (v_max3_i32; a float maximum of MFMA results
+        // costs a canonicalising instruction per operand): B_j >= +0, among non-negative floats the integer order is
+        // the float order, and every negative float is a negative integer.  A NaN output (NaN descriptor) can pass
+        // this test; the per-output float compare below then rejects it.
+        int m = max(max(__float_as_int(v[0]), __float_as_int(v[1])), __float_as_int(v[2]));
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m = max(max(m, __float_as_int(v[r])), __float_as_int(v[r + 1]));
+        m = max(m, __float_as_int(v[15]));
+        if (__ballot(m > __float_as_int(bj[j])) != 0ull) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (v[r] > bj[j]) {
+              const uint2 e = make_uint2((unsigned)(row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h),
+                                         (unsigned)(col0 + 64 * wc + 32 * j + l31));
+              const unsigned lp = atomicAdd(&s_nhits[0], 1u);
+              if (lp < (unsigned)NN_K128_HITS) {
+                s_hits[lp] = e;
+              } else {                        // dense tile: past the LDS list every hit takes its own slot
+                const unsigned pos = atomicAdd(cand_count, 1u);
+                if (pos < cand_cap) cand[pos] = e;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#undef SF_K128_LOAD
+#undef SF_K128_STORE
+  __syncthreads();
+  const unsigned nh = min(s_nhits[0], (unsigned)NN_K128_HITS);
+  if (tid == 0 && nh) s_nhits[1] = atomicAdd(cand_count, nh);
+  __syncthreads();
+  if (nh) {
+    const unsigned base = s_nhits[1];
+    for (unsigned e = tid; e < nh; e += 256)
+      if (base + e < cand_cap) cand[base + e] = s_hits[e];
   }
 }
 
@@ -719,22 +892,43 @@ static int nn_run_filter(sf_context* c, int* done) {
     // prefix level: rebuilt when one of them changed, not per query
     const bool coef_ok = c->nn_coef_level == level && c->nn_coef_nl == n_l && c->nn_coef_nr == n_r &&
                          c->nn_coef_thr == thr && c->nn_coef_ptr == (const void*)rowc && c->nn_coef_scale == scale;
+    const float delta = 2e-6f + (float)((double)(kdims + 8) * ldexp(1.0, -24));
     if (!coef_ok)
     hipLaunchKernelGGL(k_nn_filter_row_coef, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, rowc,
                        (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad,
-                       0.5f * scale, thr2, eps_rel * scale);
+                       0.5f * scale, thr2, eps_rel * c->nn_local.h_scale * 64.f, delta);
     if (!coef_ok) {
       hipLaunchKernelGGL(k_nn_filter_col_coef, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, colc,
                          (const float*)c->nn_recv.norms_k.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad,
-                         0.5f * scale);
+                         0.5f * scale, c->nn_recv.h_scale / 64.f, delta);
       c->nn_coef_level = level; c->nn_coef_nl = n_l; c->nn_coef_nr = n_r; c->nn_coef_thr = thr;
       c->nn_coef_ptr = (const void*)rowc;
       c->nn_coef_scale = scale;
     }
     sf_prof_begin(c, SF_K_NN_FILTER);
-    hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
-                       (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
-                       pitch16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
+    if (kdims == 128 && getenv("SF_NN_K128_OFF") == nullptr) {
+      // resident row panel, strips of column tiles: about two workgroups per CU in one wave of the grid
+      const int gx = n_r_pad / NN_BN, gy = n_l_pad / NN_BM;
+      if (c->cu_count <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || v <= 0) v = 256;
+        c->cu_count = v;
+      }
+      const int strips = std::max(1, std::min(gx, (2 * c->cu_count) / std::max(1, gy)));
+      const int tps = (gx + strips - 1) / strips;
+      if (!c->nn_k128_attr) {
+        SF_HIP(c, hipFuncSetAttribute((const void*)k_nn_filter_f16_k128, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      NN_K128_LDS));
+        c->nn_k128_attr = true;
+      }
+      hipLaunchKernelGGL(k_nn_filter_f16_k128, dim3(gy * ((gx + tps - 1) / tps)), dim3(256), NN_K128_LDS, c->stream,
+                         (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc, gx, gy,
+                         tps, cand, count, cap);
+    } else {
+      hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
+                         (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
+                         pitch16, kdims, n_r_pad / NN_BN, n_l_pad / NN_BM, cand, count, cap);
+    }
     sf_prof_end(c, SF_K_NN_FILTER);
     SF_HIP(c, hipGetLastError());
     const bool prefix_level = level < n_levels - 1;
