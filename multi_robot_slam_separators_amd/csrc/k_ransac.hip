@@ -203,28 +203,63 @@ __device__ inline SelCounts select_within(const RansacLds& L, int m, const float
 }
 
 // 2.1981 * median (element n>>1 in sorted order) of the members' squared residuals
-// [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by rank counting
-// over the +inf-padded residual array (4 values per LDS read, broadcast).
-__device__ inline double variance_of(const RansacLds& L, int m, int n, int tid) {
-  const int med = n >> 1;
-  const int m4 = (m + 3) & ~3;
-  __syncthreads();
-  for (int i = tid; i < m; i += SF_BLOCK) {
-    const float v = L.d2[i];
-    if (v < __int_as_float(0x7F800000)) {   // member
-      int lt = 0, eq = 0;
-      const float4* d4 = reinterpret_cast<const float4*>(L.d2);
-      for (int j = 0; j < m4 / 4; ++j) {
-        const float4 u = d4[j];
-        lt += (u.x < v ? 1 : 0) + (u.y < v ? 1 : 0) + (u.z < v ? 1 : 0) + (u.w < v ? 1 : 0);
-        eq += (u.x == v ? 1 : 0) + (u.y == v ? 1 : 0) + (u.z == v ? 1 : 0) + (u.w == v ? 1 : 0);
-      }
-      if (lt <= med && med < lt + eq) L.red[15] = (double)v;  // every writer holds the same value
+// [upstream pcl::SampleConsensusModel::computeVariance].  Exact order statistic by a most-significant-digit radix
+// select over the +inf-padded residual array: the residuals are non-negative floats, whose bit patterns order like
+// unsigned integers, non-members hold +inf and sort behind every member, so the member of rank n >> 1 is the
+// element of that rank in the whole array.  Four passes of an 8-bit histogram (LDS atomics; the four histograms live
+// in the hypothesis models of the finished search, L.hyp .. L.hyp_cnt) and a 256-bin scan by one wavefront: O(m)
+// work, ~200 instructions per wavefront -- round 1 counted ranks, O(m^2): ~2 000 instructions per wavefront and call,
+// a quarter of the whole chain's vector instructions.
+// (a real call, LDS pointers in their own address space: inlined at its two call sites the select tipped the
+//  register allocation of the fused kernel into spilling around the hypothesis loop)
+typedef __attribute__((address_space(3))) const float* lds_cfloat_p;
+typedef __attribute__((address_space(3))) unsigned* lds_uint_p;
+typedef __attribute__((address_space(3))) int* lds_int_p;
+__device__ __attribute__((noinline)) float radix_select_rank(lds_cfloat_p d2, lds_uint_p hist, lds_int_p misc, int m4,
+                                                             int rank, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int b = tid; b < 4 * 256; b += SF_BLOCK) hist[b] = 0u;
+  __syncthreads();                                       // histograms cleared, the selection's d2 visible
+  unsigned prefix = 0u;
+#pragma unroll 1
+  for (int p = 0; p < 4; ++p) {
+    const int shift = 24 - 8 * p;
+    for (int i = tid; i < m4; i += SF_BLOCK) {
+      const unsigned bits = __float_as_uint(d2[i]);
+      if (p == 0 || (bits >> (shift + 8)) == prefix)
+        __hip_atomic_fetch_add(&hist[p * 256 + ((bits >> shift) & 255u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    __syncthreads();
+    if (wave == 0) {
+      const unsigned h0 = hist[p * 256 + 4 * lane], h1 = hist[p * 256 + 4 * lane + 1], h2 = hist[p * 256 + 4 * lane + 2],
+                     h3 = hist[p * 256 + 4 * lane + 3];
+      const unsigned s = (h0 + h1) + (h2 + h3);
+      unsigned incl = s;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+      }
+      const unsigned excl = incl - s;
+      if (excl <= (unsigned)rank && (unsigned)rank < incl) {   // exactly one lane
+        unsigned r = (unsigned)rank - excl;
+        int b = 0;
+        if (r >= h0) { r -= h0; b = 1; if (r >= h1) { r -= h1; b = 2; if (r >= h2) { r -= h2; b = 3; } } }
+        misc[2] = (int)((prefix << 8) | (unsigned)(4 * lane + b));
+        misc[3] = (int)r;
+      }
+    }
+    __syncthreads();
+    prefix = (unsigned)misc[2];
+    rank = misc[3];
   }
-  __syncthreads();
-  const double medv = L.red[15];
-  return 2.1981 * medv;
+  return __uint_as_float(prefix);
+}
+
+__device__ __forceinline__ double variance_of(const RansacLds& L, int m, int n, int tid) {
+  const float medv = radix_select_rank((lds_cfloat_p)L.d2, (lds_uint_p) reinterpret_cast<unsigned*>(L.hyp),
+                                       (lds_int_p)L.misc, (m + 3) & ~3, n >> 1, tid);
+  return 2.1981 * (double)medv;
 }
 
 // Inlier counts of a round of R hypotheses (R = 16: four lanes per hypothesis, R = 64: one) over this wavefront's
@@ -418,6 +453,8 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
 
   // ---- computeSampleDistanceThreshold (PCA of the source cloud) ----------------------------------
   const double inv_m = 1.0 / (double)m;
+  if (tid == 0) reinterpret_cast<double*>(L.sums)[2] = inv_m;   // (the replay reads it back: not worth two registers
+                                                                //  across the whole hypothesis loop)
   double sdt = 0.0;     // only the solving wavefront needs (and computes) it; kept in LDS from here on
   {
     double mean[3];
@@ -522,7 +559,8 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       ScanState S;
       S.best = L.misc[12]; S.best_it = L.misc[13]; S.it = L.misc[14];
       S.k = reinterpret_cast<const double*>(L.sums)[1];
-      const bool stop = replay_round(L, S, base, R, lane_r, c, present, max_it, P.adaptive_stop != 0, 1.0 / (double)m,
+      const bool stop = replay_round(L, S, base, R, lane_r, c, present, max_it, P.adaptive_stop != 0,
+                                     reinterpret_cast<const double*>(L.sums)[2],
                                      sfd::canon_log(1.0 - 0.99));
       if (lane_r == 0) {
         L.misc[12] = S.best; L.misc[13] = S.best_it; L.misc[14] = S.it;
