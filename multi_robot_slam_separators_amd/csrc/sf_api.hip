@@ -1141,7 +1141,6 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
     if (f < 0 || f >= c->store.slots || t < 0 || t >= c->store.slots)
       return sf_fail(c, SF_ERANGE, "match %d: slot (%d,%d) outside the store (%d slots)", i, f, t, c->store.slots);
   }
-  if ((rc = sf_buf_reserve(c, c->spec_index, (size_t)n * 4)) != SF_OK) return rc;
   SF_HIP(c, hipEventSynchronize(c->spec_index_staged));   // (never recorded: returns at once) previous upload done
   const size_t need = (size_t)n * 4;
   if (need > c->spec_index_pinned_bytes) {
@@ -1158,12 +1157,14 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
     if (ci < 0 || (unsigned)ci >= c->spec.grid) return sf_fail(c, SF_EHIP, "speculation: match %d has no candidate slot", i);
     hi[i] = ci;
   }
-  SF_HIP(c, hipMemcpyAsync(c->spec_index.p, hi, need, hipMemcpyHostToDevice, c->stream));
-  SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));
+  // The gather reads the index list straight from the pinned host block (40 KB over PCIe inside the kernel): an
+  // H2D copy queued on the handle's stream would run AFTER the verification it sits behind -- ~15 us of copy
+  // engine latency on the step's critical path for nothing.
   constexpr int PIECES = sizeof(sf_result) / 16;
   hipLaunchKernelGGL(k_spec_gather, dim3(((size_t)n * PIECES + 255) / 256), dim3(256), 0, c->stream,
-                     (const sf_result*)c->spec_results.p, (const int32_t*)c->spec_index.p, n, d_out);
+                     (const sf_result*)c->spec_results.p, (const int32_t*)hi, n, d_out);
   SF_HIP(c, hipGetLastError());
+  SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));   // the block may be rewritten after this
   return SF_OK;
 }
 
