@@ -373,6 +373,38 @@ def test_fused_pipeline_equals_stage_kernels(monkeypatch, est):
             assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[1], c0[1])
 
 
+def test_split_pipeline_equals_fused_kernel(monkeypatch):
+    """SF_FUSED=2 (k_match_split over all pairs + k_chain over the survivors, the pass-1 lists of the survivors taking
+    one trip through HBM) runs the same per-pair bodies as k_verify_fused: identical bytes, identical lists, on both
+    descriptor widths, with ragged / empty frames in the batch and with bundle adjustment on."""
+    from multi_robot_slam_separators_amd import lib
+    from test_gpu_fuzz import random_frame
+    rng = np.random.default_rng(7)
+    A, B, _, _ = synth.make_pairs(615, 60, k=500, cols=32, true_frac=0.4)
+    A += [random_frame(rng, 0, 32), random_frame(rng, 37, 32), A[0]]
+    B += [random_frame(rng, 20, 32), random_frame(rng, 0, 32), A[0]]
+    A2, B2, _, _ = synth.make_pairs(616, 16, k=300, cols=64, true_frac=0.5)
+    for AA, BB, ba in ((A, B, 0), (A2, B2, 0), (A[:24], B[:24], 1)):
+        p = synth.camera_params()
+        p.iterations = 300
+        p.bundle_adjustment = ba
+        p.stereo_baseline = 0.12 if ba else 0.0
+        out = {}
+        monkeypatch.setenv("SF_DEBUG_CORR", "1")
+        for mode in ("1", "2"):
+            monkeypatch.setenv("SF_FUSED", mode)
+            with lib.SeparatorFinder(p) as f:
+                f.prof_enable(True)
+                res = f.estimate_transform_batch(AA, BB)
+                corr = [f.debug_correspondences(i, w) for i in range(len(AA)) for w in (1, 2)]
+                prof = f.prof_get()
+            out[mode] = (res, corr, prof)
+        assert out["1"][2]["k_match_global"][0] == 0 and out["2"][2]["k_match_global"][0] >= 1   # (the split's matching launch)
+        assert out["1"][0].tobytes() == out["2"][0].tobytes()
+        for c1, c2 in zip(out["1"][1], out["2"][1]):
+            assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1])
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_matrix_core_matcher_equals_valu_matcher(monkeypatch, fused):
     """The Hamming table on the fp4 matrix cores (default) and on the VALU (SF_MATCH_MFMA=0) must give the
