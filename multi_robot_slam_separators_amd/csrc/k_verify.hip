@@ -112,9 +112,12 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
               int32_t* __restrict__ list, int32_t* __restrict__ counter, sf_result* __restrict__ out, DeviceParams P) {
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
   const int pair = blockIdx.x;
+  SF_TRACE_MARK(P, pair, 0);
   const bool survivor = match_v2_body<W, 0, SF_BLOCK, 4>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
                                                          0, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
-                                                         list, counter, smem_i);
+                                                         list, counter, smem_i,
+                                                         P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
+  SF_TRACE_MARK(P, pair, 36);
   if (!survivor && threadIdx.x == 0) {
     // no motion estimate: guided matching is not eligible (its pass state is pass 1's), the result is final
     const PassState p = pass1[pair];

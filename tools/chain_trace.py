@@ -24,7 +24,7 @@ from multi_robot_slam_separators_amd import _abi, lib, synth  # noqa: E402
 PHASES = [
     ("match", 0, 1),
     ("match stage rows", 0, 32), ("match scan (wave 0)", 32, 33), ("match scan (wait others)", 33, 34),
-    ("match compact", 34, 35), ("match header", 35, 1),
+    ("match compact", 34, 35), ("match header", 35, 1), ("split: match kernel, whole", 0, 36),
     ("r1 gather", 1, 2), ("r1 pca", 2, 3), ("r1 hypotheses", 3, 4), ("r1 select", 4, 5), ("r1 refine", 5, 6),
     ("r1 variance+out", 6, 7),
     ("guided bucket", 7, 8), ("guided search", 8, 9), ("guided compact", 9, 10),
