@@ -73,12 +73,25 @@ __global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
                uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
-               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int tail_off) {
+               uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int tail_off,
+               PairSource src) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const int kcap = st.kcap;
-  const int sF = pair_from[pair], sT = pair_to[pair];
+  int sF, sT;
+  if (src.cand) {               // (what k_spec_pairs would have written to pair_from / pair_to)
+    sF = -1; sT = -1;
+    if ((unsigned)pair < *src.count) {
+      const uint2 rc = src.cand[pair];
+      if ((int)rc.x < src.n_l && (int)rc.y < src.n_r) {
+        const int f = src.slot_other + (int)rc.y, t = src.slot_local + (int)rc.x;
+        if ((unsigned)f < (unsigned)src.n_slots && (unsigned)t < (unsigned)src.n_slots) { sF = f; sT = t; }
+      }
+    }
+  } else {
+    sF = pair_from[pair]; sT = pair_to[pair];
+  }
   FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
   uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);          // [kcap] the current pass's correspondence list
   unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;        // RANSAC / guided working set behind it
@@ -165,7 +178,7 @@ int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32
   hipLaunchKernelGGL((k_verify_fused<W, NQ, BA>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
                      (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams,
-                     tail_off);
+                     tail_off, c->pair_src);
   return SF_OK;
 }
 

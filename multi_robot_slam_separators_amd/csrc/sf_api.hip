@@ -1077,6 +1077,20 @@ extern "C" int sf_verify_matches_device(sf_handle c, const sf_match* matches, in
 // the device, then the verification of every candidate slot, all on the handle's stream.
 int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
   const unsigned grid = c->spec.grid;
+  // one chunk on the fused kernel: it derives the pairs from the candidate list itself (one launch and its gap less
+  // between the NN filter and the verification)
+  if (grid <= (unsigned)SF_CHUNK && !c->overlap && !c->split && c->store.slots > 0 &&
+      sf_fused_lds_bytes(c, sf_store_view(c->store)) != 0) {
+    c->pair_src.cand = (const uint2*)d_cand;
+    c->pair_src.count = d_count;
+    c->pair_src.n_l = c->nn_local.n; c->pair_src.n_r = c->nn_recv.n;
+    c->pair_src.slot_other = c->spec.slot_other; c->pair_src.slot_local = c->spec.slot_local;
+    c->pair_src.n_slots = c->store.slots;
+    const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
+                                 (sf_result*)c->spec_results.p);
+    c->pair_src = PairSource();
+    return rc;
+  }
   hipLaunchKernelGGL(k_spec_pairs, dim3((grid + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_cand, d_count, grid,
                      c->nn_local.n, c->nn_recv.n, c->spec.slot_other, c->spec.slot_local, c->store.slots,
                      (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
@@ -1169,11 +1183,74 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
 }
 
 // The two compaction kernels, asynchronous: the number of accepted results is left at d_count (device).
+// Ordered compaction in ONE launch: a chunk of 1024 candidates per workgroup; chunk i publishes the number of
+// accepted candidates up to and including itself as {epoch, inclusive count} once chunk i - 1 has published its own
+// (a chain of waits in dispatch order: every chunk is resident -- at most 128 chunks of 1024 threads -- and chunk i
+// never waits for a later one).  The epoch (one per launch, kept by the handle) makes stale entries of the previous
+// launch unreadable without a memset in between.  Replaces k_compact_count + k_compact_move (kept for batches with
+// more chunks than can be resident at once).
+__global__ void __launch_bounds__(1024)
+k_compact_chain(const sf_result* __restrict__ res, int n, sf_result* __restrict__ acc, uint8_t* __restrict__ flags,
+                unsigned long long* __restrict__ state, unsigned epoch, int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int s_dst[1024];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * 1024;
+  const int i = base + tid;
+  const bool ok = i < n && res[i].success != 0;
+  if (i < n && flags) flags[i] = ok ? 1 : 0;
+  const unsigned long long bal = __ballot(ok);
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wave] = __popcll(bal);
+  __syncthreads();
+  int woff = 0, own = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { woff += (w < wave) ? wsum[w] : 0; own += wsum[w]; }
+  if (tid == 0) {
+    unsigned prefix = 0;
+    if (blockIdx.x > 0) {
+      unsigned long long v;
+      do {
+        v = __hip_atomic_load(&state[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((unsigned)(v >> 32) != epoch);
+      prefix = (unsigned)v;
+    }
+    __hip_atomic_store(&state[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)(prefix + (unsigned)own),
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    s_base = (int)prefix;
+    if (blockIdx.x == gridDim.x - 1) *total = (int)prefix + own;
+  }
+  __syncthreads();
+  s_dst[tid] = ok ? s_base + woff + before : -1;
+  __syncthreads();
+  const int m = min(1024, n - base);
+  for (int e = tid; e < m * 23; e += 1024) {
+    const int c = e / 23, piece = e - c * 23;
+    const int dst = s_dst[c];
+    if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + base + c)[piece];
+  }
+}
+
 static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
                           int32_t* d_count) {
   const int chunks = (n + 1023) / 1024;
   int rc;
-  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 1) * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
+  if (chunks <= 128) {
+    if (c->compact_state_chunks < chunks || c->compact_state_ptr != c->compact_scratch.p) {
+      // fresh (or regrown / reallocated) state: make every epoch tag invalid once
+      SF_HIP(c, hipMemsetAsync(c->compact_scratch.p, 0, (size_t)(chunks + 1) * 8, c->stream));
+      c->compact_state_chunks = chunks;
+      c->compact_state_ptr = c->compact_scratch.p;
+    }
+    if (++c->compact_epoch == 0) c->compact_epoch = 1;
+    hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted, d_flags,
+                       (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count);
+    SF_HIP(c, hipGetLastError());
+    return SF_OK;
+  }
+  c->compact_state_chunks = 0;                  // (the two-kernel form reuses the buffer as plain counts)
   int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
   hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
   hipLaunchKernelGGL(k_compact_move, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted,
@@ -1201,8 +1278,8 @@ extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_result
   SF_HIP(c, hipSetDevice(c->device));
   const int chunks = (n + 1023) / 1024;
   int rc;
-  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 1) * 4)) != SF_OK) return rc;
-  int32_t* d_count = (int32_t*)c->compact_scratch.p + chunks;
+  if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
+  int32_t* d_count = (int32_t*)((char*)c->compact_scratch.p + (size_t)(chunks + 1) * 8);   // behind the chunk states
   if ((rc = compact_launch(c, d_results, n, d_accepted, d_flags, d_count)) != SF_OK) return rc;
   if (!c->count_pinned && hipHostMalloc((void**)&c->count_pinned, 64, hipHostMallocDefault) != hipSuccess)
     return sf_fail(c, SF_ENOMEM, "hipHostMalloc(64) failed");

@@ -91,6 +91,16 @@ struct DeviceParams {
 #define SF_TRACE_ROW_MARK(row, slot) do { } while (0)
 #endif
 
+// Where the fused verification kernel takes its pairs from when they are NN candidates still on the device
+// (sf_find_matches_and_verify_device): candidate i = (local row, received column) -> pair (slot_other + column,
+// slot_local + row); slots past *count, and candidates outside the databases / the store, are void pairs (-1, -1).
+// cand == nullptr: the pair_from / pair_to arrays are used.
+struct PairSource {
+  const uint2* cand = nullptr;
+  const unsigned* count = nullptr;
+  int n_l = 0, n_r = 0, slot_other = 0, slot_local = 0, n_slots = 0;
+};
+
 struct Buf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -225,6 +235,10 @@ struct sf_context {
   // Speculative verification (sf_find_matches_and_verify_device): every candidate (row, column) the NN filter
   // emits is verified on the device while the host still reduces the candidates to row minima, sorts and
   // walks them; the walk's matches then pick their results out of the speculative ones.
+  unsigned compact_epoch = 0;   // k_compact_chain: tag of the current launch's prefix entries
+  int compact_state_chunks = 0; // ... and how many state entries have been initialised
+  void* compact_state_ptr = nullptr;
+  PairSource pair_src;          // candidate list the fused kernel derives its pairs from (speculative path), or empty
   struct Spec {
     bool requested = false;     // set by the entry point for the duration of one sf_nn_run
     bool launched = false;      // the candidates of some filter level were handed to the verification
