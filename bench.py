@@ -590,6 +590,11 @@ def main():
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
 
+    # single GPU: the compaction kernel writes count, flags and the accepted records STRAIGHT into the pinned host block
+    # (posted PCIe writes from the kernel, 16-byte pieces of consecutive lanes): the records reach the host while the
+    # kernel runs, instead of through a 0.9 MB copy behind it (BENCH_HOST_COPY=1: the copy, as up to round r02c)
+    zero_copy = exch is None and os.environ.get("BENCH_HOST_COPY") is None
+    hp = h_pack.data_ptr()
     trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
     two_calls = os.environ.get("BENCH_TWO_CALLS") is not None
 
@@ -630,11 +635,16 @@ def main():
                 acc, cnt_ptr, d_cnt_view = exch.payload, exch.count_ptr, exch.send[0, :4].view(torch.int32)
             else:
                 acc, cnt_ptr, d_cnt_view = d_acc, d_cnt.data_ptr(), d_cnt
-            f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)
+            if zero_copy:
+                f.compact_accepted_device_async(d_res.data_ptr(), n, hp + acc_off, hp + flags_off, hp)
+            else:
+                f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)
             if exch is not None:
                 exch.exchange(None, finish=False)             # ONE all-gather, in flight beside the copies below
         k_spec = min(n, spec_cap)
-        if acc is d_acc:
+        if zero_copy:
+            k_spec = n                                        # (everything is already in the pinned block)
+        elif acc is d_acc:
             # count + flags + the speculative prefix of the accepted separators: one copy to the pinned mirror
             nb = acc_off + k_spec * RB
             h_pack[:nb].copy_(d_pack[:nb], non_blocking=True)
