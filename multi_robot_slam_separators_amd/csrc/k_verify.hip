@@ -122,12 +122,13 @@ __global__ void __launch_bounds__(SF_BLOCK, 3)
 k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
               CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
-              int32_t* __restrict__ list, int32_t* __restrict__ counter, sf_result* __restrict__ out, DeviceParams P) {
+              int32_t* __restrict__ list, int32_t* __restrict__ counter, sf_result* __restrict__ out, DeviceParams P,
+              int est) {
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
   const int pair = blockIdx.x;
   SF_TRACE_MARK(P, pair, 0);
   const bool survivor = match_v2_body<W, 0, SF_BLOCK, 4>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
-                                                         0, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
+                                                         est, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
                                                          list, counter, smem_i,
                                                          P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
   SF_TRACE_MARK(P, pair, 36);
@@ -228,9 +229,61 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
   return SF_OK;
 }
 
+// The PnP estimator's chain for the survivors of k_match_split: PnP -> guess-guided matching -> PnP -> result in ONE
+// launch (the stage path: k_pnp, k_guided over ALL pairs, k_pnp, k_finalize).  The bodies keep handing their lists
+// and pass states over through the global workspace (k_pnp's 168 registers leave no room for the LDS-resident form of
+// the 3D-3D chain); what the fusion saves is three launches, the guided kernel's 10 000 workgroups that find nothing
+// to do, and the gaps between them.  Same bodies, same bytes.
+template <int W, bool BA>
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
+k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+            const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
+            uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
+            uint8_t* __restrict__ guided_flag, const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+            sf_result* __restrict__ out, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x >= *counter) return;
+  const int pair = list[blockIdx.x];
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  unsigned char* ba_lds = smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15);
+  __builtin_amdgcn_s_setprio(3);
+  {
+    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    if constexpr (BA) {
+      if (P.bundle_adjustment && tail.ran)
+        ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass1[pair], P, ba_lds);
+    }
+  }
+  __syncthreads();     // pass1[pair] (written by thread 0) is read by every lane below
+  const bool est2 = guided_body<W>(st, pair, sF, sT, pass1[pair], pass2[pair], guided_flag[pair],
+                                   corr2 + (size_t)pair * st.kcap, hdr2[pair], nullptr, nullptr, P,
+                                   reinterpret_cast<int*>(smem_raw));
+  __syncthreads();
+  if (est2) {
+    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    if constexpr (BA) {
+      if (P.bundle_adjustment && tail.ran)
+        ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass2[pair], P, ba_lds);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) finalize_one(pass1[pair], pass2[pair], guided_flag[pair], out[pair]);
+}
+
 // The split pipeline (k_match_split + k_chain); applies where the fused kernel does.
 bool sf_split_applicable(const sf_context* c, const StoreView& st) {
   return sf_fused_lds_bytes(c, st) != 0 && c->match_mfma && st.kcap <= MF_MAX_ROWS;
+}
+
+// the PnP form: k_match_split + k_chain_pnp
+bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st) {
+  if (c->dparams.estimation_type != 1 || !c->fused || c->match_variant != 0) return false;
+  if (!(c->match_mfma && st.kcap <= MF_MAX_ROWS)) return false;
+  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  const size_t lds = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
+                                  (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0),
+                              sf_guided_lds_bytes(st.kcap, nc));
+  return lds <= 160 * 1024 && (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int) <= 160 * 1024;
 }
 
 namespace {
@@ -254,7 +307,9 @@ int launch_chain(sf_context* c, StoreView st, const int32_t* d_from, const int32
 int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out) {
   if (n <= 0) return SF_OK;
-  if (!sf_split_applicable(c, st)) return sf_fail(c, SF_EINVAL, "split verification pipeline not applicable");
+  const bool pnp = c->dparams.estimation_type == 1;
+  if (!(pnp ? sf_split_pnp_applicable(c, st) : sf_split_applicable(c, st)))
+    return sf_fail(c, SF_EINVAL, "split verification pipeline not applicable");
   SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
   const size_t lds_m = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
   int32_t* counters = (int32_t*)c->counters.p;
@@ -269,15 +324,42 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
 #define SF_SPLIT_MATCH(W_)                                                                                         \
   hipLaunchKernelGGL((k_match_split<W_>), dim3(n), dim3(SF_BLOCK), lds_m, c->stream, st, d_from, d_to,             \
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p, \
-                     (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams)
+                     (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams, \
+                     sf_est_mode(c))
   if (st.w == 8) SF_SPLIT_MATCH(8); else SF_SPLIT_MATCH(16);
 #undef SF_SPLIT_MATCH
   sf_prof_end(c, SF_K_MATCH);
   SF_HIP(c, hipGetLastError());
-  const int tail_off = (int)fused_tail_offset(c, st, false);
-  const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);
   const bool ba = c->dparams.bundle_adjustment != 0;
   int rc;
+  if (pnp) {
+    const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+    const size_t lds_p = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
+                                      (ba ? sf_ba_lds_bytes(st.kcap) : 0),
+                                  sf_guided_lds_bytes(st.kcap, nc));
+    sf_prof_begin(c, SF_K_FUSED);
+#define SF_CHAIN_PNP(W_, BA_)                                                                                         \
+    do {                                                                                                              \
+      bool& attr = c->chain_pnp_attr[W_ == 16][BA_];                                                                  \
+      if (lds_p > 64 * 1024 && !attr) {                                                                               \
+        SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W_, BA_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      160 * 1024));                                                                   \
+        attr = true;                                                                                                  \
+      }                                                                                                               \
+      hipLaunchKernelGGL((k_chain_pnp<W_, BA_>), dim3(n), dim3(SF_BLOCK), lds_p, c->stream, st, d_from, d_to,          \
+                         (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,            \
+                         (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,  \
+                         (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams);               \
+    } while (0)
+    if (st.w == 8) { if (ba) SF_CHAIN_PNP(8, true); else SF_CHAIN_PNP(8, false); }
+    else { if (ba) SF_CHAIN_PNP(16, true); else SF_CHAIN_PNP(16, false); }
+#undef SF_CHAIN_PNP
+    sf_prof_end(c, SF_K_FUSED);
+    SF_HIP(c, hipGetLastError());
+    return SF_OK;
+  }
+  const int tail_off = (int)fused_tail_offset(c, st, false);
+  const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);
   sf_prof_begin(c, SF_K_FUSED);
   if (st.w == 8) rc = ba ? launch_chain<8, true>(c, st, d_from, d_to, n, d_out, lds_c, tail_off)
                          : launch_chain<8, false>(c, st, d_from, d_to, n, d_out, lds_c, tail_off);

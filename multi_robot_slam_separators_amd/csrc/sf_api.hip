@@ -697,6 +697,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
     c->fused = atoi(v) != 0;
     c->split = atoi(v) == 2;
   }
+  if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;      // 0: PnP on the five stage launches
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
@@ -929,6 +930,11 @@ static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t
                            sf_result* d_out, bool allow_fused) {
   int rc;
   ctx->dparams.dbg_corr = ctx->debug_corr ? 1 : 0;
+  if (allow_fused && ctx->chain_pnp && sf_split_pnp_applicable(ctx, view)) {
+    ctx->last_lists_valid = true;
+    if ((rc = sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out)) != SF_OK) return rc;
+    return SF_OK;
+  }
   if (allow_fused && ctx->split && sf_split_applicable(ctx, view)) {
     ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
     return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
@@ -974,6 +980,7 @@ static int ensure_twin(sf_context* c) {
   t->match_mfma = c->match_mfma;
   t->fused = c->fused;
   t->split = c->split;
+  t->chain_pnp = c->chain_pnp;
   t->debug_corr = c->debug_corr;
   t->prof = c->prof;
   return SF_OK;

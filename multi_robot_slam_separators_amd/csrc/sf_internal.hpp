@@ -205,6 +205,9 @@ struct sf_context {
   bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
   bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
   bool split_match_attr[2] = {};   // k_match_split [W == 16]
+  bool chain_pnp_attr[2][2] = {};  // k_chain_pnp [W == 16][bundle adjustment]
+  bool chain_pnp = true;           // PnP estimator: k_match_split + k_chain_pnp instead of the five stage launches
+                                   // (SF_CHAIN_PNP=0: the stage launches)
   bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)
   void* nn_pinned = nullptr;   // pinned host staging of the NN filter's small D2H copies
   size_t nn_pinned_bytes = 0;
@@ -290,6 +293,7 @@ int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const i
 // Fused per-pair pipeline (k_verify.hip): match -> RANSAC -> guided -> RANSAC -> result in one launch.
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
 bool sf_split_applicable(const sf_context* c, const StoreView& st);
+bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st);
 int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out);
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
