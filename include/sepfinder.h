@@ -252,6 +252,16 @@ typedef struct sf_stereo_camera {
    install OpenCV's generated_<bytes>.i values here for descriptors identical to the reference build's.       */
 int  sf_brief_set_pattern(sf_handle h, const int8_t* tests, int32_t bytes);
 int  sf_brief_get_pattern(sf_handle h, int8_t* tests, int32_t cap_bytes, int32_t* bytes);
+/* Corner detection of the reference's default feature type (rtabmap GFTT/BRIEF: Feature2D::generateKeypoints ->
+   cv::goodFeaturesToTrack, called from myRegistrationVis.cpp:281-283), on the device: minimum-eigenvalue response
+   (blockSize 3, Sobel 3), corners = local maxima above quality_level * max, strongest first, at least min_distance
+   apart, at most max_corners (<= 0: no limit).  d_kpts_out receives up to `cap` keypoints {x, y, size 3, angle -1,
+   response 0, octave 0, class_id -1} in that order; *n_out = corners found.  rtabmap's defaults: max_corners =
+   Vis/MaxFeatures (1000), quality_level 0.001, min_distance 3.  Synchronises the stream twice (candidate count,
+   result count).                                                                                              */
+int  sf_detect_corners_device(sf_handle h, const uint8_t* d_image, int32_t width, int32_t height, int32_t pitch,
+                              int32_t max_corners, double quality_level, double min_distance,
+                              sf_keypoint* d_kpts_out, int32_t cap, int32_t* n_out);
 /* d_left: 8-bit image on the device (height rows of `pitch` bytes); d_kpts: n corners; d_right_x: their x in the
    right image (NULL: no 3D); d_status: per-corner validity of d_right_x (NULL: all valid).  Appends ONE keyframe
    to the store; *out_slot = its slot, *out_rows = features kept (the call synchronises the stream to read it;

@@ -731,7 +731,8 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
-                 &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests};
+                 &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests,
+                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar};
   for (Buf* b : bufs) buf_free(*b);
   sf_ingest_pool_destroy(c);
   if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
@@ -849,6 +850,21 @@ extern "C" int sf_brief_get_pattern(sf_handle c, int8_t* tests, int32_t cap_byte
     memcpy(tests, c->brief_host, (size_t)c->brief_bytes * 32);
   }
   return SF_OK;
+}
+
+extern "C" int sf_detect_corners_device(sf_handle c, const uint8_t* d_image, int32_t width, int32_t height, int32_t pitch,
+                                        int32_t max_corners, double quality_level, double min_distance,
+                                        sf_keypoint* d_kpts_out, int32_t cap, int32_t* n_out) {
+  if (!c || !n_out || cap < 0 || (cap > 0 && !d_kpts_out)) return SF_EINVAL;
+  *n_out = 0;
+  if (!d_image || width < 3 || height < 3 || pitch < width)
+    return sf_fail(c, SF_EINVAL, "image missing or malformed (%d x %d, pitch %d)", width, height, pitch);
+  if (!(quality_level > 0.0) || !(min_distance >= 0.0))
+    return sf_fail(c, SF_EINVAL, "qualityLevel must be > 0 and minDistance >= 0 (cv::goodFeaturesToTrack asserts the same)");
+  if ((long long)width * height > (1ll << 26)) return sf_fail(c, SF_ERANGE, "image of %d x %d pixels is too large", width, height);
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_launch_detect_corners(c, d_image, width, height, pitch, max_corners, quality_level, min_distance, d_kpts_out,
+                                  cap, n_out);
 }
 
 extern "C" int sf_extract_keyframe_device(sf_handle c, const uint8_t* d_left, int32_t width, int32_t height,

@@ -164,6 +164,9 @@ struct sf_context {
   Buf flags;                    // uint8[n] pass2_guided
   // feature extraction (k_extract.hip): integral image, per-corner scratch, the BRIEF test table
   Buf ex_integral, ex_desc, ex_xyz, ex_keep, ex_rows, brief_tests;
+  // corner detection (k_gftt.hip): derivative-product / response planes, candidate keys (in + sorted), sort scratch,
+  // the selection's cell lists, three scalars
+  Buf gf_planes, gf_keys, gf_tmp, gf_lists, gf_scalar;
   int brief_bytes = 0;                 // 0: table not uploaded yet
   int8_t brief_host[64 * 8 * 4] = {};
   Buf trace;                    // SF_CHAIN_TRACE builds: uint64[n][32] phase timestamps of the fused kernel
@@ -303,6 +306,9 @@ size_t sf_ba_lds_bytes(int kcap);
 size_t sf_pnp_lds_bytes(int kcap, int iterations);
 size_t sf_guided_lds_bytes(int kcap, int n_cells);
 void sf_brief_default_pattern(int8_t* tests, int bytes);
+int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, int height, int pitch, int max_corners,
+                             double quality_level, double min_distance, sf_keypoint* d_kpts_out, int cap,
+                             int32_t* n_out);
 int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int height, int pitch, const sf_keypoint* d_kpts,
                       const float* d_right_x, const uint8_t* d_status, int n, const sf_stereo_camera* cam, int bytes,
                       const int8_t* d_tests, uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap,

@@ -83,6 +83,7 @@ def load():
         "sf_brief_get_pattern": (C.c_int, [vp, vp, i32, P(i32)]),
         "sf_extract_keyframe_device": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i32, P(_abi.StereoCamera),
                                                  P(i32), P(i32), vp, vp, vp]),
+        "sf_detect_corners_device": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i32, P(i32)]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
         "sf_store_clear": (C.c_int, [vp]),
         "sf_estimate_transform": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), vp]),
@@ -125,7 +126,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
-    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_estimate_transform",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -287,6 +288,15 @@ class SeparatorFinder:
         buf = np.zeros((64 * 8, 4), np.int8)
         self._check(self._L.sf_brief_get_pattern(self._h, C.c_void_p(buf.ctypes.data), 64, C.byref(n)))
         return buf[:8 * n.value].copy()
+
+    def detect_corners_device(self, d_image, width, height, pitch, max_corners, quality_level, min_distance,
+                              d_kpts_out, cap):
+        """cv::goodFeaturesToTrack on the device; returns the number of corners found (<= cap are written)."""
+        n = C.c_int32()
+        self._check(self._L.sf_detect_corners_device(self._h, C.c_void_p(d_image), width, height, pitch, max_corners,
+                                                     float(quality_level), float(min_distance), C.c_void_p(d_kpts_out),
+                                                     cap, C.byref(n)))
+        return n.value
 
     def extract_keyframe_device(self, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam,
                                 d_desc_out=None, d_xyz_out=None, d_kpts_out=None, want_rows=True):

@@ -20,7 +20,7 @@ def build(force=False):
     """Compile oracle/libsf_oracle.so with gcc (Makefile in this directory)."""
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in
-                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle_ba.c", "sf_oracle_extract.c", "sf_oracle.h",
+                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle_ba.c", "sf_oracle_extract.c", "sf_oracle_gftt.c", "sf_oracle.h",
                                            "sf_oracle_internal.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -75,6 +75,9 @@ def lib():
         L.sfo_sample_triplet.restype = None
         L.sfo_sample_triplet.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.sfo_num_threads.restype = C.c_int
+        L.sfo_detect_corners.restype = C.c_int
+        L.sfo_detect_corners.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                         C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]
         L.sfo_extract_keyframe.restype = C.c_int
         L.sfo_extract_keyframe.argtypes = [
             C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -310,3 +313,21 @@ def extract_keyframe(image, kpts, right_x, status, cam, tests):
         raise RuntimeError("sfo_extract_keyframe failed: %d" % rc)
     r = rows.value
     return desc[:r].copy(), xyz[:r].copy(), kout[:r].copy()
+
+
+def detect_corners(image, max_corners=1000, quality_level=0.001, min_distance=3.0, want_eig=False):
+    """sfo_detect_corners: image uint8 [h, w] (unit column stride).  Returns kpts (KEYPOINT_DTYPE) [, eig float32 [h, w]]."""
+    L = lib()
+    image = np.asarray(image, np.uint8)
+    assert image.ndim == 2 and image.strides[1] == 1
+    h, w = image.shape
+    cap = w * h
+    kp = np.zeros(cap, _abi.KEYPOINT_DTYPE)
+    eig = np.zeros((h, w), np.float32) if want_eig else None
+    n = C.c_int32()
+    rc = L.sfo_detect_corners(image.ctypes.data, w, h, image.strides[0], max_corners, quality_level, min_distance,
+                              kp.ctypes.data, cap, C.byref(n), None if eig is None else eig.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("sfo_detect_corners failed: %d" % rc)
+    kp = kp[:min(n.value, cap)].copy()
+    return (kp, eig) if want_eig else kp

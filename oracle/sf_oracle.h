@@ -132,6 +132,12 @@ int sfo_extract_keyframe(const uint8_t* image, int32_t width, int32_t height, in
                          const int8_t* tests, int32_t bytes, uint8_t* desc_out, float* xyz_out, sf_keypoint* kp_out,
                          int32_t* rows_out);
 
+/* SURVEY section 8 row f3, the detector (sf_oracle_gftt.c): cv::goodFeaturesToTrack restated; *n_out = corners found
+ * (only the first `cap` are written); eig_out (optional, width * height floats) receives the response map.      */
+int sfo_detect_corners(const uint8_t* image, int32_t width, int32_t height, int32_t pitch, int32_t max_corners,
+                       double quality_level, double min_distance, sf_keypoint* kpts_out, int32_t cap, int32_t* n_out,
+                       float* eig_out);
+
 #ifdef __cplusplus
 }
 #endif
