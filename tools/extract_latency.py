@@ -42,6 +42,18 @@ def main():
                                            cam)
     print("%d x %d image, %d corners (%d kept): %.1f us per keyframe (asynchronous, %d back to back)" % (
         w, h, n, rows, e0.elapsed_time(e1) * 1e3 / reps, reps))
+    # the detector in front of it (two synchronisations inside the call: candidate count, corner count)
+    import time
+    d_out = torch.zeros((4096, 28), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        nc = f.detect_corners_device(d_img.data_ptr(), w, h, w, 1000, 0.001, 3.0, d_out.data_ptr(), 4096)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        nc = f.detect_corners_device(d_img.data_ptr(), w, h, w, 1000, 0.001, 3.0, d_out.data_ptr(), 4096)
+    torch.cuda.synchronize()
+    print("sf_detect_corners_device (max 1000, quality 0.001, minDistance 3): %d corners, %.1f us per call (wall, "
+          "synchronous)" % (nc, (time.perf_counter() - t0) * 1e6 / 50))
     f.close()
 
 
