@@ -707,6 +707,18 @@ def test_verify_matches_and_compaction_entry_points(finder):
     finder.compact_accepted_device_async(big.data_ptr(), 0, out2.data_ptr(), None, cnt.data_ptr())
     torch.cuda.synchronize()
     assert cnt.tolist() == [0, -7]
+    # repeated launches of the one-kernel form (epoch tags), sizes around the chunk, a size that grows the chunk-state
+    # array, one beyond 128 chunks (the two-kernel form) and back again
+    rng = np.random.default_rng(8)
+    for n_big in (1, 1023, 1024, 1025, 5000, 70_000, 140_000, 3000):
+        flags = rng.random(n_big) < 0.3
+        src = torch.zeros((n_big, 368), dtype=torch.uint8, device=dev)
+        src[:, off] = torch.from_numpy(flags.astype(np.uint8)).to(dev)
+        src[:, 1] = torch.arange(n_big, device=dev).remainder(253).to(torch.uint8)
+        dst = torch.zeros_like(src)
+        kk = finder.compact_accepted_device(src.data_ptr(), n_big, dst.data_ptr())
+        assert kk == int(flags.sum())
+        assert torch.equal(dst[:kk], src[torch.from_numpy(flags).to(dev)])
     with pytest.raises(Exception):
         m_bad = m.copy(); m_bad["idx_other"][0] = 10_000
         finder.verify_matches_device(m_bad, sa, sb, d_res.data_ptr())
