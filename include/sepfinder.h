@@ -252,6 +252,32 @@ typedef struct sf_stereo_camera {
    install OpenCV's generated_<bytes>.i values here for descriptors identical to the reference build's.       */
 int  sf_brief_set_pattern(sf_handle h, const int8_t* tests, int32_t bytes);
 int  sf_brief_get_pattern(sf_handle h, int8_t* tests, int32_t cap_bytes, int32_t* bytes);
+/* ---- NetVLAD descriptor inference --------------------------------- */
+/* replaces: DataHandler.compute_descriptors (data_handler.py:143-164): `self.sess.run(self.net_out, ...)` of
+   `nets.vgg16NetvladPca` (data_handler.py:63; netvlad_tf_open: VGG16 trunk to conv5_3, NetVLAD layer, WPCA), keeping
+   the first n_out of the 4096 values like data_handler.py:157-158.  Weights come from the caller (the reference
+   restores netvlad_tf_open's checkpoint, data_handler.py:70) in TensorFlow's own layouts:
+     conv_kernel[i]   [3][3][Cin][Cout] (HWIO) of conv1_1, conv1_2, conv2_1, ... conv5_3 (13 layers), conv_bias[i] [Cout]
+     average_rgb      [3]              assignment [512][clusters] (the 1 x 1 kernel, no bias)
+     cluster_centers  [512][clusters]  wpca_kernel [512 * clusters][pca_dim], wpca_bias [pca_dim]                  */
+typedef struct sf_netvlad_weights {
+  const float* conv_kernel[13];
+  const float* conv_bias[13];
+  const float* average_rgb;
+  const float* assignment;
+  const float* cluster_centers;
+  const float* wpca_kernel;
+  const float* wpca_bias;
+  int32_t      clusters;   /* 64 in the reference's network */
+  int32_t      pca_dim;    /* 4096 */
+} sf_netvlad_weights;
+int  sf_netvlad_load(sf_handle h, const sf_netvlad_weights* w);      /* host pointers; copies and transposes */
+/* d_image_rgb: [height][width][3] float32 on the device (the values the reference feeds its placeholder,
+   data_handler.py:60-61); d_out: n_out floats = the first n_out values of the unit-norm descriptor, ready for
+   sf_nn_append_local_f32_device.  Asynchronous on the handle's stream.                                           */
+int  sf_netvlad_infer_device(sf_handle h, const float* d_image_rgb, int32_t width, int32_t height, float* d_out,
+                             int32_t n_out);
+
 /* Corner detection of the reference's default feature type (rtabmap GFTT/BRIEF: Feature2D::generateKeypoints ->
    cv::goodFeaturesToTrack, called from myRegistrationVis.cpp:281-283), on the device: minimum-eigenvalue response
    (blockSize 3, Sobel 3), corners = local maxima above quality_level * max, strongest first, at least min_distance

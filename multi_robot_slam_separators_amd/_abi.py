@@ -96,6 +96,20 @@ def stereo_camera(fx, fy, cx, cy, baseline, cx_right=0.0, local_transform=None, 
     return cam
 
 
+class NetvladWeights(C.Structure):
+    """sf_netvlad_weights (include/sepfinder.h): host pointers to the NetVLAD network's weights, TensorFlow layouts."""
+    _fields_ = [
+        ("conv_kernel", C.c_void_p * 13), ("conv_bias", C.c_void_p * 13),
+        ("average_rgb", C.c_void_p), ("assignment", C.c_void_p), ("cluster_centers", C.c_void_p),
+        ("wpca_kernel", C.c_void_p), ("wpca_bias", C.c_void_p),
+        ("clusters", C.c_int32), ("pca_dim", C.c_int32),
+    ]
+
+
+VGG16_CONVS = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512),
+               (512, 512), (512, 512), (512, 512), (512, 512)]          # (Cin, Cout) of conv1_1 ... conv5_3
+
+
 class Features(C.Structure):
     _fields_ = [
         ("desc", C.c_void_p),

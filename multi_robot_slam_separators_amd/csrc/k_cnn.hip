@@ -1,0 +1,433 @@
+// k_cnn.hip -- SURVEY.md section 8(f) rank 4, first half: NetVLAD descriptor inference (VGG16 trunk + NetVLAD layer +
+// PCA whitening) on the device, the step in front of the NN search: DataHandler.compute_descriptors
+// (data_handler.py:143-164) runs `nets.vgg16NetvladPca` (data_handler.py:63) on a batch of RGB keyframe images and
+// keeps the first `netvlad_dimensions` values of every 4096-D row (data_handler.py:157-158).
+//
+// The network itself is third-party code the reference imports but does not vendor (netvlad_tf_open, python/netvlad_tf/
+// nets.py + layers.py; weights from its checkpoint, not in the tree): PARITY UNPINNED.  Restated from its published
+// definition, float32 throughout like the TensorFlow graph:
+//   vgg16:   x - average_rgb;  conv1_1 relu conv1_2 pool relu | conv2_1 relu conv2_2 pool relu | conv3_1 relu conv3_2
+//            relu conv3_3 pool relu | conv4_1 relu conv4_2 relu conv4_3 pool relu | conv5_1 relu conv5_2 relu conv5_3
+//            (3 x 3, stride 1, 'same' zero padding, bias; 2 x 2 max pooling, stride 2, 'valid'; NO relu after conv5_3)
+//   netVLAD: descriptor-wise L2 normalisation of conv5_3; soft assignment s = 1 x 1 conv to K = 64 clusters (no bias),
+//            a = softmax(s); v[d][k] = sum_pixels a[p][k] (x[p][d] + C[d][k]); per-cluster normalisation
+//            v / sqrt(sum_d v^2 + 1e-12) ("matconvnetNormalize"); flatten d-major, k-minor; the same normalisation of
+//            the whole 32768-vector
+//   WPCA:    1 x 1 conv = dense 32768 -> 4096 with bias, then tf.nn.l2_normalize (x / sqrt(max(sum x^2, 1e-12)))
+//
+// Layouts: activations NHWC float32 (one image at a time; a batch is a loop -- the layers are far past the size at
+// which batching helps a 256-CU chip); conv weights [Cout][3][3][Cin] (= rows of a [Cout] x [9 Cin] matrix, K
+// ordered tap-major), 1 x 1 weights [Cout][Cin], WPCA [4096][32768].  sf_netvlad_load documents the order it takes
+// them in (TensorFlow's HWIO) and transposes on upload.
+//
+// Kernels:
+//   k_conv3x3_first   Cin = 3 (27 MACs per output): direct, one thread per (pixel, 4 output channels)
+//   k_conv_igemm      every other convolution as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2f32, the
+//                     128 x 128 x 32 tile of k_nn_argmin): M = pixels, N = Cout, K = taps x Cin; a 32-wide K step lies
+//                     inside one tap (Cin is a multiple of 32), so the A tile of a step is 128 pixels x 128 B read
+//                     straight from the NHWC activations of the shifted pixel (zero outside the image) -- no im2col
+//                     buffer; bias + optional ReLU in the epilogue, 128-byte coalesced stores
+//   k_pool2_relu      2 x 2 max pooling + ReLU
+//   k_vlad_*          normalisation, softmax, aggregation (the assignment itself is k_conv_igemm with one tap)
+//   k_wpca            one wavefront per output row of the 4096 x 32768 matrix (HBM-bound: 537 MB of weights per image)
+// fp32 MFMA products are exact and accumulate in fp32, so the result differs from a CPU fp32 evaluation only by
+// summation order (tests: 1e-4 absolute on the unit-norm descriptor against a PyTorch fp32 CPU evaluation).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "sf_internal.hpp"
+
+namespace {
+
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+constexpr int CB = 128, CK = 32, CP = 36;    // tile 128 x 128, K step 32 floats, LDS pitch 36 floats
+
+// in: [H][W][3] float, wgt: [64][27] (tap-major, channel-minor), out: [H][W][64]; mean subtraction fused
+__global__ void __launch_bounds__(256)
+k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restrict__ wgt, const float* __restrict__ bias,
+                const float* __restrict__ mean, float* __restrict__ out, int relu) {
+  __shared__ float sw[64 * 27];
+  __shared__ float sb[64];
+  for (int i = threadIdx.x; i < 64 * 27; i += 256) sw[i] = wgt[i];
+  if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int g = blockIdx.x * 256 + threadIdx.x;        // (pixel, group of 4 output channels)
+  const int p = g >> 4, c4 = (g & 15) * 4;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  float v[27];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[3 * t + c] = ok ? in[((size_t)yy * W + xx) * 3 + c] - mean[c] : 0.f;
+  }
+  float o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a = sb[c4 + q];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a = fmaf(v[k], sw[(c4 + q) * 27 + k], a);
+    o[q] = relu ? fmaxf(a, 0.f) : a;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)p * 64 + c4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Implicit GEMM: out[p][n] = act(bias[n] + sum_{t, c} in[shift_t(p)][c] * wgt[n][t * Cin + c]).
+// TAPS = 9 (3 x 3, 'same') or 1 (1 x 1).  P = H * W pixels, Cin % 32 == 0, Cout % 32 == 0.
+template <int TAPS>
+__global__ void __launch_bounds__(256)
+k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* __restrict__ wgt, int Cout,
+             const float* __restrict__ bias, float* __restrict__ out, int relu) {
+  __shared__ __attribute__((aligned(16))) float sA[CB * CP];
+  __shared__ __attribute__((aligned(16))) float sB[CB * CP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int P = H * W;
+  const int row0 = blockIdx.x * CB, col0 = blockIdx.y * CB;
+  const int K = TAPS * Cin;
+  cf32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;     // staging: 32 rows x 8 float4 per pass
+  // the four pixels / output channels this thread stages per K step
+  int py[4], px[4];
+  bool pv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = row0 + srow + 32 * q;
+    pv[q] = p < P;
+    py[q] = pv[q] ? p / W : 0;
+    px[q] = pv[q] ? p - py[q] * W : 0;
+  }
+  for (int k0 = 0; k0 < K; k0 += CK) {
+    const int tap = TAPS == 1 ? 0 : k0 / Cin, c0 = k0 - tap * Cin;
+    const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap % 3 - 1;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = srow + 32 * q;
+      const int yy = py[q] + dy, xx = px[q] + dx;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (pv[q] && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        va = *reinterpret_cast<const float4*>(in + ((size_t)yy * W + xx) * Cin + c0 + sk4);
+      if (col0 + r < Cout) vb = *reinterpret_cast<const float4*>(wgt + (size_t)(col0 + r) * K + k0 + sk4);
+      *reinterpret_cast<float4*>(&sA[r * CP + sk4]) = va;
+      *reinterpret_cast<float4*>(&sB[r * CP + sk4]) = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[(64 * wr + 32 * i + l31) * CP + 8 * q + 4 * h]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[(64 * wc + 32 * j + l31) * CP + 8 * q + 4 * h]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // C layout: column (= output channel) = lane & 31, row (= pixel) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = col0 + 64 * wc + 32 * j + l31;
+    if (n >= Cout) continue;
+    const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (p < P) {
+          const float v = acc[i][j][r] + bn;
+          out[(size_t)p * Cout + n] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+  }
+}
+
+// 2 x 2 max pooling (stride 2, 'valid') + ReLU; in [H][W][C] -> out [H/2][W/2][C], 4 channels per thread
+__global__ void __launch_bounds__(256)
+k_pool2_relu(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (size_t)Ho * Wo * C4) return;
+  const int c4 = (int)(g % C4);
+  const size_t p = g / C4;
+  const int xo = (int)(p % Wo), yo = (int)(p / Wo);
+  const float4* src = reinterpret_cast<const float4*>(in);
+  const float4 a = src[((size_t)(2 * yo) * W + 2 * xo) * C4 + c4], b = src[((size_t)(2 * yo) * W + 2 * xo + 1) * C4 + c4];
+  const float4 c = src[((size_t)(2 * yo + 1) * W + 2 * xo) * C4 + c4], d = src[((size_t)(2 * yo + 1) * W + 2 * xo + 1) * C4 + c4];
+  float4 m;
+  m.x = fmaxf(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), 0.f);
+  m.y = fmaxf(fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)), 0.f);
+  m.z = fmaxf(fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), 0.f);
+  m.w = fmaxf(fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)), 0.f);
+  reinterpret_cast<float4*>(out)[g] = m;
+}
+
+// tf.nn.l2_normalize over the channels of every pixel: x / sqrt(max(sum x^2, 1e-12)); one wavefront per pixel
+__global__ void __launch_bounds__(256)
+k_l2norm_rows(float* __restrict__ x, int rows, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* p = x + (size_t)row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(p[c], p[c], s);
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  const float inv = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+  for (int c = lane; c < C; c += 64) p[c] *= inv;
+}
+
+// softmax over the K clusters of every pixel (in place); one thread per pixel, K <= 64
+__global__ void __launch_bounds__(256)
+k_softmax_rows(float* __restrict__ s, int rows, int K) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  float* p = s + (size_t)row * K;
+  float m = p[0];
+  for (int k = 1; k < K; ++k) m = fmaxf(m, p[k]);
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) { const float e = expf(p[k] - m); p[k] = e; sum += e; }
+  const float inv = 1.0f / sum;
+  for (int k = 0; k < K; ++k) p[k] *= inv;
+}
+
+// v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per d (256 threads over the pixels), K <= 64
+__global__ void __launch_bounds__(256)
+k_vlad_aggregate(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ centers, int P,
+                 int D, int K, float* __restrict__ v) {
+  __shared__ float red[4][64];
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // lane = cluster; the four wavefronts split the pixels
+  float acc = 0.f;
+  if (lane < K) {
+    const float c = centers[(size_t)d * K + lane];
+    for (int p = wave; p < P; p += 4) acc = fmaf(a[(size_t)p * K + lane], x[(size_t)p * D + d] + c, acc);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < K) v[(size_t)d * K + lane] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// matconvnetNormalize per cluster (over d) of v[d][k], in place; then of the whole vector; one workgroup
+__global__ void __launch_bounds__(256)
+k_vlad_normalize(float* __restrict__ v, int D, int K) {
+  __shared__ float s_inv[64];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  if (tid < K) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) { const float t = v[(size_t)d * K + tid]; s = fmaf(t, t, s); }
+    s_inv[tid] = 1.0f / sqrtf(s + 1e-12f);
+  }
+  __syncthreads();
+  float tot = 0.f;
+  for (int i = tid; i < D * K; i += 256) {
+    const float t = v[i] * s_inv[i % K];
+    v[i] = t;
+    tot = fmaf(t, t, tot);
+  }
+  red[tid] = tot;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float inv = 1.0f / sqrtf(red[0] + 1e-12f);
+  for (int i = tid; i < D * K; i += 256) v[i] *= inv;
+}
+
+// y[r] = b[r] + W[r][:] . v ; one wavefront per row
+__global__ void __launch_bounds__(256)
+k_wpca(const float* __restrict__ Wm, const float* __restrict__ b, const float* __restrict__ v, int rows, int cols,
+       float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* w4 = reinterpret_cast<const float4*>(Wm + (size_t)row * cols);
+  const float4* v4 = reinterpret_cast<const float4*>(v);
+  float s = 0.f;
+  for (int c = lane; c < cols / 4; c += 64) {
+    const float4 a = w4[c], q = v4[c];
+    s = fmaf(a.x, q.x, s); s = fmaf(a.y, q.y, s); s = fmaf(a.z, q.z, s); s = fmaf(a.w, q.w, s);
+  }
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) y[row] = s + b[row];
+}
+
+// tf.nn.l2_normalize of one vector, writing the first n_out values; one workgroup
+__global__ void __launch_bounds__(256)
+k_l2norm_vec(const float* __restrict__ y, int n, float* __restrict__ out, int n_out) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < n; i += 256) s = fmaf(y[i], y[i], s);
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float inv = 1.0f / sqrtf(fmaxf(red[0], 1e-12f));
+  for (int i = tid; i < n_out; i += 256) out[i] = y[i] * inv;
+}
+
+const int VGG_COUT[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+const int VGG_CIN[13] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+const bool VGG_RELU[13] = {true, false, true, false, true, true, false, true, true, false, true, true, false};
+const bool VGG_POOL[13] = {false, true, false, true, false, false, true, false, false, true, false, false, false};
+
+}  // namespace
+
+struct sf_netvlad_model {
+  Buf conv_w[13], conv_b[13], mean, assign_w, centers, pca_w, pca_b;
+  Buf act[2], vlad, pca_y;
+  int clusters = 0, pca_dim = 0;
+};
+
+void sf_netvlad_free(sf_context* c) {
+  if (!c->netvlad) return;
+  sf_netvlad_model* m = c->netvlad;
+  for (int i = 0; i < 13; ++i) { sf_buf_free(m->conv_w[i]); sf_buf_free(m->conv_b[i]); }
+  Buf* bs[] = {&m->mean, &m->assign_w, &m->centers, &m->pca_w, &m->pca_b, &m->act[0], &m->act[1], &m->vlad, &m->pca_y};
+  for (Buf* b : bs) sf_buf_free(*b);
+  delete m;
+  c->netvlad = nullptr;
+}
+
+static int upload(sf_context* c, Buf& b, const float* host, size_t n) {
+  int rc = sf_buf_reserve(c, b, n * sizeof(float));
+  if (rc != SF_OK) return rc;
+  SF_HIP(c, hipMemcpyAsync(b.p, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return SF_OK;
+}
+
+// Host weights in TensorFlow's layouts: conv kernels HWIO [3][3][Cin][Cout], assignment [1][1][512][K] = [512][K],
+// cluster centers [512][K], WPCA kernel [1][1][512 K][pca_dim] = [512 K][pca_dim].  Transposed here to output-major.
+int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
+  if (!w || !w->average_rgb || !w->assignment || !w->cluster_centers || !w->wpca_kernel || !w->wpca_bias)
+    return sf_fail(c, SF_EINVAL, "NetVLAD weights missing");
+  if (w->clusters < 1 || w->clusters > 64 || w->pca_dim < 1)
+    return sf_fail(c, SF_ERANGE, "NetVLAD: 1..64 clusters and a positive WPCA dimension, not %d / %d", w->clusters, w->pca_dim);
+  for (int i = 0; i < 13; ++i)
+    if (!w->conv_kernel[i] || !w->conv_bias[i]) return sf_fail(c, SF_EINVAL, "VGG16 convolution %d missing", i);
+  sf_netvlad_free(c);
+  sf_netvlad_model* m = new (std::nothrow) sf_netvlad_model();
+  if (!m) return sf_fail(c, SF_ENOMEM, "out of host memory");
+  c->netvlad = m;
+  m->clusters = w->clusters;
+  m->pca_dim = w->pca_dim;
+  int rc;
+  std::vector<float> t;
+  for (int i = 0; i < 13; ++i) {
+    const int ci = VGG_CIN[i], co = VGG_COUT[i];
+    t.resize((size_t)co * 9 * ci);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int a = 0; a < ci; ++a)
+        for (int o = 0; o < co; ++o) t[((size_t)o * 9 + tap) * ci + a] = w->conv_kernel[i][((size_t)tap * ci + a) * co + o];
+    if ((rc = upload(c, m->conv_w[i], t.data(), t.size())) != SF_OK) return rc;
+    SF_HIP(c, hipStreamSynchronize(c->stream));          // (t is reused)
+    if ((rc = upload(c, m->conv_b[i], w->conv_bias[i], co)) != SF_OK) return rc;
+  }
+  if ((rc = upload(c, m->mean, w->average_rgb, 3)) != SF_OK) return rc;
+  const int K = w->clusters, D = 512;
+  t.resize((size_t)K * D);
+  for (int d = 0; d < D; ++d)
+    for (int k = 0; k < K; ++k) t[(size_t)k * D + d] = w->assignment[(size_t)d * K + k];
+  // (the assignment runs on the 128-wide tile: its K <= 64 rows are padded with zero rows by the kernel's guard)
+  if ((rc = upload(c, m->assign_w, t.data(), t.size())) != SF_OK) return rc;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if ((rc = upload(c, m->centers, w->cluster_centers, (size_t)D * K)) != SF_OK) return rc;
+  const size_t cols = (size_t)D * K;
+  if ((rc = sf_buf_reserve(c, m->pca_w, cols * w->pca_dim * sizeof(float))) != SF_OK) return rc;
+  {
+    // [cols][pca_dim] -> [pca_dim][cols], in slabs of rows so that the host copy stays small
+    const int slab = 64;
+    t.resize((size_t)slab * cols);
+    for (int r0 = 0; r0 < w->pca_dim; r0 += slab) {
+      const int nr = std::min(slab, w->pca_dim - r0);
+      for (size_t cidx = 0; cidx < cols; ++cidx)
+        for (int r = 0; r < nr; ++r) t[(size_t)r * cols + cidx] = w->wpca_kernel[cidx * w->pca_dim + r0 + r];
+      SF_HIP(c, hipMemcpyAsync((float*)m->pca_w.p + (size_t)r0 * cols, t.data(), (size_t)nr * cols * sizeof(float),
+                               hipMemcpyHostToDevice, c->stream));
+      SF_HIP(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  if ((rc = upload(c, m->pca_b, w->wpca_bias, w->pca_dim)) != SF_OK) return rc;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  return SF_OK;
+}
+
+// d_image: [H][W][3] float32 RGB on the device (what the reference feeds the placeholder, data_handler.py:60-61);
+// d_out: n_out floats (the first n_out of the pca_dim-D unit vector).  Asynchronous on the handle's stream.
+int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out) {
+  sf_netvlad_model* m = c->netvlad;
+  if (!m) return sf_fail(c, SF_EINVAL, "no NetVLAD model loaded (sf_netvlad_load)");
+  if (H < 16 || W < 16) return sf_fail(c, SF_ERANGE, "image of %d x %d is smaller than the four poolings need", W, H);
+  if (n_out < 1 || n_out > m->pca_dim) return sf_fail(c, SF_ERANGE, "%d output dimensions of %d", n_out, m->pca_dim);
+  int rc;
+  const size_t act_max = (size_t)H * W * 64;
+  if ((rc = sf_buf_reserve(c, m->act[0], act_max * sizeof(float))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, m->act[1], act_max * sizeof(float))) != SF_OK) return rc;
+  const int K = m->clusters, D = 512;
+  if ((rc = sf_buf_reserve(c, m->vlad, (size_t)D * K * sizeof(float))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)m->pca_dim * sizeof(float))) != SF_OK) return rc;
+  int h = H, w = W, cur = 0;
+  const float* src = d_image;
+  for (int i = 0; i < 13; ++i) {
+    float* dst = (float*)m->act[cur].p;
+    const int P = h * w;
+    if (i == 0) {
+      hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
+                         (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
+                         VGG_RELU[0] ? 1 : 0);
+    } else {
+      hipLaunchKernelGGL(k_conv_igemm<9>, dim3((P + CB - 1) / CB, (VGG_COUT[i] + CB - 1) / CB), dim3(256), 0, c->stream, src,
+                         h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, VGG_COUT[i], (const float*)m->conv_b[i].p, dst,
+                         VGG_RELU[i] ? 1 : 0);
+    }
+    src = dst;
+    cur ^= 1;
+    if (VGG_POOL[i]) {
+      float* pd = (float*)m->act[cur].p;
+      const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
+      hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd);
+      h /= 2; w /= 2;
+      src = pd;
+      cur ^= 1;
+    }
+  }
+  // src = conv5_3 output [h][w][512] (in act[cur ^ 1]); normalise in place, assignment into act[cur]
+  const int P = h * w;
+  float* x = const_cast<float*>(src);
+  float* a = (float*)m->act[cur].p;
+  hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
+  hipLaunchKernelGGL(k_conv_igemm<1>, dim3((P + CB - 1) / CB, 1), dim3(256), 0, c->stream, (const float*)x, h, w, D,
+                     (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
+  hipLaunchKernelGGL(k_softmax_rows, dim3((P + 255) / 256), dim3(256), 0, c->stream, a, P, K);
+  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
+                     (const float*)m->centers.p, P, D, K, (float*)m->vlad.p);
+  hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(256), 0, c->stream, (float*)m->vlad.p, D, K);
+  hipLaunchKernelGGL(k_wpca, dim3((m->pca_dim + 3) / 4), dim3(256), 0, c->stream, (const float*)m->pca_w.p,
+                     (const float*)m->pca_b.p, (const float*)m->vlad.p, m->pca_dim, D * K, (float*)m->pca_y.p);
+  hipLaunchKernelGGL(k_l2norm_vec, dim3(1), dim3(256), 0, c->stream, (const float*)m->pca_y.p, m->pca_dim, d_out, n_out);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

@@ -50,7 +50,9 @@ int sf_buf_reserve(sf_context* c, Buf& b, size_t bytes, bool keep) {
   return SF_OK;
 }
 
-static void buf_free(Buf& b) {
+void sf_buf_free(Buf& b);
+static void buf_free(Buf& b) { sf_buf_free(b); }
+void sf_buf_free(Buf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
   b.bytes = 0;
@@ -734,6 +736,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests,
                  &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar};
   for (Buf* b : bufs) buf_free(*b);
+  sf_netvlad_free(c);
   sf_ingest_pool_destroy(c);
   if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
   if (c->nn_stage_pinned) (void)hipHostFree(c->nn_stage_pinned);
@@ -850,6 +853,19 @@ extern "C" int sf_brief_get_pattern(sf_handle c, int8_t* tests, int32_t cap_byte
     memcpy(tests, c->brief_host, (size_t)c->brief_bytes * 32);
   }
   return SF_OK;
+}
+
+extern "C" int sf_netvlad_load(sf_handle c, const sf_netvlad_weights* w) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_netvlad_load_impl(c, w);
+}
+
+extern "C" int sf_netvlad_infer_device(sf_handle c, const float* d_image_rgb, int32_t width, int32_t height, float* d_out,
+                                       int32_t n_out) {
+  if (!c || !d_image_rgb || !d_out) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_netvlad_infer_impl(c, d_image_rgb, height, width, d_out, n_out);
 }
 
 extern "C" int sf_detect_corners_device(sf_handle c, const uint8_t* d_image, int32_t width, int32_t height, int32_t pitch,

@@ -167,6 +167,7 @@ struct sf_context {
   // corner detection (k_gftt.hip): derivative-product / response planes, candidate keys (in + sorted), sort scratch,
   // the selection's cell lists, three scalars
   Buf gf_planes, gf_keys, gf_tmp, gf_lists, gf_scalar;
+  struct sf_netvlad_model* netvlad = nullptr;   // NetVLAD inference (k_cnn.hip): weights + activation buffers
   int brief_bytes = 0;                 // 0: table not uploaded yet
   int8_t brief_host[64 * 8 * 4] = {};
   Buf trace;                    // SF_CHAIN_TRACE builds: uint64[n][32] phase timestamps of the fused kernel
@@ -269,6 +270,11 @@ struct sf_context {
 // ---- helpers implemented in sf_api.hip ---------------------------------------------------------
 int sf_fail(sf_context* c, int code, const char* fmt, ...);
 int sf_buf_reserve(sf_context* c, Buf& b, size_t bytes, bool keep = false);
+void sf_buf_free(Buf& b);
+struct sf_netvlad_model;
+void sf_netvlad_free(sf_context* c);
+int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w);
+int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out);
 StoreView sf_store_view(const Store& s);
 void sf_prof_begin(sf_context* c, int kernel);
 void sf_prof_end(sf_context* c, int kernel);

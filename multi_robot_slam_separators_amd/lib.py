@@ -84,6 +84,8 @@ def load():
         "sf_extract_keyframe_device": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i32, P(_abi.StereoCamera),
                                                  P(i32), P(i32), vp, vp, vp]),
         "sf_detect_corners_device": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i32, P(i32)]),
+        "sf_netvlad_load": (C.c_int, [vp, P(_abi.NetvladWeights)]),
+        "sf_netvlad_infer_device": (C.c_int, [vp, vp, i32, i32, vp, i32]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
         "sf_store_clear": (C.c_int, [vp]),
         "sf_estimate_transform": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), vp]),
@@ -126,7 +128,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
-    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_estimate_transform",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -288,6 +290,33 @@ class SeparatorFinder:
         buf = np.zeros((64 * 8, 4), np.int8)
         self._check(self._L.sf_brief_get_pattern(self._h, C.c_void_p(buf.ctypes.data), 64, C.byref(n)))
         return buf[:8 * n.value].copy()
+
+    # -- NetVLAD inference -------------------------------------------------
+    def netvlad_load(self, weights):
+        """weights: dict of float32 numpy arrays in TensorFlow layouts -- conv_kernel[13] ([3, 3, Cin, Cout]),
+        conv_bias[13], average_rgb [3], assignment [512, K], cluster_centers [512, K], wpca_kernel [512 K, pca_dim],
+        wpca_bias [pca_dim]."""
+        w = _abi.NetvladWeights()
+        keep = []
+
+        def ptr(a):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data
+        for i in range(13):
+            w.conv_kernel[i] = ptr(weights["conv_kernel"][i])
+            w.conv_bias[i] = ptr(weights["conv_bias"][i])
+        w.average_rgb = ptr(weights["average_rgb"])
+        w.assignment = ptr(weights["assignment"])
+        w.cluster_centers = ptr(weights["cluster_centers"])
+        w.wpca_kernel = ptr(weights["wpca_kernel"])
+        w.wpca_bias = ptr(weights["wpca_bias"])
+        w.clusters = int(np.asarray(weights["assignment"]).shape[1])
+        w.pca_dim = int(np.asarray(weights["wpca_bias"]).shape[0])
+        self._check(self._L.sf_netvlad_load(self._h, C.byref(w)))
+
+    def netvlad_infer_device(self, d_image_rgb, width, height, d_out, n_out):
+        self._check(self._L.sf_netvlad_infer_device(self._h, C.c_void_p(d_image_rgb), width, height, C.c_void_p(d_out), n_out))
 
     def detect_corners_device(self, d_image, width, height, pitch, max_corners, quality_level, min_distance,
                               d_kpts_out, cap):

@@ -1,0 +1,60 @@
+"""GPU: NetVLAD descriptor inference (csrc/k_cnn.hip) against the PyTorch fp32 CPU
+evaluation of the same published network (oracle/netvlad_torch.py).  fp32 matrix-core products are exact and
+accumulate in fp32, so the two differ by summation order only: tolerance 1e-4 absolute on the unit-norm descriptor
+(the NN stage thresholds distances at 0.13), 2e-3 relative on the raw trunk activations."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import lib, synth
+from oracle import netvlad_torch as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    import torch
+    w = ref.random_weights(3, clusters=64, pca_dim=512)
+    f = lib.SeparatorFinder(synth.camera_params(), device=0)
+    f.set_stream(torch.cuda.current_stream().cuda_stream)
+    f.netvlad_load(w)
+    yield f, w
+    f.close()
+
+
+def infer(f, torch, image, n_out):
+    dev = torch.device("cuda:0")
+    d_img = torch.from_numpy(np.ascontiguousarray(image, np.float32)).to(dev)
+    d_out = torch.zeros(n_out, dtype=torch.float32, device=dev)
+    f.netvlad_infer_device(d_img.data_ptr(), image.shape[1], image.shape[0], d_out.data_ptr(), n_out)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (120, 160), (50, 70), (240, 320)])
+def test_descriptor_equals_torch_reference(model, shape):
+    import torch
+    f, w = model
+    rng = np.random.default_rng(shape[0])
+    image = rng.uniform(0, 255, size=(shape[0], shape[1], 3)).astype(np.float32)
+    got = infer(f, torch, image, 512)
+    want = ref.netvlad(image, w)
+    assert abs(float(np.linalg.norm(got)) - 1.0) < 1e-5
+    assert np.max(np.abs(got - want)) < 1e-4, float(np.max(np.abs(got - want)))
+    # the prefix the reference keeps (data_handler.py:157-158) is the same prefix
+    assert np.array_equal(infer(f, torch, image, 128), got[:128])
+
+
+def test_distinct_images_give_distinct_descriptors_and_errors(model):
+    import torch
+    f, w = model
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 255, size=(64, 96, 3)).astype(np.float32)
+    b = a + rng.normal(0, 2.0, size=a.shape).astype(np.float32)
+    c = rng.uniform(0, 255, size=(64, 96, 3)).astype(np.float32)
+    da, db, dc = infer(f, torch, a, 512), infer(f, torch, b, 512), infer(f, torch, c, 512)
+    assert np.linalg.norm(da - db) < np.linalg.norm(da - dc)
+    with pytest.raises(lib.SepfinderError):
+        infer(f, torch, a[:8, :8], 16)                       # smaller than the four poolings need
+    with pytest.raises(lib.SepfinderError):
+        infer(f, torch, a, 4096)                             # more dimensions than the loaded WPCA has
