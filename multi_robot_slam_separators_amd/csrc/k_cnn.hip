@@ -45,7 +45,7 @@
 namespace {
 
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
-constexpr int CB = 128, CK = 32, CP = 36;    // tile 128 x 128, K step 32 floats, LDS pitch 36 floats
+constexpr int CK = 32, CP = 36;    // K step 32 floats, LDS pitch 36 floats
 
 // in: [H][W][3] float, wgt: [64][27] (tap-major, channel-minor), out: [H][W][64]; mean subtraction fused
 __global__ void __launch_bounds__(256)
@@ -80,63 +80,83 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
 }
 
 // Implicit GEMM: out[p][n] = act(bias[n] + sum_{t, c} in[shift_t(p)][c] * wgt[n][t * Cin + c]).
-// TAPS = 9 (3 x 3, 'same') or 1 (1 x 1).  P = H * W pixels, Cin % 32 == 0, Cout % 32 == 0.
-template <int TAPS>
+// TAPS = 9 (3 x 3, 'same') or 1 (1 x 1).  P = H * W pixels, Cin % 32 == 0.  Tile TM pixels x TN output channels
+// (64 or 128 each; a wavefront owns a (TM / 2) x (TN / 2) quarter): the late VGG layers have few pixels (40 x 30 at
+// conv5 for a 640 x 480 image) and take the 64-wide tiles so that the grid still covers the chip.  The operand tiles
+// of K step s + 1 are requested into registers before the MFMAs of step s and written to LDS after them.
+template <int TAPS, int TM, int TN>
 __global__ void __launch_bounds__(256)
 k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* __restrict__ wgt, int Cout,
              const float* __restrict__ bias, float* __restrict__ out, int relu) {
-  __shared__ __attribute__((aligned(16))) float sA[CB * CP];
-  __shared__ __attribute__((aligned(16))) float sB[CB * CP];
+  constexpr int NI = TM / 64, NJ = TN / 64, QA = TM / 32, QB = TN / 32;
+  __shared__ __attribute__((aligned(16))) float sA[TM * CP];
+  __shared__ __attribute__((aligned(16))) float sB[TN * CP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
   const int P = H * W;
-  const int row0 = blockIdx.x * CB, col0 = blockIdx.y * CB;
+  const int row0 = blockIdx.x * TM, col0 = blockIdx.y * TN;
   const int K = TAPS * Cin;
-  cf32x16 acc[2][2];
+  // split K (gridDim.z > 1): slice z contracts taps [z TAPS / Z, (z + 1) TAPS / Z) into its own partial output
+  // [z][P][Cout]; bias and ReLU are then applied by k_sum_partials (a fixed summation order: deterministic)
+  const int k_lo = (int)((blockIdx.z * TAPS) / gridDim.z) * Cin, k_hi = (int)(((blockIdx.z + 1) * TAPS) / gridDim.z) * Cin;
+  out += (size_t)blockIdx.z * P * Cout;
+  cf32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int srow = tid >> 3, sk4 = (tid & 7) * 4;     // staging: 32 rows x 8 float4 per pass
-  // the four pixels / output channels this thread stages per K step
-  int py[4], px[4];
-  bool pv[4];
+  int py[QA], px[QA];
+  bool pv[QA];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < QA; ++q) {
     const int p = row0 + srow + 32 * q;
     pv[q] = p < P;
     py[q] = pv[q] ? p / W : 0;
     px[q] = pv[q] ? p - py[q] * W : 0;
   }
-  for (int k0 = 0; k0 < K; k0 += CK) {
+  float4 ra[QA], rb[QB];
+  auto fetch = [&](int k0) {
     const int tap = TAPS == 1 ? 0 : k0 / Cin, c0 = k0 - tap * Cin;
     const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap % 3 - 1;
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = srow + 32 * q;
+    for (int q = 0; q < QA; ++q) {
       const int yy = py[q] + dy, xx = px[q] + dx;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pv[q] && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        va = *reinterpret_cast<const float4*>(in + ((size_t)yy * W + xx) * Cin + c0 + sk4);
-      if (col0 + r < Cout) vb = *reinterpret_cast<const float4*>(wgt + (size_t)(col0 + r) * K + k0 + sk4);
-      *reinterpret_cast<float4*>(&sA[r * CP + sk4]) = va;
-      *reinterpret_cast<float4*>(&sB[r * CP + sk4]) = vb;
+        ra[q] = *reinterpret_cast<const float4*>(in + ((size_t)yy * W + xx) * Cin + c0 + sk4);
     }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col0 + srow + 32 * q < Cout)
+        rb[q] = *reinterpret_cast<const float4*>(wgt + (size_t)(col0 + srow + 32 * q) * K + k0 + sk4);
+    }
+  };
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += CK) {
+    __syncthreads();                                  // the previous step's LDS reads are complete
+#pragma unroll
+    for (int q = 0; q < QA; ++q) *reinterpret_cast<float4*>(&sA[(srow + 32 * q) * CP + sk4]) = ra[q];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) *reinterpret_cast<float4*>(&sB[(srow + 32 * q) * CP + sk4]) = rb[q];
     __syncthreads();
+    if (k0 + CK < k_hi) fetch(k0 + CK);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 a[2], b[2];
+      float4 a[NI], b[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&sA[(64 * wr + 32 * i + l31) * CP + 8 * q + 4 * h]);
+      for (int i = 0; i < NI; ++i)
+        a[i] = *reinterpret_cast<const float4*>(&sA[((TM / 2) * wr + 32 * i + l31) * CP + 8 * q + 4 * h]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const float4*>(&sB[(64 * wc + 32 * j + l31) * CP + 8 * q + 4 * h]);
+      for (int j = 0; j < NJ; ++j)
+        b[j] = *reinterpret_cast<const float4*>(&sB[((TN / 2) * wc + 32 * j + l31) * CP + 8 * q + 4 * h]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
@@ -146,15 +166,15 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
   }
   // C layout: column (= output channel) = lane & 31, row (= pixel) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = col0 + 64 * wc + 32 * j + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const int n = col0 + (TN / 2) * wc + 32 * j + l31;
     if (n >= Cout) continue;
     const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int p = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int p = row0 + (TM / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (p < P) {
           const float v = acc[i][j][r] + bn;
           out[(size_t)p * Cout + n] = relu ? fmaxf(v, 0.f) : v;
@@ -196,18 +216,36 @@ k_l2norm_rows(float* __restrict__ x, int rows, int C) {
   for (int c = lane; c < C; c += 64) p[c] *= inv;
 }
 
-// softmax over the K clusters of every pixel (in place); one thread per pixel, K <= 64
+// out[i] = act(bias[i % C] + (part[0][i] + part[1][i]) + ... ), 4 values per thread
+__global__ void __launch_bounds__(256)
+k_sum_partials(const float* __restrict__ part, int S, size_t n, int C, const float* __restrict__ bias, float* __restrict__ out,
+               int relu) {
+  const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (g >= n) return;
+  float4 a = *reinterpret_cast<const float4*>(part + g);
+  for (int z = 1; z < S; ++z) {
+    const float4 q = *reinterpret_cast<const float4*>(part + (size_t)z * n + g);
+    a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+  }
+  const float4 bz = *reinterpret_cast<const float4*>(bias + (g % C));
+  a.x += bz.x; a.y += bz.y; a.z += bz.z; a.w += bz.w;
+  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  *reinterpret_cast<float4*>(out + g) = a;
+}
+
+// softmax over the K clusters of every pixel (in place); one wavefront per pixel, lane = cluster, K <= 64
 __global__ void __launch_bounds__(256)
 k_softmax_rows(float* __restrict__ s, int rows, int K) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   float* p = s + (size_t)row * K;
-  float m = p[0];
-  for (int k = 1; k < K; ++k) m = fmaxf(m, p[k]);
-  float sum = 0.f;
-  for (int k = 0; k < K; ++k) { const float e = expf(p[k] - m); p[k] = e; sum += e; }
-  const float inv = 1.0f / sum;
-  for (int k = 0; k < K; ++k) p[k] *= inv;
+  const float v = lane < K ? p[lane] : -INFINITY;
+  float m = v;
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  const float e = lane < K ? expf(v - m) : 0.f;
+  float sum = e;
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane < K) p[lane] = e / sum;
 }
 
 // v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per d (256 threads over the pixels), K <= 64
@@ -227,32 +265,41 @@ k_vlad_aggregate(const float* __restrict__ x, const float* __restrict__ a, const
   if (wave == 0 && lane < K) v[(size_t)d * K + lane] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
-// matconvnetNormalize per cluster (over d) of v[d][k], in place; then of the whole vector; one workgroup
+// matconvnetNormalize per cluster (over d) of v[d][k]: inv[k] = 1 / sqrt(sum_d v^2 + 1e-12); one workgroup per cluster
 __global__ void __launch_bounds__(256)
-k_vlad_normalize(float* __restrict__ v, int D, int K) {
-  __shared__ float s_inv[64];
+k_vlad_cluster_norms(const float* __restrict__ v, int D, int K, float* __restrict__ inv) {
   __shared__ float red[256];
-  const int tid = threadIdx.x;
-  if (tid < K) {
-    float s = 0.f;
-    for (int d = 0; d < D; ++d) { const float t = v[(size_t)d * K + tid]; s = fmaf(t, t, s); }
-    s_inv[tid] = 1.0f / sqrtf(s + 1e-12f);
-  }
-  __syncthreads();
-  float tot = 0.f;
-  for (int i = tid; i < D * K; i += 256) {
-    const float t = v[i] * s_inv[i % K];
-    v[i] = t;
-    tot = fmaf(t, t, tot);
-  }
-  red[tid] = tot;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) { const float t = v[(size_t)d * K + k]; s = fmaf(t, t, s); }
+  red[tid] = s;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
+  if (tid == 0) inv[k] = 1.0f / sqrtf(red[0] + 1e-12f);
+}
+
+// v <- v * inv[k], then matconvnetNormalize of the whole vector; one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024)
+k_vlad_normalize(float* __restrict__ v, int D, int K, const float* __restrict__ inv_k) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  float tot = 0.f;
+  for (int i = tid; i < D * K; i += 1024) {
+    const float t = v[i] * inv_k[i % K];
+    v[i] = t;
+    tot = fmaf(t, t, tot);
+  }
+  red[tid] = tot;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
   const float inv = 1.0f / sqrtf(red[0] + 1e-12f);
-  for (int i = tid; i < D * K; i += 256) v[i] *= inv;
+  for (int i = tid; i < D * K; i += 1024) v[i] *= inv;
 }
 
 // y[r] = b[r] + W[r][:] . v ; one wavefront per row
@@ -298,7 +345,7 @@ const bool VGG_POOL[13] = {false, true, false, true, false, false, true, false, 
 
 struct sf_netvlad_model {
   Buf conv_w[13], conv_b[13], mean, assign_w, centers, pca_w, pca_b;
-  Buf act[2], vlad, pca_y;
+  Buf act[2], vlad, pca_y, partial;
   int clusters = 0, pca_dim = 0;
 };
 
@@ -306,7 +353,7 @@ void sf_netvlad_free(sf_context* c) {
   if (!c->netvlad) return;
   sf_netvlad_model* m = c->netvlad;
   for (int i = 0; i < 13; ++i) { sf_buf_free(m->conv_w[i]); sf_buf_free(m->conv_b[i]); }
-  Buf* bs[] = {&m->mean, &m->assign_w, &m->centers, &m->pca_w, &m->pca_b, &m->act[0], &m->act[1], &m->vlad, &m->pca_y};
+  Buf* bs[] = {&m->mean, &m->assign_w, &m->centers, &m->pca_w, &m->pca_b, &m->act[0], &m->act[1], &m->vlad, &m->pca_y, &m->partial};
   for (Buf* b : bs) sf_buf_free(*b);
   delete m;
   c->netvlad = nullptr;
@@ -388,7 +435,7 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   if ((rc = sf_buf_reserve(c, m->act[1], act_max * sizeof(float))) != SF_OK) return rc;
   const int K = m->clusters, D = 512;
   if ((rc = sf_buf_reserve(c, m->vlad, (size_t)D * K * sizeof(float))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)m->pca_dim * sizeof(float))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)std::max(m->pca_dim, 64) * sizeof(float))) != SF_OK) return rc;
   int h = H, w = W, cur = 0;
   const float* src = d_image;
   for (int i = 0; i < 13; ++i) {
@@ -399,9 +446,32 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
                          (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
                          VGG_RELU[0] ? 1 : 0);
     } else {
-      hipLaunchKernelGGL(k_conv_igemm<9>, dim3((P + CB - 1) / CB, (VGG_COUT[i] + CB - 1) / CB), dim3(256), 0, c->stream, src,
-                         h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, VGG_COUT[i], (const float*)m->conv_b[i].p, dst,
-                         VGG_RELU[i] ? 1 : 0);
+      // tile choice: 64 output channels -> 64-wide N; few pixels -> 64-wide tiles so that the grid covers the chip
+      const int co = VGG_COUT[i];
+      const int tn = (co == 64 || (long long)((P + 127) / 128) * ((co + 127) / 128) < 512) ? 64 : 128;
+      const int tm = (long long)((P + 127) / 128) * ((co + tn - 1) / tn) < 512 ? 64 : 128;
+      // still fewer workgroups than CUs with the smallest tile: split the contraction by taps (3 slices)
+      const int wgs = ((P + tm - 1) / tm) * ((co + tn - 1) / tn);
+      const int S = wgs < 256 ? 3 : 1;
+      float* cdst = dst;
+      if (S > 1) {
+        if ((rc = sf_buf_reserve(c, m->partial, (size_t)S * P * co * sizeof(float))) != SF_OK) return rc;
+        cdst = (float*)m->partial.p;
+      }
+#define SF_CONV(TM_, TN_)                                                                                           \
+      hipLaunchKernelGGL((k_conv_igemm<9, TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
+                         c->stream, src, h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, co,                          \
+                         S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst, S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0))
+      if (tm == 128 && tn == 128) SF_CONV(128, 128);
+      else if (tm == 128) SF_CONV(128, 64);
+      else if (tn == 128) SF_CONV(64, 128);
+      else SF_CONV(64, 64);
+#undef SF_CONV
+      if (S > 1) {
+        const size_t n = (size_t)P * co;
+        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, c->stream,
+                           (const float*)cdst, S, n, co, (const float*)m->conv_b[i].p, dst, VGG_RELU[i] ? 1 : 0);
+      }
     }
     src = dst;
     cur ^= 1;
@@ -419,12 +489,14 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   float* x = const_cast<float*>(src);
   float* a = (float*)m->act[cur].p;
   hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
-  hipLaunchKernelGGL(k_conv_igemm<1>, dim3((P + CB - 1) / CB, 1), dim3(256), 0, c->stream, (const float*)x, h, w, D,
+  hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
                      (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
-  hipLaunchKernelGGL(k_softmax_rows, dim3((P + 255) / 256), dim3(256), 0, c->stream, a, P, K);
+  hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
   hipLaunchKernelGGL(k_vlad_aggregate, dim3(D), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
                      (const float*)m->centers.p, P, D, K, (float*)m->vlad.p);
-  hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(256), 0, c->stream, (float*)m->vlad.p, D, K);
+  hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)m->vlad.p, D, K,
+                     (float*)m->pca_y.p);                                        // (pca_y doubles as the K norms)
+  hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(1024), 0, c->stream, (float*)m->vlad.p, D, K, (const float*)m->pca_y.p);
   hipLaunchKernelGGL(k_wpca, dim3((m->pca_dim + 3) / 4), dim3(256), 0, c->stream, (const float*)m->pca_w.p,
                      (const float*)m->pca_b.p, (const float*)m->vlad.p, m->pca_dim, D * K, (float*)m->pca_y.p);
   hipLaunchKernelGGL(k_l2norm_vec, dim3(1), dim3(256), 0, c->stream, (const float*)m->pca_y.p, m->pca_dim, d_out, n_out);

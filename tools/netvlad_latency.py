@@ -1,0 +1,58 @@
+"""Time of one NetVLAD descriptor inference (csrc/k_cnn.hip) on a 640 x 480 RGB image with the reference's network size
+(64 clusters, 4096-D WPCA; random weights), per kernel through rocprofv3 if run under it, else wall time over `reps`.
+FLOPs of the VGG16 trunk at H x W: 2 * sum(9 Cin Cout H_l W_l).
+usage: python tools/netvlad_latency.py [width=640] [height=480] [reps=20] [pca_dim=4096]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from multi_robot_slam_separators_amd import _abi, lib, synth  # noqa: E402
+
+
+def main():
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 640
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 480
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    pca = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    rng = np.random.default_rng(0)
+    w = {"conv_kernel": [], "conv_bias": []}
+    for ci, co in _abi.VGG16_CONVS:
+        w["conv_kernel"].append((rng.standard_normal((3, 3, ci, co), dtype=np.float32) * np.float32(np.sqrt(2.0 / (9 * ci)))))
+        w["conv_bias"].append(np.zeros(co, np.float32))
+    w["average_rgb"] = np.array([123.68, 116.779, 103.939], np.float32)
+    w["assignment"] = rng.standard_normal((512, 64), dtype=np.float32)
+    w["cluster_centers"] = rng.standard_normal((512, 64), dtype=np.float32) * np.float32(0.05)
+    w["wpca_kernel"] = rng.standard_normal((512 * 64, pca), dtype=np.float32) * np.float32(1.0 / 181.0)
+    w["wpca_bias"] = np.zeros(pca, np.float32)
+    f = lib.SeparatorFinder(synth.camera_params(), device=0)
+    f.set_stream(torch.cuda.current_stream().cuda_stream)
+    f.netvlad_load(w)
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(rng.uniform(0, 255, size=(H, W, 3)).astype(np.float32)).to(dev)
+    out = torch.zeros(pca, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        f.netvlad_infer_device(img.data_ptr(), W, H, out.data_ptr(), pca)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f.netvlad_infer_device(img.data_ptr(), W, H, out.data_ptr(), pca)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops, h, ww = 0.0, H, W
+    pool = [False, True, False, True, False, False, True, False, False, True, False, False, False]
+    for (ci, co), p in zip(_abi.VGG16_CONVS, pool):
+        flops += 2.0 * 9 * ci * co * h * ww
+        if p:
+            h, ww = h // 2, ww // 2
+    print("%d x %d, WPCA %d: %.3f ms per image; VGG16 trunk %.1f GFLOP -> %.1f TFLOP/s over the whole call "
+          "(fp32 matrix-core peak 157.3)" % (W, H, pca, ms, flops / 1e9, flops / (ms * 1e-3) / 1e12))
+    f.close()
+
+
+if __name__ == "__main__":
+    main()
