@@ -56,8 +56,8 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
   for (int i = threadIdx.x; i < 64 * 27; i += 256) sw[i] = wgt[i];
   if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
   __syncthreads();
-  const int g = blockIdx.x * 256 + threadIdx.x;        // (pixel, group of 4 output channels)
-  const int p = g >> 4, c4 = (g & 15) * 4;
+  const int g = blockIdx.x * 256 + threadIdx.x;        // (pixel, group of 16 output channels)
+  const int p = g >> 2, c16 = (g & 3) * 16;
   if (p >= H * W) return;
   const int y = p / W, x = p - y * W;
   float v[27];
@@ -68,15 +68,19 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[3 * t + c] = ok ? in[((size_t)yy * W + xx) * 3 + c] - mean[c] : 0.f;
   }
-  float o[4];
+  // (four threads per pixel: the 27 inputs are fetched 4 times instead of 16, and the four write one 256-byte row)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float a = sb[c4 + q];
+  for (int c4 = 0; c4 < 16; c4 += 4) {
+    float o[4];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) a = fmaf(v[k], sw[(c4 + q) * 27 + k], a);
-    o[q] = relu ? fmaxf(a, 0.f) : a;
+    for (int q = 0; q < 4; ++q) {
+      float a = sb[c16 + c4 + q];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) a = fmaf(v[k], sw[(c16 + c4 + q) * 27 + k], a);
+      o[q] = relu ? fmaxf(a, 0.f) : a;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)p * 64 + c16 + c4) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  *reinterpret_cast<float4*>(out + (size_t)p * 64 + c4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // Implicit GEMM: out[p][n] = act(bias[n] + sum_{t, c} in[shift_t(p)][c] * wgt[n][t * Cin + c]).
@@ -248,21 +252,34 @@ k_softmax_rows(float* __restrict__ s, int rows, int K) {
   if (lane < K) p[lane] = e / sum;
 }
 
-// v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per d (256 threads over the pixels), K <= 64
+// v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per 4 consecutive d (lane = cluster, the four wavefronts
+// split the pixels; x is read 16 bytes at a time, a[p][:] 256 bytes per wavefront), K <= 64
 __global__ void __launch_bounds__(256)
 k_vlad_aggregate(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ centers, int P,
                  int D, int K, float* __restrict__ v) {
-  __shared__ float red[4][64];
-  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // lane = cluster; the four wavefronts split the pixels
-  float acc = 0.f;
+  __shared__ float red[4][4][64];
+  const int d0 = blockIdx.x * 4, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (lane < K) {
-    const float c = centers[(size_t)d * K + lane];
-    for (int p = wave; p < P; p += 4) acc = fmaf(a[(size_t)p * K + lane], x[(size_t)p * D + d] + c, acc);
+    float c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = centers[(size_t)(d0 + q) * K + lane];
+    for (int p = wave; p < P; p += 4) {
+      const float ap = a[(size_t)p * K + lane];
+      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * D + d0);
+      acc[0] = fmaf(ap, xv.x + c[0], acc[0]);
+      acc[1] = fmaf(ap, xv.y + c[1], acc[1]);
+      acc[2] = fmaf(ap, xv.z + c[2], acc[2]);
+      acc[3] = fmaf(ap, xv.w + c[3], acc[3]);
+    }
   }
-  red[wave][lane] = acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[wave][q][lane] = acc[q];
   __syncthreads();
-  if (wave == 0 && lane < K) v[(size_t)d * K + lane] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (lane < K) {
+    const int q = wave;          // wavefront q finishes d0 + q
+    v[(size_t)(d0 + q) * K + lane] = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
+  }
 }
 
 // matconvnetNormalize per cluster (over d) of v[d][k]: inv[k] = 1 / sqrt(sum_d v^2 + 1e-12); one workgroup per cluster
@@ -442,7 +459,7 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
     float* dst = (float*)m->act[cur].p;
     const int P = h * w;
     if (i == 0) {
-      hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
+      hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
                          (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
                          VGG_RELU[0] ? 1 : 0);
     } else {
@@ -492,7 +509,7 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
                      (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
   hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
-  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
+  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 4), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
                      (const float*)m->centers.p, P, D, K, (float*)m->vlad.p);
   hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)m->vlad.p, D, K,
                      (float*)m->pca_y.p);                                        // (pca_y doubles as the K norms)
