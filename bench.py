@@ -172,6 +172,7 @@ def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
                       S, n_kf, t_ver, R, n_kf, n_kf, nv_a.shape[1], t_nn),
         "verify_pairs_per_s": S / t_ver, "accepted_in_sample": int(res["success"].sum()),
         "verify_pairs_per_s_single_thread": S1 / t_one,
+        "_results": res,          # (popped by the caller: the oracle's results of pairs 0 .. S-1, for the parity count)
     }
 
 
@@ -991,8 +992,17 @@ def main():
                 np.array_equal(alt_m["idx_local"], m["idx_local"]) and np.array_equal(alt_m["idx_other"], m["idx_other"])
                 and np.array_equal(alt_m["distance"], m["distance"]))
         if world == 1 and not args.no_cpu_baseline:
+            # parity of the timed work itself: every accepted separator of the last step whose pair the oracle sample
+            # covers is compared with the oracle's result of that pair, byte for byte (368 B each)
             out["cpu_baseline"] = cpu_baseline(p, feats, nv_a, nv_b, n_kf, args.cpu_sample_pairs,
                                                args.cpu_sample_rows)
+            ores = out["cpu_baseline"].pop("_results")
+            acc_idx = m["idx_local"][flags.astype(bool) & same]          # pair index of every accepted separator
+            acc_rec = sep[(same[flags.astype(bool)])] if len(sep) == int(flags.sum()) else sep[:0]
+            inside = acc_idx < len(ores)
+            ident = sum(1 for rec, j in zip(acc_rec[inside], acc_idx[inside]) if rec.tobytes() == ores[j].tobytes())
+            out["parity_in_this_run"] = {"accepted_separators_compared_with_the_oracle": int(inside.sum()),
+                                         "byte_identical": int(ident)}
         print(json.dumps(out))
     f.close()
     if dist_on:
