@@ -31,7 +31,7 @@ def infer(f, torch, image, n_out):
     return d_out.cpu().numpy()
 
 
-@pytest.mark.parametrize("shape", [(64, 96), (120, 160), (50, 70), (240, 320)])
+@pytest.mark.parametrize("shape", [(64, 96), (120, 160), (50, 70), (240, 320), (480, 752)])
 def test_descriptor_equals_torch_reference(model, shape):
     import torch
     f, w = model
