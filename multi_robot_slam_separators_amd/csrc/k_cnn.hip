@@ -463,13 +463,25 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
                          (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
                          VGG_RELU[0] ? 1 : 0);
     } else {
-      // tile choice: 64 output channels -> 64-wide N; few pixels -> 64-wide tiles so that the grid covers the chip
+      // Tile and split choice.  All workgroups of a layer are (nearly) resident at once and the matrix pipe is what
+      // they share, so a layer takes as long as its most loaded CU: the score of a configuration is its measured
+      // intrinsic rate (128 x 128: 120 TF, the 64-wide forms ~105) x the fill of the busiest CU, load / ceil(load)
+      // with load = workgroups / CUs; a 3-way tap split (own partial outputs, summed by k_sum_partials) is allowed
+      // where the output is small enough for that extra pass not to matter.
       const int co = VGG_COUT[i];
-      const int tn = (co == 64 || (long long)((P + 127) / 128) * ((co + 127) / 128) < 512) ? 64 : 128;
-      const int tm = (long long)((P + 127) / 128) * ((co + tn - 1) / tn) < 512 ? 64 : 128;
-      // still fewer workgroups than CUs with the smallest tile: split the contraction by taps (3 slices)
-      const int wgs = ((P + tm - 1) / tm) * ((co + tn - 1) / tn);
-      const int S = wgs < 256 ? 3 : 1;
+      const int cus = 256;
+      int tm = 64, tn = 64, S = 1;
+      double best_score = -1.0;
+      for (int cand = 0; cand < 8; ++cand) {
+        const int ctm = (cand & 1) ? 128 : 64, ctn = (cand & 2) ? 128 : 64, cs = (cand & 4) ? 3 : 1;
+        if (co == 64 && ctn == 128) continue;
+        if (cs == 3 && (size_t)P * co > (size_t)3 << 20) continue;          // partial outputs beyond ~36 MB: not worth it
+        const double wgs = (double)((P + ctm - 1) / ctm) * ((co + ctn - 1) / ctn) * cs;
+        const double load = wgs / cus;
+        const double rate = (ctm == 128 && ctn == 128) ? 120.0 : (ctm == 64 && ctn == 64) ? 104.0 : 107.0;
+        const double score = rate * load / std::ceil(load) * (cs == 3 ? 0.94 : 1.0);
+        if (score > best_score) { best_score = score; tm = ctm; tn = ctn; S = cs; }
+      }
       float* cdst = dst;
       if (S > 1) {
         if ((rc = sf_buf_reserve(c, m->partial, (size_t)S * P * co * sizeof(float))) != SF_OK) return rc;
