@@ -609,6 +609,11 @@ def main():
             m = f.nn_find_matches(cap=n_kf)                   # NN kernels + row minima to host + walk
             t_1 = time.perf_counter()
             f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())
+        elif zero_copy and not trace:
+            # only the ACCEPTED separators leave the device: no gathered copy of all results (d_out = NULL), the
+            # compaction below reads them through the index list the call left behind
+            m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
+            t_1 = time.perf_counter()
         else:
             m = f.find_matches_and_verify_device(slot_a, slot_b, d_res.data_ptr(), cap=n_kf)
             t_1 = time.perf_counter()
@@ -636,7 +641,10 @@ def main():
                 acc, cnt_ptr, d_cnt_view = exch.payload, exch.count_ptr, exch.send[0, :4].view(torch.int32)
             else:
                 acc, cnt_ptr, d_cnt_view = d_acc, d_cnt.data_ptr(), d_cnt
-            if zero_copy:
+            if zero_copy and not trace and not two_calls:
+                r_ptr, r_idx, r_n = f.last_match_results()
+                f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, hp + acc_off, hp + flags_off, hp)
+            elif zero_copy:
                 f.compact_accepted_device_async(d_res.data_ptr(), n, hp + acc_off, hp + flags_off, hp)
             else:
                 f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)

@@ -374,6 +374,15 @@ int  sf_allgather_separators_device(sf_handle h, const sf_separator* d_send, sf_
    host part of the NN stage off the critical path.                                                     */
 int  sf_find_matches_and_verify_device(sf_handle h, int32_t slot_base_other, int32_t slot_base_local,
                                        sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out);
+/* d_out may be NULL: the call then leaves the results where the verification wrote them, and
+   sf_last_match_results says where: the record of match i is d_results[index ? index[i] : i] (index, if not NULL, is
+   device-readable pinned host memory owned by the handle, valid until the next sf_find_matches_and_verify_device).
+   sf_compact_accepted_indexed_device_async consumes exactly that pair (any index == NULL means "in order"), so a
+   caller that only needs the ACCEPTED separators saves the gathered copy of all of them.                        */
+int  sf_last_match_results(sf_handle h, const sf_result** d_results, const int32_t** index, int32_t* n);
+int  sf_compact_accepted_indexed_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
+                                              int32_t n, sf_result* d_accepted, uint8_t* d_flags,
+                                              int32_t* d_n_accepted);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */

@@ -1140,8 +1140,9 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
 
 extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_other, int32_t slot_base_local,
                                                  sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out) {
-  if (!c || !n_out || cap < 0 || (cap > 0 && (!out || !d_out))) return SF_EINVAL;
+  if (!c || !n_out || cap < 0 || (cap > 0 && !out)) return SF_EINVAL;
   *n_out = 0;
+  c->last_results = nullptr; c->last_results_index = nullptr; c->last_results_n = 0;
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
@@ -1186,7 +1187,13 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   if (!(c->spec.launched && c->spec.valid)) {
     // no speculation, or its candidate set was not the one the matches came from: verify the matches now
     // (a wasted speculative verification, if any, is simply queued in front)
-    return sf_verify_matches_device(c, out, n, slot_base_other, slot_base_local, d_out);
+    if (!d_out) {       // the caller only wants sf_last_match_results: an internal block takes the results
+      if ((rc = sf_buf_reserve(c, c->results, (size_t)n * sizeof(sf_result))) != SF_OK) return rc;
+      d_out = (sf_result*)c->results.p;
+    }
+    if ((rc = sf_verify_matches_device(c, out, n, slot_base_other, slot_base_local, d_out)) != SF_OK) return rc;
+    c->last_results = d_out; c->last_results_index = nullptr; c->last_results_n = n;
+    return SF_OK;
   }
   // the matches' results are among the speculative ones: index of each match's candidate, then one gather
   for (int i = 0; i < n; ++i) {
@@ -1213,6 +1220,8 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   // The gather reads the index list straight from the pinned host block (40 KB over PCIe inside the kernel): an
   // H2D copy queued on the handle's stream would run AFTER the verification it sits behind -- ~15 us of copy
   // engine latency on the step's critical path for nothing.
+  c->last_results = (const sf_result*)c->spec_results.p; c->last_results_index = hi; c->last_results_n = n;
+  if (!d_out) return SF_OK;       // no gathered copy wanted: sf_last_match_results + an indexed consumer
   constexpr int PIECES = sizeof(sf_result) / 16;
   hipLaunchKernelGGL(k_spec_gather, dim3(((size_t)n * PIECES + 255) / 256), dim3(256), 0, c->stream,
                      (const sf_result*)c->spec_results.p, (const int32_t*)hi, n, d_out);
@@ -1229,15 +1238,19 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
 // launch unreadable without a memset in between.  Replaces k_compact_count + k_compact_move (kept for batches with
 // more chunks than can be resident at once).
 __global__ void __launch_bounds__(1024)
-k_compact_chain(const sf_result* __restrict__ res, int n, sf_result* __restrict__ acc, uint8_t* __restrict__ flags,
-                unsigned long long* __restrict__ state, unsigned epoch, int32_t* __restrict__ total) {
+k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ index, int n, sf_result* __restrict__ acc,
+                uint8_t* __restrict__ flags, unsigned long long* __restrict__ state, unsigned epoch,
+                int32_t* __restrict__ total) {
   __shared__ int wsum[16];
   __shared__ int s_dst[1024];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_src[1024];
   const int base = blockIdx.x * 1024;
   const int i = base + tid;
-  const bool ok = i < n && res[i].success != 0;
+  const int src = i < n ? (index ? index[i] : i) : 0;      // candidate i's record (index: e.g. its speculative slot)
+  s_src[tid] = src;
+  const bool ok = i < n && res[src].success != 0;
   if (i < n && flags) flags[i] = ok ? 1 : 0;
   const unsigned long long bal = __ballot(ok);
   const int before = __popcll(bal & ((1ull << lane) - 1ull));
@@ -1267,12 +1280,12 @@ k_compact_chain(const sf_result* __restrict__ res, int n, sf_result* __restrict_
   for (int e = tid; e < m * 23; e += 1024) {
     const int c = e / 23, piece = e - c * 23;
     const int dst = s_dst[c];
-    if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + base + c)[piece];
+    if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + s_src[c])[piece];
   }
 }
 
 static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
-                          int32_t* d_count) {
+                          int32_t* d_count, const int32_t* index = nullptr) {
   const int chunks = (n + 1023) / 1024;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
@@ -1284,11 +1297,14 @@ static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_r
       c->compact_state_ptr = c->compact_scratch.p;
     }
     if (++c->compact_epoch == 0) c->compact_epoch = 1;
-    hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted, d_flags,
+    hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(1024), 0, c->stream, d_results, index, n, d_accepted, d_flags,
                        (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count);
     SF_HIP(c, hipGetLastError());
+    if (index && index == (const int32_t*)c->spec_index_pinned)
+      SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));   // the pinned index block may be rewritten after this
     return SF_OK;
   }
+  if (index) return sf_fail(c, SF_ERANGE, "indexed compaction of %d records: more than 128 chunks", n);
   c->compact_state_chunks = 0;                  // (the two-kernel form reuses the buffer as plain counts)
   int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
   hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
@@ -1307,6 +1323,24 @@ extern "C" int sf_compact_accepted_device_async(sf_handle c, const sf_result* d_
     return SF_OK;
   }
   return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted);
+}
+
+extern "C" int sf_last_match_results(sf_handle c, const sf_result** d_results, const int32_t** index, int32_t* n) {
+  if (!c || !d_results || !index || !n) return SF_EINVAL;
+  *d_results = c->last_results; *index = c->last_results_index; *n = c->last_results_n;
+  return SF_OK;
+}
+
+extern "C" int sf_compact_accepted_indexed_device_async(sf_handle c, const sf_result* d_results, const int32_t* index,
+                                                        int32_t n, sf_result* d_accepted, uint8_t* d_flags,
+                                                        int32_t* d_n_accepted) {
+  if (!c || n < 0 || !d_n_accepted || (n > 0 && (!d_results || !d_accepted))) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  if (n == 0) {
+    SF_HIP(c, hipMemsetAsync(d_n_accepted, 0, 4, c->stream));
+    return SF_OK;
+  }
+  return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted, index);
 }
 
 extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_results, int32_t n, sf_result* d_accepted,

@@ -242,6 +242,10 @@ struct sf_context {
   // Speculative verification (sf_find_matches_and_verify_device): every candidate (row, column) the NN filter
   // emits is verified on the device while the host still reduces the candidates to row minima, sorts and
   // walks them; the walk's matches then pick their results out of the speculative ones.
+  // results of the last sf_find_matches_and_verify_device: record of match i = last_results[index ? index[i] : i]
+  const sf_result* last_results = nullptr;
+  const int32_t* last_results_index = nullptr;
+  int last_results_n = 0;
   unsigned compact_epoch = 0;   // k_compact_chain: tag of the current launch's prefix entries
   int compact_state_chunks = 0; // ... and how many state entries have been initialised
   void* compact_state_ptr = nullptr;

@@ -484,6 +484,54 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     assert out["single"][0][0]["success"][is_true].all()
 
 
+def test_indexed_compaction_of_the_last_match_results():
+    """sf_find_matches_and_verify_device with d_out = NULL + sf_last_match_results + the indexed compaction give the
+    accepted records, flags and count of the gathered form (d_out given, then sf_compact_accepted_device), on the
+    speculative path and on the fallback (small cap: no speculation, results in an internal block)."""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    n_kf, k, cols, dim = 96, 200, 32, 512
+    feats = synth.make_store_batch(78, n_kf, k=k, cols=cols, true_frac=0.5)
+    rng = np.random.default_rng(6)
+    nv_a = rng.normal(size=(n_kf, dim)); nv_a /= np.linalg.norm(nv_a, axis=1, keepdims=True)
+    nv_b = nv_a + 0.002 * rng.normal(size=(n_kf, dim)); nv_b /= np.linalg.norm(nv_b, axis=1, keepdims=True)
+    dev = torch.device("cuda:0")
+    for cap, maxnb in ((n_kf, n_kf), (10, 10)):
+        p = synth.camera_params()
+        p.netvlad_dimensions = dim
+        p.netvlad_max_matches_nb = maxnb
+        p.netvlad_distance = 0.13
+        p.iterations = 200
+        p.max_features = k
+        with lib.SeparatorFinder(p) as f:
+            f.set_stream(torch.cuda.current_stream().cuda_stream)
+
+            def up(x):
+                x = np.ascontiguousarray(x)
+                return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+            T = {key: up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}   # kept alive
+            sa = f.store_add_keyframes_device(n_kf, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+            sb = f.store_add_keyframes_device(n_kf, k, cols, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+            torch.cuda.synchronize()
+            f.nn_append_received(nv_a); f.nn_append_local(nv_b)
+            d_res = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
+            m1 = f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=cap)
+            acc1 = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
+            fl1 = torch.zeros(n_kf, dtype=torch.uint8, device=dev)
+            k1 = f.compact_accepted_device(d_res.data_ptr(), len(m1), acc1.data_ptr(), fl1.data_ptr())
+            m2 = f.find_matches_and_verify_device(sa, sb, None, cap=cap)
+            r, ix, n2 = f.last_match_results()
+            assert n2 == len(m2) == len(m1) >= 8 and m2.tobytes() == m1.tobytes() and r
+            assert (ix is not None) == (cap == n_kf)          # an index list only on the speculative path
+            acc2 = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
+            fl2 = torch.zeros(n_kf, dtype=torch.uint8, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            f.compact_accepted_indexed_device_async(r, ix, n2, acc2.data_ptr(), fl2.data_ptr(), cnt.data_ptr())
+            torch.cuda.synchronize()
+            assert int(cnt[0]) == k1 and k1 >= 1
+            assert torch.equal(acc2[:k1], acc1[:k1]) and torch.equal(fl2[:n2], fl1[:n2])
+
+
 @pytest.mark.parametrize("est", [0, 1])
 def test_find_matches_and_verify_speculative_equals_two_calls(est):
     """sf_find_matches_and_verify_device (speculative verification of the NN candidates while the host walks
