@@ -237,8 +237,8 @@ int  sf_store_clear(sf_handle h);
 /* replaces: RegistrationVis::getFeaturesImpl (myRegistrationVis.cpp:343-436: descriptors for the given keypoints,
    3D keypoints of the stereo pair, removal of keypoints without a finite 3D point) as called by
    StereoCamGeometricTools::getFeaturesAndDescriptor (stereoCamGeometricTools.cpp:100-120), writing the keyframe
-   straight into the device-resident store.  Corner detection and the right-image position of every corner
-   (rtabmap: GFTT + pyramidal LK) stay upstream of this call.                                      */
+   straight into the device-resident store.  Corner detection (sf_detect_corners_device) and the right-image
+   position of every corner (sf_stereo_correspondences_device) are the two calls before this one.  */
 typedef struct sf_stereo_camera {
   float fx, fy, cx, cy;        /* left camera (StereoCameraModel::left())                                  */
   float cx_right;              /* right camera cx (0: unknown, no principal-point correction)              */
@@ -288,6 +288,31 @@ int  sf_netvlad_infer_device(sf_handle h, const float* d_image_rgb, int32_t widt
 int  sf_detect_corners_device(sf_handle h, const uint8_t* d_image, int32_t width, int32_t height, int32_t pitch,
                               int32_t max_corners, double quality_level, double min_distance,
                               sf_keypoint* d_kpts_out, int32_t cap, int32_t* n_out);
+/* Stereo correspondence of the corners: replaces Feature2D::generateKeypoints3D's call of
+   StereoOpticalFlow::computeCorrespondences [upstream rtabmap] behind myRegistrationVis.cpp:382 --
+   cv::calcOpticalFlowPyrLK(left, right, corners, winSize, maxLevel, {COUNT + EPS, iterations, epsilon},
+   OPTFLOW_LK_GET_MIN_EIGENVALS, min_eig_threshold) followed by the disparity gate (status = 0 where left.x - right.x
+   is <= min_disparity or > max_disparity).  sf_stereo_flow_defaults fills rtabmap's defaults: Stereo/WinWidth 15,
+   Stereo/WinHeight 3, Stereo/MaxLevel 5 (3 before rtabmap 0.20), Stereo/Iterations 30, Stereo/Eps 0.01,
+   Stereo/MinDisparity 0.5, Stereo/MaxDisparity 128, threshold 1e-4.                                              */
+typedef struct sf_stereo_flow_params {
+  int32_t win_width, win_height;    /* > 2 each, win_width * win_height <= 1024                      */
+  int32_t max_level;                /* 0 .. 15; fewer levels are used when the image is small         */
+  int32_t iterations;               /* clamped to 0 .. 100 like cv::TermCriteria in calcOpticalFlowPyrLK */
+  double  epsilon;                  /* clamped to 0 .. 10, compared squared with |delta|^2            */
+  float   min_disparity, max_disparity;
+  float   min_eig_threshold;
+} sf_stereo_flow_params;
+void sf_stereo_flow_defaults(sf_stereo_flow_params* p);
+/* d_left / d_right: rectified 8-bit images on the device (height rows of `pitch` bytes); d_kpts: n corners of the
+   left image (sf_detect_corners_device's output).  Outputs on the device, asynchronous on the handle's stream:
+   d_right_xy [n][2] (cv::Point2f of every corner in the right image), d_status [n], d_right_x [n] (optional: the x
+   alone, the layout sf_extract_keyframe_device takes), d_err [n] (optional: the minimum eigenvalue of the level-0
+   window, what calcOpticalFlowPyrLK returns as err under OPTFLOW_LK_GET_MIN_EIGENVALS).  params NULL = defaults.  */
+int  sf_stereo_correspondences_device(sf_handle h, const uint8_t* d_left, const uint8_t* d_right, int32_t width,
+                                      int32_t height, int32_t pitch, const sf_keypoint* d_kpts, int32_t n,
+                                      const sf_stereo_flow_params* params, float* d_right_xy, uint8_t* d_status,
+                                      float* d_right_x, float* d_err);
 /* d_left: 8-bit image on the device (height rows of `pitch` bytes); d_kpts: n corners; d_right_x: their x in the
    right image (NULL: no 3D); d_status: per-corner validity of d_right_x (NULL: all valid).  Appends ONE keyframe
    to the store; *out_slot = its slot, *out_rows = features kept (the call synchronises the stream to read it;

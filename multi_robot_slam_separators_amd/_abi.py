@@ -96,6 +96,24 @@ def stereo_camera(fx, fy, cx, cy, baseline, cx_right=0.0, local_transform=None, 
     return cam
 
 
+class StereoFlowParams(C.Structure):
+    """sf_stereo_flow_params (include/sepfinder.h): cv::calcOpticalFlowPyrLK + disparity gate of the stereo correspondence."""
+    _fields_ = [
+        ("win_width", C.c_int32), ("win_height", C.c_int32), ("max_level", C.c_int32), ("iterations", C.c_int32),
+        ("epsilon", C.c_double), ("min_disparity", C.c_float), ("max_disparity", C.c_float),
+        ("min_eig_threshold", C.c_float),
+    ]
+
+
+def stereo_flow_params(win_width=15, win_height=3, max_level=5, iterations=30, epsilon=0.01, min_disparity=0.5,
+                       max_disparity=128.0, min_eig_threshold=1e-4):
+    """rtabmap's Stereo/* defaults (what sf_stereo_flow_defaults fills)."""
+    p = StereoFlowParams()
+    p.win_width, p.win_height, p.max_level, p.iterations = win_width, win_height, max_level, iterations
+    p.epsilon, p.min_disparity, p.max_disparity, p.min_eig_threshold = epsilon, min_disparity, max_disparity, min_eig_threshold
+    return p
+
+
 class NetvladWeights(C.Structure):
     """sf_netvlad_weights (include/sepfinder.h): host pointers to the NetVLAD network's weights, TensorFlow layouts."""
     _fields_ = [

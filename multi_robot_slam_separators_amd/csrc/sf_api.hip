@@ -734,7 +734,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
                  &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests,
-                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar};
+                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr};
   for (Buf* b : bufs) buf_free(*b);
   sf_netvlad_free(c);
   sf_ingest_pool_destroy(c);
@@ -881,6 +881,36 @@ extern "C" int sf_detect_corners_device(sf_handle c, const uint8_t* d_image, int
   SF_HIP(c, hipSetDevice(c->device));
   return sf_launch_detect_corners(c, d_image, width, height, pitch, max_corners, quality_level, min_distance, d_kpts_out,
                                   cap, n_out);
+}
+
+extern "C" void sf_stereo_flow_defaults(sf_stereo_flow_params* p) {
+  if (!p) return;
+  p->win_width = 15; p->win_height = 3;        // Stereo/WinWidth, Stereo/WinHeight [upstream rtabmap Parameters.h]
+  p->max_level = 5;                            // Stereo/MaxLevel
+  p->iterations = 30;                          // Stereo/Iterations
+  p->epsilon = 0.01;                           // Stereo/Eps
+  p->min_disparity = 0.5f; p->max_disparity = 128.0f;
+  p->min_eig_threshold = 1e-4f;                // the literal in StereoOpticalFlow::computeCorrespondences
+}
+
+extern "C" int sf_stereo_correspondences_device(sf_handle c, const uint8_t* d_left, const uint8_t* d_right, int32_t width,
+                                                int32_t height, int32_t pitch, const sf_keypoint* d_kpts, int32_t n,
+                                                const sf_stereo_flow_params* params, float* d_right_xy,
+                                                uint8_t* d_status, float* d_right_x, float* d_err) {
+  if (!c || n < 0) return SF_EINVAL;
+  if (!d_left || !d_right || width < 1 || height < 1 || pitch < width)
+    return sf_fail(c, SF_EINVAL, "stereo pair missing or malformed (%d x %d, pitch %d)", width, height, pitch);
+  if (n > 0 && (!d_kpts || !d_right_xy || !d_status)) return sf_fail(c, SF_EINVAL, "corners or output arrays missing");
+  sf_stereo_flow_params prm;
+  if (params) prm = *params; else sf_stereo_flow_defaults(&prm);
+  if (prm.win_width <= 2 || prm.win_height <= 2)
+    return sf_fail(c, SF_EINVAL, "window of %d x %d: both sides must be > 2 (cv::calcOpticalFlowPyrLK asserts the same)", prm.win_width, prm.win_height);
+  if ((long long)prm.win_width * prm.win_height > 1024) return sf_fail(c, SF_ERANGE, "window of %d x %d exceeds 1024 pixels", prm.win_width, prm.win_height);
+  if (prm.max_level < 0 || prm.max_level > 15) return sf_fail(c, SF_ERANGE, "max_level %d outside 0 .. 15", prm.max_level);
+  if (!(prm.epsilon == prm.epsilon)) return sf_fail(c, SF_EINVAL, "epsilon is NaN");
+  if (n == 0) return SF_OK;
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_launch_stereo_flow(c, d_left, d_right, width, height, pitch, d_kpts, n, &prm, d_right_xy, d_status, d_right_x, d_err);
 }
 
 extern "C" int sf_extract_keyframe_device(sf_handle c, const uint8_t* d_left, int32_t width, int32_t height,

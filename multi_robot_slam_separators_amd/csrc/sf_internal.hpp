@@ -167,6 +167,7 @@ struct sf_context {
   // corner detection (k_gftt.hip): derivative-product / response planes, candidate keys (in + sorted), sort scratch,
   // the selection's cell lists, three scalars
   Buf gf_planes, gf_keys, gf_tmp, gf_lists, gf_scalar;
+  Buf lk_pyr;                      // pyramid levels >= 1 of both images (k_lk.hip)
   struct sf_netvlad_model* netvlad = nullptr;   // NetVLAD inference (k_cnn.hip): weights + activation buffers
   int brief_bytes = 0;                 // 0: table not uploaded yet
   int8_t brief_host[64 * 8 * 4] = {};
@@ -319,6 +320,9 @@ void sf_brief_default_pattern(int8_t* tests, int bytes);
 int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, int height, int pitch, int max_corners,
                              double quality_level, double min_distance, sf_keypoint* d_kpts_out, int cap,
                              int32_t* n_out);
+int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d_right, int width, int height, int pitch,
+                          const sf_keypoint* d_kpts, int n, const sf_stereo_flow_params* prm, float* d_right_xy,
+                          uint8_t* d_status, float* d_right_x, float* d_err);
 int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int height, int pitch, const sf_keypoint* d_kpts,
                       const float* d_right_x, const uint8_t* d_status, int n, const sf_stereo_camera* cam, int bytes,
                       const int8_t* d_tests, uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap,

@@ -84,6 +84,9 @@ def load():
         "sf_extract_keyframe_device": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, i32, P(_abi.StereoCamera),
                                                  P(i32), P(i32), vp, vp, vp]),
         "sf_detect_corners_device": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i32, P(i32)]),
+        "sf_stereo_flow_defaults": (None, [P(_abi.StereoFlowParams)]),
+        "sf_stereo_correspondences_device": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, P(_abi.StereoFlowParams),
+                                                       vp, vp, vp, vp]),
         "sf_netvlad_load": (C.c_int, [vp, P(_abi.NetvladWeights)]),
         "sf_netvlad_infer_device": (C.c_int, [vp, vp, i32, i32, vp, i32]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
@@ -130,7 +133,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
-    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_last_match_results", "sf_compact_accepted_indexed_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -328,6 +331,14 @@ class SeparatorFinder:
                                                      float(quality_level), float(min_distance), C.c_void_p(d_kpts_out),
                                                      cap, C.byref(n)))
         return n.value
+
+    def stereo_correspondences_device(self, d_left, d_right, width, height, pitch, d_kpts, n, d_right_xy, d_status,
+                                      d_right_x=None, d_err=None, params=None):
+        """cv::calcOpticalFlowPyrLK + rtabmap's disparity gate on the device (asynchronous); device pointers (ints)."""
+        self._check(self._L.sf_stereo_correspondences_device(
+            self._h, C.c_void_p(d_left), C.c_void_p(d_right), width, height, pitch, C.c_void_p(d_kpts), n,
+            C.byref(params) if params is not None else None, C.c_void_p(d_right_xy), C.c_void_p(d_status),
+            C.c_void_p(d_right_x), C.c_void_p(d_err)))
 
     def extract_keyframe_device(self, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam,
                                 d_desc_out=None, d_xyz_out=None, d_kpts_out=None, want_rows=True):

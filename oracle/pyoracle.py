@@ -20,7 +20,7 @@ def build(force=False):
     """Compile oracle/libsf_oracle.so with gcc (Makefile in this directory)."""
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in
-                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle_ba.c", "sf_oracle_extract.c", "sf_oracle_gftt.c", "sf_oracle.h",
+                                          ("sf_oracle.c", "sf_oracle_pnp.c", "sf_oracle_ba.c", "sf_oracle_extract.c", "sf_oracle_gftt.c", "sf_oracle_lk.c", "sf_oracle.h",
                                            "sf_oracle_internal.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -78,6 +78,13 @@ def lib():
         L.sfo_detect_corners.restype = C.c_int
         L.sfo_detect_corners.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                          C.c_void_p, C.c_int32, P(C.c_int32), C.c_void_p]
+        L.sfo_stereo_correspondences.restype = C.c_int
+        L.sfo_stereo_correspondences.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                 P(_abi.StereoFlowParams), C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int32)]
+        L.sfo_pyr_down.restype = None
+        L.sfo_pyr_down.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.sfo_scharr_deriv.restype = None
+        L.sfo_scharr_deriv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         L.sfo_extract_keyframe.restype = C.c_int
         L.sfo_extract_keyframe.argtypes = [
             C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -331,3 +338,46 @@ def detect_corners(image, max_corners=1000, quality_level=0.001, min_distance=3.
         raise RuntimeError("sfo_detect_corners failed: %d" % rc)
     kp = kp[:min(n.value, cap)].copy()
     return (kp, eig) if want_eig else kp
+
+
+def pyr_down(image):
+    """sfo_pyr_down: cv::pyrDown of an 8-bit image [h, w] (unit column stride)."""
+    L = lib()
+    image = np.asarray(image, np.uint8)
+    assert image.ndim == 2 and image.strides[1] == 1
+    h, w = image.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    L.sfo_pyr_down(image.ctypes.data, w, h, image.strides[0], out.ctypes.data)
+    return out
+
+
+def scharr_deriv(image):
+    """sfo_scharr_deriv: int16 [h, w, 2] {Ix, Iy} of lkpyramid.cpp's calcSharrDeriv."""
+    L = lib()
+    image = np.asarray(image, np.uint8)
+    assert image.ndim == 2 and image.strides[1] == 1
+    h, w = image.shape
+    out = np.zeros((h, w, 2), np.int16)
+    L.sfo_scharr_deriv(image.ctypes.data, w, h, image.strides[0], out.ctypes.data)
+    return out
+
+
+def stereo_correspondences(left, right, kpts, params=None, want_levels=False):
+    """sfo_stereo_correspondences: left / right uint8 [h, w] with the SAME row stride.  Returns right_xy float32 [n, 2],
+    status uint8 [n], err float32 [n] [, pyramid levels built]."""
+    L = lib()
+    left, right = np.asarray(left, np.uint8), np.asarray(right, np.uint8)
+    assert left.shape == right.shape and left.strides == right.strides and left.strides[1] == 1
+    h, w = left.shape
+    kpts = np.ascontiguousarray(kpts, _abi.KEYPOINT_DTYPE)
+    n = len(kpts)
+    prm = params if params is not None else _abi.stereo_flow_params()
+    xy = np.zeros((n, 2), np.float32)
+    st = np.zeros(n, np.uint8)
+    err = np.zeros(n, np.float32)
+    lv = C.c_int32()
+    rc = L.sfo_stereo_correspondences(left.ctypes.data, right.ctypes.data, w, h, left.strides[0], kpts.ctypes.data, n,
+                                      C.byref(prm), xy.ctypes.data, st.ctypes.data, err.ctypes.data, C.byref(lv))
+    if rc != 0:
+        raise RuntimeError("sfo_stereo_correspondences failed: %d" % rc)
+    return (xy, st, err, lv.value) if want_levels else (xy, st, err)

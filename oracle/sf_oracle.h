@@ -138,6 +138,14 @@ int sfo_detect_corners(const uint8_t* image, int32_t width, int32_t height, int3
                        double quality_level, double min_distance, sf_keypoint* kpts_out, int32_t cap, int32_t* n_out,
                        float* eig_out);
 
+/* SURVEY section 8 row f3, the stereo correspondence (sf_oracle_lk.c): cv::calcOpticalFlowPyrLK + rtabmap's disparity
+ * gate restated.  right_xy [n][2], status [n], err [n] (optional), *levels_used (optional) = pyramid levels built. */
+int sfo_stereo_correspondences(const uint8_t* left, const uint8_t* right, int32_t width, int32_t height, int32_t pitch,
+                               const sf_keypoint* kpts, int32_t n, const sf_stereo_flow_params* prm, float* right_xy,
+                               uint8_t* status, float* err, int32_t* levels_used);
+void sfo_pyr_down(const uint8_t* src, int32_t w, int32_t h, int32_t pitch, uint8_t* dst);        /* cv::pyrDown, 8-bit */
+void sfo_scharr_deriv(const uint8_t* src, int32_t w, int32_t h, int32_t pitch, int16_t* dst);    /* calcSharrDeriv */
+
 #ifdef __cplusplus
 }
 #endif

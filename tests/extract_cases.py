@@ -97,3 +97,33 @@ def numpy_extract(image, kp, right_x, status, cam, tests):
     if cam.min_depth > 0 or cam.max_depth > 0:
         keep = np.isfinite(p).all(axis=1)
     return desc[keep], p[keep], kp[idx][keep]
+
+
+def make_stereo_pair(seed, width=752, height=480, pad=8, max_disp=40.0, noise=1.5):
+    """A rectified pair for the stereo-correspondence tests: multi-scale texture on the left, the right image is the
+    left one resampled along the rows by a smooth disparity field (2 .. max_disp px) plus sensor noise.  Both images
+    share one pitch (width + pad).  Returns left, right (views with pitch > width) and the disparity field."""
+    rng = np.random.default_rng(seed)
+    tex = np.zeros((height, width + 160))
+    for cell, amp in ((32, 60.0), (12, 50.0), (5, 35.0), (2, 20.0)):
+        g = rng.normal(size=(height // cell + 3, (width + 160) // cell + 3))
+        ys = np.arange(height) / cell
+        xs = np.arange(width + 160) / cell
+        y0, x0 = ys.astype(int), xs.astype(int)
+        fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+        tex += amp * ((1 - fy) * (1 - fx) * g[y0][:, x0] + (1 - fy) * fx * g[y0][:, x0 + 1]
+                      + fy * (1 - fx) * g[y0 + 1][:, x0] + fy * fx * g[y0 + 1][:, x0 + 1])
+    tex = 128 + tex * 0.6
+    yy, xx = np.mgrid[0:height, 0:width]
+    disp = 2.0 + (max_disp - 2.0) * (0.5 + 0.5 * np.sin(xx / width * 2.1 + 0.4) * np.cos(yy / height * 1.7))
+    left = tex[:, 80:80 + width]
+    # right(x) = left(x + d): a point at x in the left image appears at x - d in the right one
+    src = xx + 80 + disp
+    s0 = np.floor(src).astype(int)
+    f = src - s0
+    right = (1 - f) * tex[yy, np.clip(s0, 0, width + 159)] + f * tex[yy, np.clip(s0 + 1, 0, width + 159)]
+    bl = np.zeros((height, width + pad), np.uint8)
+    br = np.zeros((height, width + pad), np.uint8)
+    bl[:, :width] = np.clip(left + rng.normal(0, noise, left.shape), 0, 255).astype(np.uint8)
+    br[:, :width] = np.clip(right + rng.normal(0, noise, right.shape), 0, 255).astype(np.uint8)
+    return bl[:, :width], br[:, :width], disp

@@ -1,0 +1,149 @@
+"""GPU: sf_stereo_correspondences_device (csrc/k_lk.hip, SURVEY section 8 row f3 -- the stereo correspondence,
+cv::calcOpticalFlowPyrLK + rtabmap's disparity gate) against the CPU oracle: positions, status and err byte for byte;
+and the whole keyframe path on device pointers: pixels -> corners -> right-image positions -> store slot."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi, lib, synth
+from oracle import pyoracle
+from tests import extract_cases as ec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def finder():
+    import torch
+    p = synth.camera_params()
+    p.max_features = 2048
+    f = lib.SeparatorFinder(p, device=0)
+    f.set_stream(torch.cuda.current_stream().cuda_stream)
+    yield f
+    f.close()
+
+
+def upload_image(torch, image):
+    h, w = image.shape
+    pitch = image.strides[0]
+    base = np.lib.stride_tricks.as_strided(image, shape=(h, pitch), strides=(pitch, 1)) if pitch != w else image
+    return torch.from_numpy(np.ascontiguousarray(base)).to("cuda:0")
+
+
+def track(f, torch, left, right, kp, prm=None, want_rx=True):
+    assert left.strides == right.strides
+    h, w = left.shape
+    n = len(kp)
+    dl, dr = upload_image(torch, left), upload_image(torch, right)
+    d_kp = torch.from_numpy(np.frombuffer(np.ascontiguousarray(kp).tobytes() + b"\0" * 28, np.uint8).copy()).to("cuda:0")
+    d_xy = torch.full((max(n, 1), 2), -7.0, dtype=torch.float32, device="cuda:0")
+    d_st = torch.full((max(n, 1),), 9, dtype=torch.uint8, device="cuda:0")
+    d_rx = torch.full((max(n, 1),), -7.0, dtype=torch.float32, device="cuda:0")
+    d_er = torch.full((max(n, 1),), -7.0, dtype=torch.float32, device="cuda:0")
+    f.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, left.strides[0], d_kp.data_ptr(), n, d_xy.data_ptr(),
+                                    d_st.data_ptr(), d_rx.data_ptr() if want_rx else None, d_er.data_ptr() if want_rx else None,
+                                    params=prm)
+    torch.cuda.synchronize()
+    return d_xy.cpu().numpy()[:n], d_st.cpu().numpy()[:n], d_rx.cpu().numpy()[:n], d_er.cpu().numpy()[:n]
+
+
+def corners_for(left, n, seed):
+    kp = pyoracle.detect_corners(left, n, 0.001, 3.0)
+    h, w = left.shape
+    extra = np.zeros(8, _abi.KEYPOINT_DTYPE)
+    extra["x"] = [0, w - 1, 0.5, w - 1.5, w / 2 + 0.25, 3.75, w - 2, 7]
+    extra["y"] = [0, h - 1, h - 1, 0.5, 1.5, h / 2 + 0.5, 2, h - 3]
+    rng = np.random.default_rng(seed)
+    kp = np.concatenate([kp, extra])
+    kp["x"][:len(kp) // 3] += rng.uniform(-0.5, 0.5, len(kp) // 3).astype(np.float32)
+    kp["x"] = np.clip(kp["x"], 0, w - 1)
+    return kp
+
+
+@pytest.mark.parametrize("seed,shape,win,max_level,n,iters", [
+    (1, (120, 160), (15, 3), 5, 200, 30), (2, (97, 131), (21, 21), 3, 150, 30), (3, (240, 376), (15, 3), 5, 400, 30),
+    (4, (64, 80), (5, 7), 0, 60, 30), (5, (480, 752), (15, 3), 5, 1000, 30), (6, (480, 752), (15, 3), 3, 1000, 30),
+    (7, (720, 1280), (15, 3), 5, 2000, 30), (8, (200, 300), (32, 32), 4, 300, 100), (9, (480, 752), (9, 9), 15, 500, 5),
+    (10, (50, 40), (3, 3), 5, 50, 30),
+])
+def test_positions_equal_oracle(finder, seed, shape, win, max_level, n, iters):
+    import torch
+    left, right, _ = ec.make_stereo_pair(seed, width=shape[1], height=shape[0], max_disp=min(40.0, shape[1] / 6))
+    kp = corners_for(left, n, seed)
+    prm = _abi.stereo_flow_params(win_width=win[0], win_height=win[1], max_level=max_level, iterations=iters)
+    xy, st, rx, er = track(finder, torch, left, right, kp, prm)
+    xy0, st0, er0 = pyoracle.stereo_correspondences(left, right, kp, prm)
+    assert np.array_equal(st, st0)
+    assert xy.tobytes() == xy0.tobytes() and er.tobytes() == er0.tobytes() and rx.tobytes() == xy0[:, 0].tobytes()
+    assert st.sum() >= 3
+
+
+def test_defaults_gates_and_degenerate_inputs(finder):
+    import torch
+    left, right, _ = ec.make_stereo_pair(12, width=200, height=120, max_disp=20.0)
+    kp = corners_for(left, 120, 12)
+    # NULL params = rtabmap's defaults = what sf_stereo_flow_defaults fills
+    d = _abi.StereoFlowParams()
+    finder._L.sf_stereo_flow_defaults(d)
+    ref = _abi.stereo_flow_params()
+    assert bytes(d) == bytes(ref)
+    xy, st, _, _ = track(finder, torch, left, right, kp, None, want_rx=False)      # (optional outputs absent)
+    xy0, st0, _ = pyoracle.stereo_correspondences(left, right, kp)
+    assert xy.tobytes() == xy0.tobytes() and np.array_equal(st, st0)
+    # identical images (zero disparity), flat images (no structure), a narrow gate, no iterations
+    flat = np.full_like(np.ascontiguousarray(left), 90)
+    for a, b, prm in ((left, left, None), (flat, flat, None),
+                      (left, right, _abi.stereo_flow_params(min_disparity=8.0, max_disparity=12.0)),
+                      (left, right, _abi.stereo_flow_params(iterations=0)),
+                      (left, right, _abi.stereo_flow_params(epsilon=50.0, iterations=1000))):
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        xy, st, rx, er = track(finder, torch, a, b, kp, prm)
+        xy0, st0, er0 = pyoracle.stereo_correspondences(a, b, kp, prm)
+        assert xy.tobytes() == xy0.tobytes() and np.array_equal(st, st0) and er.tobytes() == er0.tobytes()
+    # no corners: nothing is launched, nothing is written
+    xy, st, _, _ = track(finder, torch, left, right, kp[:0])
+    assert len(xy) == 0
+    # malformed calls
+    for bad in (_abi.stereo_flow_params(win_width=2), _abi.stereo_flow_params(win_width=40, win_height=40),
+                _abi.stereo_flow_params(max_level=16), _abi.stereo_flow_params(max_level=-1)):
+        with pytest.raises(lib.SepfinderError):
+            track(finder, torch, left, right, kp, bad)
+
+
+def test_pixels_to_store_slot_with_tracked_disparities(finder):
+    """detector -> stereo correspondence -> extraction on device pointers only; the slot holds what the oracle chain
+    computes from the same pair, and the 3D points sit at the planted depths."""
+    import torch
+    dev = torch.device("cuda:0")
+    left, right, disp = ec.make_stereo_pair(21)
+    h, w = left.shape
+    pitch = left.strides[0]
+    cam = _abi.stereo_camera(460.0, 458.0, 367.2, 248.4, 0.11)
+    dl, dr = upload_image(torch, left), upload_image(torch, right)
+    cap = 1000
+    d_kp = torch.zeros((cap, 28), dtype=torch.uint8, device=dev)
+    n = finder.detect_corners_device(dl.data_ptr(), w, h, pitch, cap, 0.001, 3.0, d_kp.data_ptr(), cap)
+    assert n > 500
+    d_xy = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    d_rx = torch.zeros(n, dtype=torch.float32, device=dev)
+    finder.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, pitch, d_kp.data_ptr(), n, d_xy.data_ptr(),
+                                         d_st.data_ptr(), d_rx.data_ptr())
+    tests = ec.brief_tests(9, 32)
+    finder.brief_set_pattern(tests)
+    d_desc = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    d_xyz = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    slot, rows = finder.extract_keyframe_device(dl.data_ptr(), w, h, pitch, d_kp.data_ptr(), d_rx.data_ptr(), d_st.data_ptr(),
+                                                n, cam, d_desc.data_ptr(), d_xyz.data_ptr())
+    torch.cuda.synchronize()
+    kp0 = pyoracle.detect_corners(left, cap, 0.001, 3.0)
+    xy0, st0, _ = pyoracle.stereo_correspondences(left, right, kp0)
+    d0, p0, k0 = pyoracle.extract_keyframe(left, kp0, np.ascontiguousarray(xy0[:, 0]), st0, cam, tests)
+    assert rows == len(d0) and d_desc.cpu().numpy()[:rows].tobytes() == d0.tobytes()
+    got = d_xyz.cpu().numpy()[:rows]
+    assert np.array_equal(np.isnan(got), np.isnan(p0)) and got[~np.isnan(got)].tobytes() == p0[~np.isnan(p0)].tobytes()
+    ok = ~np.isnan(got[:, 2])
+    assert ok.mean() > 0.8
+    # depth = fx * baseline / disparity at the tracked right-image position
+    xr = np.clip(np.rint(k0["x"][ok] - 460.0 * 0.11 / got[ok, 2]).astype(int), 0, w - 1)
+    want = 460.0 * 0.11 / disp[np.clip(np.rint(k0["y"][ok]).astype(int), 0, h - 1), xr]
+    assert np.median(np.abs(got[ok, 2] - want) / want) < 0.02

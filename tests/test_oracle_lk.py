@@ -1,0 +1,240 @@
+"""CPU: the C restatement of the stereo correspondence (oracle/sf_oracle_lk.c, SURVEY section 8 row f3:
+cv::calcOpticalFlowPyrLK + rtabmap's disparity gate) against an independent numpy restatement -- pyramid and
+derivatives to the last bit, tracked positions / status / err exactly -- and against what the algorithm must do on a
+pair with a planted disparity field."""
+import numpy as np
+import pytest
+
+from multi_robot_slam_separators_amd import _abi
+from oracle import pyoracle
+from tests import extract_cases as ec
+
+f32 = np.float32
+
+
+def refl_index(n, lo, hi):
+    """BORDER_REFLECT_101 indices lo .. hi - 1 into a length-n axis (cv::borderInterpolate)."""
+    i = np.arange(lo, hi)
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * n - 2
+    i = np.mod(i, period)
+    return np.where(i >= n, period - i, i)
+
+
+def numpy_pyr_down(img):
+    h, w = img.shape
+    dh, dw = (h + 1) // 2, (w + 1) // 2
+    a = img.astype(np.int64)[refl_index(h, -2, 2 * dh + 3)][:, refl_index(w, -2, 2 * dw + 3)]
+    k = (1, 4, 6, 4, 1)
+    rows = sum(k[i] * a[:, i:i + 2 * dw:2] for i in range(5))
+    out = sum(k[j] * rows[j:j + 2 * dh:2] for j in range(5))
+    return ((out + 128) >> 8).astype(np.uint8)
+
+
+def numpy_scharr(img):
+    h, w = img.shape
+    a = img.astype(np.int64)[refl_index(h, -1, h + 1)][:, refl_index(w, -1, w + 1)]
+    sm = (a[:-2] + a[2:]) * 3 + a[1:-1] * 10
+    df = a[2:] - a[:-2]
+    ix = sm[:, 2:] - sm[:, :-2]
+    iy = (df[:, 2:] + df[:, :-2]) * 3 + df[:, 1:-1] * 10
+    return np.stack([ix, iy], axis=2).astype(np.int16)
+
+
+def build_levels(img, ww, wh, max_level):
+    lv = [np.ascontiguousarray(img)]
+    for _ in range(max_level):
+        h, w = lv[-1].shape
+        if (w + 1) // 2 <= ww or (h + 1) // 2 <= wh:
+            break
+        lv.append(numpy_pyr_down(lv[-1]))
+    return lv
+
+
+def descale(x, n):
+    return (x + (1 << (n - 1))) >> n
+
+
+def numpy_lk(left, right, kpts, prm):
+    ww, wh = prm.win_width, prm.win_height
+    L = build_levels(left, ww, wh, prm.max_level)
+    R = build_levels(right, ww, wh, prm.max_level)
+    D = [numpy_scharr(a) for a in L]
+    max_level = len(L) - 1
+    max_count = min(max(prm.iterations, 0), 100)
+    eps = min(max(prm.epsilon, 0.0), 10.0) ** 2
+    half = (f32(ww - 1) * f32(0.5), f32(wh - 1) * f32(0.5))
+    scale20 = f32(1.0 / (1 << 20))
+    n = len(kpts)
+    xy = np.zeros((n, 2), f32)
+    st = np.zeros(n, np.uint8)
+    err = np.zeros(n, f32)
+
+    def weights(a, b):
+        w00 = int(np.rint((f32(1) - a) * (f32(1) - b) * f32(16384)))
+        w01 = int(np.rint(a * (f32(1) - b) * f32(16384)))
+        w10 = int(np.rint((f32(1) - a) * b * f32(16384)))
+        return w00, w01, w10, 16384 - w00 - w01 - w10
+
+    def patch(img, ix, iy):                 # (wh + 1) x (ww + 1) window with the REFLECT_101 border
+        h, w = img.shape
+        return img.astype(np.int64)[refl_index(h, iy, iy + wh + 1)][:, refl_index(w, ix, ix + ww + 1)]
+
+    def dpatch(der, ix, iy):                # derivative window, zero outside the image
+        h, w = der.shape[:2]
+        out = np.zeros((wh + 1, ww + 1, 2), np.int64)
+        ys, xs = np.arange(iy, iy + wh + 1), np.arange(ix, ix + ww + 1)
+        my, mx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+        if my.any() and mx.any():
+            out[np.ix_(my, mx)] = der[np.ix_(ys[my], xs[mx])]
+        return out
+
+    def bil(p, w4, bits):
+        return descale(p[:-1, :-1] * w4[0] + p[:-1, 1:] * w4[1] + p[1:, :-1] * w4[2] + p[1:, 1:] * w4[3], bits)
+
+    with np.errstate(over="ignore", invalid="ignore"):
+        for p in range(n):
+            s, e = 1, f32(0)
+            nx = ny = f32(0)
+            for level in range(max_level, -1, -1):
+                I, J, dI = L[level], R[level], D[level]
+                sc = f32(1.0 / (1 << level))
+                px, py = f32(kpts["x"][p]) * sc, f32(kpts["y"][p]) * sc
+                if level == max_level:
+                    qx, qy = px, py
+                else:
+                    qx, qy = nx * f32(2), ny * f32(2)
+                nx, ny = qx, qy
+                px, py = px - half[0], py - half[1]
+                ipx, ipy = int(np.floor(px)), int(np.floor(py))
+                if ipx < -ww or ipx >= I.shape[1] or ipy < -wh or ipy >= I.shape[0]:
+                    if level == 0:
+                        s, e = 0, f32(0)
+                    continue
+                w4 = weights(px - f32(ipx), py - f32(ipy))
+                Iw = bil(patch(I, ipx, ipy), w4, 9)
+                dp = dpatch(dI, ipx, ipy)
+                Ix, Iy = bil(dp[:, :, 0], w4, 14), bil(dp[:, :, 1], w4, 14)
+                A11 = f32(int((Ix * Ix).sum())) * scale20
+                A12 = f32(int((Ix * Iy).sum())) * scale20
+                A22 = f32(int((Iy * Iy).sum())) * scale20
+                Dt = A11 * A22 - A12 * A12
+                min_eig = (A22 + A11 - np.sqrt((A11 - A22) * (A11 - A22) + f32(4) * A12 * A12)) / f32(2 * ww * wh)
+                e = f32(min_eig)
+                if min_eig < f32(prm.min_eig_threshold) or Dt < f32(1.1920929e-07):
+                    if level == 0:
+                        s = 0
+                    continue
+                Dt = f32(1) / Dt
+                qx, qy = qx - half[0], qy - half[1]
+                pdx = pdy = f32(0)
+                for j in range(max_count):
+                    iqx, iqy = int(np.floor(qx)), int(np.floor(qy))
+                    if iqx < -ww or iqx >= J.shape[1] or iqy < -wh or iqy >= J.shape[0]:
+                        if level == 0:
+                            s = 0
+                        break
+                    w4 = weights(qx - f32(iqx), qy - f32(iqy))
+                    diff = bil(patch(J, iqx, iqy), w4, 9) - Iw
+                    b1 = f32(int((diff * Ix).sum())) * scale20
+                    b2 = f32(int((diff * Iy).sum())) * scale20
+                    dx = f32((A12 * b2 - A22 * b1) * Dt)
+                    dy = f32((A12 * b1 - A11 * b2) * Dt)
+                    qx, qy = qx + dx, qy + dy
+                    nx, ny = qx + half[0], qy + half[1]
+                    if float(dx) * float(dx) + float(dy) * float(dy) <= eps:
+                        break
+                    if j > 0 and abs(float(dx + pdx)) < 0.01 and abs(float(dy + pdy)) < 0.01:
+                        nx, ny = nx - dx * f32(0.5), ny - dy * f32(0.5)
+                        break
+                    pdx, pdy = dx, dy
+            if s:
+                d = f32(kpts["x"][p]) - nx
+                if d <= f32(prm.min_disparity) or d > f32(prm.max_disparity):
+                    s = 0
+            xy[p] = (nx, ny)
+            st[p] = s
+            err[p] = e
+    return xy, st, err
+
+
+def corners_for(left, n, seed):
+    """Detector corners plus a few awkward ones: image corners / edges, half-pixel positions."""
+    kp = pyoracle.detect_corners(left, n, 0.001, 3.0)
+    h, w = left.shape
+    extra = np.zeros(8, _abi.KEYPOINT_DTYPE)
+    extra["x"] = [0, w - 1, 0.5, w - 1.5, w / 2 + 0.25, 3.75, w - 2, 7]
+    extra["y"] = [0, h - 1, h - 1, 0.5, 1.5, h / 2 + 0.5, 2, h - 3]
+    rng = np.random.default_rng(seed)
+    kp = np.concatenate([kp, extra])
+    kp["x"][:len(kp) // 3] += rng.uniform(-0.5, 0.5, len(kp) // 3).astype(f32)      # sub-pixel corners too
+    kp["x"] = np.clip(kp["x"], 0, w - 1)
+    return kp
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (97, 131), (33, 35), (5, 9), (2, 2), (1, 7), (64, 1)])
+def test_pyramid_and_derivatives_match_numpy(shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(0, 256, size=shape).astype(np.uint8)
+    img[: shape[0] // 2, : shape[1] // 2] = 255                  # saturated block: the extreme derivative values
+    assert pyoracle.pyr_down(img).tobytes() == numpy_pyr_down(img).tobytes()
+    assert pyoracle.scharr_deriv(img).tobytes() == numpy_scharr(img).tobytes()
+    buf = np.zeros((shape[0], shape[1] + 5), np.uint8)           # pitch > width
+    buf[:, :shape[1]] = img
+    assert pyoracle.pyr_down(buf[:, :shape[1]]).tobytes() == numpy_pyr_down(img).tobytes()
+
+
+@pytest.mark.parametrize("seed,shape,win,max_level,n", [
+    (1, (120, 160), (15, 3), 5, 40), (2, (97, 131), (21, 21), 3, 25), (3, (240, 376), (15, 3), 5, 40),
+    (4, (64, 80), (5, 7), 0, 25), (5, (480, 752), (15, 3), 5, 30),
+])
+def test_tracker_matches_numpy(seed, shape, win, max_level, n):
+    left, right, _ = ec.make_stereo_pair(seed, width=shape[1], height=shape[0], max_disp=min(40.0, shape[1] / 6))
+    kp = corners_for(left, n, seed)
+    prm = _abi.stereo_flow_params(win_width=win[0], win_height=win[1], max_level=max_level)
+    xy, st, err, levels = pyoracle.stereo_correspondences(left, right, kp, prm, want_levels=True)
+    xy2, st2, err2 = numpy_lk(np.ascontiguousarray(left), np.ascontiguousarray(right), kp, prm)
+    assert levels == len(build_levels(np.ascontiguousarray(left), win[0], win[1], max_level))
+    assert np.array_equal(st, st2) and xy.tobytes() == xy2.tobytes() and err.tobytes() == err2.tobytes()
+    assert st.sum() >= (3 if max_level == 0 else n // 3)
+
+
+def test_planted_disparity_is_recovered():
+    left, right, disp = ec.make_stereo_pair(11, max_disp=40.0)
+    kp = pyoracle.detect_corners(left, 600, 0.001, 5.0)
+    xy, st, err = pyoracle.stereo_correspondences(left, right, kp)
+    assert st.mean() > 0.85
+    ok = st != 0
+    h, w = left.shape
+    # the field is defined on the RIGHT image's grid: right(x) = left(x + d(x))
+    want = disp[np.clip(np.rint(xy[:, 1]).astype(int), 0, h - 1), np.clip(np.rint(xy[:, 0]).astype(int), 0, w - 1)]
+    got = kp["x"] - xy[:, 0]
+    assert np.median(np.abs(got[ok] - want[ok])) < 0.15 and np.percentile(np.abs(got[ok] - want[ok]), 90) < 0.6
+    assert np.percentile(np.abs(xy[ok, 1] - kp["y"][ok]), 95) < 1.0   # rectified pair: rows agree
+    assert (got[ok] > 0.5).all() and (got[ok] <= 128).all()          # the disparity gate
+
+
+def test_gates_and_degenerate_inputs():
+    left, right, _ = ec.make_stereo_pair(12, width=200, height=120, max_disp=20.0)
+    kp = corners_for(left, 60, 12)
+    # identical images: zero disparity -> every status cleared by the gate, positions stay on the corners
+    xy, st, _ = pyoracle.stereo_correspondences(left, left, kp)
+    assert not st.any() and np.abs(xy - np.stack([kp["x"], kp["y"]], axis=1)).max() < 0.05
+    # flat images: no structure -> minimum-eigenvalue test fails at every level, err 0, position untouched
+    flat = np.full_like(np.ascontiguousarray(left), 90)
+    xy, st, err = pyoracle.stereo_correspondences(flat, flat, kp)
+    assert not st.any() and (err == 0).all()
+    assert np.abs(xy - np.stack([kp["x"], kp["y"]], axis=1)).max() < 1e-3       # (scaled down, doubled back up)
+    # a narrower gate rejects more, never touches the positions
+    wide = pyoracle.stereo_correspondences(left, right, kp)
+    narrow = pyoracle.stereo_correspondences(left, right, kp, _abi.stereo_flow_params(min_disparity=8.0, max_disparity=12.0))
+    assert wide[0].tobytes() == narrow[0].tobytes() and narrow[1].sum() < wide[1].sum() and (narrow[1] <= wide[1]).all()
+    d = kp["x"] - narrow[0][:, 0]
+    assert ((d > 8.0) & (d <= 12.0))[narrow[1] != 0].all()
+    # iterations 0: nothing moves (top-level start, doubled down the levels)
+    still = pyoracle.stereo_correspondences(left, right, kp, _abi.stereo_flow_params(iterations=0))
+    assert np.abs(still[0][:, 0] - kp["x"]).max() < 1e-3
+    # no corners
+    xy, st, err = pyoracle.stereo_correspondences(left, right, kp[:0])
+    assert len(xy) == 0 and len(st) == 0

@@ -54,6 +54,25 @@ def main():
     torch.cuda.synchronize()
     print("sf_detect_corners_device (max 1000, quality 0.001, minDistance 3): %d corners, %.1f us per call (wall, "
           "synchronous)" % (nc, (time.perf_counter() - t0) * 1e6 / 50))
+    # the stereo correspondence between the two (pyramids of both images + one tracker launch), on a real pair
+    left, right, _ = ec.make_stereo_pair(5, pad=0)
+    dl, dr = torch.from_numpy(np.ascontiguousarray(left)).to(dev), torch.from_numpy(np.ascontiguousarray(right)).to(dev)
+    nc = f.detect_corners_device(dl.data_ptr(), w, h, w, 1000, 0.001, 3.0, d_out.data_ptr(), 4096)
+    d_xy = torch.zeros((nc, 2), dtype=torch.float32, device=dev)
+    d_s = torch.zeros(nc, dtype=torch.uint8, device=dev)
+    d_x = torch.zeros(nc, dtype=torch.float32, device=dev)
+    for _ in range(5):
+        f.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, w, d_out.data_ptr(), nc, d_xy.data_ptr(),
+                                        d_s.data_ptr(), d_x.data_ptr())
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        f.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, w, d_out.data_ptr(), nc, d_xy.data_ptr(),
+                                        d_s.data_ptr(), d_x.data_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    print("sf_stereo_correspondences_device (15 x 3 window, 6 levels, <= 30 steps): %d corners, %d tracked, %.1f us per "
+          "call (asynchronous, %d back to back)" % (nc, int(d_s.sum()), e0.elapsed_time(e1) * 1e3 / reps, reps))
     f.close()
 
 
