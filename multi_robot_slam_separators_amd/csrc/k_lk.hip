@@ -1,8 +1,9 @@
 // k_lk.hip -- stereo correspondence of the corners: the right-image position of every
 // corner, what rtabmap's Feature2D::generateKeypoints3D obtains from StereoOpticalFlow::computeCorrespondences
 // (cv::calcOpticalFlowPyrLK + disparity gate) for the reference's getFeaturesImpl (myRegistrationVis.cpp:382, called
-// from stereoCamGeometricTools.cpp:100-120).  Arithmetic and order follow oracle/sf_oracle_lk.c (its header lists the
-// steps and the one place where OpenCV's result depends on its build); compiled with -ffp-contract=off.
+// from stereoCamGeometricTools.cpp:100-120).  Arithmetic and order are those of the CPU restatement the tests compare
+// against (deviation 17 names the one place where OpenCV's result depends on its build: float
+// versus integer accumulation of A and b); compiled with -ffp-contract=off.
 //
 //   k_lk_pyr_down   one thread per output pixel of a pyramid level, both images in one launch (blockIdx.z): 5 x 5
 //                   Gaussian in integers, BORDER_REFLECT_101.  Levels are small (361 KB at level 0 of a 752 x 480
