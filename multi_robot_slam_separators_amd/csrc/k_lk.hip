@@ -13,9 +13,11 @@
 //                   first image goes to LDS once; its Scharr derivatives are computed THERE for the (w + 1) x (h + 1)
 //                   positions the bilinear taps touch (no derivative planes in HBM: 16 B per pixel and level saved,
 //                   and one launch per level); lanes own window elements; A and b are exact integer sums reduced
-//                   across the wavefront, so the result does not depend on the reduction order.  Per Newton step one
-//                   (w + 1) x (h + 1) patch of the second image is fetched: the chain of dependent steps (<= 30 per
-//                   level) is what the kernel's duration consists of.
+//                   across the wavefront (DPP row scans + v_readlane for windows of <= 64 pixels), so the result
+//                   does not depend on the reduction order.  The second image around the level's start position
+//                   (+-8 x +-3 pixels beyond the window) is fetched into LDS together with the first image's patch:
+//                   ONE trip to memory per level, and the chain of dependent Newton steps (<= 30 per level) runs
+//                   from LDS; a step that leaves the region re-centres it (same pixels, so the same result).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,6 +28,7 @@ namespace {
 
 constexpr int LK_MAX_LEVELS = 16;
 constexpr int LK_W_BITS = 14;
+constexpr int LK_REGION_X = 8, LK_REGION_Y = 3;
 
 struct LkLevel {
   const uint8_t* l;
@@ -71,7 +74,18 @@ __device__ __forceinline__ long long wave_sum(long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-
+// 32-bit sum over the wavefront without the LDS crossbar: a shifted-add scan inside each row of 16 lanes on the DPP
+// path (lanes without a source add 0), then the four row totals through v_readlane -- the result is wave uniform.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  return (__builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31)) +
+         (__builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63));
+}
+// Up to 64 window elements (one per lane) the sums of products stay below 2^31 -- |I_x|, |I_y| <= 4080 (Scharr of 8-bit
+// data), |J - I| <= 8160 (5 fractional bits): 64 * 8160 * 4080 = 2 130 739 200 -- and take this path.
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 struct LkWeights { int w00, w01, w10, w11; };
@@ -84,6 +98,8 @@ __device__ __forceinline__ LkWeights lk_weights(float a, float b) {
   return w;
 }
 
+// SMALL: windows of <= 64 pixels (rtabmap's 15 x 3): one element per lane, kept in registers, 32-bit sums.
+template <bool SMALL>
 __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keypoint* __restrict__ kp, int n, int ww, int wh,
                                                  int max_count, double eps2, float min_eig_thr, float min_disp,
                                                  float max_disp, float* __restrict__ xy_out, uint8_t* __restrict__ st_out,
@@ -99,6 +115,14 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
   short2* dIw = der + dw * dh;
   short* Iw = reinterpret_cast<short*>(dIw + area);
   unsigned char* patch = reinterpret_cast<unsigned char*>(Iw + ((area + 1) & ~1));
+  // the second image around the level's start position: the Newton steps read it from LDS and only a step that
+  // leaves it (more than LK_REGION_X / LK_REGION_Y pixels from the start) costs another trip to memory
+  const int rw = dw + 2 * LK_REGION_X, rh = dh + 2 * LK_REGION_Y;
+  unsigned char* region = patch + ((pw * ph + 3) & ~3);
+  const int ey = SMALL ? lane / ww : 0, ex = SMALL ? lane - ey * ww : 0;      // this lane's window element (SMALL)
+  const bool act = lane < area;
+  const int roff = ey * rw + ex;
+  int rI = 0, rdx = 0, rdy = 0;
 
   const float kx = kp[p].x, ky = kp[p].y;
   const float half_x = (float)(ww - 1) * 0.5f, half_y = (float)(wh - 1) * 0.5f;
@@ -119,10 +143,15 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
       if (level == 0) { st = 0; er = 0.0f; }
       continue;
     }
-    __syncthreads();                                       // (the previous level's readers of `patch` are done)
+    __syncthreads();                                       // (the previous level's readers of the patches are done)
     for (int e = lane; e < pw * ph; e += 64) {
       const int yy = e / pw, xx = e - yy * pw;
       patch[e] = L.l[(size_t)border_101(ipy - 1 + yy, L.h) * L.pitch + border_101(ipx - 1 + xx, L.w)];
+    }
+    int rx0 = (int)floorf(qx - half_x) - LK_REGION_X, ry0 = (int)floorf(qy - half_y) - LK_REGION_Y;
+    for (int e = lane; e < rw * rh; e += 64) {             // (in flight together with the patch above)
+      const int yy = e / rw, xx = e - yy * rw;
+      region[e] = L.r[(size_t)border_101(ry0 + yy, L.h) * L.pitch + border_101(rx0 + xx, L.w)];
     }
     __syncthreads();
     // calcSharrDeriv at the positions inside the image (REFLECT_101 taps are in the patch already), 0 outside
@@ -142,19 +171,33 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
     __syncthreads();
     LkWeights W = lk_weights(px - (float)ipx, py - (float)ipy);
     long long a11 = 0, a12 = 0, a22 = 0;
-    for (int e = lane; e < area; e += 64) {
-      const int y = e / ww, x = e - y * ww;
-      const unsigned char* q0 = patch + (y + 1) * pw + x + 1;
-      const unsigned char* q1 = q0 + pw;
-      const int ival = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5);
-      const short2 e00 = der[y * dw + x], e01 = der[y * dw + x + 1], e10 = der[(y + 1) * dw + x], e11 = der[(y + 1) * dw + x + 1];
-      const int ixval = descale((int)e00.x * W.w00 + (int)e01.x * W.w01 + (int)e10.x * W.w10 + (int)e11.x * W.w11, LK_W_BITS);
-      const int iyval = descale((int)e00.y * W.w00 + (int)e01.y * W.w01 + (int)e10.y * W.w10 + (int)e11.y * W.w11, LK_W_BITS);
-      Iw[e] = (short)ival;
-      dIw[e] = make_short2((short)ixval, (short)iyval);
-      a11 += (long long)(ixval * ixval); a12 += (long long)(ixval * iyval); a22 += (long long)(iyval * iyval);
+    if constexpr (SMALL) {
+      int s11 = 0, s12 = 0, s22 = 0;
+      if (act) {
+        const unsigned char* q0 = patch + (ey + 1) * pw + ex + 1;
+        const unsigned char* q1 = q0 + pw;
+        rI = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5);
+        const short2 e00 = der[ey * dw + ex], e01 = der[ey * dw + ex + 1], e10 = der[(ey + 1) * dw + ex], e11 = der[(ey + 1) * dw + ex + 1];
+        rdx = descale((int)e00.x * W.w00 + (int)e01.x * W.w01 + (int)e10.x * W.w10 + (int)e11.x * W.w11, LK_W_BITS);
+        rdy = descale((int)e00.y * W.w00 + (int)e01.y * W.w01 + (int)e10.y * W.w10 + (int)e11.y * W.w11, LK_W_BITS);
+        s11 = rdx * rdx; s12 = rdx * rdy; s22 = rdy * rdy;
+      }
+      a11 = wave_sum_i32(s11); a12 = wave_sum_i32(s12); a22 = wave_sum_i32(s22);
+    } else {
+      for (int e = lane; e < area; e += 64) {
+        const int y = e / ww, x = e - y * ww;
+        const unsigned char* q0 = patch + (y + 1) * pw + x + 1;
+        const unsigned char* q1 = q0 + pw;
+        const int ival = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5);
+        const short2 e00 = der[y * dw + x], e01 = der[y * dw + x + 1], e10 = der[(y + 1) * dw + x], e11 = der[(y + 1) * dw + x + 1];
+        const int ixval = descale((int)e00.x * W.w00 + (int)e01.x * W.w01 + (int)e10.x * W.w10 + (int)e11.x * W.w11, LK_W_BITS);
+        const int iyval = descale((int)e00.y * W.w00 + (int)e01.y * W.w01 + (int)e10.y * W.w10 + (int)e11.y * W.w11, LK_W_BITS);
+        Iw[e] = (short)ival;
+        dIw[e] = make_short2((short)ixval, (short)iyval);
+        a11 += (long long)(ixval * ixval); a12 += (long long)(ixval * iyval); a22 += (long long)(iyval * iyval);
+      }
+      a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
     }
-    a11 = wave_sum(a11); a12 = wave_sum(a12); a22 = wave_sum(a22);
     const float A11 = (float)a11 * FLT_SCALE, A12 = (float)a12 * FLT_SCALE, A22 = (float)a22 * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww * wh);
@@ -172,23 +215,38 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
         if (level == 0) st = 0;
         break;
       }
-      __syncthreads();
-      for (int e = lane; e < dw * dh; e += 64) {
-        const int yy = e / dw, xx = e - yy * dw;
-        patch[e] = L.r[(size_t)border_101(iqy + yy, L.h) * L.pitch + border_101(iqx + xx, L.w)];
+      if (iqx < rx0 || iqx + dw > rx0 + rw || iqy < ry0 || iqy + dh > ry0 + rh) {     // left the region: centre it here
+        rx0 = iqx - LK_REGION_X; ry0 = iqy - LK_REGION_Y;
+        __syncthreads();
+        for (int e = lane; e < rw * rh; e += 64) {
+          const int yy = e / rw, xx = e - yy * rw;
+          region[e] = L.r[(size_t)border_101(ry0 + yy, L.h) * L.pitch + border_101(rx0 + xx, L.w)];
+        }
+        __syncthreads();
       }
-      __syncthreads();
       W = lk_weights(qx - (float)iqx, qy - (float)iqy);
       long long b1s = 0, b2s = 0;
-      for (int e = lane; e < area; e += 64) {
-        const int y = e / ww, x = e - y * ww;
-        const unsigned char* q0 = patch + y * dw + x;
-        const unsigned char* q1 = q0 + dw;
-        const int diff = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5) - (int)Iw[e];
-        const short2 d = dIw[e];
-        b1s += (long long)(diff * (int)d.x); b2s += (long long)(diff * (int)d.y);
+      const unsigned char* rbase = region + (iqy - ry0) * rw + (iqx - rx0);
+      if constexpr (SMALL) {
+        int t1 = 0, t2 = 0;
+        if (act) {
+          const unsigned char* q0 = rbase + roff;
+          const unsigned char* q1 = q0 + rw;
+          const int diff = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5) - rI;
+          t1 = diff * rdx; t2 = diff * rdy;
+        }
+        b1s = wave_sum_i32(t1); b2s = wave_sum_i32(t2);
+      } else {
+        for (int e = lane; e < area; e += 64) {
+          const int y = e / ww, x = e - y * ww;
+          const unsigned char* q0 = rbase + y * rw + x;
+          const unsigned char* q1 = q0 + rw;
+          const int diff = descale((int)q0[0] * W.w00 + (int)q0[1] * W.w01 + (int)q1[0] * W.w10 + (int)q1[1] * W.w11, LK_W_BITS - 5) - (int)Iw[e];
+          const short2 d = dIw[e];
+          b1s += (long long)(diff * (int)d.x); b2s += (long long)(diff * (int)d.y);
+        }
+        b1s = wave_sum(b1s); b2s = wave_sum(b2s);
       }
-      b1s = wave_sum(b1s); b2s = wave_sum(b2s);
       const float b1 = (float)b1s * FLT_SCALE, b2 = (float)b2s * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
       qx += dx; qy += dy;
@@ -255,9 +313,15 @@ int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d
   double eps = std::min(std::max(prm->epsilon, 0.0), 10.0);
   eps *= eps;
   const int area = ww * wh;
-  const size_t smem = (size_t)(ww + 1) * (wh + 1) * 4 + (size_t)area * 4 + (size_t)((area + 1) & ~1) * 2 + (size_t)(ww + 3) * (wh + 3);
-  hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
-                     prm->min_eig_threshold, prm->min_disparity, prm->max_disparity, d_right_xy, d_status, d_right_x, d_err);
+  const size_t smem = (size_t)(ww + 1) * (wh + 1) * 4 + (size_t)area * 4 + (size_t)((area + 1) & ~1) * 2 +
+                      (((size_t)(ww + 3) * (wh + 3) + 3) & ~(size_t)3) +
+                      (size_t)(ww + 1 + 2 * LK_REGION_X) * (wh + 1 + 2 * LK_REGION_Y);
+  if (area <= 64)
+    hipLaunchKernelGGL(k_lk_track<true>, dim3(n), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
+                       prm->min_eig_threshold, prm->min_disparity, prm->max_disparity, d_right_xy, d_status, d_right_x, d_err);
+  else
+    hipLaunchKernelGGL(k_lk_track<false>, dim3(n), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
+                       prm->min_eig_threshold, prm->min_disparity, prm->max_disparity, d_right_xy, d_status, d_right_x, d_err);
   SF_HIP(c, hipGetLastError());
   return SF_OK;
 }
