@@ -76,7 +76,14 @@ k_gftt_eig(const float* __restrict__ dxx, const float* __restrict__ dxy, const f
   int m = e > 0.f ? __float_as_int(e) : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_bits, m);
+  // same-address atomics serialise in L2 (a few ns each): one per workgroup, and only when it can raise the maximum
+  __shared__ int s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    if (m > __builtin_nontemporal_load(max_bits)) atomicMax(max_bits, m);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -166,6 +173,96 @@ k_gftt_select(const unsigned long long* __restrict__ keys, int n, int w, int cel
   if (lane == 0) *n_out = out;
 }
 
+// The same selection with the taken corners as a BITMAP of the image in LDS (one bit per pixel: 45 KB for 752 x 480):
+// "no taken corner closer than minDistance" is a test of the bits inside the disc around the candidate, row by row,
+// and nothing of a step waits for HBM (the cell lists of k_gftt_select cost a chain of dependent loads per step: 10 us
+// per 64 candidates).  The distance test is the reference's -- dx * dx + dy * dy < minDistance^2 in float, exact for
+// these integers -- only tabulated per row offset (span[dy] = largest |dx| inside the disc).  Within the 64 candidates
+// of a step the lanes that are still standing take their turn in list order and knock out the later ones.
+constexpr int GFTT_MAX_RADIUS = 64;
+__global__ void __launch_bounds__(256)
+k_gftt_select_lds(const unsigned long long* __restrict__ keys, int n, int w, int h, int wpr, float md2, int radius,
+                  int max_corners, sf_keypoint* __restrict__ kp_out, int cap, int32_t* __restrict__ n_out) {
+  extern __shared__ unsigned gf_bm[];
+  __shared__ int span[2 * GFTT_MAX_RADIUS + 1];
+  for (int i = threadIdx.x; i < wpr * h; i += 256) gf_bm[i] = 0u;
+  if ((int)threadIdx.x <= 2 * radius) {
+    const float dy = (float)((int)threadIdx.x - radius);
+    int s = -1;
+    while (s + 1 <= radius && (float)(s + 1) * (float)(s + 1) + dy * dy < md2) ++s;
+    span[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  int out = 0;
+  unsigned long long key = lane < n ? keys[lane] : 0ull;
+  for (int base = 0; base < n && (max_corners <= 0 || out < max_corners); base += 64) {
+    const int i = base + lane;
+    const bool valid = i < n;
+    const int idx = (int)(unsigned)(key & 0xFFFFFFFFull);
+    key = i + 64 < n ? keys[i + 64] : 0ull;                  // (the next step's candidates, in flight during this one)
+    const int y = idx / w, x = idx - y * w;
+    bool good = valid;
+    if (radius > 0 && good) {
+      for (int dy = -radius; dy <= radius && good; ++dy) {
+        const int yy = y + dy, s = span[dy + radius];
+        if (yy < 0 || yy >= h || s < 0) continue;
+        const int lo = max(x - s, 0), hi = min(x + s, w - 1);
+        const unsigned* row = gf_bm + yy * wpr;
+        for (int wd = lo >> 5; wd <= hi >> 5; ++wd) {
+          unsigned m = 0xFFFFFFFFu;
+          if (wd == lo >> 5) m &= 0xFFFFFFFFu << (lo & 31);
+          if (wd == hi >> 5) m &= 0xFFFFFFFFu >> (31 - (hi & 31));
+          if (row[wd] & m) good = false;
+        }
+      }
+    }
+    if (radius > 0) {
+      // The candidates of this step among themselves, in list order: lane i stands unless a STANDING earlier lane is
+      // within minDistance.  Every lane first collects the earlier lanes within minDistance (64 independent tests on
+      // v_readlane broadcasts, no chain), then the standing set is settled in rounds: a lane whose earlier
+      // neighbours are all settled is settled itself -- as many rounds as the longest chain of neighbours (2 - 4),
+      // instead of 64 dependent turns.
+      const unsigned long long alive = __ballot(good);
+      unsigned c_lo = 0u, c_hi = 0u;
+#pragma unroll
+      for (int j = 0; j < 63; ++j) {
+        const int xj = __builtin_amdgcn_readlane(x, j), yj = __builtin_amdgcn_readlane(y, j);
+        const float dx = (float)(x - xj), dy = (float)(y - yj);
+        const bool near = dx * dx + dy * dy < md2 && lane > j;
+        if (j < 32) c_lo |= near ? (1u << j) : 0u; else c_hi |= near ? (1u << (j - 32)) : 0u;
+      }
+      const unsigned long long conf = (((unsigned long long)c_hi << 32) | c_lo) & alive;
+      unsigned long long und = alive, acc = 0ull;
+      while (und) {
+        const bool mine = (und >> lane) & 1ull;
+        const bool rej = mine && (conf & acc) != 0ull;
+        const bool ok = mine && !rej && (conf & und) == 0ull;
+        const unsigned long long r = __ballot(rej), a = __ballot(ok);
+        acc |= a;
+        und &= ~(r | a);
+      }
+      good = (acc >> lane) & 1ull;
+    }
+    const unsigned long long bal = __ballot(good);
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    const int cnt = __popcll(bal);
+    const int room = max_corners > 0 ? max_corners - out : 0x7FFFFFFF;
+    if (good && rank < room) {
+      const int o = out + rank;
+      if (radius > 0) atomicOr(&gf_bm[y * wpr + (x >> 5)], 1u << (x & 31));
+      if (o < cap) {
+        sf_keypoint k;
+        k.x = (float)x; k.y = (float)y; k.size = 3.0f; k.angle = -1.0f; k.response = 0.0f; k.octave = 0; k.class_id = -1;
+        kp_out[o] = k;
+      }
+    }
+    out += min(cnt, room);
+  }
+  if (lane == 0) *n_out = out;
+}
+
 }  // namespace
 
 // Launch sequence on the handle's stream.  The candidate count crosses to the host once (the sort is sized by it).
@@ -207,17 +304,30 @@ int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, i
     if ((rc = sf_buf_reserve(c, c->gf_tmp, std::max<size_t>(tmp_bytes, 16))) != SF_OK) return rc;
     SF_HIP(c, rocprim::radix_sort_keys_desc(c->gf_tmp.p, tmp_bytes, keys, keys_sorted, (size_t)n, 0, 64, c->stream));
   }
-  const int cell = min_distance >= 1.0 ? (int)std::lrint(min_distance) : 0;
-  const int gw = cell > 0 ? (width + cell - 1) / cell : 1, gh = cell > 0 ? (height + cell - 1) / cell : 1;
-  const size_t list_n = (size_t)std::max(n, 1);
-  const size_t n_int = (((size_t)gw * gh + list_n) + 1) & ~(size_t)1;       // (keeps the int2 array 8-byte aligned)
-  if ((rc = sf_buf_reserve(c, c->gf_lists, n_int * sizeof(int) + list_n * sizeof(int2))) != SF_OK) return rc;
-  int* head = (int*)c->gf_lists.p;
-  int* next = head + (size_t)gw * gh;
-  int2* pts = (int2*)(head + n_int);
-  SF_HIP(c, hipMemsetAsync(head, 0xFF, (size_t)gw * gh * sizeof(int), c->stream));
-  hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)keys_sorted, n, width, cell,
-                     gw, gh, (float)(min_distance * min_distance), max_corners, head, next, pts, d_kpts_out, cap, d_n_out);
+  // taken corners as a bitmap in LDS when the image fits (up to about 1.2 Mpixel), cell lists in HBM otherwise
+  const int wpr = (width + 31) / 32;
+  const size_t bm_bytes = (size_t)wpr * height * sizeof(unsigned);
+  const int radius = min_distance >= 1.0 ? (int)std::ceil(min_distance) : 0;
+  if (bm_bytes <= 150 * 1024 && radius <= GFTT_MAX_RADIUS && !getenv("SF_GFTT_LISTS")) {
+    if (!c->gf_select_attr) {
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_gftt_select_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      c->gf_select_attr = true;
+    }
+    hipLaunchKernelGGL(k_gftt_select_lds, dim3(1), dim3(256), bm_bytes, c->stream, (const unsigned long long*)keys_sorted, n,
+                       width, height, wpr, (float)(min_distance * min_distance), radius, max_corners, d_kpts_out, cap, d_n_out);
+  } else {
+    const int cell = min_distance >= 1.0 ? (int)std::lrint(min_distance) : 0;
+    const int gw = cell > 0 ? (width + cell - 1) / cell : 1, gh = cell > 0 ? (height + cell - 1) / cell : 1;
+    const size_t list_n = (size_t)std::max(n, 1);
+    const size_t n_int = (((size_t)gw * gh + list_n) + 1) & ~(size_t)1;       // (keeps the int2 array 8-byte aligned)
+    if ((rc = sf_buf_reserve(c, c->gf_lists, n_int * sizeof(int) + list_n * sizeof(int2))) != SF_OK) return rc;
+    int* head = (int*)c->gf_lists.p;
+    int* next = head + (size_t)gw * gh;
+    int2* pts = (int2*)(head + n_int);
+    SF_HIP(c, hipMemsetAsync(head, 0xFF, (size_t)gw * gh * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_gftt_select, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)keys_sorted, n, width, cell,
+                       gw, gh, (float)(min_distance * min_distance), max_corners, head, next, pts, d_kpts_out, cap, d_n_out);
+  }
   SF_HIP(c, hipGetLastError());
   if (n_out) {
     SF_HIP(c, hipMemcpyAsync(n_out, d_n_out, 4, hipMemcpyDeviceToHost, c->stream));

@@ -206,6 +206,7 @@ struct sf_context {
   bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
   int cu_count = 0;         // compute units of the device (grids sized to the chip); filled on first use
+  bool gf_select_attr = false; // k_gftt_select_lds: dynamic LDS attribute set
   bool nn_k128_attr = false;   // k_nn_filter_f16_k128: dynamic LDS attribute set
   bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
   bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
