@@ -11,10 +11,12 @@
 //                      neighbourhood -> 64-bit keys (response bits << 32 | pixel index), one global atomic per workgroup
 //   rocprim radix sort keys descending = decreasing response, ties by decreasing address (featureselect.cpp's
 //                      greaterThanPtr); a plain library sort, the only library call of the product's compute path
-//   k_gftt_select      ONE wavefront walks the sorted list 64 candidates at a time: every lane tests its candidate
-//                      against the corners already taken (grid of minDistance cells, per-cell lists), the 64 lanes
-//                      settle conflicts among themselves in list order, the survivors are appended -- the sequential
-//                      minDistance rule of goodFeaturesToTrack, 64 candidates per step.
+//   k_gftt_select_lds  ONE wavefront walks the sorted list 64 candidates at a time: every lane tests its candidate
+//                      against the corners already taken (a bitmap of the image in LDS), the 64 lanes settle
+//                      conflicts among themselves in list order (in rounds, not in 64 turns), the survivors are
+//                      appended -- the sequential minDistance rule of goodFeaturesToTrack, 64 candidates per step.
+//   k_gftt_select      the same with the taken corners in per-cell lists in HBM: images whose bitmap does not fit
+//                      LDS (above about 1.2 Mpixel), or SF_GFTT_LISTS=1.
 #include <hip/hip_runtime.h>
 
 #include <cstring>   // (rocprim's texture_cache_iterator.hpp calls memset without declaring it)
@@ -86,37 +88,45 @@ k_gftt_eig(const float* __restrict__ dxx, const float* __restrict__ dxy, const f
   }
 }
 
+constexpr int GFTT_CAND_TILES = 4;      // 64 x 4 pixel tiles per workgroup of k_gftt_candidates
 __global__ void __launch_bounds__(256)
 k_gftt_candidates(const float* __restrict__ eig, int w, int h, const int* __restrict__ max_bits, double quality,
                   unsigned long long* __restrict__ keys, unsigned* __restrict__ count, unsigned cap) {
-  __shared__ unsigned long long s_keys[256];
+  // (the counter is ONE address: a returning atomic per 64 x 4 tile was most of this kernel's 20 us -- four tiles
+  // per workgroup share one)
+  __shared__ unsigned long long s_keys[256 * GFTT_CAND_TILES];
   __shared__ unsigned s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const float thr = (float)((double)__int_as_float(*max_bits) * quality);
-  if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-    const float v = eig[(size_t)y * w + x];
-    if (v > thr) {
-      float m = 0.f;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+  for (int t = 0; t < GFTT_CAND_TILES; ++t) {
+    const int y = (blockIdx.y * GFTT_CAND_TILES + t) * 4 + (threadIdx.x >> 6);
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+      const float v = eig[(size_t)y * w + x];
+      if (v > thr) {
+        float m = 0.f;
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const float u = eig[(size_t)(y + dy) * w + x + dx];
-          const float t = u > thr ? u : 0.f;
-          m = t > m ? t : m;
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const float u = eig[(size_t)(y + dy) * w + x + dx];
+            const float tt = u > thr ? u : 0.f;
+            m = tt > m ? tt : m;
+          }
+        if (v == m) {
+          const unsigned p = atomicAdd(&s_n, 1u);
+          s_keys[p] = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(y * w + x);
         }
-      if (v == m) {
-        const unsigned p = atomicAdd(&s_n, 1u);
-        s_keys[p] = ((unsigned long long)(unsigned)__float_as_int(v) << 32) | (unsigned)(y * w + x);
       }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
   __syncthreads();
-  if (threadIdx.x < s_n && s_base + threadIdx.x < cap) keys[s_base + threadIdx.x] = s_keys[threadIdx.x];
+  for (unsigned i = threadIdx.x; i < s_n; i += 256)
+    if (s_base + i < cap) keys[s_base + i] = s_keys[i];
 }
 
 __global__ void __launch_bounds__(64)
@@ -291,7 +301,8 @@ int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, i
                      (float)(2.0 * scale), dxx, dxy, dyy);
   hipLaunchKernelGGL(k_gftt_eig, grid, block, 0, c->stream, (const float*)dxx, (const float*)dxy, (const float*)dyy, width,
                      height, eig, max_bits);
-  hipLaunchKernelGGL(k_gftt_candidates, grid, block, 0, c->stream, (const float*)eig, width, height, (const int*)max_bits,
+  const dim3 grid_c((width + 63) / 64, (height + 4 * GFTT_CAND_TILES - 1) / (4 * GFTT_CAND_TILES));
+  hipLaunchKernelGGL(k_gftt_candidates, grid_c, block, 0, c->stream, (const float*)eig, width, height, (const int*)max_bits,
                      quality_level, keys, count, key_cap);
   SF_HIP(c, hipGetLastError());
   unsigned h_count = 0;
