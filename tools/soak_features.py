@@ -1,5 +1,6 @@
 """Parity soak of the feature path: random image sizes / textures / parameters through
-sf_detect_corners_device and sf_extract_keyframe_device against the oracle, byte for byte.
+sf_detect_corners_device, sf_stereo_correspondences_device (random stereo pairs, windows, level counts, iteration
+limits) and sf_extract_keyframe_device against the oracle, byte for byte.
 usage: python tools/soak_features.py [rounds=40]"""
 import os
 import sys
@@ -64,6 +65,37 @@ def main():
             got = d_xyz.cpu().numpy()[:rows]
             ok = ok and rows == len(d) and d_desc.cpu().numpy()[:rows].tobytes() == d.tobytes() and \
                 np.array_equal(np.isnan(got), np.isnan(pz)) and got[~np.isnan(got)].tobytes() == pz[~np.isnan(pz)].tobytes()
+        # stereo correspondence of detector corners on a random rectified pair
+        left, right, _ = ec.make_stereo_pair(rd, width=w, height=h, pad=int(rng.integers(0, 9)),
+                                             max_disp=float(rng.uniform(3.0, max(4.0, min(60.0, w / 5)))))
+        kl = pyoracle.detect_corners(left, int(rng.choice([100, 1000, 2500])), 0.001, 3.0)
+        kl["x"] += rng.uniform(-0.5, 0.5, len(kl)).astype(np.float32) * float(rng.choice([0.0, 1.0]))
+        kl["x"] = np.clip(kl["x"], 0, w - 1)
+        win = [(15, 3), (15, 3), (21, 21), (5, 5), (9, 3), (31, 31), (3, 7)][int(rng.integers(0, 7))]
+        prm = _abi.stereo_flow_params(win_width=win[0], win_height=win[1], max_level=int(rng.integers(0, 7)),
+                                      iterations=int(rng.choice([1, 10, 30, 100])), epsilon=float(rng.choice([0.0, 0.01, 0.03])),
+                                      min_disparity=float(rng.choice([0.0, 0.5])), max_disparity=float(rng.choice([16.0, 128.0])))
+        lp = left.strides[0]
+
+        def up(img):
+            b = np.lib.stride_tricks.as_strided(img, shape=(h, lp), strides=(lp, 1)) if lp != w else img
+            return torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+        dl, dr = up(left), up(right)
+        nk = len(kl)
+        d_k = torch.from_numpy(np.frombuffer(kl.tobytes() + b"\0" * 28, np.uint8).copy()).to(dev)
+        d_xy = torch.zeros((nk + 1, 2), dtype=torch.float32, device=dev)
+        d_s = torch.zeros(nk + 1, dtype=torch.uint8, device=dev)
+        d_e = torch.zeros(nk + 1, dtype=torch.float32, device=dev)
+        f.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, lp, d_k.data_ptr(), nk, d_xy.data_ptr(),
+                                        d_s.data_ptr(), None, d_e.data_ptr(), params=prm)
+        torch.cuda.synchronize()
+        xy0, st0, er0 = pyoracle.stereo_correspondences(left, right, kl, prm)
+        ok_lk = d_xy.cpu().numpy()[:nk].tobytes() == xy0.tobytes() and np.array_equal(d_s.cpu().numpy()[:nk], st0) and \
+            d_e.cpu().numpy()[:nk].tobytes() == er0.tobytes()
+        if not ok_lk:
+            print("round %d: stereo correspondence MISMATCH (%d x %d, window %s, levels %d, %d corners)" % (
+                rd, w, h, win, prm.max_level, nk), flush=True)
+        ok = ok and ok_lk
         bad += 0 if ok else 1
         if not ok or rd % 10 == 9:
             print("round %d: %d x %d, maxc %d q %g md %g: %d corners %s" % (rd, w, h, maxc, q, md, n, "OK" if ok else "MISMATCH"),
