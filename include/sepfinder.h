@@ -322,6 +322,26 @@ int  sf_extract_keyframe_device(sf_handle h, const uint8_t* d_left, int32_t widt
                                 const sf_keypoint* d_kpts, const float* d_right_x, const uint8_t* d_status,
                                 int32_t n, const sf_stereo_camera* cam, int32_t* out_slot, int32_t* out_rows,
                                 uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out);
+/* The GetFeatsAndDesc service handler in ONE call on host buffers -- replaces the body of
+   StereoCamGeometricTools::getFeaturesAndDescriptor (stereoCamGeometricTools.cpp:100-120: SensorData(img_l, img_r, cam_),
+   registrationPipeline_->getFeatures(...) = myRegistrationVis.cpp:190-439, then the three ...ToROS conversions):
+   sf_detect_corners_device -> sf_stereo_correspondences_device -> sf_extract_keyframe_device on device copies of the
+   pair.  left / right: rectified MONO8 images in host memory (what cv_bridge::toCvCopy returns at :104-105), `pitch`
+   bytes per row.  det NULL = rtabmap's defaults (Vis/MaxFeatures 1000, GFTT/QualityLevel 0.001, GFTT/MinDistance 3),
+   flow NULL = its Stereo/ defaults.  Outputs in host memory, sized for cap_rows rows (any may be NULL): desc_out
+   [rows][bytes of the BRIEF table], xyz_out [rows][3], kpts_out [rows]; *rows_out = features of the keyframe (may
+   exceed cap_rows: only cap_rows are copied); *slot_out (optional) = its slot in the device-resident store, what
+   sf_verify_pairs refers to later.  Synchronous.                                                              */
+typedef struct sf_detector_params {
+  int32_t max_features;      /* 1 .. 32767 (KeyPointVec.size is an int16) */
+  double  quality_level;
+  double  min_distance;
+} sf_detector_params;
+void sf_detector_defaults(sf_detector_params* p);
+int  sf_get_features_and_descriptor(sf_handle h, const uint8_t* left, const uint8_t* right, int32_t width, int32_t height,
+                                    int32_t pitch, const sf_stereo_camera* cam, const sf_detector_params* det,
+                                    const sf_stereo_flow_params* flow, uint8_t* desc_out, float* xyz_out,
+                                    sf_keypoint* kpts_out, int32_t cap_rows, int32_t* rows_out, int32_t* slot_out);
 
 /* ---- geometric verification (stereoCamGeometricTools.cpp:122-178) ---------------------------- */
 /* One estimate_transformation service call on host buffers.                                  */

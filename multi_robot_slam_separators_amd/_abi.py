@@ -114,6 +114,18 @@ def stereo_flow_params(win_width=15, win_height=3, max_level=5, iterations=30, e
     return p
 
 
+class DetectorParams(C.Structure):
+    """sf_detector_params (include/sepfinder.h): cv::goodFeaturesToTrack's arguments in sf_get_features_and_descriptor."""
+    _fields_ = [("max_features", C.c_int32), ("quality_level", C.c_double), ("min_distance", C.c_double)]
+
+
+def detector_params(max_features=1000, quality_level=0.001, min_distance=3.0):
+    """rtabmap's Vis/MaxFeatures, GFTT/QualityLevel, GFTT/MinDistance defaults (what sf_detector_defaults fills)."""
+    p = DetectorParams()
+    p.max_features, p.quality_level, p.min_distance = max_features, quality_level, min_distance
+    return p
+
+
 class NetvladWeights(C.Structure):
     """sf_netvlad_weights (include/sepfinder.h): host pointers to the NetVLAD network's weights, TensorFlow layouts."""
     _fields_ = [

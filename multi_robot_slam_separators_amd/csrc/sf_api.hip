@@ -734,7 +734,7 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
                  &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests,
-                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr};
+                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr, &c->ft_images, &c->ft_kpts, &c->ft_flow, &c->ft_wire};
   for (Buf* b : bufs) buf_free(*b);
   sf_netvlad_free(c);
   sf_ingest_pool_destroy(c);
@@ -939,6 +939,71 @@ extern "C" int sf_extract_keyframe_device(sf_handle c, const uint8_t* d_left, in
   if (out_slot) *out_slot = slot;
   if (out_rows) {
     SF_HIP(c, hipMemcpyAsync(out_rows, c->ex_rows.p, 4, hipMemcpyDeviceToHost, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return SF_OK;
+}
+
+extern "C" void sf_detector_defaults(sf_detector_params* p) {
+  if (!p) return;
+  p->max_features = 1000;      // Vis/MaxFeatures [upstream rtabmap Parameters.h]; the reference sets only Vis/MinInliers
+  p->quality_level = 0.001;    // GFTT/QualityLevel
+  p->min_distance = 3.0;       // GFTT/MinDistance
+}
+
+// The GetFeatsAndDesc handler in one call on HOST buffers: upload the pair, detect, track, extract, download the
+// response.  Everything between the two copies stays on the device; the keyframe is in the store when it returns.
+extern "C" int sf_get_features_and_descriptor(sf_handle c, const uint8_t* left, const uint8_t* right, int32_t width,
+                                              int32_t height, int32_t pitch, const sf_stereo_camera* cam,
+                                              const sf_detector_params* det, const sf_stereo_flow_params* flow,
+                                              uint8_t* desc_out, float* xyz_out, sf_keypoint* kpts_out, int32_t cap_rows,
+                                              int32_t* rows_out, int32_t* slot_out) {
+  if (!c || !cam || !rows_out || cap_rows < 0) return SF_EINVAL;
+  *rows_out = 0;
+  if (!left || !right || width < 3 || height < 3 || pitch < width)
+    return sf_fail(c, SF_EINVAL, "stereo pair missing or malformed (%d x %d, pitch %d)", width, height, pitch);
+  sf_detector_params dp;
+  if (det) dp = *det; else sf_detector_defaults(&dp);
+  if (dp.max_features <= 0 || dp.max_features > SF_MAX_FEATURES)
+    return sf_fail(c, SF_ERANGE, "max_features %d outside 1 .. %d (KeyPointVec.size is an int16)", dp.max_features, SF_MAX_FEATURES);
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc = brief_ensure(c);
+  if (rc != SF_OK) return rc;
+  const size_t img_bytes = ((size_t)width * height + 255) & ~(size_t)255;
+  const int maxf = dp.max_features;
+  if ((rc = sf_buf_reserve(c, c->ft_images, 2 * img_bytes)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ft_kpts, (size_t)maxf * sizeof(sf_keypoint))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ft_flow, (size_t)maxf * 16)) != SF_OK) return rc;
+  const size_t row_bytes = (size_t)c->brief_bytes + 12 + sizeof(sf_keypoint);
+  if ((rc = sf_buf_reserve(c, c->ft_wire, (size_t)maxf * row_bytes + 64)) != SF_OK) return rc;
+  uint8_t* d_left = (uint8_t*)c->ft_images.p;
+  uint8_t* d_right = d_left + img_bytes;
+  SF_HIP(c, hipMemcpy2DAsync(d_left, width, left, pitch, width, height, hipMemcpyHostToDevice, c->stream));
+  SF_HIP(c, hipMemcpy2DAsync(d_right, width, right, pitch, width, height, hipMemcpyHostToDevice, c->stream));
+  sf_keypoint* d_kpts = (sf_keypoint*)c->ft_kpts.p;
+  int32_t n = 0;
+  if ((rc = sf_detect_corners_device(c, d_left, width, height, width, maxf, dp.quality_level, dp.min_distance, d_kpts, maxf, &n)) != SF_OK)
+    return rc;
+  n = std::min(n, maxf);
+  float* d_xy = (float*)c->ft_flow.p;                    // [n][2], then x [n], then status [n]
+  float* d_rx = d_xy + 2 * (size_t)maxf;
+  uint8_t* d_status = (uint8_t*)(d_rx + maxf);
+  if ((rc = sf_stereo_correspondences_device(c, d_left, d_right, width, height, width, d_kpts, n, flow, d_xy, d_status, d_rx, nullptr)) != SF_OK)
+    return rc;
+  uint8_t* d_desc = (uint8_t*)c->ft_wire.p;
+  float* d_xyz = (float*)(d_desc + (((size_t)maxf * c->brief_bytes + 15) & ~(size_t)15));
+  sf_keypoint* d_kp_out = (sf_keypoint*)(d_xyz + 3 * (size_t)maxf);
+  int32_t slot = -1, rows = 0;
+  if ((rc = sf_extract_keyframe_device(c, d_left, width, height, width, d_kpts, d_rx, d_status, n, cam, &slot, &rows, d_desc,
+                                       d_xyz, d_kp_out)) != SF_OK)
+    return rc;
+  *rows_out = rows;
+  if (slot_out) *slot_out = slot;
+  const int32_t k = std::min(rows, cap_rows);
+  if (k > 0) {
+    if (desc_out) SF_HIP(c, hipMemcpyAsync(desc_out, d_desc, (size_t)k * c->brief_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (xyz_out) SF_HIP(c, hipMemcpyAsync(xyz_out, d_xyz, (size_t)k * 12, hipMemcpyDeviceToHost, c->stream));
+    if (kpts_out) SF_HIP(c, hipMemcpyAsync(kpts_out, d_kp_out, (size_t)k * sizeof(sf_keypoint), hipMemcpyDeviceToHost, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));
   }
   return SF_OK;

@@ -168,6 +168,7 @@ struct sf_context {
   // the selection's cell lists, three scalars
   Buf gf_planes, gf_keys, gf_tmp, gf_lists, gf_scalar;
   Buf lk_pyr;                      // pyramid levels >= 1 of both images (k_lk.hip)
+  Buf ft_images, ft_kpts, ft_flow, ft_wire;   // sf_get_features_and_descriptor: device copies of the pair, corners, LK outputs, response
   struct sf_netvlad_model* netvlad = nullptr;   // NetVLAD inference (k_cnn.hip): weights + activation buffers
   int brief_bytes = 0;                 // 0: table not uploaded yet
   int8_t brief_host[64 * 8 * 4] = {};

@@ -20,8 +20,11 @@ class FinderBackend:
     """Adapter: the backend interface DataHandler / StereoCamGeometricTools use, served by a
     lib.SeparatorFinder (the product).  tests/ provide an oracle-backed twin for comparison."""
 
-    def __init__(self, finder):
+    def __init__(self, finder, cam=None, detector=None, stereo_flow=None):
+        """cam (sf_stereo_camera), detector / stereo_flow (None: rtabmap's defaults): only get_features needs them."""
         self.f = finder
+        self.cam, self.detector, self.stereo_flow = cam, detector, stereo_flow
+        self.slots = []               # store slot of every keyframe get_features produced, in call order
 
     def nn_append_local(self, rows):
         self.f.nn_append_local(rows)
@@ -44,6 +47,13 @@ class FinderBackend:
 
     def estimate_transform(self, f_from, f_to):
         return self.f.estimate_transform(f_from, f_to)
+
+    def get_features(self, left, right):
+        if self.cam is None:
+            raise ValueError("FinderBackend needs the stereo camera model for get_features")
+        desc, xyz, kp, slot = self.f.get_features_and_descriptor(left, right, self.cam, self.detector, self.stereo_flow)
+        self.slots.append(slot)
+        return desc, xyz, kp
 
 
 class DataHandler:

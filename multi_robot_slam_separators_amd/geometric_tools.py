@@ -1,8 +1,8 @@
-"""Host-side mirror of the reference's geometry node for the hot path
-(PKG/src/stereoCamGeometricTools.cpp:122-178; PKG = ros_ws/src/multi_robot_separators).
-`getFeaturesAndDescriptor` (feature extraction, :100-120) is out of scope."""
+"""Host-side mirror of the reference's geometry node (PKG/src/stereoCamGeometricTools.cpp; PKG =
+ros_ws/src/multi_robot_separators): `estimateTransformation` (:122-178, the hot path) and
+`getFeaturesAndDescriptor` (:100-120)."""
 from . import _abi
-from .messages import EstTransformResponse, PoseWithCovariance
+from .messages import EstTransformResponse, GeomFeatures, PoseWithCovariance
 
 
 class StereoCamGeometricTools:
@@ -11,6 +11,13 @@ class StereoCamGeometricTools:
         The camera model `cam_` and Vis/MinInliers (stereoCamGeometricTools.cpp:76,87) live in the
         backend's sf_params."""
         self.backend = backend
+
+    def getFeaturesAndDescriptor(self, req):
+        """GetFeatsAndDesc.srv: req.image_left / req.image_right are MONO8 images (uint8 [h, w], what
+        cv_bridge::toCvCopy yields at :104-105).  Returns the response's three arrays (:116-118); the handler itself
+        always returns true (:119)."""
+        desc, xyz, kp = self.backend.get_features(req.image_left, req.image_right)
+        return GeomFeatures(desc, xyz, kp)
 
     def estimateTransformation(self, req):
         """EstTransform.srv: always returns (the reference handler returns true at :177);

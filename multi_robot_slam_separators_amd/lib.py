@@ -85,6 +85,9 @@ def load():
                                                  P(i32), P(i32), vp, vp, vp]),
         "sf_detect_corners_device": (C.c_int, [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, vp, i32, P(i32)]),
         "sf_stereo_flow_defaults": (None, [P(_abi.StereoFlowParams)]),
+        "sf_detector_defaults": (None, [P(_abi.DetectorParams)]),
+        "sf_get_features_and_descriptor": (C.c_int, [vp, vp, vp, i32, i32, i32, P(_abi.StereoCamera), P(_abi.DetectorParams),
+                                                     P(_abi.StereoFlowParams), vp, vp, vp, i32, P(i32), P(i32)]),
         "sf_stereo_correspondences_device": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, P(_abi.StereoFlowParams),
                                                        vp, vp, vp, vp]),
         "sf_netvlad_load": (C.c_int, [vp, P(_abi.NetvladWeights)]),
@@ -133,7 +136,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
-    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_last_match_results", "sf_compact_accepted_indexed_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -339,6 +342,27 @@ class SeparatorFinder:
             self._h, C.c_void_p(d_left), C.c_void_p(d_right), width, height, pitch, C.c_void_p(d_kpts), n,
             C.byref(params) if params is not None else None, C.c_void_p(d_right_xy), C.c_void_p(d_status),
             C.c_void_p(d_right_x), C.c_void_p(d_err)))
+
+    def get_features_and_descriptor(self, left, right, cam, det=None, flow=None):
+        """GetFeatsAndDesc on host images (uint8 [h, w], same row stride): returns (descriptors [rows, bytes] uint8,
+        kpts3D [rows, 3] float32, kpts [rows] KEYPOINT_DTYPE, slot of the keyframe in the device-resident store)."""
+        left, right = np.asarray(left, np.uint8), np.asarray(right, np.uint8)
+        if left.ndim != 2 or left.shape != right.shape or left.strides != right.strides or left.strides[1] != 1:
+            raise ValueError("left / right must be 2-D uint8 images of one shape and row stride")
+        h, w = left.shape
+        cap = (det.max_features if det is not None else 1000)
+        nbytes = self.brief_get_pattern().shape[0] // 8
+        desc = np.zeros((cap, nbytes), np.uint8)
+        xyz = np.zeros((cap, 3), np.float32)
+        kp = np.zeros(cap, _abi.KEYPOINT_DTYPE)
+        rows, slot = C.c_int32(), C.c_int32()
+        self._check(self._L.sf_get_features_and_descriptor(
+            self._h, C.c_void_p(left.ctypes.data), C.c_void_p(right.ctypes.data), w, h, left.strides[0], C.byref(cam),
+            C.byref(det) if det is not None else None, C.byref(flow) if flow is not None else None,
+            C.c_void_p(desc.ctypes.data), C.c_void_p(xyz.ctypes.data), C.c_void_p(kp.ctypes.data), cap, C.byref(rows),
+            C.byref(slot)))
+        n = min(rows.value, cap)
+        return desc[:n].copy(), xyz[:n].copy(), kp[:n].copy(), slot.value
 
     def extract_keyframe_device(self, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam,
                                 d_desc_out=None, d_xyz_out=None, d_kpts_out=None, want_rows=True):

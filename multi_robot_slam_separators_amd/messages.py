@@ -39,6 +39,12 @@ class GeomFeatures:               # GetFeatsAndDesc.srv response: Descriptors + 
 
 
 @dataclass
+class GetFeatsAndDescRequest:     # GetFeatsAndDesc.srv:1-2 (sensor_msgs/Image x 2, MONO8 after cv_bridge)
+    image_left: np.ndarray        # h x w uint8
+    image_right: np.ndarray
+
+
+@dataclass
 class FindMatchesRequest:         # FindMatches.srv:1
     new_netvlad_descriptors: np.ndarray   # float64[] (flat)
 

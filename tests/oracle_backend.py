@@ -6,8 +6,9 @@ from oracle import pyoracle
 
 
 class OracleBackend:
-    def __init__(self, params):
+    def __init__(self, params, cam=None, detector=None, stereo_flow=None, brief_tests=None):
         self.p = params
+        self.cam, self.detector, self.stereo_flow, self.brief_tests = cam, detector, stereo_flow, brief_tests
         self.local, self.received = [], []
         self.local_used, self.other_used, self.ignored = [], [], []
 
@@ -34,3 +35,10 @@ class OracleBackend:
 
     def estimate_transform(self, f_from, f_to):
         return pyoracle.estimate_transform(self.p, f_from, f_to)
+
+    def get_features(self, left, right):
+        from multi_robot_slam_separators_amd import _abi
+        det = self.detector if self.detector is not None else _abi.detector_params()
+        kp = pyoracle.detect_corners(left, det.max_features, det.quality_level, det.min_distance)
+        xy, st, _ = pyoracle.stereo_correspondences(left, right, kp, self.stereo_flow)
+        return pyoracle.extract_keyframe(left, kp, np.ascontiguousarray(xy[:, 0]), st, self.cam, self.brief_tests)
