@@ -445,6 +445,10 @@ enum {
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);
+/* Which kernels are bracketed (bit k = kernel k of the enum above; default all).  Two timing events per launch cost
+   host time and a marker on the queue -- about 4 us per bracketed launch in a 0.6 ms step -- so a throughput
+   measurement brackets only the kernel it prices (bench.py: the dominant one) and surveys the rest separately.  */
+int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
 int  sf_prof_reset(sf_handle h);
 int  sf_prof_get(sf_handle h, int kernel, int64_t* launches, double* total_ms);
 const char* sf_kernel_name(int kernel);

@@ -77,9 +77,12 @@ static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
 void sf_prof_begin(sf_context* c, int kernel) {
-  if (!c->prof) return;
+  if (!c->prof || !((c->prof_mask >> kernel) & 1u)) return;
   hipEvent_t a = nullptr, b = nullptr;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  for (hipEvent_t* e : {&a, &b}) {
+    if (!c->prof_event_pool.empty()) { *e = c->prof_event_pool.back(); c->prof_event_pool.pop_back(); }
+    else if (hipEventCreate(e) != hipSuccess) { if (a) c->prof_event_pool.push_back(a); return; }
+  }
   (void)hipEventRecord(a, c->stream);
   c->pending_events.push_back({kernel, {a, b}});
 }
@@ -100,8 +103,8 @@ static void prof_resolve(sf_context* c) {
       c->prof_slots[pe.first].launches += 1;
       c->prof_slots[pe.first].total_ms += (double)ms;
     }
-    (void)hipEventDestroy(pe.second.first);
-    (void)hipEventDestroy(pe.second.second);
+    c->prof_event_pool.push_back(pe.second.first);
+    c->prof_event_pool.push_back(pe.second.second);
   }
   c->pending_events.clear();
 }
@@ -716,6 +719,7 @@ extern "C" void sf_destroy(sf_handle c) {
     sf_context* t = c->twin;
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     prof_resolve(t);
+    for (hipEvent_t e : t->prof_event_pool) (void)hipEventDestroy(e);
     Buf* tb[] = {&t->corr1, &t->corr2, &t->hdr1, &t->hdr2, &t->pass1, &t->pass2, &t->list1, &t->list3, &t->counters, &t->flags};
     for (Buf* b : tb) buf_free(*b);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -727,6 +731,7 @@ extern "C" void sf_destroy(sf_handle c) {
   (void)sf_comm_destroy(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   prof_resolve(c);
+  for (hipEvent_t e : c->prof_event_pool) (void)hipEventDestroy(e);
   Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
                  &c->scratch.kp, &c->scratch.meta, &c->pair_from, &c->pair_to, &c->corr1, &c->corr2, &c->hdr1,
                  &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
@@ -1569,6 +1574,14 @@ extern "C" int sf_prof_enable(sf_handle c, int on) {
   prof_resolve(c);
   c->prof = on != 0;
   if (c->twin) { prof_resolve(c->twin); c->twin->prof = c->prof; }
+  return SF_OK;
+}
+
+extern "C" int sf_prof_select(sf_handle c, uint32_t kernel_mask) {
+  if (!c) return SF_EINVAL;
+  prof_resolve(c);
+  c->prof_mask = kernel_mask;
+  if (c->twin) { prof_resolve(c->twin); c->twin->prof_mask = kernel_mask; }
   return SF_OK;
 }
 

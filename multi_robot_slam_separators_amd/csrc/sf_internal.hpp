@@ -270,6 +270,8 @@ struct sf_context {
 
   // profiling
   bool prof = false;
+  uint32_t prof_mask = 0xFFFFFFFFu;      // bit k: kernel k is bracketed when profiling is on (sf_prof_select)
+  std::vector<hipEvent_t> prof_event_pool;   // timing events are reused, not created per launch
   ProfSlot prof_slots[SF_K_COUNT];
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
 };

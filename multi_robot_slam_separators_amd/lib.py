@@ -112,6 +112,7 @@ def load():
         "sf_allgather_separators": (C.c_int, [vp, vp, i32, vp, i32, vp]),
         "sf_allgather_separators_device": (C.c_int, [vp, vp, vp, i32]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
+        "sf_prof_select": (C.c_int, [vp, C.c_uint32]),
         "sf_prof_reset": (C.c_int, [vp]),
         "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
         "sf_kernel_name": (C.c_char_p, [C.c_int]),
@@ -140,7 +141,7 @@ EXPORTED = [
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_last_match_results", "sf_compact_accepted_indexed_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
-    "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_reset", "sf_prof_get",
+    "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
 
@@ -481,6 +482,16 @@ class SeparatorFinder:
 
     def prof_enable(self, on=True):
         self._check(self._L.sf_prof_enable(self._h, int(on)))
+
+    def prof_select(self, names=None):
+        """Bracket only the named kernels (sf_kernel_name strings) while profiling is on; None = all."""
+        mask = 0xFFFFFFFF
+        if names is not None:
+            mask = 0
+            for k in range(_abi.SF_K_COUNT):
+                if self._L.sf_kernel_name(k).decode() in names:
+                    mask |= 1 << k
+        self._check(self._L.sf_prof_select(self._h, mask))
 
     def prof_reset(self):
         self._check(self._L.sf_prof_reset(self._h))
