@@ -39,6 +39,8 @@ def detect(f, torch, image, maxc, q, md, cap=None):
     (1, (120, 160), 1000, 0.001, 3.0), (2, (97, 131), 200, 0.01, 7.0), (3, (64, 64), 0, 0.001, 1.0),
     (4, (480, 752), 1000, 0.001, 3.0), (5, (50, 70), 50, 0.05, 0.0), (6, (33, 35), 1000, 0.001, 2.4),
     (7, (720, 1280), 2000, 0.001, 3.0), (8, (480, 752), 0, 0.0005, 2.0),
+    (9, (1080, 1920), 1500, 0.001, 4.5),          # the taken-corner bitmap does not fit LDS: per-cell lists in HBM
+    (10, (300, 400), 400, 0.001, 30.0),           # a large minDistance: 59 rows of the bitmap per test
 ])
 def test_corners_equal_oracle(finder, seed, shape, maxc, q, md):
     import torch
