@@ -596,8 +596,37 @@ def main():
     # kernel runs, instead of through a 0.9 MB copy behind it (BENCH_HOST_COPY=1: the copy, as up to round r02c)
     zero_copy = exch is None and os.environ.get("BENCH_HOST_COPY") is None
     hp = h_pack.data_ptr()
+    h_cnt_np = h_cnt.numpy()                                  # (a view of the pinned word: no tensor indexing per step)
     trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
     two_calls = os.environ.get("BENCH_TWO_CALLS") is not None
+    # Consecutive steps overlap on the single-GPU path (BENCH_NO_PIPELINE=1: one synchronisation per step, as up to
+    # round r02d): step k's NN filter is queued before the host has looked at step k - 1's separators, so the device
+    # does not idle through the host's wake-up, bookkeeping and first launches (~45 us of a 0.58 ms step).  Step
+    # k - 1 is retired -- count read, records handed on -- once the library call of step k has returned: that call
+    # waits for step k's candidate distances, which the stream produces AFTER step k - 1's compaction.  Two pinned
+    # blocks alternate, so a step's separators stay untouched for a whole step.  All K steps are issued and retired
+    # inside the timed region.
+    pipelined = zero_copy and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
+    h_pack2 = torch.zeros_like(h_pack).pin_memory() if pipelined else None
+    blocks = []
+    for hb in ([h_pack, h_pack2] if pipelined else []):
+        blocks.append({"ptr": hb.data_ptr(), "cnt": hb[:4].view(torch.int32).numpy(), "res": hb[acc_off:].view(n_kf, RB)})
+    inflight = []
+
+    def issue(k):
+        m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
+        n = len(m)
+        b = blocks[k & 1]
+        r_ptr, r_idx, r_n = f.last_match_results()
+        f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
+        inflight.append((m, n, b))
+
+    def retire():
+        m, n, b = inflight.pop(0)
+        n_acc = int(b["cnt"][0])
+        state["pairs"] += n
+        state["last"] = (m, b["res"][:n_acc], n)
+        state["gathered"] = n_acc
 
     def step():
         t_0 = time.perf_counter()
@@ -664,8 +693,12 @@ def main():
             h_res[:k_spec].copy_(acc[:k_spec], non_blocking=True)   # accepted separators delivered to the host (pinned)
         if exch is not None:
             exch.finish()                                     # the copies above ran beside the collective
-        torch.cuda.synchronize()
-        n_acc = int(h_cnt[0])
+        if zero_copy:
+            f.synchronize()                                   # (everything of the step is on the handle's stream)
+            n_acc = int(h_cnt_np[0])
+        else:
+            torch.cuda.synchronize()
+            n_acc = int(h_cnt[0])
         if n_acc > k_spec:                                    # more accepted than the speculative prefix held
             h_res[k_spec:n_acc].copy_(acc[k_spec:n_acc], non_blocking=True)
             torch.cuda.synchronize()
@@ -699,10 +732,20 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step_ms = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()                      # (ends with the step's one synchronisation)
-        step_ms.append((time.perf_counter() - ts) * 1e3)
+    if pipelined:
+        for k in range(args.steps):
+            ts = time.perf_counter()
+            issue(k)                    # (returns once step k's candidates are walked: step k - 1 has left the device)
+            if k > 0:
+                retire()
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+        f.synchronize()
+        retire()
+    else:
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            step()                      # (ends with the step's one synchronisation)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if dist_on:
         td.barrier()
@@ -754,6 +797,24 @@ def main():
             alt = None
         f.nn_set_precision(1)
         step()
+
+    # ---- the same steps with ONE synchronisation per step (no overlap of consecutive steps), untimed ----
+    alt_sync = None
+    if pipelined:
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_alt = 0
+            for _ in range(min(args.steps, 50)):
+                n_alt += step()
+            torch.cuda.synchronize()
+            alt_sync = n_alt / (time.perf_counter() - t1) * world
+        except Exception as e:
+            print("bench: one-synchronisation-per-step comparison run failed: %r" % (e,), file=sys.stderr)
+        state["pairs"] = pairs_timed
+        state["last"] = last_timed
 
     # ---- the same step with the prefix ladder of the NN filter forced to the FULL descriptor length (the cost on a
     # data set whose prefixes are uninformative; the timed steps contract `filter_dims` dimensions), untimed ----
@@ -1003,6 +1064,9 @@ def main():
             "step_ms_spread": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
                                "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
         }
+        out["steps_overlap"] = bool(pipelined)
+        if alt_sync is not None:
+            out["value_one_synchronisation_per_step"] = alt_sync
         if alt_fixed is not None:
             out["value_fixed_iterations"] = alt_fixed["value"]
             out["fixed_iterations"] = alt_fixed

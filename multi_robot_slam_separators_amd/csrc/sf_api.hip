@@ -1331,22 +1331,23 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
 }
 
 // The two compaction kernels, asynchronous: the number of accepted results is left at d_count (device).
-// Ordered compaction in ONE launch: a chunk of 1024 candidates per workgroup; chunk i publishes the number of
-// accepted candidates up to and including itself as {epoch, inclusive count} once chunk i - 1 has published its own
-// (a chain of waits in dispatch order: every chunk is resident -- at most 128 chunks of 1024 threads -- and chunk i
-// never waits for a later one).  The epoch (one per launch, kept by the handle) makes stale entries of the previous
-// launch unreadable without a memset in between.  Replaces k_compact_count + k_compact_move (kept for batches with
-// more chunks than can be resident at once).
-__global__ void __launch_bounds__(1024)
+// Ordered compaction in ONE launch: a chunk of 256 candidates per workgroup; every chunk publishes its own number of
+// accepted candidates as {epoch, count} and sums the counts of the chunks before it (all chunks are resident -- at
+// most 1024 of 256 threads -- and a chunk only ever waits for earlier ones).  The epoch (one per launch, kept by the
+// handle) makes stale entries of the previous launch unreadable without a memset in between.  Replaces
+// k_compact_count + k_compact_move (kept for batches with more chunks than can be resident at once).
+constexpr int COMPACT_CHUNK = 256;        // records per workgroup of k_compact_chain
+constexpr int COMPACT_MAX_CHUNKS = 1024;  // all resident at once (256 CUs x 8 workgroups of 256 threads)
+__global__ void __launch_bounds__(COMPACT_CHUNK)
 k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ index, int n, sf_result* __restrict__ acc,
                 uint8_t* __restrict__ flags, unsigned long long* __restrict__ state, unsigned epoch,
                 int32_t* __restrict__ total) {
-  __shared__ int wsum[16];
-  __shared__ int s_dst[1024];
+  __shared__ int wsum[COMPACT_CHUNK / 64];
+  __shared__ int s_dst[COMPACT_CHUNK];
+  __shared__ int s_src[COMPACT_CHUNK];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ int s_src[1024];
-  const int base = blockIdx.x * 1024;
+  const int base = blockIdx.x * COMPACT_CHUNK;
   const int i = base + tid;
   const int src = i < n ? (index ? index[i] : i) : 0;      // candidate i's record (index: e.g. its speculative slot)
   s_src[tid] = src;
@@ -1358,26 +1359,34 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
   __syncthreads();
   int woff = 0, own = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) { woff += (w < wave) ? wsum[w] : 0; own += wsum[w]; }
-  if (tid == 0) {
-    unsigned prefix = 0;
-    if (blockIdx.x > 0) {
+  for (int w = 0; w < COMPACT_CHUNK / 64; ++w) { woff += (w < wave) ? wsum[w] : 0; own += wsum[w]; }
+  // every chunk publishes its OWN count at once (tagged with the launch's epoch) and sums its predecessors' -- two
+  // hops however many chunks there are, where a chain of inclusive prefixes costs one per chunk; the word itself is
+  // the message, so relaxed agent-scope accesses do and no cache is flushed between XCDs
+  if (tid == 0)
+    __hip_atomic_store(&state[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)own,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wave == 0) {
+    unsigned sum = 0;
+    for (int j = lane; j < (int)blockIdx.x; j += 64) {
       unsigned long long v;
       do {
-        v = __hip_atomic_load(&state[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        v = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } while ((unsigned)(v >> 32) != epoch);
-      prefix = (unsigned)v;
+      sum += (unsigned)v;
     }
-    __hip_atomic_store(&state[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)(prefix + (unsigned)own),
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    s_base = (int)prefix;
-    if (blockIdx.x == gridDim.x - 1) *total = (int)prefix + own;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) {
+      s_base = (int)sum;
+      if (blockIdx.x == gridDim.x - 1) *total = (int)sum + own;
+    }
   }
   __syncthreads();
   s_dst[tid] = ok ? s_base + woff + before : -1;
   __syncthreads();
-  const int m = min(1024, n - base);
-  for (int e = tid; e < m * 23; e += 1024) {
+  const int m = min(COMPACT_CHUNK, n - base);
+  for (int e = tid; e < m * 23; e += COMPACT_CHUNK) {
     const int c = e / 23, piece = e - c * 23;
     const int dst = s_dst[c];
     if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + s_src[c])[piece];
@@ -1386,10 +1395,10 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
 
 static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
                           int32_t* d_count, const int32_t* index = nullptr) {
-  const int chunks = (n + 1023) / 1024;
+  const int chunks = (n + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
-  if (chunks <= 128) {
+  if (chunks <= COMPACT_MAX_CHUNKS) {
     if (c->compact_state_chunks < chunks || c->compact_state_ptr != c->compact_scratch.p) {
       // fresh (or regrown / reallocated) state: make every epoch tag invalid once
       SF_HIP(c, hipMemsetAsync(c->compact_scratch.p, 0, (size_t)(chunks + 1) * 8, c->stream));
@@ -1397,18 +1406,19 @@ static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_r
       c->compact_state_ptr = c->compact_scratch.p;
     }
     if (++c->compact_epoch == 0) c->compact_epoch = 1;
-    hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(1024), 0, c->stream, d_results, index, n, d_accepted, d_flags,
+    hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(COMPACT_CHUNK), 0, c->stream, d_results, index, n, d_accepted, d_flags,
                        (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count);
     SF_HIP(c, hipGetLastError());
     if (index && index == (const int32_t*)c->spec_index_pinned)
       SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));   // the pinned index block may be rewritten after this
     return SF_OK;
   }
-  if (index) return sf_fail(c, SF_ERANGE, "indexed compaction of %d records: more than 128 chunks", n);
+  if (index) return sf_fail(c, SF_ERANGE, "indexed compaction of %d records: more than %d chunks", n, COMPACT_MAX_CHUNKS);
   c->compact_state_chunks = 0;                  // (the two-kernel form reuses the buffer as plain counts)
   int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
-  hipLaunchKernelGGL(k_compact_count, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
-  hipLaunchKernelGGL(k_compact_move, dim3(chunks), dim3(1024), 0, c->stream, d_results, n, d_accepted,
+  const int chunks2 = (n + 1023) / 1024;
+  hipLaunchKernelGGL(k_compact_count, dim3(chunks2), dim3(1024), 0, c->stream, d_results, n, d_flags, d_chunk);
+  hipLaunchKernelGGL(k_compact_move, dim3(chunks2), dim3(1024), 0, c->stream, d_results, n, d_accepted,
                      (const int32_t*)d_chunk, d_count);
   SF_HIP(c, hipGetLastError());
   return SF_OK;
@@ -1449,7 +1459,7 @@ extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_result
   *n_accepted = 0;
   if (n == 0) return SF_OK;
   SF_HIP(c, hipSetDevice(c->device));
-  const int chunks = (n + 1023) / 1024;
+  const int chunks = (n + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
   int32_t* d_count = (int32_t*)((char*)c->compact_scratch.p + (size_t)(chunks + 1) * 8);   // behind the chunk states
