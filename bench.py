@@ -616,6 +616,8 @@ def main():
     def issue(k):
         m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
         n = len(m)
+        if inflight:
+            retire()                    # step k - 1: its compaction ran before this step's NN filter (stream order)
         b = blocks[k & 1]
         r_ptr, r_idx, r_n = f.last_match_results()
         f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
@@ -735,9 +737,7 @@ def main():
     if pipelined:
         for k in range(args.steps):
             ts = time.perf_counter()
-            issue(k)                    # (returns once step k's candidates are walked: step k - 1 has left the device)
-            if k > 0:
-                retire()
+            issue(k)                    # (retires step k - 1 once step k's candidates are walked)
             step_ms.append((time.perf_counter() - ts) * 1e3)
         f.synchronize()
         retire()
