@@ -22,7 +22,11 @@
 //
 // Kernels:
 //   k_conv3x3_first   Cin = 3 (27 MACs per output): direct, one thread per (pixel, 4 output channels)
-//   k_conv_igemm      every other convolution as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2f32, the
+//   k_conv_igemm_h    every other convolution as an implicit GEMM with SPLIT fp16 operands (x = hi + lo, three
+//                     v_mfma_f32_32x32x8f16 per product term: fp32-grade results, 3.1e-7 on the descriptor like the
+//                     fp32 kernel, at a third of its matrix-pipe time); tile / tap split per layer MEASURED at the
+//                     first inference of an image size (conv_autotune).  SF_CNN_FP32=1: k_conv_igemm below.
+//   k_conv_igemm      the same on the fp32 matrix cores (v_mfma_f32_32x32x2f32, the
 //                     128 x 128 x 32 tile of k_nn_argmin): M = pixels, N = Cout, K = taps x Cin; a 32-wide K step lies
 //                     inside one tap (Cin is a multiple of 32), so the A tile of a step is 128 pixels x 128 B read
 //                     straight from the NHWC activations of the shifted pixel (zero outside the image) -- no im2col
@@ -30,13 +34,15 @@
 //   k_pool2_relu      2 x 2 max pooling + ReLU
 //   k_vlad_*          normalisation, softmax, aggregation (the assignment itself is k_conv_igemm with one tap)
 //   k_wpca            one wavefront per output row of the 4096 x 32768 matrix (HBM-bound: 537 MB of weights per image)
-// fp32 MFMA products are exact and accumulate in fp32, so the result differs from a CPU fp32 evaluation only by
-// summation order (tests: 1e-4 absolute on the unit-norm descriptor against a PyTorch fp32 CPU evaluation).
+// MFMA products are exact and accumulate in fp32 (the split drops only a_lo b_lo, 2^-22 of a product), so the result
+// differs from a CPU fp32 evaluation essentially by summation order (tests: 1e-4 absolute on the unit-norm descriptor
+// against a PyTorch fp32 CPU evaluation; measured 3.1e-7 for both kernels, tools/netvlad_error.py).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -181,6 +187,146 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
         const int p = row0 + (TM / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (p < P) {
           const float v = acc[i][j][r] + bn;
+          out[(size_t)p * Cout + n] = relu ? fmaxf(v, 0.f) : v;
+        }
+      }
+  }
+}
+
+// The same implicit GEMM with SPLIT fp16 operands on the fp16 matrix cores (v_mfma_f32_32x32x8f16, 16 x the rate of the
+// fp32 form): x = hi + lo with hi = fp16(x), lo = fp16(x - hi) -- 22 significant bits -- and
+//   a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi   (the dropped a_lo b_lo is 2^-22 of the product),
+// three MFMAs where the fp32 form needs four, each a quarter as long; products are exact in the fp32 accumulator.  The
+// weights are split once at load time (and scaled by a power of two so that the largest is about 8: small weights keep
+// their low part out of the subnormals), the activations when a tile is staged into LDS (scaled by 2^-4: headroom for
+// activations up to 10^6); both scalings are undone exactly in the epilogue.  The lane layout is the fp32 kernel's:
+// the float4 a lane used for four x2 MFMAs is the 4-half operand of ONE x8 MFMA.
+typedef _Float16 ch16x4 __attribute__((ext_vector_type(4)));
+constexpr int CPH = 40;            // LDS pitch in halves (32 + 8)
+constexpr float CONV_ACT_SCALE = 0.0625f;
+
+__device__ __forceinline__ void split4(const float4 v, float s, ch16x4& hi, ch16x4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(x[i] - (float)h);
+  }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float16* __restrict__ wgt_hi,
+               const _Float16* __restrict__ wgt_lo, float out_scale, int Cout, const float* __restrict__ bias,
+               float* __restrict__ out, int relu) {
+  constexpr int TAPS = 9;
+  constexpr int NI = TM / 64, NJ = TN / 64, QA = TM / 32, QB = TN / 32;
+  __shared__ __attribute__((aligned(16))) _Float16 sAh[TM * CPH];
+  __shared__ __attribute__((aligned(16))) _Float16 sAl[TM * CPH];
+  __shared__ __attribute__((aligned(16))) _Float16 sBh[TN * CPH];
+  __shared__ __attribute__((aligned(16))) _Float16 sBl[TN * CPH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int P = H * W;
+  const int row0 = blockIdx.x * TM, col0 = blockIdx.y * TN;
+  const int K = TAPS * Cin;
+  const int k_lo = (int)((blockIdx.z * TAPS) / gridDim.z) * Cin, k_hi = (int)(((blockIdx.z + 1) * TAPS) / gridDim.z) * Cin;
+  out += (size_t)blockIdx.z * P * Cout;
+  cf32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;     // staging: 32 rows x 8 groups of 4 k per pass
+  int py[QA], px[QA];
+  bool pv[QA];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int p = row0 + srow + 32 * q;
+    pv[q] = p < P;
+    py[q] = pv[q] ? p / W : 0;
+    px[q] = pv[q] ? p - py[q] * W : 0;
+  }
+  float4 ra[QA];
+  ch16x4 rbh[QB], rbl[QB];
+  auto fetch = [&](int k0) {
+    const int tap = k0 / Cin, c0 = k0 - tap * Cin;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int yy = py[q] + dy, xx = px[q] + dx;
+      ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pv[q] && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        ra[q] = *reinterpret_cast<const float4*>(in + ((size_t)yy * W + xx) * Cin + c0 + sk4);
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      rbh[q] = ch16x4{0, 0, 0, 0};
+      rbl[q] = ch16x4{0, 0, 0, 0};
+      if (col0 + srow + 32 * q < Cout) {
+        const size_t o = (size_t)(col0 + srow + 32 * q) * K + k0 + sk4;
+        rbh[q] = *reinterpret_cast<const ch16x4*>(wgt_hi + o);
+        rbl[q] = *reinterpret_cast<const ch16x4*>(wgt_lo + o);
+      }
+    }
+  };
+  fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += CK) {
+    __syncthreads();                                  // the previous step's LDS reads are complete
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      ch16x4 ah, al;
+      split4(ra[q], CONV_ACT_SCALE, ah, al);
+      *reinterpret_cast<ch16x4*>(&sAh[(srow + 32 * q) * CPH + sk4]) = ah;
+      *reinterpret_cast<ch16x4*>(&sAl[(srow + 32 * q) * CPH + sk4]) = al;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      *reinterpret_cast<ch16x4*>(&sBh[(srow + 32 * q) * CPH + sk4]) = rbh[q];
+      *reinterpret_cast<ch16x4*>(&sBl[(srow + 32 * q) * CPH + sk4]) = rbl[q];
+    }
+    __syncthreads();
+    if (k0 + CK < k_hi) fetch(k0 + CK);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ch16x4 ah[NI], al[NI], bh[NJ], bl[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int o = ((TM / 2) * wr + 32 * i + l31) * CPH + 8 * q + 4 * h;
+        ah[i] = *reinterpret_cast<const ch16x4*>(&sAh[o]);
+        al[i] = *reinterpret_cast<const ch16x4*>(&sAl[o]);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int o = ((TN / 2) * wc + 32 * j + l31) * CPH + 8 * q + 4 * h;
+        bh[j] = *reinterpret_cast<const ch16x4*>(&sBh[o]);
+        bl[j] = *reinterpret_cast<const ch16x4*>(&sBl[o]);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = col0 + (TN / 2) * wc + 32 * j + l31;
+    if (n >= Cout) continue;
+    const float bn = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = row0 + (TM / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (p < P) {
+          const float v = acc[i][j][r] * out_scale + bn;
           out[(size_t)p * Cout + n] = relu ? fmaxf(v, 0.f) : v;
         }
       }
@@ -360,8 +506,15 @@ const bool VGG_POOL[13] = {false, true, false, true, false, false, true, false, 
 
 }  // namespace
 
+struct ConvCfg { int tm, tn, split; };
+
 struct sf_netvlad_model {
   Buf conv_w[13], conv_b[13], mean, assign_w, centers, pca_w, pca_b;
+  Buf conv_wh[13], conv_wl[13];     // fp16 high / low parts of the scaled weights (k_conv_igemm_h)
+  float conv_out_scale[13] = {};    // 1 / (weight scale x activation scale): exact powers of two
+  bool split_f16 = true;            // SF_CNN_FP32=1: the fp32 matrix-core kernels
+  ConvCfg cfg[13] = {};             // tile / split of every layer, measured for ...
+  int tuned_h = 0, tuned_w = 0;     // ... this image size (conv_autotune)
   Buf act[2], vlad, pca_y, partial;
   int clusters = 0, pca_dim = 0;
 };
@@ -369,7 +522,7 @@ struct sf_netvlad_model {
 void sf_netvlad_free(sf_context* c) {
   if (!c->netvlad) return;
   sf_netvlad_model* m = c->netvlad;
-  for (int i = 0; i < 13; ++i) { sf_buf_free(m->conv_w[i]); sf_buf_free(m->conv_b[i]); }
+  for (int i = 0; i < 13; ++i) { sf_buf_free(m->conv_w[i]); sf_buf_free(m->conv_b[i]); sf_buf_free(m->conv_wh[i]); sf_buf_free(m->conv_wl[i]); }
   Buf* bs[] = {&m->mean, &m->assign_w, &m->centers, &m->pca_w, &m->pca_b, &m->act[0], &m->act[1], &m->vlad, &m->pca_y, &m->partial};
   for (Buf* b : bs) sf_buf_free(*b);
   delete m;
@@ -396,6 +549,7 @@ int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
   sf_netvlad_model* m = new (std::nothrow) sf_netvlad_model();
   if (!m) return sf_fail(c, SF_ENOMEM, "out of host memory");
   c->netvlad = m;
+  m->split_f16 = getenv("SF_CNN_FP32") == nullptr;
   m->clusters = w->clusters;
   m->pca_dim = w->pca_dim;
   int rc;
@@ -408,6 +562,28 @@ int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
         for (int o = 0; o < co; ++o) t[((size_t)o * 9 + tap) * ci + a] = w->conv_kernel[i][((size_t)tap * ci + a) * co + o];
     if ((rc = upload(c, m->conv_w[i], t.data(), t.size())) != SF_OK) return rc;
     SF_HIP(c, hipStreamSynchronize(c->stream));          // (t is reused)
+    if (i > 0) {
+      // split once: w 2^e = hi + lo in fp16, 2^e chosen so that the largest |w| lands in [8, 16)
+      float wmax = 0.f;
+      for (float v : t) wmax = std::max(wmax, std::fabs(v));
+      int e = 0;
+      if (wmax > 0.f && std::isfinite(wmax)) e = 3 - (int)std::floor(std::log2(wmax));
+      e = std::max(-20, std::min(20, e));
+      const float ws = std::ldexp(1.0f, e);
+      std::vector<_Float16> th(t.size()), tl(t.size());
+      for (size_t k = 0; k < t.size(); ++k) {
+        const float x = t[k] * ws;
+        const _Float16 hh = (_Float16)x;
+        th[k] = hh;
+        tl[k] = (_Float16)(x - (float)hh);
+      }
+      if ((rc = sf_buf_reserve(c, m->conv_wh[i], t.size() * 2)) != SF_OK) return rc;
+      if ((rc = sf_buf_reserve(c, m->conv_wl[i], t.size() * 2)) != SF_OK) return rc;
+      SF_HIP(c, hipMemcpyAsync(m->conv_wh[i].p, th.data(), t.size() * 2, hipMemcpyHostToDevice, c->stream));
+      SF_HIP(c, hipMemcpyAsync(m->conv_wl[i].p, tl.data(), t.size() * 2, hipMemcpyHostToDevice, c->stream));
+      SF_HIP(c, hipStreamSynchronize(c->stream));
+      m->conv_out_scale[i] = std::ldexp(1.0f, -e) / CONV_ACT_SCALE;
+    }
     if ((rc = upload(c, m->conv_b[i], w->conv_bias[i], co)) != SF_OK) return rc;
   }
   if ((rc = upload(c, m->mean, w->average_rgb, 3)) != SF_OK) return rc;
@@ -439,6 +615,90 @@ int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
   return SF_OK;
 }
 
+// One 3 x 3 convolution layer (i >= 1) in a given configuration: tile tm x tn, S-way tap split (S > 1: partial outputs,
+// summed -- with bias and ReLU -- by k_sum_partials in a fixed order).
+static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* src, int h, int w, float* dst, ConvCfg cfg) {
+  const int P = h * w, co = VGG_COUT[i], S = cfg.split, tm = cfg.tm, tn = cfg.tn;
+  int rc;
+  float* cdst = dst;
+  if (S > 1) {
+    if ((rc = sf_buf_reserve(c, m->partial, (size_t)S * P * co * sizeof(float))) != SF_OK) return rc;
+    cdst = (float*)m->partial.p;
+  }
+#define SF_CONV(TM_, TN_)                                                                                           \
+  do {                                                                                                              \
+    if (m->split_f16)                                                                                               \
+      hipLaunchKernelGGL((k_conv_igemm_h<TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
+                         c->stream, src, h, w, VGG_CIN[i], (const _Float16*)m->conv_wh[i].p,                          \
+                         (const _Float16*)m->conv_wl[i].p, m->conv_out_scale[i], co,                                  \
+                         S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                          \
+                         S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0));                                                          \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_conv_igemm<9, TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
+                         c->stream, src, h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, co,                          \
+                         S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                          \
+                         S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0));                                                          \
+  } while (0)
+  if (tm == 128 && tn == 128) SF_CONV(128, 128);
+  else if (tm == 128) SF_CONV(128, 64);
+  else if (tn == 128) SF_CONV(64, 128);
+  else SF_CONV(64, 64);
+#undef SF_CONV
+  if (S > 1) {
+    const size_t n = (size_t)P * co;
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float*)cdst, S, n, co, (const float*)m->conv_b[i].p, dst, VGG_RELU[i] ? 1 : 0);
+  }
+  return SF_OK;
+}
+
+// Tile and split of every layer for one image size, MEASURED: the first inference at a new size times each layer in
+// its (up to) twelve configurations -- tiles 64 / 128 x 64 / 128, 1 / 3 / 9-way tap split where the partial outputs
+// stay small -- on the buffers it is about to use and keeps the fastest (HIP events, three runs each; ~20 ms once per
+// image size, synchronous).  A model of the matrix pipe's fill picked these for the fp32 kernels; the split-fp16
+// kernels are bound by the latency of their operand fetches, where more, smaller workgroups often win, and a
+// measurement is the honest way to choose.
+static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SF_HIP(c, hipEventCreate(&e0));
+  SF_HIP(c, hipEventCreate(&e1));
+  int h = H, w = W, rc = SF_OK;
+  const float* src = (const float*)m->act[0].p;
+  float* dst = (float*)m->act[1].p;
+  for (int i = 0; i < 13 && rc == SF_OK; ++i) {
+    if (i > 0) {
+      const int P = h * w, co = VGG_COUT[i];
+      float best = 1e30f;
+      ConvCfg pick = {64, 64, 1};
+      for (int tm = 64; tm <= 128; tm *= 2)
+        for (int tn = 64; tn <= 128; tn *= 2)
+          for (int S = 1; S <= 9; S *= 3) {
+            if (co == 64 && tn == 128) continue;
+            if (S > 1 && (size_t)P * co * S > (size_t)9 << 20) continue;      // partial outputs beyond ~36 MB
+            const ConvCfg cfg = {tm, tn, S};
+            if ((rc = conv_layer(c, m, i, src, h, w, dst, cfg)) != SF_OK) break;      // warm-up (and buffer growth)
+            float t_min = 1e30f;
+            for (int rep = 0; rep < 3 && rc == SF_OK; ++rep) {
+              (void)hipEventRecord(e0, c->stream);
+              rc = conv_layer(c, m, i, src, h, w, dst, cfg);
+              (void)hipEventRecord(e1, c->stream);
+              if (hipEventSynchronize(e1) != hipSuccess) { rc = sf_fail(c, SF_EHIP, "autotune: event wait failed"); break; }
+              float ms = 0.f;
+              (void)hipEventElapsedTime(&ms, e0, e1);
+              t_min = std::min(t_min, ms);
+            }
+            if (t_min < best) { best = t_min; pick = cfg; }
+          }
+      m->cfg[i] = pick;
+    }
+    if (VGG_POOL[i]) { h /= 2; w /= 2; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc == SF_OK) { m->tuned_h = H; m->tuned_w = W; }
+  return rc;
+}
+
 // d_image: [H][W][3] float32 RGB on the device (what the reference feeds the placeholder, data_handler.py:60-61);
 // d_out: n_out floats (the first n_out of the pca_dim-D unit vector).  Asynchronous on the handle's stream.
 int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out) {
@@ -453,6 +713,9 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   const int K = m->clusters, D = 512;
   if ((rc = sf_buf_reserve(c, m->vlad, (size_t)D * K * sizeof(float))) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)std::max(m->pca_dim, 64) * sizeof(float))) != SF_OK) return rc;
+  if (m->tuned_h != H || m->tuned_w != W) {
+    if ((rc = conv_autotune(c, m, H, W)) != SF_OK) return rc;
+  }
   int h = H, w = W, cur = 0;
   const float* src = d_image;
   for (int i = 0; i < 13; ++i) {
@@ -463,44 +726,7 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
                          (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
                          VGG_RELU[0] ? 1 : 0);
     } else {
-      // Tile and split choice.  All workgroups of a layer are (nearly) resident at once and the matrix pipe is what
-      // they share, so a layer takes as long as its most loaded CU: the score of a configuration is its measured
-      // intrinsic rate (128 x 128: 120 TF, the 64-wide forms ~105) x the fill of the busiest CU, load / ceil(load)
-      // with load = workgroups / CUs; a 3-way tap split (own partial outputs, summed by k_sum_partials) is allowed
-      // where the output is small enough for that extra pass not to matter.
-      const int co = VGG_COUT[i];
-      const int cus = 256;
-      int tm = 64, tn = 64, S = 1;
-      double best_score = -1.0;
-      for (int cand = 0; cand < 8; ++cand) {
-        const int ctm = (cand & 1) ? 128 : 64, ctn = (cand & 2) ? 128 : 64, cs = (cand & 4) ? 3 : 1;
-        if (co == 64 && ctn == 128) continue;
-        if (cs == 3 && (size_t)P * co > (size_t)3 << 20) continue;          // partial outputs beyond ~36 MB: not worth it
-        const double wgs = (double)((P + ctm - 1) / ctm) * ((co + ctn - 1) / ctn) * cs;
-        const double load = wgs / cus;
-        const double rate = (ctm == 128 && ctn == 128) ? 120.0 : (ctm == 64 && ctn == 64) ? 104.0 : 107.0;
-        const double score = rate * load / std::ceil(load) * (cs == 3 ? 0.94 : 1.0);
-        if (score > best_score) { best_score = score; tm = ctm; tn = ctn; S = cs; }
-      }
-      float* cdst = dst;
-      if (S > 1) {
-        if ((rc = sf_buf_reserve(c, m->partial, (size_t)S * P * co * sizeof(float))) != SF_OK) return rc;
-        cdst = (float*)m->partial.p;
-      }
-#define SF_CONV(TM_, TN_)                                                                                           \
-      hipLaunchKernelGGL((k_conv_igemm<9, TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
-                         c->stream, src, h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, co,                          \
-                         S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst, S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0))
-      if (tm == 128 && tn == 128) SF_CONV(128, 128);
-      else if (tm == 128) SF_CONV(128, 64);
-      else if (tn == 128) SF_CONV(64, 128);
-      else SF_CONV(64, 64);
-#undef SF_CONV
-      if (S > 1) {
-        const size_t n = (size_t)P * co;
-        hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, c->stream,
-                           (const float*)cdst, S, n, co, (const float*)m->conv_b[i].p, dst, VGG_RELU[i] ? 1 : 0);
-      }
+      if ((rc = conv_layer(c, m, i, src, h, w, dst, m->cfg[i])) != SF_OK) return rc;
     }
     src = dst;
     cur ^= 1;
