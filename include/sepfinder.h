@@ -274,7 +274,9 @@ typedef struct sf_netvlad_weights {
 int  sf_netvlad_load(sf_handle h, const sf_netvlad_weights* w);      /* host pointers; copies and transposes */
 /* d_image_rgb: [height][width][3] float32 on the device (the values the reference feeds its placeholder,
    data_handler.py:60-61); d_out: n_out floats = the first n_out values of the unit-norm descriptor, ready for
-   sf_nn_append_local_f32_device.  Asynchronous on the handle's stream.                                           */
+   sf_nn_append_local_f32_device.  Asynchronous on the handle's stream -- except the FIRST call at an image size,
+   which measures every convolution layer in its tile / split configurations (about 20 ms, synchronous) and keeps
+   the fastest for that size.                                                                                     */
 int  sf_netvlad_infer_device(sf_handle h, const float* d_image_rgb, int32_t width, int32_t height, float* d_out,
                              int32_t n_out);
 
