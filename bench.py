@@ -139,6 +139,102 @@ def generate_inputs(seed, n_kf, k, cols, dim, true_frac):
     return feats, a, b, time.time() - t0
 
 
+def measure_next_rows(dev):
+    """SURVEY section 8(f) rows 3 and 4 beside the headline (rank 0, N = 1, not timed into `value`): one stereo keyframe
+    pixels -> store slot (corner detection, stereo correspondence, descriptors + 3D points) and one NetVLAD inference,
+    each with its CPU restatement (oracle/, one thread for the features, torch fp32 on this process' cores for the
+    network) timed on the same input."""
+    import torch
+    from multi_robot_slam_separators_amd import _abi, lib, synth
+    from oracle import pyoracle
+    from tests import extract_cases as ec
+    out = {}
+    p = synth.camera_params()
+    p.max_features = 1024
+    p.store_capacity = 600
+    g = lib.SeparatorFinder(p, device=dev.index or 0)
+    try:
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        left, right, _ = ec.make_stereo_pair(5, pad=0)
+        h, w = left.shape
+        cam = _abi.stereo_camera(460.0, 458.0, 367.2, 248.4, 0.11)
+        tests = ec.brief_tests(9, 32)
+        g.brief_set_pattern(tests)
+        dl = torch.from_numpy(np.ascontiguousarray(left)).to(dev)
+        dr = torch.from_numpy(np.ascontiguousarray(right)).to(dev)
+        d_kp = torch.zeros((1000, 28), dtype=torch.uint8, device=dev)
+        d_xy = torch.zeros((1000, 2), dtype=torch.float32, device=dev)
+        d_rx = torch.zeros(1000, dtype=torch.float32, device=dev)
+        d_st = torch.zeros(1000, dtype=torch.uint8, device=dev)
+
+        def keyframe():
+            n = g.detect_corners_device(dl.data_ptr(), w, h, w, 1000, 0.001, 3.0, d_kp.data_ptr(), 1000)
+            g.stereo_correspondences_device(dl.data_ptr(), dr.data_ptr(), w, h, w, d_kp.data_ptr(), n, d_xy.data_ptr(),
+                                            d_st.data_ptr(), d_rx.data_ptr())
+            return g.extract_keyframe_device(dl.data_ptr(), w, h, w, d_kp.data_ptr(), d_rx.data_ptr(), d_st.data_ptr(), n, cam)
+        for _ in range(5):
+            keyframe()
+        torch.cuda.synchronize()
+        reps = 100
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            slot, rows = keyframe()
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t1) / reps * 1e3
+        t1 = time.perf_counter()
+        kp0 = pyoracle.detect_corners(left, 1000, 0.001, 3.0)
+        t2 = time.perf_counter()
+        xy0, st0, _ = pyoracle.stereo_correspondences(left, right, kp0)
+        t3 = time.perf_counter()
+        d0, p0, k0 = pyoracle.extract_keyframe(left, kp0, np.ascontiguousarray(xy0[:, 0]), st0, cam, tests)
+        t4 = time.perf_counter()
+        out["keyframe_features"] = {
+            "what": "752 x 480 stereo pair -> 1000 corners (goodFeaturesToTrack) -> pyramidal LK -> BRIEF-32 + stereo 3D, "
+                    "written into the device-resident store; synchronous calls, pixels resident in HBM",
+            "ms_per_keyframe": gpu_ms, "features_kept": int(rows), "rows_equal_cpu_restatement": bool(rows == len(d0)),
+            "cpu_baseline": {"kind": "port", "cores": 1, "ms_per_keyframe": (t4 - t1) * 1e3,
+                             "detect_ms": (t2 - t1) * 1e3, "stereo_ms": (t3 - t2) * 1e3, "extract_ms": (t4 - t3) * 1e3}}
+    except Exception as e:
+        print("bench: keyframe-feature measurement failed: %r" % (e,), file=sys.stderr)
+    try:
+        from oracle import netvlad_torch as nv
+        wts = nv.random_weights(3, clusters=64, pca_dim=4096)
+        g.netvlad_load(wts)
+        H, W = 480, 640
+        img = np.random.default_rng(2).uniform(0, 255, size=(H, W, 3)).astype(np.float32)
+        d_img = torch.from_numpy(img).to(dev)
+        d_out = torch.zeros(128, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            g.netvlad_infer_device(d_img.data_ptr(), W, H, d_out.data_ptr(), 128)
+        torch.cuda.synchronize()
+        reps = 20
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.netvlad_infer_device(d_img.data_ptr(), W, H, d_out.data_ptr(), 128)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t1) / reps * 1e3
+        t1 = time.perf_counter()
+        want = nv.netvlad(img, wts)
+        cpu_ms = (time.perf_counter() - t1) * 1e3
+        flop = 0.0
+        hh, ww = H, W
+        for i, (ci, co) in enumerate(_abi.VGG16_CONVS):
+            flop += 2.0 * hh * ww * 9 * ci * co
+            if nv.POOL[i]:
+                hh, ww = hh // 2, ww // 2
+        out["netvlad_inference"] = {
+            "what": "VGG16 + NetVLAD + WPCA (4096) on a 640 x 480 image, random weights of the published shapes, first "
+                    "128 dimensions kept (data_handler.py:157-158)",
+            "ms_per_image": gpu_ms, "trunk_gflop": flop / 1e9, "tflops_fp32_equivalent": flop / (gpu_ms * 1e-3) / 1e12,
+            "max_abs_error_vs_cpu_fp32": float(np.abs(d_out.cpu().numpy() - want[:128]).max()),
+            "cpu_baseline": {"kind": "port", "cores": torch.get_num_threads(), "ms_per_image": cpu_ms,
+                             "what": "PyTorch fp32 CPU evaluation of the same network (oracle/netvlad_torch.py)"}}
+    except Exception as e:
+        print("bench: NetVLAD measurement failed: %r" % (e,), file=sys.stderr)
+    g.close()
+    return out
+
+
 def cpu_baseline(params, feats, nv_a, nv_b, n_kf, sample_pairs, sample_rows):
     """The oracle (kind "port") timed on this box's host cores on a bounded sample of the same
     workload; scaled to the full step."""
@@ -721,6 +817,26 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # a garbage collection inside the timed region shows up as one 8 - 10 ms step, and one right in front of it lets
+    # the device idle long enough to drop its clocks (the first timed step then takes 7 ms): collect here, in front
+    # of the last warm-up steps, and keep the collector off until the timed region has ended
+    import gc
+    gc.collect()
+    gc.disable()
+    # (the overlapped form, its second pinned block and the profiler's timing events are warmed too: the first
+    # hipEventCreate of a process can cost milliseconds)
+    f.prof_select(("k_verify_fused", "k_match_global"))
+    f.prof_enable(True)
+    if pipelined:
+        for k in range(4):
+            issue(k)
+        f.synchronize()
+        while inflight:
+            retire()
+    else:
+        for _ in range(2):
+            step()
+    f.prof_enable(False)
     # HIP events over the timed region bracket ONLY the kernel the roofline prices (two timing events per launch
     # cost host time and a marker on the queue: with every kernel bracketed a step took 0.594 ms instead of 0.568);
     # the other kernels are surveyed in a short pass after the timed region (BENCH_PROF_ALL=1: all, as up to r02d)
@@ -750,6 +866,10 @@ def main():
     if dist_on:
         td.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("BENCH_DEBUG_SPREAD"):
+        order = np.argsort(step_ms)[::-1][:4]
+        print("[bench] slowest steps: " + ", ".join("#%d %.3f ms" % (int(i), step_ms[int(i)]) for i in order), file=sys.stderr)
     prof = f.prof_get()
     f.prof_enable(False)
     # survey of every kernel (not timed): per-kernel HIP-event times of `survey_steps` further steps
@@ -972,6 +1092,14 @@ def main():
             print("bench: NN-only run failed: %r" % (e,), file=sys.stderr)
     del ta, tb
 
+    # ---- the rows next to the hot path: keyframe features and NetVLAD inference ----
+    next_rows = None
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_cpu_baseline:
+        try:
+            next_rows = measure_next_rows(dev)
+        except Exception as e:
+            print("bench: next-rows measurement failed: %r" % (e,), file=sys.stderr)
+
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
     flags = h_flags[:n].numpy().copy()
@@ -1075,6 +1203,8 @@ def main():
             out["full_length_filter"] = alt_full
         if nn_only is not None:
             out["nn_only_survey_8d_generator"] = nn_only
+        if next_rows:
+            out["next_rows"] = next_rows
         if piped is not None:
             out["pipelined_two_streams"] = piped
         if alt_valu is not None:

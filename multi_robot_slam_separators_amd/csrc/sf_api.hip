@@ -76,8 +76,28 @@ static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "
                                           "k_nn_filter_f16", "k_nn_refine", "k_verify_fused"};
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
+// Brackets that have completed are booked and their events reused without waiting for anything: a long profiled
+// run then lives on a handful of events (creating two per launch made the runtime grow its signal pool in the
+// middle of a timed region: one 7 ms step every few hundred launches).
+static void prof_harvest(sf_context* c) {
+  size_t done = 0;
+  while (done < c->pending_events.size() && hipEventQuery(c->pending_events[done].second.second) == hipSuccess) {
+    auto& pe = c->pending_events[done];
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+      c->prof_slots[pe.first].launches += 1;
+      c->prof_slots[pe.first].total_ms += (double)ms;
+    }
+    c->prof_event_pool.push_back(pe.second.first);
+    c->prof_event_pool.push_back(pe.second.second);
+    ++done;
+  }
+  if (done) c->pending_events.erase(c->pending_events.begin(), c->pending_events.begin() + (long)done);
+}
+
 void sf_prof_begin(sf_context* c, int kernel) {
   if (!c->prof || !((c->prof_mask >> kernel) & 1u)) return;
+  if (c->prof_event_pool.size() < 2 && c->pending_events.size() >= 4) prof_harvest(c);
   hipEvent_t a = nullptr, b = nullptr;
   for (hipEvent_t* e : {&a, &b}) {
     if (!c->prof_event_pool.empty()) { *e = c->prof_event_pool.back(); c->prof_event_pool.pop_back(); }
