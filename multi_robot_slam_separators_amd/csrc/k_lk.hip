@@ -138,8 +138,10 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
     if (level == max_level) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
     nx = qx; ny = qy;
     px -= half_x; py -= half_y;
-    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-    if (ipx < -ww || ipx >= L.w || ipy < -wh || ipy >= L.h) {
+    // (not finite or beyond +-2^30 = outside: x86's float -> int conversion in OpenCV gives INT_MIN there)
+    const bool p_bad = !(fabsf(px) < 1073741824.f && fabsf(py) < 1073741824.f);
+    const int ipx = p_bad ? 0 : (int)floorf(px), ipy = p_bad ? 0 : (int)floorf(py);
+    if (p_bad || ipx < -ww || ipx >= L.w || ipy < -wh || ipy >= L.h) {
       if (level == 0) { st = 0; er = 0.0f; }
       continue;
     }
@@ -210,8 +212,9 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
     qx -= half_x; qy -= half_y;
     float pdx = 0.0f, pdy = 0.0f;
     for (int j = 0; j < max_count; ++j) {
-      const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
-      if (iqx < -ww || iqx >= L.w || iqy < -wh || iqy >= L.h) {
+      const bool q_bad = !(fabsf(qx) < 1073741824.f && fabsf(qy) < 1073741824.f);
+      const int iqx = q_bad ? 0 : (int)floorf(qx), iqy = q_bad ? 0 : (int)floorf(qy);
+      if (q_bad || iqx < -ww || iqx >= L.w || iqy < -wh || iqy >= L.h) {
         if (level == 0) st = 0;
         break;
       }

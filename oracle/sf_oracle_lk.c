@@ -148,8 +148,11 @@ int sfo_stereo_correspondences(const uint8_t* left, const uint8_t* right, int32_
       if (level == max_level) { qx = px; qy = py; } else { qx = nx * 2.f; qy = ny * 2.f; }
       nx = qx; ny = qy;
       px -= half_x; py -= half_y;
-      const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-      if (ipx < -ww || ipx >= I->w || ipy < -wh || ipy >= I->h) {
+      /* a position that is not finite or beyond +-2^30 is OUTSIDE (what x86's float -> int conversion makes of it
+         in OpenCV: INT_MIN, which fails the test below; spelled out because the conversion itself is undefined) */
+      const int p_bad = !(fabsf(px) < 1073741824.f && fabsf(py) < 1073741824.f);
+      const int ipx = p_bad ? 0 : (int)floorf(px), ipy = p_bad ? 0 : (int)floorf(py);
+      if (p_bad || ipx < -ww || ipx >= I->w || ipy < -wh || ipy >= I->h) {
         if (level == 0) { st = 0; er = 0.0f; }
         continue;
       }
@@ -182,8 +185,9 @@ int sfo_stereo_correspondences(const uint8_t* left, const uint8_t* right, int32_
       qx -= half_x; qy -= half_y;
       float pdx = 0.0f, pdy = 0.0f;
       for (int j = 0; j < max_count; ++j) {
-        const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
-        if (iqx < -ww || iqx >= J->w || iqy < -wh || iqy >= J->h) {
+        const int q_bad = !(fabsf(qx) < 1073741824.f && fabsf(qy) < 1073741824.f);
+        const int iqx = q_bad ? 0 : (int)floorf(qx), iqy = q_bad ? 0 : (int)floorf(qy);
+        if (q_bad || iqx < -ww || iqx >= J->w || iqy < -wh || iqy >= J->h) {
           if (level == 0) st = 0;
           break;
         }

@@ -102,6 +102,15 @@ def test_defaults_gates_and_degenerate_inputs(finder):
     # no corners: nothing is launched, nothing is written
     xy, st, _, _ = track(finder, torch, left, right, kp[:0])
     assert len(xy) == 0
+    # corners that are not numbers, infinite, or far outside the image
+    odd = kp[:6].copy()
+    odd["x"] = [np.nan, np.inf, -np.inf, 3e9, -1e5, 50.0]
+    odd["y"] = [10.0, 10.0, np.nan, 10.0, 1e7, np.inf]
+    both = np.concatenate([odd, kp])
+    xy, st, rx, er = track(finder, torch, left, right, both)
+    xy0, st0, er0 = pyoracle.stereo_correspondences(left, right, both)
+    assert np.array_equal(st, st0) and not st[:6].any() and er.tobytes() == er0.tobytes()
+    assert np.array_equal(np.isnan(xy), np.isnan(xy0)) and xy[~np.isnan(xy)].tobytes() == xy0[~np.isnan(xy0)].tobytes()
     # malformed calls
     for bad in (_abi.stereo_flow_params(win_width=2), _abi.stereo_flow_params(win_width=40, win_height=40),
                 _abi.stereo_flow_params(max_level=16), _abi.stereo_flow_params(max_level=-1)):

@@ -107,8 +107,9 @@ def numpy_lk(left, right, kpts, prm):
                     qx, qy = nx * f32(2), ny * f32(2)
                 nx, ny = qx, qy
                 px, py = px - half[0], py - half[1]
-                ipx, ipy = int(np.floor(px)), int(np.floor(py))
-                if ipx < -ww or ipx >= I.shape[1] or ipy < -wh or ipy >= I.shape[0]:
+                p_bad = not (abs(px) < 2.0 ** 30 and abs(py) < 2.0 ** 30)
+                ipx, ipy = (0, 0) if p_bad else (int(np.floor(px)), int(np.floor(py)))
+                if p_bad or ipx < -ww or ipx >= I.shape[1] or ipy < -wh or ipy >= I.shape[0]:
                     if level == 0:
                         s, e = 0, f32(0)
                     continue
@@ -130,8 +131,9 @@ def numpy_lk(left, right, kpts, prm):
                 qx, qy = qx - half[0], qy - half[1]
                 pdx = pdy = f32(0)
                 for j in range(max_count):
-                    iqx, iqy = int(np.floor(qx)), int(np.floor(qy))
-                    if iqx < -ww or iqx >= J.shape[1] or iqy < -wh or iqy >= J.shape[0]:
+                    q_bad = not (abs(qx) < 2.0 ** 30 and abs(qy) < 2.0 ** 30)
+                    iqx, iqy = (0, 0) if q_bad else (int(np.floor(qx)), int(np.floor(qy)))
+                    if q_bad or iqx < -ww or iqx >= J.shape[1] or iqy < -wh or iqy >= J.shape[0]:
                         if level == 0:
                             s = 0
                         break
@@ -238,3 +240,13 @@ def test_gates_and_degenerate_inputs():
     # no corners
     xy, st, err = pyoracle.stereo_correspondences(left, right, kp[:0])
     assert len(xy) == 0 and len(st) == 0
+    # corners that are not numbers, infinite, or far outside the image: status 0, nothing else disturbed
+    odd = kp[:6].copy()
+    odd["x"] = [np.nan, np.inf, -np.inf, 3e9, -1e5, 50.0]
+    odd["y"] = [10.0, 10.0, np.nan, 10.0, 1e7, np.inf]
+    both = np.concatenate([odd, kp])
+    xy, st, err = pyoracle.stereo_correspondences(left, right, both)
+    assert not st[:6].any() and np.array_equal(st[6:], wide[1]) and xy[6:].tobytes() == wide[0].tobytes()
+    xy2, st2, err2 = numpy_lk(np.ascontiguousarray(left), np.ascontiguousarray(right), both[:10], _abi.stereo_flow_params())
+    assert np.array_equal(st[:10], st2) and err[:10].tobytes() == err2.tobytes()
+    assert np.array_equal(np.isnan(xy[:10]), np.isnan(xy2)) and xy[:10][~np.isnan(xy[:10])].tobytes() == xy2[~np.isnan(xy2)].tobytes()
