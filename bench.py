@@ -707,9 +707,9 @@ def main():
     # (one set of buffers suffices: step k - 1 is retired before step k's outputs are queued).
     dist_cuda = exch is not None and coll_dev.type == "cuda"
     pipelined = (zero_copy or dist_cuda) and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
-    h_pack2 = torch.zeros_like(h_pack).pin_memory() if (pipelined and zero_copy) else None
+    h_pack2 = torch.zeros_like(h_pack).pin_memory() if pipelined else None
     blocks = []
-    for hb in ([h_pack, h_pack2] if (pipelined and zero_copy) else []):
+    for hb in ([h_pack, h_pack2] if pipelined else []):
         blocks.append({"ptr": hb.data_ptr(), "cnt": hb[:4].view(torch.int32).numpy(), "res": hb[acc_off:].view(n_kf, RB)})
     inflight = []
 
@@ -719,37 +719,24 @@ def main():
         if inflight:
             retire()                    # step k - 1: its outputs were queued before this step's NN filter (stream order)
         r_ptr, r_idx, r_n = f.last_match_results()
+        b = blocks[k & 1]
         if zero_copy:
-            b = blocks[k & 1]
             f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
             inflight.append((m, n, b, n))
         else:
             # records and count straight into the exchange's send buffer, ONE all-gather in flight beside the copies of
             # this rank's count, flags and a speculative prefix of its own separators
-            f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, exch.payload.data_ptr(), d_flags.data_ptr(),
-                                                    exch.count_ptr)
-            exch.exchange(None, finish=False)
-            k_spec = min(n, spec_cap)
-            h_cnt.copy_(exch.send[0, :4].view(torch.int32), non_blocking=True)
-            h_flags[:n].copy_(d_flags[:n], non_blocking=True)
-            h_res[:k_spec].copy_(exch.payload[:k_spec], non_blocking=True)
-            exch.finish()
-            inflight.append((m, n, None, k_spec))
+            # (mirrored: the same kernel also writes this rank's own count, flags and records into the pinned block)
+            f.compact_accepted_indexed_mirrored_device_async(r_ptr, r_idx, n, exch.payload.data_ptr(), d_flags.data_ptr(),
+                                                             exch.count_ptr, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
+            exch.exchange(None, finish=True)
+            inflight.append((m, n, b, n))
 
     def retire():
         m, n, b, k_spec = inflight.pop(0)
-        if b is not None:
-            n_acc = int(b["cnt"][0])
-            host = b["res"][:n_acc]
-            gathered = n_acc
-        else:
-            n_acc = int(h_cnt_np[0])
-            if n_acc > k_spec:          # more accepted than the speculative prefix held (not on this workload)
-                torch.cuda.synchronize()
-                h_res[k_spec:n_acc].copy_(exch.payload[k_spec:n_acc], non_blocking=True)
-                torch.cuda.synchronize()
-            host = h_res[:n_acc]
-            gathered = sum(exch.counts())
+        n_acc = int(b["cnt"][0])
+        host = b["res"][:n_acc]
+        gathered = n_acc if exch is None else sum(exch.counts())
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = gathered

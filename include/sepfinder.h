@@ -430,6 +430,13 @@ int  sf_last_match_results(sf_handle h, const sf_result** d_results, const int32
 int  sf_compact_accepted_indexed_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
                                               int32_t n, sf_result* d_accepted, uint8_t* d_flags,
                                               int32_t* d_n_accepted);
+/* The same with every output written TWICE: accepted records, flags and count also go to d_accepted2 / d_flags2
+   (optional) / d_n_accepted2 -- e.g. a collective's send buffer on the device AND this rank's own copy in pinned host
+   memory, without a copy behind the kernel (bench.py, N > 1).                                                     */
+int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
+                                                       int32_t n, sf_result* d_accepted, uint8_t* d_flags,
+                                                       int32_t* d_n_accepted, sf_result* d_accepted2, uint8_t* d_flags2,
+                                                       int32_t* d_n_accepted2);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */

@@ -1361,7 +1361,8 @@ constexpr int COMPACT_MAX_CHUNKS = 1024;  // all resident at once (256 CUs x 8 w
 __global__ void __launch_bounds__(COMPACT_CHUNK)
 k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ index, int n, sf_result* __restrict__ acc,
                 uint8_t* __restrict__ flags, unsigned long long* __restrict__ state, unsigned epoch,
-                int32_t* __restrict__ total) {
+                int32_t* __restrict__ total, sf_result* __restrict__ acc2, uint8_t* __restrict__ flags2,
+                int32_t* __restrict__ total2) {
   __shared__ int wsum[COMPACT_CHUNK / 64];
   __shared__ int s_dst[COMPACT_CHUNK];
   __shared__ int s_src[COMPACT_CHUNK];
@@ -1373,6 +1374,7 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
   s_src[tid] = src;
   const bool ok = i < n && res[src].success != 0;
   if (i < n && flags) flags[i] = ok ? 1 : 0;
+  if (i < n && flags2) flags2[i] = ok ? 1 : 0;
   const unsigned long long bal = __ballot(ok);
   const int before = __popcll(bal & ((1ull << lane) - 1ull));
   if (lane == 0) wsum[wave] = __popcll(bal);
@@ -1399,7 +1401,10 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     if (lane == 0) {
       s_base = (int)sum;
-      if (blockIdx.x == gridDim.x - 1) *total = (int)sum + own;
+      if (blockIdx.x == gridDim.x - 1) {
+        *total = (int)sum + own;
+        if (total2) *total2 = (int)sum + own;
+      }
     }
   }
   __syncthreads();
@@ -1409,12 +1414,17 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
   for (int e = tid; e < m * 23; e += COMPACT_CHUNK) {
     const int c = e / 23, piece = e - c * 23;
     const int dst = s_dst[c];
-    if (dst >= 0) reinterpret_cast<uint4*>(acc + dst)[piece] = reinterpret_cast<const uint4*>(res + s_src[c])[piece];
+    if (dst >= 0) {
+      const uint4 v = reinterpret_cast<const uint4*>(res + s_src[c])[piece];
+      reinterpret_cast<uint4*>(acc + dst)[piece] = v;
+      if (acc2) reinterpret_cast<uint4*>(acc2 + dst)[piece] = v;
+    }
   }
 }
 
 static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
-                          int32_t* d_count, const int32_t* index = nullptr) {
+                          int32_t* d_count, const int32_t* index = nullptr, sf_result* d_accepted2 = nullptr,
+                          uint8_t* d_flags2 = nullptr, int32_t* d_count2 = nullptr) {
   const int chunks = (n + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
@@ -1427,13 +1437,13 @@ static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_r
     }
     if (++c->compact_epoch == 0) c->compact_epoch = 1;
     hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(COMPACT_CHUNK), 0, c->stream, d_results, index, n, d_accepted, d_flags,
-                       (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count);
+                       (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count, d_accepted2, d_flags2, d_count2);
     SF_HIP(c, hipGetLastError());
     if (index && index == (const int32_t*)c->spec_index_pinned)
       SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));   // the pinned index block may be rewritten after this
     return SF_OK;
   }
-  if (index) return sf_fail(c, SF_ERANGE, "indexed compaction of %d records: more than %d chunks", n, COMPACT_MAX_CHUNKS);
+  if (index || d_accepted2) return sf_fail(c, SF_ERANGE, "indexed / mirrored compaction of %d records: more than %d chunks", n, COMPACT_MAX_CHUNKS);
   c->compact_state_chunks = 0;                  // (the two-kernel form reuses the buffer as plain counts)
   int32_t* d_chunk = (int32_t*)c->compact_scratch.p;
   const int chunks2 = (n + 1023) / 1024;
@@ -1471,6 +1481,21 @@ extern "C" int sf_compact_accepted_indexed_device_async(sf_handle c, const sf_re
     return SF_OK;
   }
   return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted, index);
+}
+
+extern "C" int sf_compact_accepted_indexed_mirrored_device_async(sf_handle c, const sf_result* d_results,
+                                                                 const int32_t* index, int32_t n, sf_result* d_accepted,
+                                                                 uint8_t* d_flags, int32_t* d_n_accepted,
+                                                                 sf_result* d_accepted2, uint8_t* d_flags2,
+                                                                 int32_t* d_n_accepted2) {
+  if (!c || n < 0 || !d_n_accepted || !d_n_accepted2 || (n > 0 && (!d_results || !d_accepted || !d_accepted2))) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  if (n == 0) {
+    SF_HIP(c, hipMemsetAsync(d_n_accepted, 0, 4, c->stream));
+    SF_HIP(c, hipMemsetAsync(d_n_accepted2, 0, 4, c->stream));
+    return SF_OK;
+  }
+  return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted, index, d_accepted2, d_flags2, d_n_accepted2);
 }
 
 extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_results, int32_t n, sf_result* d_accepted,
