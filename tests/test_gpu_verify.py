@@ -530,6 +530,19 @@ def test_indexed_compaction_of_the_last_match_results():
             torch.cuda.synchronize()
             assert int(cnt[0]) == k1 and k1 >= 1
             assert torch.equal(acc2[:k1], acc1[:k1]) and torch.equal(fl2[:n2], fl1[:n2])
+            # mirrored: every output twice (a device block and a pinned host block)
+            acc3 = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
+            fl3 = torch.zeros(n_kf, dtype=torch.uint8, device=dev)
+            cnt3 = torch.zeros(1, dtype=torch.int32, device=dev)
+            h_blk = torch.zeros(16 + n_kf + n_kf * 368, dtype=torch.uint8).pin_memory()
+            hb = h_blk.data_ptr()
+            f.compact_accepted_indexed_mirrored_device_async(r, ix, n2, acc3.data_ptr(), fl3.data_ptr(), cnt3.data_ptr(),
+                                                             hb + 16 + n_kf, hb + 16, hb)
+            torch.cuda.synchronize()
+            assert int(cnt3[0]) == k1 == int(h_blk[:4].view(torch.int32)[0])
+            assert torch.equal(acc3[:k1], acc1[:k1]) and torch.equal(fl3[:n2], fl1[:n2])
+            assert torch.equal(h_blk[16 + n_kf: 16 + n_kf + k1 * 368].view(k1, 368), acc1[:k1].cpu())
+            assert torch.equal(h_blk[16: 16 + n2], fl1[:n2].cpu())
 
 
 @pytest.mark.parametrize("est", [0, 1])
