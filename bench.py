@@ -843,8 +843,8 @@ def main():
     f.prof_select(("k_verify_fused", "k_match_global"))
     f.prof_enable(True)
     if pipelined:
-        for k in range(4):
-            issue(k)
+        for step_i in range(4):
+            issue(step_i)
         torch.cuda.synchronize()
         while inflight:
             retire()
@@ -866,9 +866,9 @@ def main():
     t0 = time.perf_counter()
     step_ms = []
     if pipelined:
-        for k in range(args.steps):
+        for step_i in range(args.steps):
             ts = time.perf_counter()
-            issue(k)                    # (retires step k - 1 once step k's candidates are walked)
+            issue(step_i)                 # (retires step k - 1 once step k's candidates are walked)
             step_ms.append((time.perf_counter() - ts) * 1e3)
         if zero_copy:
             f.synchronize()
@@ -1138,6 +1138,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         pairs_per_step = total_pairs / args.steps / world
+        assert k == args.features and cols == args.desc_bytes      # (a loop variable once shadowed k: 5 544 B per pair)
         bpp = bytes_per_pair(k, cols)
         # dominant kernel: the fused per-pair pipeline (matching + both RANSAC passes + guided matching +
         # result: the whole verification the 44 352 B/pair figure of SURVEY 8(d) describes), or the
