@@ -1071,7 +1071,7 @@ def main():
             piped = {"value": n_p / dt, "unit": "pairs/s", "ms_per_step": dt / max(10, args.steps) * 1e3,
                      "accepted_last_step": got_p,
                      "note": "NN stage of batch i+1 on a second handle/stream while batch i is verified; "
-                             "informational, `value` runs its steps strictly in sequence"}
+                             "informational (round 1's two-handle form); `value` overlaps consecutive steps on ONE handle, see steps_overlap"}
         except Exception as e:   # informational only: never let it take the headline line down
             piped = {"error": repr(e)}
         f_nn.close()
