@@ -28,6 +28,7 @@ environment's WORLD_SIZE must equal --gpus):
       configs[1] shape round-robin over the ranks, accepted separators all-gathered.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -713,13 +714,39 @@ def main():
         blocks.append({"ptr": hb.data_ptr(), "cnt": hb[:4].view(torch.int32).numpy(), "res": hb[acc_off:].view(n_kf, RB)})
     inflight = []
 
+    # Single GPU: the accepted separators STREAM out of the verification kernel (sf_accept_stream_*): each accepted
+    # result is written into the step's pinned block the moment its pair is final, so no compaction kernel (25 us of
+    # PCIe writes) follows the launch; the host keeps the records whose index belongs to a match.
+    # BENCH_NO_STREAM=1: the one-launch compaction into the pinned block, as before.
+    stream_out = pipelined and zero_copy and args.estimator == "3d3d" and os.environ.get("BENCH_NO_STREAM") is None
+    sblocks = []
+    if stream_out:
+        grid_cap = n_kf + n_kf // 8 + 256 + 64
+        for which in (0, 1):
+            # (no per-pair flag array in host memory: a 1-byte PCIe write at the end of EVERY pair keeps its workgroup
+            # alive until the write is acknowledged -- +10 us on the launch; the flags follow from the index list, whose
+            # unused entries stay -1)
+            rec = torch.zeros((n_kf, RB), dtype=torch.uint8).pin_memory()
+            idx = torch.full((n_kf,), -1, dtype=torch.int32).pin_memory()
+            f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, n_kf)
+            sblocks.append({"rec": rec, "idx": idx.numpy(), "flags": np.zeros(grid_cap, dtype=np.uint8)})
+
     def issue(k):
+        if stream_out:
+            f.accept_stream_select(k & 1)
         m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
         n = len(m)
         if inflight:
             retire()                    # step k - 1: its outputs were queued before this step's NN filter (stream order)
         r_ptr, r_idx, r_n = f.last_match_results()
         b = blocks[k & 1]
+        if stream_out:
+            streamed, pairs = f.accept_stream_status()
+            if streamed:
+                ix = np.ctypeslib.as_array(ctypes.cast(r_idx, ctypes.POINTER(ctypes.c_int32)), shape=(n,)).copy() \
+                    if r_idx else np.arange(n, dtype=np.int32)
+                inflight.append((m, n, sblocks[k & 1], (pairs, ix)))
+                return
         if zero_copy:
             f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
             inflight.append((m, n, b, n))
@@ -733,13 +760,47 @@ def main():
             inflight.append((m, n, b, n))
 
     def retire():
-        m, n, b, k_spec = inflight.pop(0)
+        m, n, b, extra = inflight.pop(0)
+        if "rec" in b:
+            # streamed block: records in completion order, one per ACCEPTED candidate; a separator is a record whose
+            # index is a match's (every candidate is one on this workload, but the consumer has to look)
+            pairs, ix = extra
+            n_all = int(np.count_nonzero(b["idx"] >= 0))
+            got = b["idx"][:n_all].copy()
+            b["idx"][:n_all] = -1                     # (ready for the step after next)
+            fl = b["flags"]
+            fl[:pairs] = 0
+            fl[got] = 1                                # success flag of every verified slot
+            is_match = np.zeros(pairs, dtype=bool)
+            is_match[ix] = True
+            keep = is_match[got]
+            n_acc = int(keep.sum())
+            b["got"] = got
+            state["pairs"] += n
+            state["last"] = (m, (b, n_all, keep, ix), n)
+            state["gathered"] = n_acc
+            return
         n_acc = int(b["cnt"][0])
         host = b["res"][:n_acc]
         gathered = n_acc if exch is None else sum(exch.counts())
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = gathered
+
+    def materialize_last():
+        """The last retired step's separators in MATCH order (what the compaction delivers), for the checks below."""
+        m, host, n = state["last"]
+        if not isinstance(host, tuple):
+            return
+        b, n_all, keep, ix = host
+        recs = b["rec"][:n_all].clone()
+        idx = b["got"]
+        slot_of = {int(j): i for i, j in enumerate(idx)}
+        fl = b["flags"]
+        order = [slot_of[int(j)] for j in ix if fl[int(j)]]
+        ordered = recs[torch.tensor(order, dtype=torch.int64)] if order else recs[:0]
+        state["flags_last"] = fl[ix].astype(bool).copy()
+        state["last"] = (m, ordered, n)
 
     def step():
         t_0 = time.perf_counter()
@@ -848,6 +909,8 @@ def main():
         torch.cuda.synchronize()
         while inflight:
             retire()
+        if stream_out:
+            f.accept_stream_select(-1)
     else:
         for _ in range(2):
             step()
@@ -875,6 +938,7 @@ def main():
         else:
             torch.cuda.synchronize()    # (the collective's stream and the copies too)
         retire()
+        materialize_last()
     else:
         for _ in range(args.steps):
             ts = time.perf_counter()
@@ -885,6 +949,8 @@ def main():
         td.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if stream_out:
+        f.accept_stream_select(-1)        # (the survey and comparison runs below use the compaction)
     if os.environ.get("BENCH_DEBUG_SPREAD"):
         order = np.argsort(step_ms)[::-1][:4]
         print("[bench] slowest steps: " + ", ".join("#%d %.3f ms" % (int(i), step_ms[int(i)]) for i in order), file=sys.stderr)
@@ -1120,7 +1186,7 @@ def main():
 
     # ---- sanity of the timed work (rank 0): the separators found are the planted revisits -----------
     m, host, n = state["last"]
-    flags = h_flags[:n].numpy().copy()
+    flags = state["flags_last"] if state.get("flags_last") is not None else h_flags[:n].numpy().copy()
     truth = feats["is_true"][m["idx_local"]]
     same = m["idx_local"] == m["idx_other"]
     accepted = int(flags.sum())
@@ -1212,6 +1278,7 @@ def main():
                                "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
         }
         out["steps_overlap"] = bool(pipelined)
+        out["accepted_separators_streamed_from_the_kernel"] = bool(stream_out)
         if alt_sync is not None:
             out["value_one_synchronisation_per_step"] = alt_sync
         if alt_fixed is not None:

@@ -438,6 +438,22 @@ int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_res
                                                        int32_t* d_n_accepted, sf_result* d_accepted2, uint8_t* d_flags2,
                                                        int32_t* d_n_accepted2);
 
+/* Accepted results STREAMED out of the verification kernel (3D-3D estimator, speculative path of
+   sf_find_matches_and_verify_device): every pair whose result is accepted writes its record into the selected block
+   the moment it is final -- posted writes beside the other pairs' work -- instead of a compaction kernel behind the
+   launch.  A block = host-pinned (device-accessible) arrays: records [cap], index [cap] (the record's slot in the
+   sf_last_match_results block, i.e. match i owns the record whose index equals index_of_match[i]), flags [pairs]
+   (optional: success of EVERY verified slot, 0 for slots without a candidate -- if that array is host memory every
+   pair ends on a 1-byte PCIe write its workgroup has to see acknowledged, measured as +10 us on a 10 000-pair launch:
+   pass NULL and derive the flags from the index list, whose entries beyond the streamed count keep their old value).  Records arrive in completion order and
+   cover every verified candidate (a superset of the matches when a row had several candidates): the host keeps those
+   whose index is a match's.  Their number is the sum of flags over the `pairs` slots sf_accept_stream_status reports.
+   Two blocks can be registered and selected alternately, so that one query's separators stay untouched while the
+   next one runs.  `streamed` = 0 after a call that could not stream (fallback paths): use the compaction then.     */
+int  sf_accept_stream_set(sf_handle h, int32_t which, sf_result* records, int32_t* index, uint8_t* flags, int32_t cap);
+int  sf_accept_stream_select(sf_handle h, int32_t which);      /* 0 / 1, -1 = off (default) */
+int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */
 enum {

@@ -29,6 +29,7 @@ struct FusedTail {
   PassState pass1, pass2;
   CorrHeader hdr1, hdr2;
   uint8_t guided_flag;
+  int32_t stream_slot;       // accepted-result stream: this pair's slot in the host block (-1: not accepted / full)
 };
 
 // Everything after the pass-1 correspondence list of a pair: RANSAC, guess-guided matching, RANSAC, result.
@@ -65,6 +66,25 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
   if (tid == 0) {
     if (P.dbg_corr) { pass1[pair] = T.pass1; pass2[pair] = T.pass2; guided_flag[pair] = T.guided_flag; }
     finalize_one(T.pass1, T.pass2, T.guided_flag, out[pair]);
+  }
+  if (P.accept) {
+    // the accepted result leaves for the host NOW (posted PCIe writes beside the other pairs' work) instead of through
+    // a compaction kernel behind the launch: thread 0 takes the slot, 23 lanes move the 368 bytes
+    const AcceptStream S = *P.accept;
+    if (tid == 0) {
+      const bool ok = out[pair].success != 0;
+      if (S.flags) S.flags[pair] = ok ? 1 : 0;
+      int slot = -1;
+      if (ok) {
+        const unsigned sl = atomicAdd(S.counter, 1u);
+        if (sl < (unsigned)S.cap) { slot = (int)sl; S.index[sl] = pair; }
+      }
+      T.stream_slot = slot;
+    }
+    __syncthreads();
+    const int slot = T.stream_slot;
+    if (slot >= 0 && tid < (int)(sizeof(sf_result) / 16))
+      reinterpret_cast<uint4*>(S.records + slot)[tid] = reinterpret_cast<const uint4*>(out + pair)[tid];
   }
 }
 

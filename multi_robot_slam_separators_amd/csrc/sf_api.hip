@@ -754,7 +754,7 @@ extern "C" void sf_destroy(sf_handle c) {
   for (hipEvent_t e : c->prof_event_pool) (void)hipEventDestroy(e);
   Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
                  &c->scratch.kp, &c->scratch.meta, &c->pair_from, &c->pair_to, &c->corr1, &c->corr2, &c->hdr1,
-                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
+                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->accept_dev, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
@@ -1245,8 +1245,26 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
     c->pair_src.n_l = c->nn_local.n; c->pair_src.n_r = c->nn_recv.n;
     c->pair_src.slot_other = c->spec.slot_other; c->pair_src.slot_local = c->spec.slot_local;
     c->pair_src.n_slots = c->store.slots;
+    c->accept_streamed = false;
+    if (c->accept_sel >= 0 && c->accept_blocks[c->accept_sel].set && c->dparams.estimation_type == 0) {
+      // accepted results leave the fused kernel for the registered block as they are produced; the counter is word 4
+      // of the candidate list's header, zeroed with the candidate count before the filter ran
+      sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
+      unsigned* counter = const_cast<unsigned*>(d_count) + 4;
+      int rc0;
+      if ((rc0 = sf_buf_reserve(c, c->accept_dev, 2 * 64, true)) != SF_OK) return rc0;
+      if (!ab.uploaded || ab.s.counter != counter) {
+        ab.s.counter = counter;
+        SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + 64 * c->accept_sel, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
+        SF_HIP(c, hipStreamSynchronize(c->stream));      // (rare: first use, or the candidate buffer moved)
+        ab.uploaded = true;
+      }
+      c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + 64 * c->accept_sel);
+      c->accept_streamed = true;
+    }
     const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
                                  (sf_result*)c->spec_results.p);
+    c->dparams.accept = nullptr;
     c->pair_src = PairSource();
     return rc;
   }
@@ -1263,6 +1281,7 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   if (!c || !n_out || cap < 0 || (cap > 0 && !out)) return SF_EINVAL;
   *n_out = 0;
   c->last_results = nullptr; c->last_results_index = nullptr; c->last_results_n = 0;
+  c->accept_streamed = false;
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
@@ -1463,6 +1482,29 @@ extern "C" int sf_compact_accepted_device_async(sf_handle c, const sf_result* d_
     return SF_OK;
   }
   return compact_launch(c, d_results, n, d_accepted, d_flags, d_n_accepted);
+}
+
+extern "C" int sf_accept_stream_set(sf_handle c, int32_t which, sf_result* records, int32_t* index, uint8_t* flags,
+                                    int32_t cap) {
+  if (!c || which < 0 || which > 1) return SF_EINVAL;
+  if (!records || !index || cap < 1) { c->accept_blocks[which] = sf_context::AcceptHost(); return SF_OK; }   // (unregister)
+  sf_context::AcceptHost& ab = c->accept_blocks[which];
+  ab.s.records = records; ab.s.index = index; ab.s.flags = flags; ab.s.cap = cap; ab.s.counter = nullptr;
+  ab.set = true; ab.uploaded = false;
+  return SF_OK;
+}
+
+extern "C" int sf_accept_stream_select(sf_handle c, int32_t which) {
+  if (!c || which < -1 || which > 1) return SF_EINVAL;
+  c->accept_sel = which;
+  return SF_OK;
+}
+
+extern "C" int sf_accept_stream_status(sf_handle c, int32_t* streamed, int32_t* pairs) {
+  if (!c || !streamed) return SF_EINVAL;
+  *streamed = c->accept_streamed ? 1 : 0;
+  if (pairs) *pairs = c->accept_streamed ? (int32_t)c->spec.grid : 0;
+  return SF_OK;
 }
 
 extern "C" int sf_last_match_results(sf_handle c, const sf_result** d_results, const int32_t** index, int32_t* n) {

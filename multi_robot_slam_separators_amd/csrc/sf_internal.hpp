@@ -45,6 +45,16 @@ struct CorrHeader {
   int32_t words_to_2d;   // wordsTo.size()
 };
 
+// Accepted results streamed out of the fused kernel (device-resident block the kernel reads at the END of a pair):
+// records / index / flags are host-pinned (device-accessible) arrays, counter a device word zeroed before the launch.
+struct AcceptStream {
+  sf_result* records;      // [cap] accepted results in the order they were produced
+  int32_t* index;          // [cap] pair index of each record
+  uint8_t* flags;          // [pairs] success of every pair (may be null)
+  unsigned* counter;       // device
+  int32_t cap;
+};
+
 struct DeviceParams {
   float nndr;
   int32_t min_inliers;
@@ -72,6 +82,7 @@ struct DeviceParams {
   float ba_robust_kernel_delta, ba_pixel_variance, stereo_baseline;
   int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
                               // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
+  const struct AcceptStream* accept;   // fused kernel: accepted results also stream to the host as they are produced (or null)
   unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][SF_TRACE_SLOTS] timestamps; else null
 };
 
@@ -262,6 +273,12 @@ struct sf_context {
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_refined = nullptr, ev_copied = nullptr;
   } spec;
+  // accepted-result streams (sf_accept_stream_set / _select): two registered blocks, the one selected for the next
+  // speculative query is handed to the fused kernel; `streamed` says whether the last query used it
+  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, 0}; bool set = false; bool uploaded = false; } accept_blocks[2];
+  Buf accept_dev;                    // the two AcceptStream blocks on the device
+  int accept_sel = -1;
+  bool accept_streamed = false;
   Buf spec_from, spec_to, spec_results, spec_index;
   void* spec_index_pinned = nullptr;
   size_t spec_index_pinned_bytes = 0;

@@ -102,6 +102,9 @@ def load():
         "sf_find_matches_and_verify_device": (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(i32), vp]),
         "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
         "sf_compact_accepted_device_async": (C.c_int, [vp, vp, i32, vp, vp, vp]),
+        "sf_accept_stream_set": (C.c_int, [vp, i32, vp, vp, vp, i32]),
+        "sf_accept_stream_select": (C.c_int, [vp, i32]),
+        "sf_accept_stream_status": (C.c_int, [vp, P(i32), P(i32)]),
         "sf_compact_accepted_indexed_mirrored_device_async": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
         "sf_last_match_results": (C.c_int, [vp, P(vp), P(vp), P(i32)]),
         "sf_compact_accepted_indexed_device_async": (C.c_int, [vp, vp, vp, i32, vp, vp, vp]),
@@ -140,7 +143,7 @@ EXPORTED = [
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
-    "sf_compact_accepted_device_async", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
+    "sf_compact_accepted_device_async", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
@@ -441,6 +444,20 @@ class SeparatorFinder:
         self._check(self._L.sf_compact_accepted_indexed_device_async(
             self._h, C.c_void_p(d_results), C.c_void_p(index), n, C.c_void_p(d_accepted),
             C.c_void_p(d_flags) if d_flags else None, C.c_void_p(d_count)))
+
+    def accept_stream_set(self, which, records, index, flags, cap):
+        """Register block `which` (0 / 1) of the accepted-result stream: pinned host pointers (ints)."""
+        self._check(self._L.sf_accept_stream_set(self._h, which, C.c_void_p(records), C.c_void_p(index),
+                                                 C.c_void_p(flags) if flags else None, cap))
+
+    def accept_stream_select(self, which):
+        self._check(self._L.sf_accept_stream_select(self._h, which))
+
+    def accept_stream_status(self):
+        """(streamed, pairs) of the last sf_find_matches_and_verify_device."""
+        s, n = C.c_int32(), C.c_int32()
+        self._check(self._L.sf_accept_stream_status(self._h, C.byref(s), C.byref(n)))
+        return bool(s.value), n.value
 
     def compact_accepted_indexed_mirrored_device_async(self, d_results, index, n, d_accepted, d_flags, d_count, d_accepted2,
                                                        d_flags2, d_count2):

@@ -3,6 +3,8 @@ C-ABI, against the CPU oracle on identical seeded inputs.
 
 Bars: correspondences, match / inlier counts and success flags are integer work -> bit-exact;
 poses within BASELINE.json's 1e-4 m / 1e-3 rad; covariance within 1e-9 relative."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -482,6 +484,86 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     for c2, c1 in zip(out["two"][1], out["single"][1]):
         assert np.array_equal(c2[0], c1[0]) and np.array_equal(c2[1], c1[1])
     assert out["single"][0][0]["success"][is_true].all()
+
+
+def test_accepted_results_streamed_from_the_kernel():
+    """sf_accept_stream_*: the fused kernel writes every accepted result into a pinned block as it becomes final.  The
+    streamed records, keyed by their index, are exactly the accepted results the gathered form returns -- on the
+    speculative path; the fallback paths report streamed = 0 and leave the block alone."""
+    import torch
+    from multi_robot_slam_separators_amd import lib
+    n_kf, k, cols, dim = 96, 200, 32, 512
+    feats = synth.make_store_batch(81, n_kf, k=k, cols=cols, true_frac=0.5)
+    rng = np.random.default_rng(8)
+    nv_a = rng.normal(size=(n_kf, dim)); nv_a /= np.linalg.norm(nv_a, axis=1, keepdims=True)
+    nv_b = nv_a + 0.002 * rng.normal(size=(n_kf, dim)); nv_b /= np.linalg.norm(nv_b, axis=1, keepdims=True)
+    nv_b[10] = nv_b[11] = nv_b[12]            # rows sharing a column: candidates that are not matches
+    dev = torch.device("cuda:0")
+    p = synth.camera_params()
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.netvlad_distance = 0.13
+    p.iterations = 200
+    p.max_features = k
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        T = {key: up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}
+        sa = f.store_add_keyframes_device(n_kf, k, cols, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+        sb = f.store_add_keyframes_device(n_kf, k, cols, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+        torch.cuda.synchronize()
+        f.nn_append_received(nv_a); f.nn_append_local(nv_b)
+        cap = 512
+        blocks = []
+        for which in (0, 1):
+            rec = torch.zeros((cap, 368), dtype=torch.uint8).pin_memory()
+            idx = torch.full((cap,), -1, dtype=torch.int32).pin_memory()
+            fl = torch.full((cap,), 7, dtype=torch.uint8).pin_memory()
+            f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), fl.data_ptr(), cap)
+            blocks.append((rec, idx, fl))
+        d_res = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
+        for rep in range(4):
+            which = rep & 1
+            rec, idx, fl = blocks[which]
+            rec.zero_(); idx.fill_(-1); fl.fill_(7)
+            f.accept_stream_select(which)
+            m = f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=n_kf)
+            torch.cuda.synchronize()
+            streamed, pairs = f.accept_stream_status()
+            assert streamed and pairs >= len(m)
+            r, ix, n = f.last_match_results()
+            index_of_match = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_int32)), shape=(n,)).copy()
+            res = np.frombuffer(d_res.cpu().numpy()[:n].tobytes(), dtype=_abi.RESULT_DTYPE)
+            flags = fl.numpy()[:pairs]
+            assert set(np.unique(flags)) <= {0, 1}
+            n_acc = int(flags.sum())
+            got_idx = idx.numpy()[:n_acc]
+            assert (got_idx >= 0).all() and (idx.numpy()[n_acc:] == -1).all() and len(set(got_idx.tolist())) == n_acc
+            recs = np.frombuffer(rec.numpy()[:n_acc].tobytes(), dtype=_abi.RESULT_DTYPE)
+            assert recs["success"].all() and (flags[got_idx] == 1).all()
+            by_index = {int(j): recs[i] for i, j in enumerate(got_idx)}
+            acc_matches = [i for i in range(n) if res["success"][i]]
+            assert len(acc_matches) >= 10 and n_acc >= len(acc_matches)
+            for i in range(n):
+                j = int(index_of_match[i])
+                assert bool(flags[j]) == bool(res["success"][i])
+                if res["success"][i]:
+                    assert by_index[j].tobytes() == res[i].tobytes()
+        # off: nothing is written
+        rec, idx, fl = blocks[0]
+        rec.zero_(); idx.fill_(-1); fl.fill_(7)
+        f.accept_stream_select(-1)
+        f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=n_kf)
+        torch.cuda.synchronize()
+        assert f.accept_stream_status() == (False, 0) and (idx.numpy() == -1).all() and (fl.numpy() == 7).all()
+        # the fallback (a small cap: no speculation) does not stream either
+        f.accept_stream_select(0)
+        f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=7)
+        torch.cuda.synchronize()
+        assert f.accept_stream_status()[0] is False and (idx.numpy() == -1).all()
 
 
 def test_indexed_compaction_of_the_last_match_results():
