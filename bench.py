@@ -718,7 +718,7 @@ def main():
     # result is written into the step's pinned block the moment its pair is final, so no compaction kernel (25 us of
     # PCIe writes) follows the launch; the host keeps the records whose index belongs to a match.
     # BENCH_NO_STREAM=1: the one-launch compaction into the pinned block, as before.
-    stream_out = pipelined and zero_copy and args.estimator == "3d3d" and os.environ.get("BENCH_NO_STREAM") is None
+    stream_out = pipelined and zero_copy and os.environ.get("BENCH_NO_STREAM") is None
     sblocks = []
     if stream_out:
         grid_cap = n_kf + n_kf // 8 + 256 + 64

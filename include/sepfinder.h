@@ -438,7 +438,7 @@ int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_res
                                                        int32_t* d_n_accepted, sf_result* d_accepted2, uint8_t* d_flags2,
                                                        int32_t* d_n_accepted2);
 
-/* Accepted results STREAMED out of the verification kernel (3D-3D estimator, speculative path of
+/* Accepted results STREAMED out of the verification kernels (both estimators; the speculative path of
    sf_find_matches_and_verify_device): every pair whose result is accepted writes its record into the selected block
    the moment it is final -- posted writes beside the other pairs' work -- instead of a compaction kernel behind the
    launch.  A block = host-pinned (device-accessible) arrays: records [cap], index [cap] (the record's slot in the

@@ -160,6 +160,7 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
       hdr2[pair] = h; pass2[pair] = p; guided_flag[pair] = 0;
     }
     finalize_one(p, p, 0, out[pair]);
+    if (P.accept && P.accept->flags) P.accept->flags[pair] = 0;      // (accepted-result stream: not accepted)
   }
 }
 
@@ -288,6 +289,25 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
     __syncthreads();
   }
   if (threadIdx.x == 0) finalize_one(pass1[pair], pass2[pair], guided_flag[pair], out[pair]);
+  if (P.accept) {                 // accepted-result stream (see chain_after_match)
+    __syncthreads();              // (the bodies are done with the LDS: its first word carries the slot)
+    int& s_slot = *reinterpret_cast<int*>(smem_raw);
+    const AcceptStream S = *P.accept;
+    if (threadIdx.x == 0) {
+      const bool ok = out[pair].success != 0;
+      if (S.flags) S.flags[pair] = ok ? 1 : 0;
+      int slot = -1;
+      if (ok) {
+        const unsigned sl = atomicAdd(S.counter, 1u);
+        if (sl < (unsigned)S.cap) { slot = (int)sl; S.index[sl] = pair; }
+      }
+      s_slot = slot;
+    }
+    __syncthreads();
+    const int slot = s_slot;
+    if (slot >= 0 && threadIdx.x < sizeof(sf_result) / 16)
+      reinterpret_cast<uint4*>(S.records + slot)[threadIdx.x] = reinterpret_cast<const uint4*>(out + pair)[threadIdx.x];
+  }
 }
 
 // The split pipeline (k_match_split + k_chain); applies where the fused kernel does.

@@ -1234,6 +1234,26 @@ extern "C" int sf_verify_matches_device(sf_handle c, const sf_match* matches, in
 
 // Called by the NN filter behind the refinement launch of a prefix level (k_nn.hip): candidate pair list on
 // the device, then the verification of every candidate slot, all on the handle's stream.
+// Hands the selected accepted-result block to the verification kernels of the launch that follows (fused kernel, chain
+// kernels): the counter is word 4 of the candidate list's header, zeroed with the candidate count before the filter ran.
+static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
+  c->accept_streamed = false;
+  if (c->accept_sel < 0 || !c->accept_blocks[c->accept_sel].set) return SF_OK;
+  sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
+  unsigned* counter = const_cast<unsigned*>(d_count) + 4;
+  int rc0;
+  if ((rc0 = sf_buf_reserve(c, c->accept_dev, 2 * 64, true)) != SF_OK) return rc0;
+  if (!ab.uploaded || ab.s.counter != counter) {
+    ab.s.counter = counter;
+    SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + 64 * c->accept_sel, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
+    SF_HIP(c, hipStreamSynchronize(c->stream));      // (rare: first use, or the candidate buffer moved)
+    ab.uploaded = true;
+  }
+  c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + 64 * c->accept_sel);
+  c->accept_streamed = true;
+  return SF_OK;
+}
+
 int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
   const unsigned grid = c->spec.grid;
   // one chunk on the fused kernel: it derives the pairs from the candidate list itself (one launch and its gap less
@@ -1245,23 +1265,8 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
     c->pair_src.n_l = c->nn_local.n; c->pair_src.n_r = c->nn_recv.n;
     c->pair_src.slot_other = c->spec.slot_other; c->pair_src.slot_local = c->spec.slot_local;
     c->pair_src.n_slots = c->store.slots;
-    c->accept_streamed = false;
-    if (c->accept_sel >= 0 && c->accept_blocks[c->accept_sel].set && c->dparams.estimation_type == 0) {
-      // accepted results leave the fused kernel for the registered block as they are produced; the counter is word 4
-      // of the candidate list's header, zeroed with the candidate count before the filter ran
-      sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
-      unsigned* counter = const_cast<unsigned*>(d_count) + 4;
-      int rc0;
-      if ((rc0 = sf_buf_reserve(c, c->accept_dev, 2 * 64, true)) != SF_OK) return rc0;
-      if (!ab.uploaded || ab.s.counter != counter) {
-        ab.s.counter = counter;
-        SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + 64 * c->accept_sel, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
-        SF_HIP(c, hipStreamSynchronize(c->stream));      // (rare: first use, or the candidate buffer moved)
-        ab.uploaded = true;
-      }
-      c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + 64 * c->accept_sel);
-      c->accept_streamed = true;
-    }
+    int rc0 = arm_accept_stream(c, d_count);
+    if (rc0 != SF_OK) return rc0;
     const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
                                  (sf_result*)c->spec_results.p);
     c->dparams.accept = nullptr;
@@ -1272,8 +1277,16 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
                      c->nn_local.n, c->nn_recv.n, c->spec.slot_other, c->spec.slot_local, c->store.slots,
                      (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
   SF_HIP(c, hipGetLastError());
-  return verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
-                       (sf_result*)c->spec_results.p);
+  // the PnP estimator's chain kernel streams too (one chunk, one stream: a pair's index is its candidate slot)
+  if (grid <= (unsigned)SF_CHUNK && !c->overlap && c->store.slots > 0 && c->dparams.estimation_type == 1 && c->fused &&
+      c->chain_pnp && sf_split_pnp_applicable(c, sf_store_view(c->store))) {
+    int rc0 = arm_accept_stream(c, d_count);
+    if (rc0 != SF_OK) return rc0;
+  }
+  const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
+                               (sf_result*)c->spec_results.p);
+  c->dparams.accept = nullptr;
+  return rc;
 }
 
 extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_other, int32_t slot_base_local,

@@ -486,7 +486,8 @@ def test_two_stream_batches_equal_single_stream(monkeypatch, est):
     assert out["single"][0][0]["success"][is_true].all()
 
 
-def test_accepted_results_streamed_from_the_kernel():
+@pytest.mark.parametrize("est", [0, 1])
+def test_accepted_results_streamed_from_the_kernel(est):
     """sf_accept_stream_*: the fused kernel writes every accepted result into a pinned block as it becomes final.  The
     streamed records, keyed by their index, are exactly the accepted results the gathered form returns -- on the
     speculative path; the fallback paths report streamed = 0 and leave the block alone."""
@@ -500,6 +501,7 @@ def test_accepted_results_streamed_from_the_kernel():
     nv_b[10] = nv_b[11] = nv_b[12]            # rows sharing a column: candidates that are not matches
     dev = torch.device("cuda:0")
     p = synth.camera_params()
+    p.estimation_type = est
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf
     p.netvlad_distance = 0.13
