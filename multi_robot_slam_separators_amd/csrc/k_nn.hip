@@ -512,8 +512,12 @@ constexpr int NN_K128_LDS = 2 * NN_BM * NN_KP * 4 + NN_K128_HITS * 8 + 16;
 __global__ void __launch_bounds__(256, 2)
 k_nn_filter_f16_k128(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float2* __restrict__ rowc,
                      const float2* __restrict__ colc, int gx, int gy, int tiles_per_strip,
-                     uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
+                     uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap,
+                     unsigned* __restrict__ next_count) {
   extern __shared__ __attribute__((aligned(16))) float nn_lds[];
+  // the NEXT launch's counter block (the launches alternate between two): zeroed here, so that no memset launch
+  // stands in front of the next query's filter
+  if (blockIdx.x == 0 && threadIdx.x < 16 && next_count) next_count[threadIdx.x] = 0u;
   float* sA = nn_lds;                         // [128][NN_KP]
   float* sB = nn_lds + NN_BM * NN_KP;         // [128][NN_KP]
   uint2* s_hits = reinterpret_cast<uint2*>(nn_lds + 2 * NN_BM * NN_KP);   // [NN_K128_HITS]
@@ -861,13 +865,17 @@ static int nn_run_filter(sf_context* c, int* done) {
     --c->nn_level_cooldown;
   }
   const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
-  if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 64)) != SF_OK) return rc;
+  {
+    const void* before = c->nn_cand.p;
+    if ((rc = sf_buf_reserve(c, c->nn_cand, (size_t)cap * 16 + 128)) != SF_OK) return rc;
+    if (c->nn_cand.p != before) c->nn_count_primed = false;      // (a fresh buffer: nobody zeroed its counter blocks)
+  }
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 8)) != SF_OK) return rc;
   float2* rowc = (float2*)c->nn_rowmin.p;
   float2* colc = rowc + n_l_pad;
-  unsigned* count = (unsigned*)c->nn_cand.p;
-  uint2* cand = (uint2*)((char*)c->nn_cand.p + 64);
-  double* cdist = (double*)((char*)c->nn_cand.p + 64 + (size_t)cap * 8);
+  unsigned* count = (unsigned*)c->nn_cand.p;      // (re-pointed per launch below: two 64-byte blocks alternate)
+  uint2* cand = (uint2*)((char*)c->nn_cand.p + 128);
+  double* cdist = (double*)((char*)c->nn_cand.p + 128 + (size_t)cap * 8);
 
   const double thr = c->params.netvlad_distance;
   float thr2 = (float)(thr * thr);
@@ -887,7 +895,11 @@ static int nn_run_filter(sf_context* c, int* done) {
     // |dot16 - dot32| <= (2^-10 (1 + 2^-11) + k 2^-24) * ||a|| ||b||  (operand rounding + fp32 accumulation)
     const float eps_rel = (float)(ldexp(1.0, -10) * 1.001 + (double)kdims * ldexp(1.0, -24));
     const float scale = c->nn_local.h_scale * c->nn_recv.h_scale;   // product of two powers of two: exact
-    SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
+    count = (unsigned*)((char*)c->nn_cand.p + 64 * c->nn_count_idx);
+    unsigned* const count_next = (unsigned*)((char*)c->nn_cand.p + 64 * (c->nn_count_idx ^ 1));
+    if (!c->nn_count_primed) SF_HIP(c, hipMemsetAsync(count, 0, 64, c->stream));
+    c->nn_count_idx ^= 1;
+    c->nn_count_primed = false;
     // the per-row / per-column coefficients depend only on the norms, the masks, the threshold and the
     // prefix level: rebuilt when one of them changed, not per query
     const bool coef_ok = c->nn_coef_level == level && c->nn_coef_nl == n_l && c->nn_coef_nr == n_r &&
@@ -923,7 +935,8 @@ static int nn_run_filter(sf_context* c, int* done) {
       }
       hipLaunchKernelGGL(k_nn_filter_f16_k128, dim3(gy * ((gx + tps - 1) / tps)), dim3(256), NN_K128_LDS, c->stream,
                          (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc, gx, gy,
-                         tps, cand, count, cap);
+                         tps, cand, count, cap, count_next);
+      c->nn_count_primed = true;                 // (this launch zeroes the other block for the next one)
     } else {
       hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                          (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,

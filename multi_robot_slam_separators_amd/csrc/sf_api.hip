@@ -1240,16 +1240,19 @@ static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   c->accept_streamed = false;
   if (c->accept_sel < 0 || !c->accept_blocks[c->accept_sel].set) return SF_OK;
   sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
-  unsigned* counter = const_cast<unsigned*>(d_count) + 4;
+  const unsigned* counter = d_count + 4;
+  // (the candidate list's counter blocks alternate: one device copy of the block per counter block)
+  const int ci = (d_count == (const unsigned*)c->nn_cand.p) ? 0 : 1;
+  const size_t off = 64 * (size_t)(2 * c->accept_sel + ci);
   int rc0;
-  if ((rc0 = sf_buf_reserve(c, c->accept_dev, 2 * 64, true)) != SF_OK) return rc0;
-  if (!ab.uploaded || ab.s.counter != counter) {
-    ab.s.counter = counter;
-    SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + 64 * c->accept_sel, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
+  if ((rc0 = sf_buf_reserve(c, c->accept_dev, 4 * 64, true)) != SF_OK) return rc0;
+  if (ab.uploaded[ci] != counter) {
+    ab.s.counter = const_cast<unsigned*>(counter);
+    SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + off, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));      // (rare: first use, or the candidate buffer moved)
-    ab.uploaded = true;
+    ab.uploaded[ci] = counter;
   }
-  c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + 64 * c->accept_sel);
+  c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + off);
   c->accept_streamed = true;
   return SF_OK;
 }
@@ -1503,7 +1506,7 @@ extern "C" int sf_accept_stream_set(sf_handle c, int32_t which, sf_result* recor
   if (!records || !index || cap < 1) { c->accept_blocks[which] = sf_context::AcceptHost(); return SF_OK; }   // (unregister)
   sf_context::AcceptHost& ab = c->accept_blocks[which];
   ab.s.records = records; ab.s.index = index; ab.s.flags = flags; ab.s.cap = cap; ab.s.counter = nullptr;
-  ab.set = true; ab.uploaded = false;
+  ab.set = true; ab.uploaded[0] = ab.uploaded[1] = nullptr;
   return SF_OK;
 }
 

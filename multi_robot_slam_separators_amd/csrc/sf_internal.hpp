@@ -194,7 +194,9 @@ struct sf_context {
   bool masks_dirty = true;
   Buf nn_rowmin;     // per-row packed (dist bits, idx) uint64 [n_local]
   Buf nn_exact;      // double [n_local]
-  Buf nn_cand;       // filter path: counter + candidate (row, col) pairs + exact distances
+  Buf nn_cand;       // filter path: two 64-byte counter blocks (alternating per launch) + candidate (row, col) pairs + exact distances
+  int nn_count_idx = 0;          // counter block of the next filter launch
+  bool nn_count_primed = false;  // ... and whether the previous k128 launch already zeroed it
   Buf nn_scalar;     // small reduction scratch
   int nn_level = 0, nn_level_cooldown = 32, nn_last_kdims = 0;   // adaptive prefix ladder of the filter
   bool nn_force_full = false;   // SF_OPT_NN_FULL_FILTER: always contract the full descriptor length
@@ -275,8 +277,8 @@ struct sf_context {
   } spec;
   // accepted-result streams (sf_accept_stream_set / _select): two registered blocks, the one selected for the next
   // speculative query is handed to the fused kernel; `streamed` says whether the last query used it
-  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, 0}; bool set = false; bool uploaded = false; } accept_blocks[2];
-  Buf accept_dev;                    // the two AcceptStream blocks on the device
+  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, 0}; bool set = false; const unsigned* uploaded[2] = {nullptr, nullptr}; } accept_blocks[2];
+  Buf accept_dev;                    // AcceptStream blocks on the device: [registered block][counter block]
   int accept_sel = -1;
   bool accept_streamed = false;
   Buf spec_from, spec_to, spec_results, spec_index;
