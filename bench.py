@@ -718,7 +718,10 @@ def main():
     # result is written into the step's pinned block the moment its pair is final, so no compaction kernel (25 us of
     # PCIe writes) follows the launch; the host keeps the records whose index belongs to a match.
     # BENCH_NO_STREAM=1: the one-launch compaction into the pinned block, as before.
-    stream_out = pipelined and zero_copy and os.environ.get("BENCH_NO_STREAM") is None
+    # N > 1: every record is also written into the exchange's send buffer on the device, the slot counter IS that
+    # buffer's count header (zeroed by a fill queued behind the previous all-gather), and the all-gather starts right
+    # behind the verification.
+    stream_out = pipelined and (zero_copy or dist_cuda) and os.environ.get("BENCH_NO_STREAM") is None
     sblocks = []
     if stream_out:
         grid_cap = n_kf + n_kf // 8 + 256 + 64
@@ -728,12 +731,18 @@ def main():
             # unused entries stay -1)
             rec = torch.zeros((n_kf, RB), dtype=torch.uint8).pin_memory()
             idx = torch.full((n_kf,), -1, dtype=torch.int32).pin_memory()
-            f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, n_kf)
+            if dist_cuda:
+                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, min(n_kf, exch.payload.shape[0]),
+                                    exch.payload.data_ptr(), exch.count_ptr)
+            else:
+                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, n_kf)
             sblocks.append({"rec": rec, "idx": idx.numpy(), "flags": np.zeros(grid_cap, dtype=np.uint8)})
 
     def issue(k):
         if stream_out:
             f.accept_stream_select(k & 1)
+            if dist_cuda:
+                exch.send[0, :8].zero_()          # this rank's count header = the stream's slot counter
         m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
         n = len(m)
         if inflight:
@@ -745,6 +754,8 @@ def main():
             if streamed:
                 ix = np.ctypeslib.as_array(ctypes.cast(r_idx, ctypes.POINTER(ctypes.c_int32)), shape=(n,)).copy() \
                     if r_idx else np.arange(n, dtype=np.int32)
+                if dist_cuda:
+                    exch.exchange(None, finish=True)       # (behind the verification in stream order)
                 inflight.append((m, n, sblocks[k & 1], (pairs, ix)))
                 return
         if zero_copy:
@@ -778,7 +789,7 @@ def main():
             b["got"] = got
             state["pairs"] += n
             state["last"] = (m, (b, n_all, keep, ix), n)
-            state["gathered"] = n_acc
+            state["gathered"] = n_acc if exch is None else sum(exch.counts())
             return
         n_acc = int(b["cnt"][0])
         host = b["res"][:n_acc]

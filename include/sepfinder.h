@@ -450,7 +450,12 @@ int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_res
    whose index is a match's.  Their number is the sum of flags over the `pairs` slots sf_accept_stream_status reports.
    Two blocks can be registered and selected alternately, so that one query's separators stay untouched while the
    next one runs.  `streamed` = 0 after a call that could not stream (fallback paths): use the compaction then.     */
-int  sf_accept_stream_set(sf_handle h, int32_t which, sf_result* records, int32_t* index, uint8_t* flags, int32_t cap);
+/* d_records2 (optional): every record is written there too, at the same slot -- e.g. a collective's send buffer on the
+   device.  d_counter (optional): the slot counter is this device word instead of the handle's own; the CALLER zeroes
+   it before each query (e.g. the count header of that send buffer, so that the all-gather can start behind the
+   verification with nothing in between).                                                                       */
+int  sf_accept_stream_set(sf_handle h, int32_t which, sf_result* records, int32_t* index, uint8_t* flags, int32_t cap,
+                          sf_result* d_records2, uint32_t* d_counter);
 int  sf_accept_stream_select(sf_handle h, int32_t which);      /* 0 / 1, -1 = off (default) */
 int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
 

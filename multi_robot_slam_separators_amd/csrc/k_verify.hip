@@ -83,8 +83,11 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
     }
     __syncthreads();
     const int slot = T.stream_slot;
-    if (slot >= 0 && tid < (int)(sizeof(sf_result) / 16))
-      reinterpret_cast<uint4*>(S.records + slot)[tid] = reinterpret_cast<const uint4*>(out + pair)[tid];
+    if (slot >= 0 && tid < (int)(sizeof(sf_result) / 16)) {
+      const uint4 v = reinterpret_cast<const uint4*>(out + pair)[tid];
+      reinterpret_cast<uint4*>(S.records + slot)[tid] = v;
+      if (S.records2) reinterpret_cast<uint4*>(S.records2 + slot)[tid] = v;
+    }
   }
 }
 
@@ -305,8 +308,11 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
     }
     __syncthreads();
     const int slot = s_slot;
-    if (slot >= 0 && threadIdx.x < sizeof(sf_result) / 16)
-      reinterpret_cast<uint4*>(S.records + slot)[threadIdx.x] = reinterpret_cast<const uint4*>(out + pair)[threadIdx.x];
+    if (slot >= 0 && threadIdx.x < sizeof(sf_result) / 16) {
+      const uint4 v = reinterpret_cast<const uint4*>(out + pair)[threadIdx.x];
+      reinterpret_cast<uint4*>(S.records + slot)[threadIdx.x] = v;
+      if (S.records2) reinterpret_cast<uint4*>(S.records2 + slot)[threadIdx.x] = v;
+    }
   }
 }
 

@@ -1240,7 +1240,7 @@ static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   c->accept_streamed = false;
   if (c->accept_sel < 0 || !c->accept_blocks[c->accept_sel].set) return SF_OK;
   sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
-  const unsigned* counter = d_count + 4;
+  const unsigned* counter = ab.s.ext_counter ? ab.s.counter : d_count + 4;
   // (the candidate list's counter blocks alternate: one device copy of the block per counter block)
   const int ci = (d_count == (const unsigned*)c->nn_cand.p) ? 0 : 1;
   const size_t off = 64 * (size_t)(2 * c->accept_sel + ci);
@@ -1501,11 +1501,13 @@ extern "C" int sf_compact_accepted_device_async(sf_handle c, const sf_result* d_
 }
 
 extern "C" int sf_accept_stream_set(sf_handle c, int32_t which, sf_result* records, int32_t* index, uint8_t* flags,
-                                    int32_t cap) {
+                                    int32_t cap, sf_result* d_records2, uint32_t* d_counter) {
   if (!c || which < 0 || which > 1) return SF_EINVAL;
   if (!records || !index || cap < 1) { c->accept_blocks[which] = sf_context::AcceptHost(); return SF_OK; }   // (unregister)
   sf_context::AcceptHost& ab = c->accept_blocks[which];
-  ab.s.records = records; ab.s.index = index; ab.s.flags = flags; ab.s.cap = cap; ab.s.counter = nullptr;
+  ab.s.records = records; ab.s.index = index; ab.s.flags = flags; ab.s.cap = cap;
+  ab.s.records2 = d_records2;
+  ab.s.counter = d_counter; ab.s.ext_counter = d_counter ? 1 : 0;
   ab.set = true; ab.uploaded[0] = ab.uploaded[1] = nullptr;
   return SF_OK;
 }

@@ -52,7 +52,9 @@ struct AcceptStream {
   int32_t* index;          // [cap] pair index of each record
   uint8_t* flags;          // [pairs] success of every pair (may be null)
   unsigned* counter;       // device
+  sf_result* records2;     // [cap] optional second copy of every record (e.g. a collective's send buffer on the device)
   int32_t cap;
+  int32_t ext_counter;     // the counter is the caller's (zeroed by the caller before each query)
 };
 
 struct DeviceParams {
@@ -277,7 +279,7 @@ struct sf_context {
   } spec;
   // accepted-result streams (sf_accept_stream_set / _select): two registered blocks, the one selected for the next
   // speculative query is handed to the fused kernel; `streamed` says whether the last query used it
-  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, 0}; bool set = false; const unsigned* uploaded[2] = {nullptr, nullptr}; } accept_blocks[2];
+  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; bool set = false; const unsigned* uploaded[2] = {nullptr, nullptr}; } accept_blocks[2];
   Buf accept_dev;                    // AcceptStream blocks on the device: [registered block][counter block]
   int accept_sel = -1;
   bool accept_streamed = false;

@@ -102,7 +102,7 @@ def load():
         "sf_find_matches_and_verify_device": (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(i32), vp]),
         "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
         "sf_compact_accepted_device_async": (C.c_int, [vp, vp, i32, vp, vp, vp]),
-        "sf_accept_stream_set": (C.c_int, [vp, i32, vp, vp, vp, i32]),
+        "sf_accept_stream_set": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
         "sf_accept_stream_select": (C.c_int, [vp, i32]),
         "sf_accept_stream_status": (C.c_int, [vp, P(i32), P(i32)]),
         "sf_compact_accepted_indexed_mirrored_device_async": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
@@ -445,10 +445,13 @@ class SeparatorFinder:
             self._h, C.c_void_p(d_results), C.c_void_p(index), n, C.c_void_p(d_accepted),
             C.c_void_p(d_flags) if d_flags else None, C.c_void_p(d_count)))
 
-    def accept_stream_set(self, which, records, index, flags, cap):
-        """Register block `which` (0 / 1) of the accepted-result stream: pinned host pointers (ints)."""
+    def accept_stream_set(self, which, records, index, flags, cap, d_records2=None, d_counter=None):
+        """Register block `which` (0 / 1) of the accepted-result stream: pinned host pointers (ints); optionally a
+        second (device) destination of every record and a caller-owned device counter."""
         self._check(self._L.sf_accept_stream_set(self._h, which, C.c_void_p(records), C.c_void_p(index),
-                                                 C.c_void_p(flags) if flags else None, cap))
+                                                 C.c_void_p(flags) if flags else None, cap,
+                                                 C.c_void_p(d_records2) if d_records2 else None,
+                                                 C.c_void_p(d_counter) if d_counter else None))
 
     def accept_stream_select(self, which):
         self._check(self._L.sf_accept_stream_select(self._h, which))

@@ -524,13 +524,20 @@ def test_accepted_results_streamed_from_the_kernel(est):
             rec = torch.zeros((cap, 368), dtype=torch.uint8).pin_memory()
             idx = torch.full((cap,), -1, dtype=torch.int32).pin_memory()
             fl = torch.full((cap,), 7, dtype=torch.uint8).pin_memory()
-            f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), fl.data_ptr(), cap)
+            if which == 0:
+                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), fl.data_ptr(), cap)
+            else:                              # a second (device) copy of every record and a caller-owned counter
+                rec2 = torch.zeros((cap, 368), dtype=torch.uint8, device=dev)
+                ctr = torch.zeros(2, dtype=torch.int32, device=dev)
+                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), fl.data_ptr(), cap, rec2.data_ptr(), ctr.data_ptr())
             blocks.append((rec, idx, fl))
         d_res = torch.zeros((n_kf, 368), dtype=torch.uint8, device=dev)
         for rep in range(4):
             which = rep & 1
             rec, idx, fl = blocks[which]
             rec.zero_(); idx.fill_(-1); fl.fill_(7)
+            if which == 1:
+                rec2.zero_(); ctr.zero_()
             f.accept_stream_select(which)
             m = f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=n_kf)
             torch.cuda.synchronize()
@@ -546,6 +553,9 @@ def test_accepted_results_streamed_from_the_kernel(est):
             assert (got_idx >= 0).all() and (idx.numpy()[n_acc:] == -1).all() and len(set(got_idx.tolist())) == n_acc
             recs = np.frombuffer(rec.numpy()[:n_acc].tobytes(), dtype=_abi.RESULT_DTYPE)
             assert recs["success"].all() and (flags[got_idx] == 1).all()
+            if which == 1:
+                assert int(ctr[0]) == n_acc and int(ctr[1]) == 0
+                assert torch.equal(rec2[:n_acc].cpu(), rec[:n_acc]) and not rec2[n_acc:].any()
             by_index = {int(j): recs[i] for i, j in enumerate(got_idx)}
             acc_matches = [i for i in range(n) if res["success"][i]]
             assert len(acc_matches) >= 10 and n_acc >= len(acc_matches)
