@@ -284,12 +284,15 @@ struct PnpTail {
 __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                          const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                          const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
-                                         const DeviceParams& P, unsigned char* smem_raw) {
+                                         const DeviceParams& P, unsigned char* smem_raw, int trace_base = 0) {
+  // (trace_base: first of five timestamp slots of the diagnostic build -- gather, RANSAC, first solve, refinement
+  //  rounds, pose + covariance; SF_TRACE_MARK compiles to nothing in the product)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
   const int sF = pair_from[pair], sT = pair_to[pair];
   const PnpTail none = {nullptr, nullptr, nullptr, 0, false};
+  (void)trace_base;
   const int max_it = P.iterations > 0 ? P.iterations : 0;
   const bool to_has_3d = st.meta[sT].y > 0;   // the "to" frame carries 3D points (selects the covariance form)
 
@@ -381,6 +384,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   }
 
   if (P.dbg_stop == 1) { if (tid == 0) pass[pair] = ps; return none; }   // diagnostic truncation (SF_RANSAC_STOP)
+  if (trace_base) SF_TRACE_MARK(P, pair, trace_base);
   PnpCam cam;
   cam.fx = P.fx; cam.fy = P.fy;
   cam.fxf = (float)P.fx; cam.fyf = (float)P.fy;
@@ -446,6 +450,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     __syncthreads();
   }
   if (P.dbg_stop == 2) { if (tid == 0) pass[pair] = ps; return none; }
+  if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 1);
   const int best_it = L.misc[0];
   if (best_it < 0) {   // solvePnPRansac returned false: no inliers
     if (tid == 0) pass[pair] = ps;
@@ -478,6 +483,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     sfd::R_to_quat(Rb, q);
   }
   pnp_lm(L, cam, m, L.mask, q, t, tid);
+  if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 2);
 
   // ---- rtabmap util3d::solvePnPRansac refinement rounds (Vis/PnPRefineIterations > 0) ---------------------
   const uint8_t* inl = L.mask;
@@ -535,6 +541,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   }
 
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return none; }
+  if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 3);
   ps.inliers = n_inl;
   if (n_inl < P.min_inliers) {
     if (tid == 0) pass[pair] = ps;
@@ -611,6 +618,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     ps.var_ang = v;
   }
   if (tid == 0) pass[pair] = ps;
+  if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 4);
   return PnpTail{L.obj, L.cidx, inl, m, true};
 }
 

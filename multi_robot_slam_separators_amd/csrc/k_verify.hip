@@ -271,8 +271,9 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
   const int sF = pair_from[pair], sT = pair_to[pair];
   unsigned char* ba_lds = smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15);
   __builtin_amdgcn_s_setprio(3);
+  SF_TRACE_MARK(P, pair, 1);
   {
-    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw);
+    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw, 37);
     if constexpr (BA) {
       if (P.bundle_adjustment && tail.ran)
         ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass1[pair], P, ba_lds);
@@ -283,14 +284,16 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
                                    corr2 + (size_t)pair * st.kcap, hdr2[pair], nullptr, nullptr, P,
                                    reinterpret_cast<int*>(smem_raw));
   __syncthreads();
+  SF_TRACE_MARK(P, pair, 42);
   if (est2) {
-    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw);
+    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 43);
     if constexpr (BA) {
       if (P.bundle_adjustment && tail.ran)
         ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass2[pair], P, ba_lds);
     }
     __syncthreads();
   }
+  SF_TRACE_MARK(P, pair, 17);
   if (threadIdx.x == 0) finalize_one(pass1[pair], pass2[pair], guided_flag[pair], out[pair]);
   if (P.accept) {                 // accepted-result stream (see chain_after_match)
     __syncthreads();              // (the bodies are done with the LDS: its first word carries the slot)

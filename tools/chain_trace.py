@@ -5,7 +5,7 @@ launch, reads the [pair][48] wall-clock stamps thread 0 of every workgroup left,
 ran the whole chain, the mean / median / p90 duration of every phase -- under load (the 10 000-pair launch) and
 uncontended (a launch with fewer surviving pairs than CUs).  Also the launch's wall time from HIP events.
 
-usage: python tools/chain_trace.py [n_pairs=10000] [k=500] [cols=32] [iterations=500]
+usage: python tools/chain_trace.py [n_pairs=10000] [k=500] [cols=32] [iterations=500] [pnp]
 """
 import ctypes
 import os
@@ -38,8 +38,20 @@ PHASES = [
 ]
 
 
-def run(n, k, cols, iters, true_frac, label):
+PHASES_PNP = [
+    ("match kernel (whole)", 0, 36),
+    ("p1 gather + bearings", 1, 37), ("p1 RANSAC", 37, 38), ("p1 mask + first solve", 38, 39),
+    ("p1 refinement rounds", 39, 40), ("p1 pose + covariance", 40, 41),
+    ("guided matching", 41, 42),
+    ("p2 gather + bearings", 42, 43), ("p2 RANSAC", 43, 44), ("p2 mask + first solve", 44, 45),
+    ("p2 refinement rounds", 45, 46), ("p2 pose + covariance", 46, 47),
+    ("CHAIN (1 -> 17)", 1, 17),
+]
+
+
+def run(n, k, cols, iters, true_frac, label, est=0):
     p = synth.camera_params()
+    p.estimation_type = est
     p.iterations = iters
     p.max_features = k
     p.desc_bytes = cols
@@ -82,6 +94,16 @@ def run(n, k, cols, iters, true_frac, label):
     rc = L.sf_debug_chain_trace(f._h, tr.ctypes.data, n)
     assert rc == 0, rc
     res = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+    if est == 1:
+        us = tr.astype(np.float64) / 100.0
+        full = (tr[:, 47] != 0) & (tr[:, 41] != 0)     # pairs whose chain ran both PnP passes to the end
+        print("== %s (PnP chain): %d pairs, K=%d, %d iterations: launch %.3f ms, %d accepted, %d full chains" % (
+            label, n, k, iters, e0.elapsed_time(e1), int(res["success"].sum()), int(full.sum())))
+        for name, a, b in PHASES_PNP:
+            d = (us[:, b] - us[:, a])[full]
+            print("   %-24s mean %7.2f  median %7.2f  p90 %7.2f us" % (name, d.mean(), np.median(d), np.percentile(d, 90)))
+        f.close()
+        return
     full = (tr[:, 16] != 0) & (tr[:, 7] != 0)          # pairs that ran both RANSAC passes to the end
     us = tr.astype(np.float64) / 100.0                 # 100 MHz wall clock -> microseconds
     print("== %s: %d pairs, K=%d, %d B, %d iterations: launch %.3f ms, %d accepted, %d full chains" % (
@@ -110,8 +132,9 @@ def main():
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     cols = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     iters = int(sys.argv[4]) if len(sys.argv) > 4 else 500
-    run(n, k, cols, iters, 0.2, "loaded")
-    run(600, k, cols, iters, 0.2, "uncontended (~120 chains on 256 CUs)")
+    est = 1 if (len(sys.argv) > 5 and sys.argv[5] == "pnp") else 0
+    run(n, k, cols, iters, 0.2, "loaded", est)
+    run(600, k, cols, iters, 0.2, "uncontended (~120 chains on 256 CUs)", est)
 
 
 if __name__ == "__main__":
