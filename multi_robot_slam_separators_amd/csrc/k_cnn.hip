@@ -398,31 +398,32 @@ k_softmax_rows(float* __restrict__ s, int rows, int K) {
   if (lane < K) p[lane] = e / sum;
 }
 
-// v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per 4 consecutive d (lane = cluster, the four wavefronts
-// split the pixels; x is read 16 bytes at a time, a[p][:] 256 bytes per wavefront), K <= 64
+// v[d][k] = sum_p a[p][k] (x[p][d] + C[d][k]); one workgroup per 2 consecutive d (lane = cluster, the four wavefronts
+// split the pixels; a[p][:] 256 bytes per wavefront), K <= 64
 __global__ void __launch_bounds__(256)
 k_vlad_aggregate(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ centers, int P,
                  int D, int K, float* __restrict__ v) {
-  __shared__ float red[4][4][64];
-  const int d0 = blockIdx.x * 4, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // (two d per workgroup: 256 workgroups for D = 512, one per CU; the pixel loop is unrolled so that eight pixels'
+  //  loads are in flight per wavefront -- it was one dependent round trip per pixel, 75 us for 1 200 pixels)
+  __shared__ float red[4][2][64];
+  const int d0 = blockIdx.x * 2, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[2] = {0.f, 0.f};
   if (lane < K) {
-    float c[4];
+    float c[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) c[q] = centers[(size_t)(d0 + q) * K + lane];
+    for (int q = 0; q < 2; ++q) c[q] = centers[(size_t)(d0 + q) * K + lane];
+#pragma unroll 8
     for (int p = wave; p < P; p += 4) {
       const float ap = a[(size_t)p * K + lane];
-      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * D + d0);
+      const float2 xv = *reinterpret_cast<const float2*>(x + (size_t)p * D + d0);
       acc[0] = fmaf(ap, xv.x + c[0], acc[0]);
       acc[1] = fmaf(ap, xv.y + c[1], acc[1]);
-      acc[2] = fmaf(ap, xv.z + c[2], acc[2]);
-      acc[3] = fmaf(ap, xv.w + c[3], acc[3]);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) red[wave][q][lane] = acc[q];
+  for (int q = 0; q < 2; ++q) red[wave][q][lane] = acc[q];
   __syncthreads();
-  if (lane < K) {
+  if (lane < K && wave < 2) {
     const int q = wave;          // wavefront q finishes d0 + q
     v[(size_t)(d0 + q) * K + lane] = ((red[0][q][lane] + red[1][q][lane]) + red[2][q][lane]) + red[3][q][lane];
   }
@@ -747,7 +748,7 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
                      (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
   hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
-  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 4), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
+  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 2), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
                      (const float*)m->centers.p, P, D, K, (float*)m->vlad.p);
   hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)m->vlad.p, D, K,
                      (float*)m->pca_y.p);                                        // (pca_y doubles as the K norms)
