@@ -57,9 +57,10 @@ constexpr int CK = 32, CP = 36;    // K step 32 floats, LDS pitch 36 floats
 __global__ void __launch_bounds__(256)
 k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restrict__ wgt, const float* __restrict__ bias,
                 const float* __restrict__ mean, float* __restrict__ out, int relu) {
-  __shared__ float sw[64 * 27];
-  __shared__ float sb[64];
-  for (int i = threadIdx.x; i < 64 * 27; i += 256) sw[i] = wgt[i];
+  __shared__ __attribute__((aligned(16))) float sw[64 * 27];
+  __shared__ __attribute__((aligned(16))) float sb[64];
+  // (tap-major in LDS: sw[k][channel], so that four channels' weights of a tap come in one 16-byte broadcast read)
+  for (int i = threadIdx.x; i < 64 * 27; i += 256) sw[(i % 27) * 64 + i / 27] = wgt[i];
   if (threadIdx.x < 64) sb[threadIdx.x] = bias[threadIdx.x];
   __syncthreads();
   const int g = blockIdx.x * 256 + threadIdx.x;        // (pixel, group of 16 output channels)
@@ -77,15 +78,14 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
   // (four threads per pixel: the 27 inputs are fetched 4 times instead of 16, and the four write one 256-byte row)
 #pragma unroll
   for (int c4 = 0; c4 < 16; c4 += 4) {
-    float o[4];
+    float4 a = *reinterpret_cast<const float4*>(&sb[c16 + c4]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float a = sb[c16 + c4 + q];
-#pragma unroll
-      for (int k = 0; k < 27; ++k) a = fmaf(v[k], sw[(c16 + c4 + q) * 27 + k], a);
-      o[q] = relu ? fmaxf(a, 0.f) : a;
+    for (int k = 0; k < 27; ++k) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&sw[k * 64 + c16 + c4]);
+      a.x = fmaf(v[k], w4.x, a.x); a.y = fmaf(v[k], w4.y, a.y); a.z = fmaf(v[k], w4.z, a.z); a.w = fmaf(v[k], w4.w, a.w);
     }
-    *reinterpret_cast<float4*>(out + (size_t)p * 64 + c16 + c4) = make_float4(o[0], o[1], o[2], o[3]);
+    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (size_t)p * 64 + c16 + c4) = a;
   }
 }
 
