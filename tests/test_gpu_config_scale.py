@@ -10,7 +10,9 @@ do not depend on the order or the batching of the pairs; (c) the oracle on a SAM
   configs[1]  10 000 x 10 000 x 4096 NN + 10 000 verifications, K = 500, 500 iterations
   configs[2]  100 000-row x 4096-D databases, 3 robots (3 ordered robot pairs through one handle), K = 1000, 2000 it.
   configs[4]  fp16 NetVLAD + 512-bit descriptors, 5 robots = 10 robot pairs flattened into ONE pair list (8(e))
-  (configs[3], 1 M pairs round-robin over 8 GPUs: bench.py --workload cfg4; its single-GPU chunking is in test_gpu_verify)
+  configs[3]  1 000 000 candidate pairs of the configs[1] shape over a replicated 10 000-keyframe store: the whole list
+              in one call, then as the G = 8 round-robin shards (p mod 8) a node's ranks would verify -- 125 000 pairs
+              per rank in ONE launch -- with the accepted separators of a shard through dist.RecordExchange over RCCL
 """
 import numpy as np
 import pytest
@@ -141,18 +143,37 @@ def exact_distances(loc, rec, il, io):
     return ((a - b) ** 2).sum(1).sqrt().cpu().numpy()
 
 
+def oracle_pair(oracle, p, d, ia, ib):
+    """The oracle's result of (A[ia] -> B[ib]) on host copies of the device-generated features."""
+    kpa = np.zeros(d["kp_a"].shape[1], dtype=_abi.KEYPOINT_DTYPE)
+    kpb = np.zeros(d["kp_b"].shape[1], dtype=_abi.KEYPOINT_DTYPE)
+    ka, kb = d["kp_a"][ia].cpu().numpy(), d["kp_b"][ib].cpu().numpy()
+    for dst, src in ((kpa, ka), (kpb, kb)):
+        dst["x"], dst["y"], dst["size"] = src[:, 0], src[:, 1], src[:, 2]
+    fa = _abi.FeatureArrays(d["desc_a"][ia].cpu().numpy(), d["xyz_a"][ia].cpu().numpy(), kpa)
+    fb = _abi.FeatureArrays(d["desc_b"][ib].cpu().numpy(), d["xyz_b"][ib].cpu().numpy(), kpb)
+    return oracle.estimate_transform(p, fa, fb)
+
+
 def oracle_sample(oracle, p, d, idx, got):
     """Byte-for-byte oracle check of a sample of pairs (host copies of the device-generated features)."""
     for i in idx:
-        kpa = np.zeros(d["kp_a"].shape[1], dtype=_abi.KEYPOINT_DTYPE)
-        kpb = np.zeros(d["kp_b"].shape[1], dtype=_abi.KEYPOINT_DTYPE)
-        ka, kb = d["kp_a"][i].cpu().numpy(), d["kp_b"][i].cpu().numpy()
-        for dst, src in ((kpa, ka), (kpb, kb)):
-            dst["x"], dst["y"], dst["size"] = src[:, 0], src[:, 1], src[:, 2]
-        fa = _abi.FeatureArrays(d["desc_a"][i].cpu().numpy(), d["xyz_a"][i].cpu().numpy(), kpa)
-        fb = _abi.FeatureArrays(d["desc_b"][i].cpu().numpy(), d["xyz_b"][i].cpu().numpy(), kpb)
-        o = oracle.estimate_transform(p, fa, fb)
+        o = oracle_pair(oracle, p, d, i, i)
         assert got[i].tobytes() == o.tobytes(), "pair %d differs from the oracle" % i
+
+
+def describe_mismatch(a, b, limit=4):
+    """Every field of the first records in which two result arrays differ (an assertion message that names the
+    records, not only the first differing byte: bytes 0-2 of a position are always zero -- the pose is a widened
+    float -- so a first difference at byte 3 of a record says nothing about how far the two results are apart)."""
+    n = min(len(a), len(b))
+    bad = [i for i in range(n) if a[i].tobytes() != b[i].tobytes()]
+    lines = ["%d of %d records differ (lengths %d / %d)" % (len(bad), n, len(a), len(b))]
+    for i in bad[:limit]:
+        for nm in a.dtype.names:
+            if nm != "pad" and not np.array_equal(a[i][nm], b[i][nm]):
+                lines.append("  record %d %s: %r != %r" % (i, nm, a[i][nm].tolist(), b[i][nm].tolist()))
+    return "\n".join(lines)
 
 
 # ---- configs[1] ------------------------------------------------------------------------------------------------------
@@ -198,8 +219,8 @@ def test_configs1_full_step(oracle):
     assert np.all(np.diff(m["distance"]) >= 0) and m["distance"].max() < p.netvlad_distance
     assert np.allclose(m["distance"], exact_distances(loc, rec, m["idx_local"], m["idx_other"]), rtol=1e-12)
     assert m.tobytes() == m0.tobytes()                      # fp16 filter == fp32 ranking, byte for byte
-    assert res.tobytes() == res0.tobytes()                  # speculative == two calls
-    assert res_rev[::-1].tobytes() == res0.tobytes()        # order / batching independence
+    assert res.tobytes() == res0.tobytes(), describe_mismatch(res, res0)                  # speculative == two calls
+    assert res_rev[::-1].tobytes() == res0.tobytes(), describe_mismatch(res_rev[::-1], res0)   # order / batching independence
     # decisions = ground truth: candidate (local row i, received row partner[i]) is keyframe pair
     # (A[partner[i]], B[i]); a true revisit only if it is the SAME index pair the features were planted for
     truth = d["is_true"][m["idx_local"]] & (m["idx_local"] == m["idx_other"])
@@ -278,6 +299,87 @@ def test_configs2_database_scale_three_robots(oracle):
     dt, dr = pose_errors(res[ok], d["R"][ok], d["t"][ok])
     assert dt.max() < 0.05 and dr.max() < 0.01
     oracle_sample(oracle, p, d, np.concatenate([np.nonzero(ok)[0][:4], np.nonzero(~ok)[0][:2]]), res)
+
+
+# ---- configs[3] ------------------------------------------------------------------------------------------------------
+def test_configs3_one_million_pairs_round_robin(oracle):
+    """BASELINE configs[3] as one GPU of the node sees it.  1 000 000 candidate pairs of the configs[1] shape (K = 500,
+    256-bit, 500 hypotheses) over a replicated store of 2 x 10 000 keyframes: candidate p is (A[i], B[j]) with
+    i = p mod N; in the even rounds q = p div N it is the aligned pair (j = i: 20 % planted revisits), in the odd rounds
+    a shifted one (never a revisit).  (a) the whole list in one sf_verify_pairs_device call (chunked inside): every
+    decision equals the planted truth; (b) the G = 8 round-robin shards p mod 8, 125 000 pairs each in ONE launch: the
+    bytes of shard r equal the single-list bytes at r::8; (c) the accepted separators of a shard compacted into
+    dist.RecordExchange's send buffer and all-gathered over RCCL (world size 1 here): exactly the accepted records, in
+    candidate order, also when more are accepted than the exchange's capacity; (d) an oracle sample, byte for byte."""
+    import os
+    import socket
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import dist, lib
+    n_kf, k, cols, G, n_pairs = 10000, 500, 32, 8, 1000000
+    RB = _abi.RESULT_DTYPE.itemsize
+    OFF = _abi.RESULT_DTYPE.fields["success"][1]
+    p = synth.camera_params()
+    p.iterations = 500
+    p.max_features = k
+    p.store_capacity = 2 * n_kf
+    d = gen_pairs(2301, n_kf, k, cols)
+    pidx = torch.arange(n_pairs, device=DEV)
+    i_of, q_of = pidx % n_kf, pidx // n_kf
+    j_of = torch.where(q_of % 2 == 0, i_of, (i_of + 1 + q_of) % n_kf)
+    truth = torch.from_numpy(d["is_true"]).to(DEV)[i_of] & (i_of == j_of)
+    own_group = not td.is_initialized()
+    if own_group:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s.getsockname()[1])
+        td.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        with lib.SeparatorFinder(p) as f:
+            f.set_stream(torch.cuda.current_stream().cuda_stream)
+            sa, sb = add_store(f, d, "a", k, cols), add_store(f, d, "b", k, cols)
+            fr = (sa + i_of).to(torch.int32).contiguous()
+            to = (sb + j_of).to(torch.int32).contiguous()
+            d_all = torch.empty((n_pairs, RB), dtype=torch.uint8, device=DEV)
+            f.verify_pairs_device(fr.data_ptr(), to.data_ptr(), n_pairs, d_all.data_ptr())       # (a)
+            torch.cuda.synchronize()
+            ok_all = d_all[:, OFF] != 0
+            assert torch.equal(ok_all, truth)
+            assert 90000 < int(truth.sum()) < 110000            # 20 % of the aligned half of the list
+            per = n_pairs // G
+            d_part = torch.empty((per, RB), dtype=torch.uint8, device=DEV)
+            d_flags = torch.empty(per, dtype=torch.bool, device=DEV)
+            for r in range(G):                                   # (b)
+                sel = torch.arange(r, n_pairs, G, device=DEV)
+                assert sel.numel() == per == 125000
+                fr_r, to_r = fr[sel].contiguous(), to[sel].contiguous()
+                d_part.fill_(0xA5)
+                f.verify_pairs_device(fr_r.data_ptr(), to_r.data_ptr(), per, d_part.data_ptr())
+                torch.cuda.synchronize()
+                assert torch.equal(d_part, d_all[sel]), "shard %d of %d differs from the single list" % (r, G)
+                if r in (0, 5):                                  # (c) cap above / below the accepted count
+                    want = d_part[ok_all[sel]]
+                    cap = per // 4 + 1024 if r == 0 else 1000
+                    ex = dist.RecordExchange(RB, per, cap, torch.device(DEV))
+                    f.compact_accepted_device_async(d_part.data_ptr(), per, ex.payload.data_ptr(), d_flags.data_ptr(),
+                                                    ex.count_ptr)
+                    ex.exchange(None)
+                    torch.cuda.synchronize()
+                    assert ex.counts() == [int(want.shape[0])] and (want.shape[0] > cap) == (r == 5)
+                    got, counts = ex.all_gathered()
+                    assert counts == [int(want.shape[0])] and torch.equal(got, want)
+                    assert torch.equal(d_flags, ok_all[sel])
+            # (d) aligned true / aligned false / shifted candidates, wherever they sit in the list
+            tr = truth.cpu().numpy()
+            qn = q_of.cpu().numpy()
+            sample = np.concatenate([np.nonzero(tr)[0][[0, 777, -1]], np.nonzero(~tr & (qn % 2 == 0))[0][[0, -1]],
+                                     np.nonzero(qn % 2 == 1)[0][[0, 123456]]])
+            res = results_of(d_all[torch.from_numpy(sample).to(DEV)], len(sample))
+            for s_i, pp in enumerate(sample):
+                o = oracle_pair(oracle, p, d, int(i_of[pp]), int(j_of[pp]))
+                assert res[s_i].tobytes() == o.tobytes(), "candidate %d differs from the oracle" % pp
+    finally:
+        if own_group:
+            td.destroy_process_group()
 
 
 # ---- configs[4] ------------------------------------------------------------------------------------------------------
