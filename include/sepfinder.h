@@ -46,7 +46,11 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+/* 2: sf_params.reserved[5] became bundle_adjustment / ba_* / stereo_baseline, sf_find_matches_and_verify_device accepts
+      d_out = NULL, sf_debug_correspondences needs SF_OPT_DEBUG_CORR, sf_step_* added, the accepted-result stream and the
+      indexed compactions moved to sf_experimental.h.  A binding checks sf_abi_version() against the header it was
+      written for (multi_robot_slam_separators_amd/lib.py does).                                                   */
+#define SF_ABI_VERSION 2
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -421,43 +425,45 @@ int  sf_allgather_separators_device(sf_handle h, const sf_separator* d_send, sf_
    host part of the NN stage off the critical path.                                                     */
 int  sf_find_matches_and_verify_device(sf_handle h, int32_t slot_base_other, int32_t slot_base_local,
                                        sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out);
-/* d_out may be NULL: the call then leaves the results where the verification wrote them, and
-   sf_last_match_results says where: the record of match i is d_results[index ? index[i] : i] (index, if not NULL, is
-   device-readable pinned host memory owned by the handle, valid until the next sf_find_matches_and_verify_device).
-   sf_compact_accepted_indexed_device_async consumes exactly that pair (any index == NULL means "in order"), so a
-   caller that only needs the ACCEPTED separators saves the gathered copy of all of them.                        */
-int  sf_last_match_results(sf_handle h, const sf_result** d_results, const int32_t** index, int32_t* n);
-int  sf_compact_accepted_indexed_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
-                                              int32_t n, sf_result* d_accepted, uint8_t* d_flags,
-                                              int32_t* d_n_accepted);
-/* The same with every output written TWICE: accepted records, flags and count also go to d_accepted2 / d_flags2
-   (optional) / d_n_accepted2 -- e.g. a collective's send buffer on the device AND this rank's own copy in pinned host
-   memory, without a copy behind the kernel (bench.py, N > 1).                                                     */
-int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
-                                                       int32_t n, sf_result* d_accepted, uint8_t* d_flags,
-                                                       int32_t* d_n_accepted, sf_result* d_accepted2, uint8_t* d_flags2,
-                                                       int32_t* d_n_accepted2);
+/* d_out may be NULL: the results then stay in the handle's own block (sf_step_* and sf_experimental.h consume them
+   there without a gathered copy of all records).                                                                  */
 
-/* Accepted results STREAMED out of the verification kernels (both estimators; the speculative path of
-   sf_find_matches_and_verify_device): every pair whose result is accepted writes its record into the selected block
-   the moment it is final -- posted writes beside the other pairs' work -- instead of a compaction kernel behind the
-   launch.  A block = host-pinned (device-accessible) arrays: records [cap], index [cap] (the record's slot in the
-   sf_last_match_results block, i.e. match i owns the record whose index equals index_of_match[i]), flags [pairs]
-   (optional: success of EVERY verified slot, 0 for slots without a candidate -- if that array is host memory every
-   pair ends on a 1-byte PCIe write its workgroup has to see acknowledged, measured as +10 us on a 10 000-pair launch:
-   pass NULL and derive the flags from the index list, whose entries beyond the streamed count keep their old value).  Records arrive in completion order and
-   cover every verified candidate (a superset of the matches when a row had several candidates): the host keeps those
-   whose index is a match's.  Their number is the sum of flags over the `pairs` slots sf_accept_stream_status reports.
-   Two blocks can be registered and selected alternately, so that one query's separators stay untouched while the
-   next one runs.  `streamed` = 0 after a call that could not stream (fallback paths): use the compaction then.     */
-/* d_records2 (optional): every record is written there too, at the same slot -- e.g. a collective's send buffer on the
-   device.  d_counter (optional): the slot counter is this device word instead of the handle's own; the CALLER zeroes
-   it before each query (e.g. the count header of that send buffer, so that the all-gather can start behind the
-   verification with nothing in between).                                                                       */
-int  sf_accept_stream_set(sf_handle h, int32_t which, sf_result* records, int32_t* index, uint8_t* flags, int32_t cap,
-                          sf_result* d_records2, uint32_t* d_counter);
-int  sf_accept_stream_select(sf_handle h, int32_t which);      /* 0 / 1, -1 = off (default) */
-int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
+/* ---- the caller's loop body as a begin / retire pair ------------------------------------------------------------ */
+/* replaces: one iteration of find_separators.py:59-133 when both robots' keyframes live in this handle --
+     sf_step_issue   = s_find_matches_query (:63) + one s_ans_est_transform per returned candidate (:83-95), QUEUED: the
+                       call returns when the candidate list is known (the NN stage has been walked on the host) and the
+                       verification of every candidate is running on the device;
+     sf_step_retire  = what the loop then does with the outcomes (:97-133): for every match, in the order
+                       DataHandler.find_matches returned them, whether the estimation succeeded and, if so, its
+                       PoseWithCovariance -- the rows of the ReceiveSeparators request (sf_pack_separators packs them).
+   Up to TWO steps may be in flight, so a host issues step k before it retires step k - 1 and the device never waits for
+   the host (bench.py, examples/bench_cli.cpp):  issue(0); for k = 1..: issue(k); retire(k - 1); ...; retire(last).
+   Accepted results leave the verification kernel for host-pinned memory the moment they are final (no compaction
+   launch, no copy); a query the speculative verification does not cover (netvlad_max_matches_nb < local rows, as in the
+   reference's default of 20; nn_precision 0; very large batches) takes sf_nn_find_matches + sf_verify_matches_device +
+   an ordered compaction inside the same two calls.  Results are identical either way.
+   Pointers in sf_step_result are owned by the handle and stay valid until the second-next sf_step_issue.          */
+typedef struct sf_step_result {
+  const sf_match*  matches;          /* n_matches candidates, walk order (data_handler.py:191-205)                   */
+  const int32_t*   record_of_match;  /* n_matches: index into `records` of the match's result, -1 = estimation failed
+                                        (transform_est_success = 0: find_separators.py:119-126 feeds the ignore list) */
+  const sf_result* records;          /* accepted results (success = 1) in host-pinned memory; completion order when
+                                        streamed, match order otherwise: always go through record_of_match           */
+  int32_t          n_matches;
+  int32_t          n_records;        /* accepted results present (>= n_accepted: a local row with two candidates under
+                                        the threshold had both verified, the walk kept one)                          */
+  int32_t          n_accepted;       /* matches whose estimation succeeded                                           */
+  int32_t          streamed;         /* 1: the records streamed out of the kernel, 0: compacted behind it            */
+} sf_step_result;
+int  sf_step_issue(sf_handle h, int32_t slot_base_other, int32_t slot_base_local);
+int  sf_step_retire(sf_handle h, sf_step_result* out);      /* the OLDEST step in flight; waits for its verification */
+/* Optional second destination of every accepted record, on the device -- e.g. the send buffer of the all-gather that
+   follows (sf_allgather_separators_device: slot 0 = header, records from slot 1): d_records2[slot] receives the record
+   the host block receives at the same slot and *d_counter (a device word the CALLER zeroes before each sf_step_issue,
+   e.g. the count in that header) counts the slots taken.  cap = record slots behind d_records2; a cap below the number
+   of verified candidates of a query (local rows * 9 / 8 + 256) switches that query to the compaction (nothing is ever
+   dropped).  NULL, NULL, 0 removes the mirror.  Not while a step is in flight.                                    */
+int  sf_step_mirror(sf_handle h, sf_result* d_records2, uint32_t* d_counter, int32_t cap);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */
@@ -475,10 +481,6 @@ enum {
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);
-/* Which kernels are bracketed (bit k = kernel k of the enum above; default all).  Two timing events per launch cost
-   host time and a marker on the queue -- about 4 us per bracketed launch in a 0.6 ms step -- so a throughput
-   measurement brackets only the kernel it prices (bench.py: the dominant one) and surveys the rest separately.  */
-int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
 int  sf_prof_reset(sf_handle h);
 int  sf_prof_get(sf_handle h, int kernel, int64_t* launches, double* total_ms);
 const char* sf_kernel_name(int kernel);

@@ -1,0 +1,64 @@
+/*
+ * sf_experimental.h -- entry points of libsepfinder.so that are NOT part of the drop-in surface (include/sepfinder.h).
+ *
+ * They are the building blocks sf_step_issue / sf_step_retire are made of, exported for the library's own tests, for
+ * tools/ and for bench.py's diagnostic variants (BENCH_NO_STREAM, the N > 1 fallbacks).  No reference interface
+ * corresponds to them one to one (the loop they serve is PKG/scripts/find_separators.py:59-133); a host written against
+ * the reference needs none of them, and they may change without a bump of SF_ABI_VERSION.
+ */
+#ifndef SF_EXPERIMENTAL_H
+#define SF_EXPERIMENTAL_H
+
+#include "sepfinder.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sf_find_matches_and_verify_device with d_out = NULL leaves the results where the verification wrote them, and
+   sf_last_match_results says where: the record of match i is d_results[index ? index[i] : i] (index, if not NULL, is
+   device-readable pinned host memory owned by the handle, valid until the next sf_find_matches_and_verify_device).
+   sf_compact_accepted_indexed_device_async consumes exactly that pair (any index == NULL means "in order"), so a
+   caller that only needs the ACCEPTED separators saves the gathered copy of all of them.                        */
+int  sf_last_match_results(sf_handle h, const sf_result** d_results, const int32_t** index, int32_t* n);
+int  sf_compact_accepted_indexed_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
+                                              int32_t n, sf_result* d_accepted, uint8_t* d_flags,
+                                              int32_t* d_n_accepted);
+/* The same with every output written TWICE: accepted records, flags and count also go to d_accepted2 / d_flags2
+   (optional) / d_n_accepted2 -- e.g. a collective's send buffer on the device AND this rank's own copy in pinned host
+   memory, without a copy behind the kernel (bench.py, N > 1).                                                     */
+int  sf_compact_accepted_indexed_mirrored_device_async(sf_handle h, const sf_result* d_results, const int32_t* index,
+                                                       int32_t n, sf_result* d_accepted, uint8_t* d_flags,
+                                                       int32_t* d_n_accepted, sf_result* d_accepted2, uint8_t* d_flags2,
+                                                       int32_t* d_n_accepted2);
+
+/* Accepted results STREAMED out of the verification kernels (both estimators; the speculative path of
+   sf_find_matches_and_verify_device): every pair whose result is accepted writes its record into the selected block
+   the moment it is final -- posted writes beside the other pairs' work -- instead of a compaction kernel behind the
+   launch.  A block = host-pinned (device-accessible) arrays: records [cap], index [cap] (the record's slot in the
+   sf_last_match_results block, i.e. match i owns the record whose index equals index_of_match[i]), flags [pairs]
+   (optional: success of EVERY verified slot, 0 for slots without a candidate -- if that array is host memory every
+   pair ends on a 1-byte PCIe write its workgroup has to see acknowledged, measured as +10 us on a 10 000-pair launch:
+   pass NULL and derive the flags from the index list, whose entries beyond the streamed count keep their old value).  Records arrive in completion order and
+   cover every verified candidate (a superset of the matches when a row had several candidates): the host keeps those
+   whose index is a match's.  Their number is the sum of flags over the `pairs` slots sf_accept_stream_status reports.
+   Two blocks can be registered and selected alternately, so that one query's separators stay untouched while the
+   next one runs.  `streamed` = 0 after a call that could not stream (fallback paths): use the compaction then.     */
+/* d_records2 (optional): every record is written there too, at the same slot -- e.g. a collective's send buffer on the
+   device.  d_counter (optional): the slot counter is this device word instead of the handle's own; the CALLER zeroes
+   it before each query (e.g. the count header of that send buffer, so that the all-gather can start behind the
+   verification with nothing in between).                                                                       */
+int  sf_accept_stream_set(sf_handle h, int32_t which, sf_result* records, int32_t* index, uint8_t* flags, int32_t cap,
+                          sf_result* d_records2, uint32_t* d_counter);
+int  sf_accept_stream_select(sf_handle h, int32_t which);      /* 0 / 1, -1 = off (default) */
+int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
+
+/* Which kernels are bracketed (bit k = kernel k of the enum above; default all).  Two timing events per launch cost
+   host time and a marker on the queue -- about 4 us per bracketed launch in a 0.6 ms step -- so a throughput
+   measurement brackets only the kernel it prices (bench.py: the dominant one) and surveys the rest separately.  */
+int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_EXPERIMENTAL_H */

@@ -209,6 +209,15 @@ MATCH_DTYPE = np.dtype([("idx_local", "<i4"), ("idx_other", "<i4"), ("distance",
 assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 
 
+class StepResult(C.Structure):
+    """sf_step_result (include/sepfinder.h): what sf_step_retire hands back; the pointers belong to the handle."""
+    _fields_ = [("matches", C.c_void_p), ("record_of_match", C.c_void_p), ("records", C.c_void_p),
+                ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32)]
+
+
+SF_ABI_VERSION = 2      # include/sepfinder.h
+
+
 def default_params() -> Params:
     """Defaults: multi_robot_separators.launch:19-23 for the reference's own knobs; rtabmap
     compiled-in defaults [upstream, SURVEY.md section 9] for the Vis/* values; estimation type

@@ -780,6 +780,10 @@ extern "C" void sf_destroy(sf_handle c) {
     if (c->spec.ev_copied) (void)hipEventDestroy(c->spec.ev_copied);
     if (c->spec.copy_stream) { (void)hipStreamSynchronize(c->spec.copy_stream); (void)hipStreamDestroy(c->spec.copy_stream); }
   }
+  for (auto& sb : c->step_blocks) {
+    if (sb.pinned) (void)hipHostFree(sb.pinned);
+    if (sb.done) (void)hipEventDestroy(sb.done);
+  }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1240,6 +1244,10 @@ static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   c->accept_streamed = false;
   if (c->accept_sel < 0 || !c->accept_blocks[c->accept_sel].set) return SF_OK;
   sf_context::AcceptHost& ab = c->accept_blocks[c->accept_sel];
+  // Every verified slot may be accepted: a block with fewer record slots than the launch has pairs could lose
+  // records (the kernel drops what does not fit and the slot counter is not the caller's to read), so such a block
+  // is not armed -- sf_accept_stream_status then reports streamed = 0 and the caller takes the compaction.
+  if ((unsigned)ab.s.cap < c->spec.grid) return SF_OK;
   const unsigned* counter = ab.s.ext_counter ? ab.s.counter : d_count + 4;
   // (the candidate list's counter blocks alternate: one device copy of the block per counter block)
   const int ci = (d_count == (const unsigned*)c->nn_cand.p) ? 0 : 1;
@@ -1254,6 +1262,7 @@ static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   }
   c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + off);
   c->accept_streamed = true;
+  c->accept_armed = true;
   return SF_OK;
 }
 
@@ -1298,6 +1307,7 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   *n_out = 0;
   c->last_results = nullptr; c->last_results_index = nullptr; c->last_results_n = 0;
   c->accept_streamed = false;
+  c->accept_armed = false;
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
@@ -1341,7 +1351,9 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
   if (n == 0) return SF_OK;
   if (!(c->spec.launched && c->spec.valid)) {
     // no speculation, or its candidate set was not the one the matches came from: verify the matches now
-    // (a wasted speculative verification, if any, is simply queued in front)
+    // (a wasted speculative verification, if any, is simply queued in front -- what it streamed into the selected
+    //  accepted-result block is not this query's answer: streamed = 0, the block's owner resets it)
+    c->accept_streamed = false;
     if (!d_out) {       // the caller only wants sf_last_match_results: an internal block takes the results
       if ((rc = sf_buf_reserve(c, c->results, (size_t)n * sizeof(sf_result))) != SF_OK) return rc;
       d_out = (sf_result*)c->results.p;
@@ -1522,6 +1534,142 @@ extern "C" int sf_accept_stream_status(sf_handle c, int32_t* streamed, int32_t* 
   if (!c || !streamed) return SF_EINVAL;
   *streamed = c->accept_streamed ? 1 : 0;
   if (pairs) *pairs = c->accept_streamed ? (int32_t)c->spec.grid : 0;
+  return SF_OK;
+}
+
+// ---- the caller's loop body as a begin / retire pair (find_separators.py:59-133) -------------------------------------
+// sf_step_issue = s_find_matches_query + the estimate_transformation calls of every returned candidate, queued;
+// sf_step_retire = the per-candidate outcome the loop forwards (find_separators.py:97-133).  What bench.py's Python
+// choreography did in round 2 (stream selection, speculative verification, accepted-result stream, index -> match
+// filtering) lives here, so that a C++ host reaches the same rate with two calls per step.
+static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t cap) {
+  if (!b.done) SF_HIP(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  if (cap <= b.cap) return SF_OK;
+  if (b.pinned) (void)hipHostFree(b.pinned);
+  b.pinned = nullptr; b.cap = 0; b.pinned_bytes = 0;
+  const int32_t want = cap + cap / 4 + 64;
+  const size_t rec_bytes = (size_t)want * sizeof(sf_result);
+  const size_t idx_off = rec_bytes, flag_off = idx_off + (size_t)want * 4, cnt_off = (flag_off + (size_t)want + 63) & ~(size_t)63;
+  const size_t total = cnt_off + 64;
+  if (hipHostMalloc(&b.pinned, total, hipHostMallocDefault) != hipSuccess)
+    return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", total);
+  b.pinned_bytes = total;
+  b.records = (sf_result*)b.pinned;
+  b.index = (int32_t*)((char*)b.pinned + idx_off);
+  b.flags = (uint8_t*)b.pinned + flag_off;
+  b.count = (int32_t*)((char*)b.pinned + cnt_off);
+  b.cap = want;
+  for (int32_t i = 0; i < want; ++i) b.index[i] = -1;
+  memset(b.flags, 0, (size_t)want);
+  *b.count = 0;
+  return SF_OK;
+}
+
+extern "C" int sf_step_mirror(sf_handle c, sf_result* d_records2, uint32_t* d_counter, int32_t cap) {
+  if (!c || cap < 0 || ((d_records2 == nullptr) != (d_counter == nullptr))) return SF_EINVAL;
+  if (c->step_inflight) return sf_fail(c, SF_EINVAL, "sf_step_mirror: %d step(s) in flight, retire them first", c->step_inflight);
+  c->step_mirror_records = d_records2;
+  c->step_mirror_counter = d_counter;
+  c->step_mirror_cap = d_records2 ? cap : 0;
+  for (auto& ab : c->accept_blocks) ab = sf_context::AcceptHost();      // (re-registered by the next sf_step_issue)
+  return SF_OK;
+}
+
+extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_base_local) {
+  if (!c) return SF_EINVAL;
+  if (c->step_inflight >= 2) return sf_fail(c, SF_EINVAL, "two steps are in flight: call sf_step_retire first");
+  if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
+    return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
+  SF_HIP(c, hipSetDevice(c->device));
+  const int which = c->step_head;
+  sf_context::StepBlock& b = c->step_blocks[which];
+  const int n_l = c->nn_local.n;
+  // every slot of a speculative verification may be accepted: the block holds them all (see arm_accept_stream)
+  const int32_t need = n_l + n_l / 8 + 256;
+  int rc;
+  if ((rc = step_block_reserve(c, b, need)) != SF_OK) return rc;
+  const int32_t mirror_cap = c->step_mirror_records ? c->step_mirror_cap : b.cap;
+  sf_context::AcceptHost& ab = c->accept_blocks[which];
+  if (!ab.set || ab.s.records != b.records || ab.s.cap != std::min(b.cap, mirror_cap) ||
+      ab.s.records2 != c->step_mirror_records) {
+    if ((rc = sf_accept_stream_set(c, which, b.records, b.index, nullptr, std::min(b.cap, mirror_cap),
+                                   c->step_mirror_records, c->step_mirror_counter)) != SF_OK) return rc;
+  }
+  b.matches.resize((size_t)std::max(n_l, 1));
+  c->accept_sel = which;
+  int32_t n = 0;
+  rc = sf_find_matches_and_verify_device(c, slot_base_other, slot_base_local, b.matches.data(), n_l, &n, nullptr);
+  c->accept_sel = -1;
+  if (rc != SF_OK) return rc;
+  b.n = n;
+  b.armed = c->accept_armed;                  // the block may hold streamed records (also of an abandoned speculation)
+  b.streamed = c->accept_streamed && n > 0;
+  b.pairs = b.armed ? (int32_t)c->spec.grid : 0;
+  if (b.streamed) {
+    b.slot_of_match.resize((size_t)n);
+    const int32_t* ix = c->last_results_index;
+    for (int i = 0; i < n; ++i) b.slot_of_match[i] = ix ? ix[i] : i;
+  } else if (n > 0) {
+    // not streamed (no speculation for this query, or a launch shape the stream does not cover): the accepted results of
+    // the matches are compacted, in match order, straight into the block
+    if (n > b.cap) return sf_fail(c, SF_ERANGE, "sf_step_issue: %d matches exceed the block's %d records", n, b.cap);
+    if ((rc = compact_launch(c, c->last_results, n, b.records, b.flags, b.count, c->last_results_index,
+                             c->step_mirror_records, nullptr, (int32_t*)c->step_mirror_counter)) != SF_OK) return rc;
+  }
+  SF_HIP(c, hipEventRecord(b.done, c->stream));
+  b.issued = true;
+  c->step_head ^= 1;
+  c->step_inflight += 1;
+  return SF_OK;
+}
+
+extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
+  if (!c || !out) return SF_EINVAL;
+  memset(out, 0, sizeof(*out));
+  if (c->step_inflight <= 0) return sf_fail(c, SF_EINVAL, "sf_step_retire: no step in flight");
+  const int which = c->step_inflight == 2 ? c->step_head : (c->step_head ^ 1);      // the OLDEST issued step
+  sf_context::StepBlock& b = c->step_blocks[which];
+  SF_HIP(c, hipSetDevice(c->device));
+  SF_HIP(c, hipEventSynchronize(b.done));        // its verification (and compaction) has left the device
+  const int n = b.n;
+  b.record_of_match.assign((size_t)std::max(n, 1), -1);
+  int32_t n_records = 0, n_accepted = 0;
+  int32_t n_streamed = 0;
+  if (b.armed) {
+    // streamed records: completion order, one per ACCEPTED verified slot; the used entries of the index list are its
+    // prefix.  They are reset here for the step after next -- also when the query fell back and never read them.
+    while (n_streamed < b.cap && b.index[n_streamed] >= 0) ++n_streamed;
+    if (b.streamed) b.rec_of_slot.assign((size_t)std::max(b.pairs, 1), -1);
+    for (int32_t r = 0; r < n_streamed; ++r) {
+      const int32_t slot = b.index[r];
+      if (b.streamed && slot < b.pairs) b.rec_of_slot[slot] = r;
+      b.index[r] = -1;
+    }
+  }
+  if (b.streamed) {
+    n_records = n_streamed;
+    for (int i = 0; i < n; ++i) {
+      const int32_t slot = b.slot_of_match[i];
+      const int32_t r = (slot >= 0 && slot < b.pairs) ? b.rec_of_slot[slot] : -1;
+      b.record_of_match[i] = r;
+      n_accepted += r >= 0;
+    }
+  } else if (n > 0) {
+    n_records = *b.count;
+    int32_t run = 0;
+    for (int i = 0; i < n; ++i) b.record_of_match[i] = b.flags[i] ? run++ : -1;
+    n_accepted = run;
+    if (run != n_records) return sf_fail(c, SF_EHIP, "sf_step_retire: %d flags set, %d records compacted", run, n_records);
+  }
+  out->matches = b.matches.data();
+  out->n_matches = n;
+  out->record_of_match = b.record_of_match.data();
+  out->records = b.records;
+  out->n_records = n_records;
+  out->n_accepted = n_accepted;
+  out->streamed = b.streamed ? 1 : 0;
+  b.issued = false;
+  c->step_inflight -= 1;
   return SF_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/sepfinder.h"
+#include "../../include/sf_experimental.h"
 
 #define SF_BLOCK 256            // every verification kernel runs 256-thread workgroups (4 waves)
 #define SF_MAX_KCAP 4096        // per-keyframe feature capacity ceiling of the GPU kernels
@@ -282,8 +283,30 @@ struct sf_context {
   struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; bool set = false; const unsigned* uploaded[2] = {nullptr, nullptr}; } accept_blocks[2];
   Buf accept_dev;                    // AcceptStream blocks on the device: [registered block][counter block]
   int accept_sel = -1;
-  bool accept_streamed = false;
+  bool accept_streamed = false;     // the last query's results are in the selected block (keyed by verified slot)
+  bool accept_armed = false;        // the selected block was handed to a verification launch of the last query (it may
+                                    // hold records even when the query then fell back: streamed = false)
   Buf spec_from, spec_to, spec_results, spec_index;
+  // sf_step_issue / sf_step_retire: the caller's loop body (find_separators.py:59-133) as a begin / retire pair.  Two
+  // blocks alternate, so that one step's separators stay untouched while the next step runs.
+  struct StepBlock {
+    void* pinned = nullptr;            // ONE host-pinned allocation: records | index | flags | count
+    size_t pinned_bytes = 0;
+    sf_result* records = nullptr;      // [cap] accepted results (streamed: completion order; compacted: match order)
+    int32_t* index = nullptr;          // [cap] streamed: verified slot of each record, -1 = unused entry
+    uint8_t* flags = nullptr;          // [cap] compacted: success of every match
+    int32_t* count = nullptr;          // compacted: number of accepted matches
+    int32_t cap = 0;
+    std::vector<sf_match> matches;
+    std::vector<int32_t> slot_of_match, record_of_match, rec_of_slot;
+    int32_t n = 0, pairs = 0;
+    bool streamed = false, armed = false, issued = false;
+    hipEvent_t done = nullptr;
+  } step_blocks[2];
+  int step_head = 0, step_inflight = 0;
+  sf_result* step_mirror_records = nullptr;   // sf_step_mirror: second (device) destination of every accepted record
+  uint32_t* step_mirror_counter = nullptr;    // ... and the caller's slot counter
+  int32_t step_mirror_cap = 0;
   void* spec_index_pinned = nullptr;
   size_t spec_index_pinned_bytes = 0;
   hipEvent_t spec_index_staged = nullptr;

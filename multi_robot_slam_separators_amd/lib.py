@@ -102,6 +102,9 @@ def load():
         "sf_find_matches_and_verify_device": (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(i32), vp]),
         "sf_compact_accepted_device": (C.c_int, [vp, vp, i32, vp, vp, P(i32)]),
         "sf_compact_accepted_device_async": (C.c_int, [vp, vp, i32, vp, vp, vp]),
+        "sf_step_issue": (C.c_int, [vp, i32, i32]),
+        "sf_step_retire": (C.c_int, [vp, P(_abi.StepResult)]),
+        "sf_step_mirror": (C.c_int, [vp, vp, vp, i32]),
         "sf_accept_stream_set": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
         "sf_accept_stream_select": (C.c_int, [vp, i32]),
         "sf_accept_stream_status": (C.c_int, [vp, P(i32), P(i32)]),
@@ -125,8 +128,9 @@ def load():
         fn = getattr(L, name)  # AttributeError here = the library does not export the ABI
         fn.restype = res
         fn.argtypes = args
-    if L.sf_abi_version() != 1:
-        raise ImportError("libsepfinder.so ABI version mismatch")
+    if L.sf_abi_version() != _abi.SF_ABI_VERSION:
+        raise ImportError("%s reports ABI version %d, this binding is written for %d (include/sepfinder.h): rebuild the "
+                          "library" % (LIB_PATH, L.sf_abi_version(), _abi.SF_ABI_VERSION))
     _lib = L
     return L
 
@@ -143,7 +147,7 @@ EXPORTED = [
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
-    "sf_compact_accepted_device_async", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
+    "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
@@ -433,6 +437,35 @@ class SeparatorFinder:
         self._check(self._L.sf_find_matches_and_verify_device(self._h, slot_base_other, slot_base_local, _ptr(out), cap,
                                                               C.byref(n), C.c_void_p(d_out) if d_out else None))
         return out[: n.value]
+
+    # -- the caller's loop body as a begin / retire pair (find_separators.py:59-133) ----------------------------------
+    def step_issue(self, slot_base_other, slot_base_local):
+        """Queue one find-and-verify step (NN search, verification of every returned candidate); returns once the
+        candidate list is known.  At most two steps in flight."""
+        self._check(self._L.sf_step_issue(self._h, int(slot_base_other), int(slot_base_local)))
+
+    def step_retire(self, copy=False):
+        """The oldest step in flight: (matches, record_of_match, records, info).  The arrays are VIEWS of memory the
+        handle owns (valid until the second-next step_issue) unless copy=True; records[record_of_match[i]] is the
+        accepted result of match i, record_of_match[i] = -1 means its estimation failed."""
+        r = _abi.StepResult()
+        self._check(self._L.sf_step_retire(self._h, C.byref(r)))
+        n, nr = r.n_matches, r.n_records
+
+        def view(ptr, count, dtype):
+            if not ptr or count <= 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            a = np.frombuffer(buf, dtype=dtype, count=count)
+            return a.copy() if copy else a
+        return (view(r.matches, n, _abi.MATCH_DTYPE), view(r.record_of_match, n, np.int32),
+                view(r.records, nr, _abi.RESULT_DTYPE),
+                {"n_matches": n, "n_records": nr, "n_accepted": r.n_accepted, "streamed": bool(r.streamed)})
+
+    def step_mirror(self, d_records2, d_counter, cap):
+        """Second (device) destination of every accepted record + the caller's slot counter; (None, None, 0) removes it."""
+        self._check(self._L.sf_step_mirror(self._h, C.c_void_p(d_records2) if d_records2 else None,
+                                           C.c_void_p(d_counter) if d_counter else None, int(cap)))
 
     def last_match_results(self):
         """(d_results pointer, index pointer or None, n) of the last find_matches_and_verify_device call."""

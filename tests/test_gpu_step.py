@@ -1,0 +1,160 @@
+"""sf_step_issue / sf_step_retire (include/sepfinder.h): the loop body of the reference's caller
+(PKG/scripts/find_separators.py:59-133 -- s_find_matches_query, one s_ans_est_transform per returned candidate, then the
+per-candidate outcome) as a begin / retire pair, against the separate calls it replaces (sf_nn_find_matches +
+sf_verify_matches_device), byte for byte."""
+import numpy as np
+import pytest
+import torch
+
+from multi_robot_slam_separators_amd import _abi, lib, synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+RB = _abi.RESULT_DTYPE.itemsize
+
+
+def _world(seed, n_kf, k, dim):
+    feats = synth.make_store_batch(seed, n_kf, k=k, cols=32, true_frac=0.5)
+    rng = np.random.default_rng(seed + 1)
+    nv_a = rng.normal(size=(n_kf, dim)); nv_a /= np.linalg.norm(nv_a, axis=1, keepdims=True)
+    nv_b = nv_a + 0.002 * rng.normal(size=(n_kf, dim)); nv_b /= np.linalg.norm(nv_b, axis=1, keepdims=True)
+    nv_b[10] = nv_b[11] = nv_b[12]                      # three local rows whose nearest received column is 12
+    nv_b[40:44] = rng.normal(size=(4, dim)) * 3.0       # rows with no candidate under the threshold
+    return feats, nv_a, nv_b
+
+
+def _up(x):
+    x = np.ascontiguousarray(x)
+    return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(DEV)
+
+
+def _fill(f, feats, nv_a, nv_b, n_kf, k):
+    T = {key: _up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}
+    sa = f.store_add_keyframes_device(n_kf, k, 32, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+    sb = f.store_add_keyframes_device(n_kf, k, 32, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+    torch.cuda.synchronize()
+    f.nn_append_received(nv_a)
+    f.nn_append_local(nv_b)
+    return sa, sb, T
+
+
+def _two_calls(f, sa, sb, cap):
+    m = f.nn_find_matches(cap=cap)
+    d = torch.zeros((max(len(m), 1), RB), dtype=torch.uint8, device=DEV)
+    f.verify_matches_device(m, sa, sb, d.data_ptr())
+    torch.cuda.synchronize()
+    return m, np.frombuffer(d[: len(m)].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE).copy()
+
+
+def _check_step(out, m_ref, res_ref, want_streamed):
+    m, rom, recs, info = out
+    assert info["n_matches"] == len(m_ref) and m.tobytes() == m_ref.tobytes()
+    assert info["streamed"] == want_streamed
+    ok = res_ref["success"].astype(bool)
+    assert np.array_equal(rom >= 0, ok) and info["n_accepted"] == int(ok.sum())
+    assert info["n_records"] >= info["n_accepted"] and len(recs) == info["n_records"]
+    used = rom[rom >= 0]
+    assert len(set(used.tolist())) == len(used) and (used < info["n_records"]).all()
+    for i in np.nonzero(ok)[0]:
+        assert recs[rom[i]].tobytes() == res_ref[i].tobytes(), "match %d" % i
+    assert recs["success"].all()          # only accepted results are ever delivered
+
+
+@pytest.mark.parametrize("est", [0, 1])
+def test_step_pair_equals_the_separate_calls(est):
+    """Batch mode (the walk may return every local row: speculative verification, separators streamed out of the kernel)
+    and the reference's cadence (netvlad_max_matches_nb = 20: no speculation, ordered compaction), both estimators, with
+    masked rows / columns and ignored pairs; steps overlapped two deep as a host would run them."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(177 + est, n_kf, k, dim)
+    for max_nb, want_streamed in ((n_kf, True), (20, False)):
+        p = synth.camera_params()
+        p.iterations = 200
+        p.estimation_type = est
+        p.netvlad_dimensions = dim
+        p.netvlad_max_matches_nb = max_nb
+        p.max_features = k
+        with lib.SeparatorFinder(p) as f:
+            f.set_stream(torch.cuda.current_stream().cuda_stream)
+            sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+            f.nn_mark_local_used(3); f.nn_mark_other_used(5); f.nn_ignore_pair(20, 20); f.nn_ignore_pair(21, 22)
+            m_ref, res_ref = _two_calls(f, sa, sb, max_nb)
+            assert len(m_ref) == min(max_nb, len(m_ref)) and res_ref["success"].sum() >= 3
+            # one step at a time
+            f.step_issue(sa, sb)
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, want_streamed)
+            # two in flight, retired oldest first; the third issue is refused until one is retired
+            f.step_issue(sa, sb)
+            f.step_issue(sa, sb)
+            with pytest.raises(lib.SepfinderError):
+                f.step_issue(sa, sb)
+            for _ in range(6):
+                _check_step(f.step_retire(copy=True), m_ref, res_ref, want_streamed)
+                f.step_issue(sa, sb)
+            # the state the caller feeds back between ticks (data_handler.py:402-408) takes effect in the next step
+            first = f.step_retire(copy=True)
+            _check_step(first, m_ref, res_ref, want_streamed)
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, want_streamed)
+            with pytest.raises(lib.SepfinderError):
+                f.step_retire()
+            row, col = int(m_ref["idx_local"][0]), int(m_ref["idx_other"][0])
+            f.nn_mark_local_used(row); f.nn_mark_other_used(col)
+            m2, res2 = _two_calls(f, sa, sb, max_nb)
+            assert row not in m2["idx_local"].tolist() and col not in m2["idx_other"].tolist()
+            f.step_issue(sa, sb)
+            _check_step(f.step_retire(copy=True), m2, res2, want_streamed)
+
+
+def test_step_with_a_mirror_for_the_exchange():
+    """sf_step_mirror: every accepted record also lands in a device buffer (an all-gather's send buffer) and the slot
+    counter is the caller's device word; a mirror too small for the query's verified candidates switches the query to
+    the compaction -- nothing is dropped."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(277, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+        n_acc = int(res_ref["success"].sum())
+        for cap, want_streamed in ((n_kf + n_kf // 8 + 256, True), (n_kf, False)):
+            send = torch.zeros((cap + 1, RB), dtype=torch.uint8, device=DEV)       # slot 0 = header (count)
+            f.step_mirror(send[1:].data_ptr(), send.data_ptr(), cap)
+            for rep in range(3):
+                send[0].zero_()
+                f.step_issue(sa, sb)
+                out = f.step_retire(copy=True)
+                _check_step(out, m_ref, res_ref, want_streamed)
+                torch.cuda.synchronize()
+                cnt = int(send[0, :4].view(torch.int32).item())
+                assert cnt == out[3]["n_records"] >= n_acc
+                mirror = np.frombuffer(send[1: 1 + cnt].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+                assert mirror.tobytes() == out[2][:cnt].tobytes()
+            f.step_mirror(None, None, 0)
+        f.step_issue(sa, sb)
+        with pytest.raises(lib.SepfinderError):
+            f.step_mirror(None, None, 0)            # not while a step is in flight
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+
+
+def test_step_on_an_empty_candidate_list_and_an_empty_database():
+    n_kf, k, dim = 32, 64, 128
+    feats, nv_a, nv_b = _world(377, 48, k, dim)
+    p = synth.camera_params()
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = 48
+    p.netvlad_distance = 1e-6               # nothing is under the threshold
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(lib.SepfinderError):
+            f.step_issue(0, 0)              # data_handler.py:308 guards the empty database
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, 48, k)
+        f.step_issue(sa, sb)
+        m, rom, recs, info = f.step_retire()
+        assert info["n_matches"] == 0 and info["n_accepted"] == 0 and len(m) == 0 and len(rom) == 0

@@ -576,6 +576,13 @@ def test_accepted_results_streamed_from_the_kernel(est):
         f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=7)
         torch.cuda.synchronize()
         assert f.accept_stream_status()[0] is False and (idx.numpy() == -1).all()
+        # a block with fewer record slots than the launch has pairs could lose accepted results: it is not armed
+        # (streamed = 0, untouched) and the caller takes the compaction
+        f.accept_stream_set(0, rec.data_ptr(), idx.data_ptr(), fl.data_ptr(), n_kf)     # < n_kf + n_kf / 8 + 256 slots
+        f.accept_stream_select(0)
+        m = f.find_matches_and_verify_device(sa, sb, d_res.data_ptr(), cap=n_kf)
+        torch.cuda.synchronize()
+        assert len(m) > 10 and f.accept_stream_status()[0] is False and (idx.numpy() == -1).all() and (fl.numpy() == 7).all()
 
 
 def test_indexed_compaction_of_the_last_match_results():

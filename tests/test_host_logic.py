@@ -2,6 +2,7 @@
 struct layouts agree between the header (gcc) and the ctypes mirror, host-only entry points work,
 the product fails loudly without a GPU, and the N > 1 exchange path is correct under gloo."""
 import ctypes as C
+import glob
 import os
 import re
 import socket
@@ -27,13 +28,18 @@ def _gpu_visible():
 def test_library_exports_every_declared_symbol():
     from multi_robot_slam_separators_amd import lib
     L = lib.load()
-    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
-    declared = sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", hdr)))
+    declared = set()
+    for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):       # sepfinder.h + sf_experimental.h
+        declared |= set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", open(h).read()))
+    declared = sorted(declared)
     assert len(declared) >= 30
     for name in declared:
         assert hasattr(L, name), "libsepfinder.so does not export %s" % name
     assert sorted(lib.EXPORTED) == declared
-    assert L.sf_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
+    assert L.sf_abi_version() == _abi.SF_ABI_VERSION == int(re.search(r"#define SF_ABI_VERSION (\d+)", hdr).group(1))
+    # the drop-in header alone declares the step pair and none of the experimental building blocks
+    assert "sf_step_issue" in hdr and "sf_accept_stream_set" not in hdr and "sf_last_match_results" not in hdr
 
 
 def test_struct_layouts_match_the_header(tmp_path):
