@@ -681,137 +681,62 @@ def main():
     # each rank hands ITS OWN accepted separators to the host, so the node delivers every record once.
     exch = None
     if dist_on:
-        exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf, n_kf // 4 + 256, coll_dev)
+        # (rows for every slot a speculative verification may accept: a smaller mirror switches the step to the compaction)
+        exch = dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf + n_kf // 8 + 256, n_kf // 4 + 256, coll_dev)
     h_flags = h_pack[flags_off: flags_off + n_kf].view(torch.bool)
     h_cnt = h_pack[:4].view(torch.int32)
     spec_cap = n_kf // 4 + 256
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
 
-    # single GPU: the compaction kernel writes count, flags and the accepted records STRAIGHT into the pinned host block
-    # (posted PCIe writes from the kernel, 16-byte pieces of consecutive lanes): the records reach the host while the
-    # kernel runs, instead of through a 0.9 MB copy behind it (BENCH_HOST_COPY=1: the copy, as up to round r02c)
+    # single GPU: the one-synchronisation form of a step (`step()` below: comparison runs, BENCH_NO_PIPELINE=1) lets the
+    # compaction kernel write count, flags and accepted records STRAIGHT into a pinned host block (BENCH_HOST_COPY=1: a
+    # copy behind it, as up to round r02c)
     zero_copy = exch is None and os.environ.get("BENCH_HOST_COPY") is None
     hp = h_pack.data_ptr()
     h_cnt_np = h_cnt.numpy()                                  # (a view of the pinned word: no tensor indexing per step)
     trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
     two_calls = os.environ.get("BENCH_TWO_CALLS") is not None
-    # Consecutive steps overlap on the single-GPU path (BENCH_NO_PIPELINE=1: one synchronisation per step, as up to
-    # round r02d): step k's NN filter is queued before the host has looked at step k - 1's separators, so the device
-    # does not idle through the host's wake-up, bookkeeping and first launches (~45 us of a 0.58 ms step).  Step
-    # k - 1 is retired -- count read, records handed on -- once the library call of step k has returned: that call
-    # waits for step k's candidate distances, which the stream produces AFTER step k - 1's compaction.  Two pinned
-    # blocks alternate, so a step's separators stay untouched for a whole step.  All K steps are issued and retired
-    # inside the timed region.
-    # N > 1 (RCCL): the same overlap -- compaction into the exchange's send buffer, the all-gather and the copies of
-    # this rank's own separators are queued behind step k's verification and retired after step k + 1's library call
-    # (one set of buffers suffices: step k - 1 is retired before step k's outputs are queued).
+    # THE TIMED STEP is the library's begin / retire pair (include/sepfinder.h: sf_step_issue / sf_step_retire, the loop
+    # body of find_separators.py:59-133): step k is issued -- NN filter, speculative verification of every candidate,
+    # accepted separators streaming from inside the verification kernel into a pinned block of the handle -- before
+    # step k - 1 is retired, so the device never waits for the host; two blocks alternate inside the library.  All K
+    # steps are issued and retired inside the timed region.  examples/bench_cli.cpp runs the same loop from C++ (no
+    # torch).  BENCH_NO_PIPELINE=1: `step()`, one synchronisation per step, through the building blocks in
+    # include/sf_experimental.h (what value_one_synchronisation_per_step reports).
+    # N > 1 (RCCL): sf_step_mirror makes every accepted record land in the exchange's send buffer too, the slot counter
+    # IS that buffer's count header (zeroed by a fill queued behind the previous all-gather), and the all-gather starts
+    # right behind the verification; it is retired with the step.
     dist_cuda = exch is not None and coll_dev.type == "cuda"
-    pipelined = (zero_copy or dist_cuda) and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
-    h_pack2 = torch.zeros_like(h_pack).pin_memory() if pipelined else None
-    blocks = []
-    for hb in ([h_pack, h_pack2] if pipelined else []):
-        blocks.append({"ptr": hb.data_ptr(), "cnt": hb[:4].view(torch.int32).numpy(), "res": hb[acc_off:].view(n_kf, RB)})
-    inflight = []
+    pipelined = (exch is None or dist_cuda) and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
+    if pipelined and dist_cuda:
+        f.step_mirror(exch.payload.data_ptr(), exch.count_ptr, int(exch.payload.shape[0]))
+    inflight = [0]
 
-    # Single GPU: the accepted separators STREAM out of the verification kernel (sf_accept_stream_*): each accepted
-    # result is written into the step's pinned block the moment its pair is final, so no compaction kernel (25 us of
-    # PCIe writes) follows the launch; the host keeps the records whose index belongs to a match.
-    # BENCH_NO_STREAM=1: the one-launch compaction into the pinned block, as before.
-    # N > 1: every record is also written into the exchange's send buffer on the device, the slot counter IS that
-    # buffer's count header (zeroed by a fill queued behind the previous all-gather), and the all-gather starts right
-    # behind the verification.
-    stream_out = pipelined and (zero_copy or dist_cuda) and os.environ.get("BENCH_NO_STREAM") is None
-    sblocks = []
-    if stream_out:
-        grid_cap = n_kf + n_kf // 8 + 256 + 64
-        for which in (0, 1):
-            # (no per-pair flag array in host memory: a 1-byte PCIe write at the end of EVERY pair keeps its workgroup
-            # alive until the write is acknowledged -- +10 us on the launch; the flags follow from the index list, whose
-            # unused entries stay -1)
-            rec = torch.zeros((n_kf, RB), dtype=torch.uint8).pin_memory()
-            idx = torch.full((n_kf,), -1, dtype=torch.int32).pin_memory()
-            if dist_cuda:
-                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, min(n_kf, exch.payload.shape[0]),
-                                    exch.payload.data_ptr(), exch.count_ptr)
-            else:
-                f.accept_stream_set(which, rec.data_ptr(), idx.data_ptr(), None, n_kf)
-            sblocks.append({"rec": rec, "idx": idx.numpy(), "flags": np.zeros(grid_cap, dtype=np.uint8)})
+    def retire(copy=False):
+        m, rom, recs, info = f.step_retire(copy=copy)
+        inflight[0] -= 1
+        state["pairs"] += info["n_matches"]
+        state["last"] = (m, rom, recs, info)
+        state["gathered"] = info["n_accepted"] if exch is None else sum(exch.counts())
 
     def issue(k):
-        if stream_out:
-            f.accept_stream_select(k & 1)
-            if dist_cuda:
-                exch.send[0, :8].zero_()          # this rank's count header = the stream's slot counter
-        m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
-        n = len(m)
-        if inflight:
-            retire()                    # step k - 1: its outputs were queued before this step's NN filter (stream order)
-        r_ptr, r_idx, r_n = f.last_match_results()
-        b = blocks[k & 1]
-        if stream_out:
-            streamed, pairs = f.accept_stream_status()
-            if streamed:
-                ix = np.ctypeslib.as_array(ctypes.cast(r_idx, ctypes.POINTER(ctypes.c_int32)), shape=(n,)).copy() \
-                    if r_idx else np.arange(n, dtype=np.int32)
-                if dist_cuda:
-                    exch.exchange(None, finish=True)       # (behind the verification in stream order)
-                inflight.append((m, n, sblocks[k & 1], (pairs, ix)))
-                return
-        if zero_copy:
-            f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
-            inflight.append((m, n, b, n))
-        else:
-            # records and count straight into the exchange's send buffer, ONE all-gather in flight beside the copies of
-            # this rank's count, flags and a speculative prefix of its own separators
-            # (mirrored: the same kernel also writes this rank's own count, flags and records into the pinned block)
-            f.compact_accepted_indexed_mirrored_device_async(r_ptr, r_idx, n, exch.payload.data_ptr(), d_flags.data_ptr(),
-                                                             exch.count_ptr, b["ptr"] + acc_off, b["ptr"] + flags_off, b["ptr"])
-            exch.exchange(None, finish=True)
-            inflight.append((m, n, b, n))
-
-    def retire():
-        m, n, b, extra = inflight.pop(0)
-        if "rec" in b:
-            # streamed block: records in completion order, one per ACCEPTED candidate; a separator is a record whose
-            # index is a match's (every candidate is one on this workload, but the consumer has to look)
-            pairs, ix = extra
-            n_all = int(np.count_nonzero(b["idx"] >= 0))
-            got = b["idx"][:n_all].copy()
-            b["idx"][:n_all] = -1                     # (ready for the step after next)
-            fl = b["flags"]
-            fl[:pairs] = 0
-            fl[got] = 1                                # success flag of every verified slot
-            is_match = np.zeros(pairs, dtype=bool)
-            is_match[ix] = True
-            keep = is_match[got]
-            n_acc = int(keep.sum())
-            b["got"] = got
-            state["pairs"] += n
-            state["last"] = (m, (b, n_all, keep, ix), n)
-            state["gathered"] = n_acc if exch is None else sum(exch.counts())
-            return
-        n_acc = int(b["cnt"][0])
-        host = b["res"][:n_acc]
-        gathered = n_acc if exch is None else sum(exch.counts())
-        state["pairs"] += n
-        state["last"] = (m, host, n)
-        state["gathered"] = gathered
+        if dist_cuda:
+            exch.send[0, :8].zero_()          # this rank's count header = the stream's slot counter
+        f.step_issue(slot_a, slot_b)
+        if dist_cuda:
+            exch.exchange(None, finish=True)  # (behind the verification in stream order)
+        if inflight[0]:
+            retire()                          # step k - 1: its outputs were queued before this step's NN filter
+        inflight[0] += 1
 
     def materialize_last():
-        """The last retired step's separators in MATCH order (what the compaction delivers), for the checks below."""
-        m, host, n = state["last"]
-        if not isinstance(host, tuple):
-            return
-        b, n_all, keep, ix = host
-        recs = b["rec"][:n_all].clone()
-        idx = b["got"]
-        slot_of = {int(j): i for i, j in enumerate(idx)}
-        fl = b["flags"]
-        order = [slot_of[int(j)] for j in ix if fl[int(j)]]
-        ordered = recs[torch.tensor(order, dtype=torch.int64)] if order else recs[:0]
-        state["flags_last"] = fl[ix].astype(bool).copy()
-        state["last"] = (m, ordered, n)
+        """The last retired step's separators in MATCH order + every match's flag, in the form the checks below take."""
+        m, rom, recs, info = state["last"]
+        ordered = np.ascontiguousarray(recs[rom[rom >= 0]])
+        state["flags_last"] = (rom >= 0).copy()
+        state["streamed_last"] = info["streamed"]
+        state["last"] = (m.copy(), torch.from_numpy(ordered.view(np.uint8).reshape(-1, RB).copy()), len(m))
 
     def step():
         t_0 = time.perf_counter()
@@ -914,17 +839,22 @@ def main():
     # hipEventCreate of a process can cost milliseconds)
     f.prof_select(("k_verify_fused", "k_match_global"))
     f.prof_enable(True)
-    if pipelined:
-        for step_i in range(4):
+    # bounded self-warm-up: the driver's few warm-up steps can leave the clocks un-ramped (round 2: 0.53 ms for a kernel
+    # that takes 0.47 once warm), so steps are run until three consecutive ones agree within 3 % (at most 50)
+    warm_ts = []
+    for step_i in range(50):
+        ts = time.perf_counter()
+        if pipelined:
             issue(step_i)
-        torch.cuda.synchronize()
-        while inflight:
-            retire()
-        if stream_out:
-            f.accept_stream_select(-1)
-    else:
-        for _ in range(2):
+        else:
             step()
+        warm_ts.append(time.perf_counter() - ts)
+        if len(warm_ts) >= 5 and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
+            break
+    if pipelined:
+        torch.cuda.synchronize()
+        while inflight[0]:
+            retire()
     f.prof_enable(False)
     # HIP events over the timed region bracket ONLY the kernel the roofline prices (two timing events per launch
     # cost host time and a marker on the queue: with every kernel bracketed a step took 0.594 ms instead of 0.568);
@@ -944,11 +874,9 @@ def main():
             ts = time.perf_counter()
             issue(step_i)                 # (retires step k - 1 once step k's candidates are walked)
             step_ms.append((time.perf_counter() - ts) * 1e3)
-        if zero_copy:
-            f.synchronize()
-        else:
-            torch.cuda.synchronize()    # (the collective's stream and the copies too)
-        retire()
+        retire(copy=True)                 # (waits for the last step's verification)
+        if dist_cuda:
+            torch.cuda.synchronize()    # (the collective's stream and the header copies too)
     else:
         for _ in range(args.steps):
             ts = time.perf_counter()
@@ -961,8 +889,8 @@ def main():
     gc.enable()
     if pipelined:
         materialize_last()                # (check infrastructure: the last step's separators in match order)
-    if stream_out:
-        f.accept_stream_select(-1)        # (the survey and comparison runs below use the compaction)
+        if dist_cuda:
+            f.step_mirror(None, None, 0)
     if os.environ.get("BENCH_DEBUG_SPREAD"):
         order = np.argsort(step_ms)[::-1][:4]
         print("[bench] slowest steps: " + ", ".join("#%d %.3f ms" % (int(i), step_ms[int(i)]) for i in order), file=sys.stderr)
@@ -1101,6 +1029,34 @@ def main():
         f.set_option(_abi.SF_OPT_MATCH_MFMA, 1)
         step()
 
+    # ---- SURVEY 8(d) "incl. H2D of features": candidate pairs handed over as HOST buffers (the wire layout of
+    # EstTransform.srv), verified, results back in host memory -- packing, PCIe both ways and the verification ----
+    pcie = None
+    if world == 1 and not args.no_extras:
+        try:
+            S = min(2048, n_kf)
+            A_h = [_abi.FeatureArrays(feats["desc_a"][i], feats["xyz_a"][i], feats["kp_a"][i]) for i in range(S)]
+            B_h = [_abi.FeatureArrays(feats["desc_b"][i], feats["xyz_b"][i], feats["kp_b"][i]) for i in range(S)]
+            f.estimate_transform_batch(A_h[:256], B_h[:256])
+            fa_h, fb_h = _abi.features_array(A_h), _abi.features_array(B_h)    # (the sf_features arrays a C host holds)
+            res_h = np.zeros(S, dtype=_abi.RESULT_DTYPE)
+
+            def call_h():
+                f._check(f._L.sf_estimate_transform_batch(f._h, fa_h, fb_h, S, res_h.ctypes.data))
+            call_h()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                call_h()
+            dt = (time.perf_counter() - t1) / reps
+            pcie = {"value": S / dt, "unit": "pairs/s", "pairs_per_call": S, "ms_per_call": dt * 1e3,
+                    "accepted": int(res_h["success"].sum()),
+                    "what": "sf_estimate_transform_batch on host buffers: features packed into pinned staging, H2D, "
+                            "verification, results D2H; never `value`"}
+            del A_h, B_h
+        except Exception as e:
+            print("bench: PCIe-inclusive run failed: %r" % (e,), file=sys.stderr)
+
     # ---- informational: the same steps software-pipelined over two streams (untimed by the driver) ----
     # A deployment that serves a stream of independent batches can run the NN stage of batch i+1 (MFMA +
     # HBM + host walk, on a second handle with its own stream) while batch i is being verified.
@@ -1208,8 +1164,10 @@ def main():
         allrec, cts = exch.all_gathered()
         gat = np.frombuffer(allrec.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
         mine = gat[sum(cts[:rank]): sum(cts[:rank + 1])]
-        all_ok = (bool(gat["success"].all()) and len(gat) == state["gathered"] and len(mine) == len(sep)
-                  and mine.tobytes() == sep.tobytes())
+        # (streamed records arrive in completion order and cover every accepted CANDIDATE: a superset of the matches')
+        have = set(r.tobytes() for r in mine)
+        all_ok = (bool(gat["success"].all()) and len(gat) == state["gathered"] and len(mine) >= len(sep)
+                  and all(r.tobytes() in have for r in sep))
     else:
         all_ok = bool(sep["success"].all()) and len(sep) == state["gathered"]
 
@@ -1289,8 +1247,10 @@ def main():
             "step_ms_spread": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
                                "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
         }
+        out["self_warmup_steps"] = len(warm_ts)
         out["steps_overlap"] = bool(pipelined)
-        out["accepted_separators_streamed_from_the_kernel"] = bool(stream_out)
+        out["timed_step_entry_points"] = "sf_step_issue + sf_step_retire" if pipelined else "sf_experimental.h building blocks"
+        out["accepted_separators_streamed_from_the_kernel"] = bool(state.get("streamed_last", False))
         if alt_sync is not None:
             out["value_one_synchronisation_per_step"] = alt_sync
         if alt_fixed is not None:
@@ -1305,6 +1265,9 @@ def main():
             out["next_rows"] = next_rows
         if piped is not None:
             out["pipelined_two_streams"] = piped
+        if pcie is not None:
+            out["value_pcie_inclusive"] = pcie["value"]
+            out["pcie_inclusive"] = pcie
         if alt_valu is not None:
             # the Hamming table by xor + popcount on the VALU instead of the fp4 matrix cores (identical outputs)
             out["value_with_valu_matcher"] = alt_valu * world
