@@ -58,6 +58,16 @@ int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
    measurement brackets only the kernel it prices (bench.py: the dominant one) and surveys the rest separately.  */
 int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
 
+/* Pass state of pair `pair` of the last verification (diagnostics, tools/diag_pair_index.py): pose of the pass (row-major
+   3 x 4, p_from = T p_to; all zero when null), is_null / inliers / matches.  Needs SF_OPT_DEBUG_CORR like
+   sf_debug_correspondences.                                                                                     */
+int  sf_debug_pass_state(sf_handle h, int32_t pair, int32_t pass, float* T12, int32_t* is_null, int32_t* inliers,
+                         int32_t* matches);
+/* Diagnostic counters the kernels bump when the process runs with SF_DIAG set (experiments; zero otherwise).      */
+int  sf_debug_counters(sf_handle h, unsigned long long* out, int32_t n);
+int  sf_debug_guided_points(sf_handle h, int32_t pair, unsigned long long* plane0, unsigned long long* plane1,
+                            int32_t* kcap_out);
+
 #ifdef __cplusplus
 }
 #endif

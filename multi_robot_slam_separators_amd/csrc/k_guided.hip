@@ -213,6 +213,16 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   //    atomics;
   //  * sequential per lane (the round-1 loop): when a frame has more combinations than the list holds
   //    (GUIDED_CPT per thread), e.g. all keypoints piled on one spot.
+#ifndef SF_CHAIN_TRACE
+  if (P.dbg_trace) {
+    // experiment: is the bucketing complete when this wavefront starts to search?  (a wavefront that is one barrier
+    // ahead of the others would see cells whose fill count is short of their size)
+    int short_cells = 0;
+    for (int c0 = tid; c0 < NC; c0 += NT) short_cells += (cell_fill[c0] != cell_start[c0 + 1] - cell_start[c0]) ? 1 : 0;
+    if (short_cells) atomicAdd(&P.dbg_trace[0], (unsigned long long)short_cells);
+    if (tid == 0) atomicAdd(&P.dbg_trace[1], 1ull);
+  }
+#endif
   int n_finite = 0, n_proj = 0;
   const int cand_cap = GUIDED_CPT * NT;
   // pass A: projections, per-point candidate count / highest candidate (:751-764 needs it), candidate list
@@ -326,6 +336,15 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
       }
     }
     if (base == 0) SF_TRACE_MARK(P, pair, 30);   // ... combinations handed over
+#ifndef SF_CHAIN_TRACE
+    if (P.dbg_trace && i < Kf) {      // experiment: what this lane projected and found (sf_debug_guided_points)
+      unsigned long long* pl0 = P.dbg_trace + 512 + (size_t)pair * kcap;
+      unsigned long long* pl1 = pl0 + (size_t)gridDim.x * kcap;
+      pl0[i] = ((unsigned long long)__float_as_uint(u) << 32) | (unsigned long long)__float_as_uint(v);
+      pl1[i] = ((unsigned long long)(unsigned)oi << 48) | ((unsigned long long)(unsigned)(last & 0xFFFF) << 32) |
+               ((unsigned long long)(inimg ? 1u : 0u) << 31) | (unsigned long long)((unsigned)octf & 0xFFFFu);
+    }
+#endif
     if (i < Kf) {
       proj[i] = make_float2(inimg ? u : __int_as_float(0x7FC00000), v);   // NaN u = "not searched"
       oilast[i] = ((uint32_t)min(oi, 0xFFFF) << 16) | (uint32_t)(last & 0xFFFF);
@@ -336,6 +355,18 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   __syncthreads();
   SF_TRACE_MARK(P, pair, 24);     // projections + candidate recording done
   const int n_cand = misc[3];
+#ifndef SF_CHAIN_TRACE
+  if (P.dbg_trace) {
+    // every point's candidate count (oilast >> 16, written by its lane) must add up to the list's length
+    int mine = 0;
+    for (int i = tid; i < Kf; i += NT) mine += (int)(oilast[i] >> 16);
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) atomicAdd(&misc[12], mine);        // misc[12..]: free words
+    __syncthreads();
+    if (tid == 0 && misc[12] != n_cand) atomicAdd(&P.dbg_trace[2], 1ull);
+    __syncthreads();
+  }
+#endif
 #ifdef SF_CHAIN_TRACE
   if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * SF_TRACE_SLOTS + 27] = (unsigned long long)n_cand;
 #endif
@@ -451,7 +482,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   n_finite = misc[0];
   n_proj = misc[1];
   SF_TRACE_MARK(P, pair, 9);
-
   // id-ordered compaction
   int running = 0;
   for (int base = 0; base < Kf; base += NT) {

@@ -140,8 +140,8 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 // pairs runs at its issue bound with 4 "to" tiles resident per wavefront (2 workgroups per CU), the survivors'
 // lists / headers take one trip through HBM (~2 KB per survivor) and their chains run four to a CU with nothing
 // else on it.  Same bodies, same bytes.
-template <int W>
-__global__ void __launch_bounds__(SF_BLOCK, 3)
+template <int W, int NTL = 4, int MINW = 3>
+__global__ void __launch_bounds__(SF_BLOCK, MINW)
 k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
               uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
               CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
@@ -150,7 +150,7 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
   const int pair = blockIdx.x;
   SF_TRACE_MARK(P, pair, 0);
-  const bool survivor = match_v2_body<W, 0, SF_BLOCK, 4>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
+  const bool survivor = match_v2_body<W, 0, SF_BLOCK, NTL>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
                                                          est, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
                                                          list, counter, smem_i,
                                                          P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
@@ -370,8 +370,8 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
       SF_HIP(c, hipFuncSetAttribute((const void*)k_match_split<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     c->split_match_attr[st.w == 16] = true;
   }
-#define SF_SPLIT_MATCH(W_)                                                                                         \
-  hipLaunchKernelGGL((k_match_split<W_>), dim3(n), dim3(SF_BLOCK), lds_m, c->stream, st, d_from, d_to,             \
+#define SF_SPLIT_MATCH(...)                                                                                        \
+  hipLaunchKernelGGL((k_match_split<__VA_ARGS__>), dim3(n), dim3(SF_BLOCK), lds_m, c->stream, st, d_from, d_to,    \
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p, \
                      (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams, \
                      sf_est_mode(c))

@@ -1068,6 +1068,17 @@ static int ws_reserve(sf_context* c, int n, int kcap, bool lists) {
   if ((rc = sf_buf_reserve(c, c->list1, np * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->list3, np * 4)) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, c->flags, np)) != SF_OK) return rc;
+#ifndef SF_CHAIN_TRACE
+  if (getenv("SF_DIAG")) {     // experiment: eight 64-bit diagnostic counters the kernels may bump (sf_debug_counters)
+    // [0..511]: counters; then two 64-bit planes of [pair][kcap] per-point records of the guided pass
+    const size_t need = 4096 + 2 * np * (size_t)kcap * 8;
+    if (c->trace.bytes < need) {
+      if ((rc = sf_buf_reserve(c, c->trace, need)) != SF_OK) return rc;
+      SF_HIP(c, hipMemsetAsync(c->trace.p, 0, c->trace.bytes, c->stream));
+    }
+    c->dparams.dbg_trace = (unsigned long long*)c->trace.p;
+  }
+#endif
 #ifdef SF_CHAIN_TRACE
   if ((rc = sf_buf_reserve(c, c->trace, np * SF_TRACE_SLOTS * 8)) != SF_OK) return rc;
   SF_HIP(c, hipMemsetAsync(c->trace.p, 0, np * SF_TRACE_SLOTS * 8, c->stream));
@@ -1803,6 +1814,47 @@ extern "C" int sf_debug_correspondences(sf_handle c, int32_t pair, int32_t pass,
     if (to_idx) to_idx[i] = (uint16_t)(tmp[i] >> 16);
   }
   *n_out = h.n_corr;
+  return SF_OK;
+}
+
+// Pass state of pair `pair` of the LAST verification (diagnostics; needs SF_OPT_DEBUG_CORR like the lists): the pass's
+// pose (row-major 3 x 4, p_from = T p_to, all zero when null), is_null / inliers / matches.
+extern "C" int sf_debug_pass_state(sf_handle c, int32_t pair, int32_t pass, float* T12, int32_t* is_null, int32_t* inliers,
+                                   int32_t* matches) {
+  if (!c || pair < 0 || (pass != 1 && pass != 2)) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->ws_split > 0 && pair >= c->ws_split) { pair -= c->ws_split; c = c->twin; }
+  if (pair >= c->ws_pairs) return SF_EINVAL;
+  if (!c->last_lists_valid) return sf_fail(c, SF_EINVAL, "set SF_OPT_DEBUG_CORR before the verification call");
+  PassState ps;
+  SF_HIP(c, hipMemcpy(&ps, (const PassState*)(pass == 1 ? c->pass1.p : c->pass2.p) + pair, sizeof(ps), hipMemcpyDeviceToHost));
+  if (T12) memcpy(T12, ps.T, sizeof(ps.T));
+  if (is_null) *is_null = ps.is_null;
+  if (inliers) *inliers = ps.inliers;
+  if (matches) *matches = ps.matches;
+  return SF_OK;
+}
+
+extern "C" int sf_debug_counters(sf_handle c, unsigned long long* out, int32_t n) {
+  if (!c || !out || n < 0) return SF_EINVAL;
+  memset(out, 0, (size_t)n * 8);
+  if (!c->trace.p) return SF_OK;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  if ((size_t)n * 8 > c->trace.bytes) return SF_ERANGE;
+  SF_HIP(c, hipMemcpy(out, c->trace.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return SF_OK;
+}
+// (experiment) per-point records of the guided pass of pair `pair` of the last verification: two planes of kcap words
+extern "C" int sf_debug_guided_points(sf_handle c, int32_t pair, unsigned long long* plane0, unsigned long long* plane1,
+                                      int32_t* kcap_out) {
+  if (!c || pair < 0 || pair >= c->ws_pairs || !c->trace.p) return SF_EINVAL;
+  SF_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t k = (size_t)c->ws_kcap, np = (size_t)c->ws_pairs;
+  if (c->trace.bytes < 4096 + 2 * np * k * 8) return SF_EINVAL;
+  const char* base = (const char*)c->trace.p + 4096;
+  SF_HIP(c, hipMemcpy(plane0, base + ((size_t)pair * k) * 8, k * 8, hipMemcpyDeviceToHost));
+  SF_HIP(c, hipMemcpy(plane1, base + ((np + (size_t)pair) * k) * 8, k * 8, hipMemcpyDeviceToHost));
+  if (kcap_out) *kcap_out = (int32_t)k;
   return SF_OK;
 }
 

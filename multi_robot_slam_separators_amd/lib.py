@@ -112,6 +112,9 @@ def load():
         "sf_last_match_results": (C.c_int, [vp, P(vp), P(vp), P(i32)]),
         "sf_compact_accepted_indexed_device_async": (C.c_int, [vp, vp, vp, i32, vp, vp, vp]),
         "sf_debug_correspondences": (C.c_int, [vp, i32, i32, vp, vp, i32, P(i32)]),
+        "sf_debug_pass_state": (C.c_int, [vp, i32, i32, vp, P(i32), P(i32), P(i32)]),
+        "sf_debug_counters": (C.c_int, [vp, vp, i32]),
+        "sf_debug_guided_points": (C.c_int, [vp, i32, vp, vp, P(i32)]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
         "sf_comm_unique_id": (C.c_int, [vp, i32]),
         "sf_comm_init": (C.c_int, [vp, vp, i32, i32]),
@@ -148,7 +151,7 @@ EXPORTED = [
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
-    "sf_debug_correspondences", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
+    "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
@@ -513,6 +516,24 @@ class SeparatorFinder:
         """The same without the synchronisation: the count (int32) is left on the device at d_count."""
         self._check(self._L.sf_compact_accepted_device_async(self._h, C.c_void_p(d_results), n, C.c_void_p(d_accepted),
                                                              C.c_void_p(d_flags) if d_flags else None, C.c_void_p(d_count)))
+
+    def debug_pass_state(self, pair, which_pass):
+        """(T [3][4] float32, is_null, inliers, matches) of one pass of pair `pair` of the last verification."""
+        T = np.zeros(12, dtype=np.float32)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.sf_debug_pass_state(self._h, pair, which_pass, T.ctypes.data, C.byref(a), C.byref(b), C.byref(c)))
+        return T.reshape(3, 4), a.value, b.value, c.value
+
+    def debug_guided_points(self, pair, kcap=4096):
+        a = np.zeros(kcap, dtype=np.uint64); b = np.zeros(kcap, dtype=np.uint64)
+        k = C.c_int32()
+        self._check(self._L.sf_debug_guided_points(self._h, pair, a.ctypes.data, b.ctypes.data, C.byref(k)))
+        return a[: k.value].copy(), b[: k.value].copy()
+
+    def debug_counters(self, n=8):
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self._L.sf_debug_counters(self._h, out.ctypes.data, n))
+        return out
 
     def debug_correspondences(self, pair, which_pass, cap=4096):
         cf = np.zeros(cap, dtype=np.uint16)

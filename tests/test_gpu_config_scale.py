@@ -228,6 +228,41 @@ def test_configs1_full_step(oracle):
     assert 800 < truth.sum() < 1600                          # ~20 % of the ~6 000 candidates are true revisits
 
 
+def test_batch_position_independence():
+    """stereoCamGeometricTools.cpp:122-178 is stateless per call: a pair's result must not depend on where the pair sits
+    in a batch.  The 10 000 aligned pairs of the configs[1] shape (about 2 000 run the whole two-pass chain) verified
+    at seven batch offsets, every record compared on the device with the first pass.  (Round 3: a build whose guided
+    pass composed its pose in packed-f32 instructions gave about one chain in a thousand a different -- valid-looking --
+    pose depending on its neighbours on the compute unit; this test saw 10 - 30 differing records per run on it, the
+    one-in-a-process comparison of test_configs1_full_step one.  DESIGN.md section 3.)"""
+    from multi_robot_slam_separators_amd import lib
+    n, k, cols = 10000, 500, 32
+    RB = _abi.RESULT_DTYPE.itemsize
+    p = synth.camera_params()
+    p.iterations = 500
+    p.max_features = k
+    p.store_capacity = 2 * n
+    d = gen_pairs(2104, n, k, cols)
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        sa, sb = add_store(f, d, "a", k, cols), add_store(f, d, "b", k, cols)
+        fr = torch.arange(sa, sa + n, dtype=torch.int32, device=DEV)
+        to = torch.arange(sb, sb + n, dtype=torch.int32, device=DEV)
+        ref = torch.empty((n, RB), dtype=torch.uint8, device=DEV)
+        f.verify_pairs_device(fr.data_ptr(), to.data_ptr(), n, ref.data_ptr())
+        torch.cuda.synchronize()
+        ref_np = results_of(ref, n).copy()
+        assert 1700 < int(ref_np["success"].sum()) < 2300
+        for shift in (1, 2, 3, 5, 64, 257):
+            frs = torch.cat([fr[:shift], fr]).contiguous()
+            tos = torch.cat([to[:shift], to]).contiguous()
+            out = torch.full((n + shift, RB), 0x5A, dtype=torch.uint8, device=DEV)
+            f.verify_pairs_device(frs.data_ptr(), tos.data_ptr(), n + shift, out.data_ptr())
+            torch.cuda.synchronize()
+            if not torch.equal(out[shift:], ref):
+                raise AssertionError("batch offset %d: %s" % (shift, describe_mismatch(results_of(out[shift:], n), ref_np)))
+
+
 def test_configs1_decisions_and_poses(oracle):
     """The verification half of configs[1] on aligned pairs (every B[i] against A[i]): 10 000 decisions equal the
     planted labels, accepted poses within 5 cm / 0.01 rad of the planted transform, 12 sampled pairs byte-identical
