@@ -95,12 +95,23 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
         GR[3 * i + j] = (g[4 * i] * Lt[j] + g[4 * i + 1] * Lt[4 + j]) + g[4 * i + 2] * Lt[8 + j];
       Gt[i] = ((g[4 * i] * Lt[3] + g[4 * i + 1] * Lt[7]) + g[4 * i + 2] * Lt[11]) + g[4 * i + 3];
     }
+    // Every coefficient goes through an (empty) register barrier: the twelve values must not be packed two to a
+    // v_pk_*_f32 instruction.  Round 3 found about one survivor chain in a thousand of k_verify_fused projecting the
+    // points of lanes 48-63 of one wavefront with different X coefficients (the LOW halves of the packed results; Y and
+    // Z, the high halves and the scalar ones, were right) when this block was SLP-vectorised -- DESIGN.md section 3.
+    // Kept scalar here AND the translation unit is built with -fno-slp-vectorize; either alone removed the symptom.
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(GR[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Gt[i]));
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) Rc[3 * i + j] = GR[3 * j + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) tc[i] = -((Rc[3 * i] * Gt[0] + Rc[3 * i + 1] * Gt[1]) + Rc[3 * i + 2] * Gt[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(tc[i]));
   }
   __syncthreads();
 
