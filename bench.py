@@ -517,6 +517,12 @@ def spawn_ranks(n):
     imported torch or touched HIP."""
     import socket
     import subprocess
+    if (os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", "")
+            or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD")):
+        # under rocprofv3 the preloaded tool has initialised the GPU in THIS process already: starting the ranks from
+        # here would be the fork + exec of GPU work from a GPU-initialised parent that this pool forbids
+        raise SystemExit("bench.py --gpus %d: running under a rocprofiler preload -- profile ONE rank per rocprofv3 "
+                         "invocation (the python program itself behind `--`, RANK / WORLD_SIZE set by hand)" % n)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

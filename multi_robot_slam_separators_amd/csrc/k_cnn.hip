@@ -653,43 +653,51 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
   return SF_OK;
 }
 
-// Tile and split of every layer for one image size, MEASURED: the first inference at a new size times each layer in
-// its (up to) twelve configurations -- tiles 64 / 128 x 64 / 128, 1 / 3 / 9-way tap split where the partial outputs
-// stay small -- on the buffers it is about to use and keeps the fastest (HIP events, three runs each; ~20 ms once per
-// image size, synchronous).  A model of the matrix pipe's fill picked these for the fp32 kernels; the split-fp16
-// kernels are bound by the latency of their operand fetches, where more, smaller workgroups often win, and a
-// measurement is the honest way to choose.
+// Tap split of a layer: a FIXED function of its shape.  The split decides the order in which a pixel's taps are summed
+// (S partial sums, then their sum), i.e. the low bits of the descriptor; it must not depend on a timing, or two robots
+// -- or two handles of one -- would produce descriptors that differ in the last bits and near-tie NetVLAD matches could
+// flip.  Rule: split the nine taps three ways when 64 x 64 tiles of the unsplit layer would not even give every compute
+// unit one workgroup (the 40 x 30 layers of a 640 x 480 image), and only while the partial outputs stay small.
+static int conv_split_rule(int P, int co) {
+  const long wgs = (long)((P + 63) / 64) * ((co + 63) / 64);
+  return (wgs < 256 && (size_t)P * co * 3 <= ((size_t)9 << 20)) ? 3 : 1;
+}
+
+// Tile of every layer for one image size, MEASURED: the first inference at a new size times each layer with tiles
+// 64 / 128 x 64 / 128 (the tap split fixed by conv_split_rule: the tile does not change the order of a pixel's sum, so
+// the choice is invisible in the results) on the buffers it is about to use and keeps the fastest (HIP events, three
+// runs each; a few ms once per image size, synchronous).  The split-fp16 kernels are bound by the latency of their
+// operand fetches, where more, smaller workgroups often win, and a measurement is the honest way to choose.
 static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  SF_HIP(c, hipEventCreate(&e0));
-  SF_HIP(c, hipEventCreate(&e1));
+  if (hipEventCreate(&e0) != hipSuccess) return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed");
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed"); }
   int h = H, w = W, rc = SF_OK;
   const float* src = (const float*)m->act[0].p;
   float* dst = (float*)m->act[1].p;
   for (int i = 0; i < 13 && rc == SF_OK; ++i) {
     if (i > 0) {
       const int P = h * w, co = VGG_COUT[i];
+      const int S = conv_split_rule(P, co);
       float best = 1e30f;
-      ConvCfg pick = {64, 64, 1};
-      for (int tm = 64; tm <= 128; tm *= 2)
-        for (int tn = 64; tn <= 128; tn *= 2)
-          for (int S = 1; S <= 9; S *= 3) {
-            if (co == 64 && tn == 128) continue;
-            if (S > 1 && (size_t)P * co * S > (size_t)9 << 20) continue;      // partial outputs beyond ~36 MB
-            const ConvCfg cfg = {tm, tn, S};
-            if ((rc = conv_layer(c, m, i, src, h, w, dst, cfg)) != SF_OK) break;      // warm-up (and buffer growth)
-            float t_min = 1e30f;
-            for (int rep = 0; rep < 3 && rc == SF_OK; ++rep) {
-              (void)hipEventRecord(e0, c->stream);
-              rc = conv_layer(c, m, i, src, h, w, dst, cfg);
-              (void)hipEventRecord(e1, c->stream);
-              if (hipEventSynchronize(e1) != hipSuccess) { rc = sf_fail(c, SF_EHIP, "autotune: event wait failed"); break; }
-              float ms = 0.f;
-              (void)hipEventElapsedTime(&ms, e0, e1);
-              t_min = std::min(t_min, ms);
-            }
-            if (t_min < best) { best = t_min; pick = cfg; }
+      ConvCfg pick = {64, 64, S};
+      for (int tm = 64; tm <= 128 && rc == SF_OK; tm *= 2)
+        for (int tn = 64; tn <= 128 && rc == SF_OK; tn *= 2) {
+          if (co == 64 && tn == 128) continue;
+          const ConvCfg cfg = {tm, tn, S};
+          rc = conv_layer(c, m, i, src, h, w, dst, cfg);      // warm-up (and buffer growth)
+          float t_min = 1e30f;
+          for (int rep = 0; rep < 3 && rc == SF_OK; ++rep) {
+            (void)hipEventRecord(e0, c->stream);
+            rc = conv_layer(c, m, i, src, h, w, dst, cfg);
+            (void)hipEventRecord(e1, c->stream);
+            if (rc == SF_OK && hipEventSynchronize(e1) != hipSuccess) rc = sf_fail(c, SF_EHIP, "autotune: event wait failed");
+            float ms = 0.f;
+            if (rc == SF_OK) (void)hipEventElapsedTime(&ms, e0, e1);
+            t_min = std::min(t_min, ms);
           }
+          if (rc == SF_OK && t_min < best) { best = t_min; pick = cfg; }
+        }
       m->cfg[i] = pick;
     }
     if (VGG_POOL[i]) { h /= 2; w /= 2; }

@@ -1447,19 +1447,31 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
     __hip_atomic_store(&state[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)own,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (wave == 0) {
+    // (the look-back assumes every earlier chunk gets to run: at most COMPACT_MAX_CHUNKS workgroups, all resident.  It
+    //  is bounded all the same -- about a second of polling -- so that a launch whose earlier chunks never start, for
+    //  whatever reason, ends with the count -1 (the host reports SF_EHIP) instead of spinning forever)
     unsigned sum = 0;
+    bool timed_out = false;
     for (int j = lane; j < (int)blockIdx.x; j += 64) {
       unsigned long long v;
+      unsigned spins = 0;
       do {
         v = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((unsigned)(v >> 32) != epoch);
+        if ((unsigned)(v >> 32) == epoch) break;
+        __builtin_amdgcn_s_sleep(8);
+      } while (++spins < (1u << 22));
+      timed_out = timed_out || (unsigned)(v >> 32) != epoch;
       sum += (unsigned)v;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const bool any_timeout = __any(timed_out);
     if (lane == 0) {
       s_base = (int)sum;
-      if (blockIdx.x == gridDim.x - 1) {
+      if (any_timeout) {
+        *total = -1;
+        if (total2) *total2 = -1;
+      } else if (blockIdx.x == gridDim.x - 1) {
         *total = (int)sum + own;
         if (total2) *total2 = (int)sum + own;
       }
@@ -1667,6 +1679,7 @@ extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
     }
   } else if (n > 0) {
     n_records = *b.count;
+    if (n_records < 0) return sf_fail(c, SF_EHIP, "sf_step_retire: the ordered compaction's look-back timed out");
     int32_t run = 0;
     for (int i = 0; i < n; ++i) b.record_of_match[i] = b.flags[i] ? run++ : -1;
     n_accepted = run;
@@ -1732,6 +1745,7 @@ extern "C" int sf_compact_accepted_device(sf_handle c, const sf_result* d_result
     return sf_fail(c, SF_ENOMEM, "hipHostMalloc(64) failed");
   SF_HIP(c, hipMemcpyAsync(c->count_pinned, d_count, 4, hipMemcpyDeviceToHost, c->stream));
   SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (*c->count_pinned < 0) return sf_fail(c, SF_EHIP, "ordered compaction: the look-back over earlier chunks timed out");
   *n_accepted = *c->count_pinned;
   return SF_OK;
 }

@@ -4,6 +4,12 @@
 # Usage: tools/profile_round.sh <tag> [bench args...]
 set -e
 tag=$1; shift
+# one rocprofv3 invocation profiles ONE process: with --gpus N > 1 bench.py would start its ranks from a parent whose
+# GPU the profiler's preloaded library has already initialised -- the program replacement this pool forbids
+for a in "$@"; do
+  if [ "$prev" = "--gpus" ] && [ "$a" != "1" ]; then echo "profile_round.sh: --gpus $a: profile one rank per rocprofv3 invocation" >&2; exit 2; fi
+  prev=$a
+done
 out=gpurun_out/prof_$tag
 mkdir -p $out
 B="python bench.py --steps 6 --warmup 2 --no-extras --no-cpu-baseline $*"
