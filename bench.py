@@ -214,6 +214,17 @@ def measure_next_rows(dev):
             g.netvlad_infer_device(d_img.data_ptr(), W, H, d_out.data_ptr(), 128)
         torch.cuda.synchronize()
         gpu_ms = (time.perf_counter() - t1) / reps * 1e3
+        # a batch of netvlad_batch_size = 3 images (data_handler.py:149-156): one pass over the WPCA weights for the three
+        d_img3 = torch.stack([d_img, d_img.flip(0), d_img.flip(1)]).contiguous()
+        d_out3 = torch.zeros((3, 128), dtype=torch.float32, device=dev)
+        g.netvlad_infer_batch_device(d_img3.data_ptr(), 3, W, H, d_out3.data_ptr(), 128)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.netvlad_infer_batch_device(d_img3.data_ptr(), 3, W, H, d_out3.data_ptr(), 128)
+        torch.cuda.synchronize()
+        gpu_ms3 = (time.perf_counter() - t1) / reps / 3 * 1e3
+        batch_same = bool(torch.equal(d_out3[0], d_out))
         t1 = time.perf_counter()
         want = nv.netvlad(img, wts)
         cpu_ms = (time.perf_counter() - t1) * 1e3
@@ -226,7 +237,8 @@ def measure_next_rows(dev):
         out["netvlad_inference"] = {
             "what": "VGG16 + NetVLAD + WPCA (4096) on a 640 x 480 image, random weights of the published shapes, first "
                     "128 dimensions kept (data_handler.py:157-158)",
-            "ms_per_image": gpu_ms, "trunk_gflop": flop / 1e9, "tflops_fp32_equivalent": flop / (gpu_ms * 1e-3) / 1e12,
+            "ms_per_image": gpu_ms, "ms_per_image_in_a_batch_of_3": gpu_ms3, "batch_bits_equal_single_image": batch_same,
+            "trunk_gflop": flop / 1e9, "tflops_fp32_equivalent": flop / (gpu_ms * 1e-3) / 1e12,
             "max_abs_error_vs_cpu_fp32": float(np.abs(d_out.cpu().numpy() - want[:128]).max()),
             "cpu_baseline": {"kind": "port", "cores": torch.get_num_threads(), "ms_per_image": cpu_ms,
                              "what": "PyTorch fp32 CPU evaluation of the same network (oracle/netvlad_torch.py)"}}

@@ -283,6 +283,11 @@ int  sf_netvlad_load(sf_handle h, const sf_netvlad_weights* w);      /* host poi
    the fastest for that size.                                                                                     */
 int  sf_netvlad_infer_device(sf_handle h, const float* d_image_rgb, int32_t width, int32_t height, float* d_out,
                              int32_t n_out);
+/* A batch, as DataHandler.compute_descriptors feeds the network (data_handler.py:149-156: up to netvlad_batch_size = 3
+   queued images per call): n_images images of one size back to back in d_images_rgb, d_out [n_images][n_out].  Same
+   bits per image as the single-image call; the WPCA matrix (537 MB) is read once per group of up to four images.     */
+int  sf_netvlad_infer_batch_device(sf_handle h, const float* d_images_rgb, int32_t n_images, int32_t width,
+                                   int32_t height, float* d_out, int32_t n_out);
 
 /* Corner detection of the reference's default feature type (rtabmap GFTT/BRIEF: Feature2D::generateKeypoints ->
    cv::goodFeaturesToTrack, called from myRegistrationVis.cpp:281-283), on the device: minimum-eigenvalue response

@@ -484,6 +484,35 @@ k_wpca(const float* __restrict__ Wm, const float* __restrict__ b, const float* _
 }
 
 // tf.nn.l2_normalize of one vector, writing the first n_out values; one workgroup
+// The same product for B <= 4 VLAD vectors of a batch (data_handler.py:149-156 infers up to netvlad_batch_size = 3 images
+// per call): one pass over the 537 MB of weights serves them all; per vector the arithmetic is k_wpca's, term by term,
+// so a batch gives the bits of the single-image calls.
+template <int B>
+__global__ void __launch_bounds__(256)
+k_wpca_batch(const float* __restrict__ Wm, const float* __restrict__ b, const float* __restrict__ v, int rows, int cols,
+             float* __restrict__ y, int y_pitch) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* w4 = reinterpret_cast<const float4*>(Wm + (size_t)row * cols);
+  float s[B];
+#pragma unroll
+  for (int k = 0; k < B; ++k) s[k] = 0.f;
+  for (int c = lane; c < cols / 4; c += 64) {
+    const float4 a = w4[c];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const float4 q = reinterpret_cast<const float4*>(v + (size_t)k * cols)[c];
+      s[k] = fmaf(a.x, q.x, s[k]); s[k] = fmaf(a.y, q.y, s[k]); s[k] = fmaf(a.z, q.z, s[k]); s[k] = fmaf(a.w, q.w, s[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    float t = s[k];
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) y[(size_t)k * y_pitch + row] = t + b[row];
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_l2norm_vec(const float* __restrict__ y, int n, float* __restrict__ out, int n_out) {
   __shared__ float red[256];
@@ -708,11 +737,14 @@ static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
   return rc;
 }
 
-// d_image: [H][W][3] float32 RGB on the device (what the reference feeds the placeholder, data_handler.py:60-61);
-// d_out: n_out floats (the first n_out of the pca_dim-D unit vector).  Asynchronous on the handle's stream.
-int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out) {
+// d_images: n images [H][W][3] float32 RGB on the device, back to back (what the reference feeds the placeholder,
+// data_handler.py:60-61, netvlad_batch_size at a time: :149-156); d_out: n x n_out floats (the first n_out of each
+// pca_dim-D unit vector).  Asynchronous on the handle's stream.  The trunk and the VLAD layer run image by image (every
+// layer already fills the chip at camera resolution); the WPCA reads its weights ONCE per group of up to four images.
+int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img, int H, int W, float* d_out, int n_out) {
   sf_netvlad_model* m = c->netvlad;
   if (!m) return sf_fail(c, SF_EINVAL, "no NetVLAD model loaded (sf_netvlad_load)");
+  if (n_img < 1 || n_img > 1024) return sf_fail(c, SF_ERANGE, "a batch of %d images", n_img);
   if (H < 16 || W < 16) return sf_fail(c, SF_ERANGE, "image of %d x %d is smaller than the four poolings need", W, H);
   if (n_out < 1 || n_out > m->pca_dim) return sf_fail(c, SF_ERANGE, "%d output dimensions of %d", n_out, m->pca_dim);
   int rc;
@@ -720,50 +752,74 @@ int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, flo
   if ((rc = sf_buf_reserve(c, m->act[0], act_max * sizeof(float))) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, m->act[1], act_max * sizeof(float))) != SF_OK) return rc;
   const int K = m->clusters, D = 512;
-  if ((rc = sf_buf_reserve(c, m->vlad, (size_t)D * K * sizeof(float))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)std::max(m->pca_dim, 64) * sizeof(float))) != SF_OK) return rc;
+  const int group = std::min(n_img, 4);
+  const int y_pitch = std::max(m->pca_dim, 64);
+  if ((rc = sf_buf_reserve(c, m->vlad, (size_t)group * D * K * sizeof(float))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)group * y_pitch * sizeof(float))) != SF_OK) return rc;
   if (m->tuned_h != H || m->tuned_w != W) {
     if ((rc = conv_autotune(c, m, H, W)) != SF_OK) return rc;
   }
-  int h = H, w = W, cur = 0;
-  const float* src = d_image;
-  for (int i = 0; i < 13; ++i) {
-    float* dst = (float*)m->act[cur].p;
-    const int P = h * w;
-    if (i == 0) {
-      hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
-                         (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
-                         VGG_RELU[0] ? 1 : 0);
-    } else {
-      if ((rc = conv_layer(c, m, i, src, h, w, dst, m->cfg[i])) != SF_OK) return rc;
+  for (int g0 = 0; g0 < n_img; g0 += group) {
+    const int gb = std::min(group, n_img - g0);
+    for (int b = 0; b < gb; ++b) {
+      const float* d_image = d_images + (size_t)(g0 + b) * H * W * 3;
+      float* vlad = (float*)m->vlad.p + (size_t)b * D * K;
+      int h = H, w = W, cur = 0;
+      const float* src = d_image;
+      for (int i = 0; i < 13; ++i) {
+        float* dst = (float*)m->act[cur].p;
+        const int P = h * w;
+        if (i == 0) {
+          hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
+                             (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
+                             VGG_RELU[0] ? 1 : 0);
+        } else {
+          if ((rc = conv_layer(c, m, i, src, h, w, dst, m->cfg[i])) != SF_OK) return rc;
+        }
+        src = dst;
+        cur ^= 1;
+        if (VGG_POOL[i]) {
+          float* pd = (float*)m->act[cur].p;
+          const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
+          hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd);
+          h /= 2; w /= 2;
+          src = pd;
+          cur ^= 1;
+        }
+      }
+      // src = conv5_3 output [h][w][512] (in act[cur ^ 1]); normalise in place, assignment into act[cur]
+      const int P = h * w;
+      float* x = const_cast<float*>(src);
+      float* a = (float*)m->act[cur].p;
+      float* norms = (float*)m->pca_y.p + (size_t)b * y_pitch;                     // (the slot doubles as the K norms)
+      hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
+      hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
+                         (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
+      hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
+      hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 2), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
+                         (const float*)m->centers.p, P, D, K, vlad);
+      hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)vlad, D, K, norms);
+      hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(1024), 0, c->stream, vlad, D, K, (const float*)norms);
     }
-    src = dst;
-    cur ^= 1;
-    if (VGG_POOL[i]) {
-      float* pd = (float*)m->act[cur].p;
-      const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
-      hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd);
-      h /= 2; w /= 2;
-      src = pd;
-      cur ^= 1;
-    }
+    const dim3 wg((m->pca_dim + 3) / 4);
+    const float* V = (const float*)m->vlad.p;
+    float* Y = (float*)m->pca_y.p;
+    if (gb == 1)
+      hipLaunchKernelGGL(k_wpca, wg, dim3(256), 0, c->stream, (const float*)m->pca_w.p, (const float*)m->pca_b.p, V, m->pca_dim, D * K, Y);
+    else if (gb == 2)
+      hipLaunchKernelGGL(k_wpca_batch<2>, wg, dim3(256), 0, c->stream, (const float*)m->pca_w.p, (const float*)m->pca_b.p, V, m->pca_dim, D * K, Y, y_pitch);
+    else if (gb == 3)
+      hipLaunchKernelGGL(k_wpca_batch<3>, wg, dim3(256), 0, c->stream, (const float*)m->pca_w.p, (const float*)m->pca_b.p, V, m->pca_dim, D * K, Y, y_pitch);
+    else
+      hipLaunchKernelGGL(k_wpca_batch<4>, wg, dim3(256), 0, c->stream, (const float*)m->pca_w.p, (const float*)m->pca_b.p, V, m->pca_dim, D * K, Y, y_pitch);
+    for (int b = 0; b < gb; ++b)
+      hipLaunchKernelGGL(k_l2norm_vec, dim3(1), dim3(256), 0, c->stream, (const float*)(Y + (size_t)b * y_pitch), m->pca_dim,
+                         d_out + (size_t)(g0 + b) * n_out, n_out);
   }
-  // src = conv5_3 output [h][w][512] (in act[cur ^ 1]); normalise in place, assignment into act[cur]
-  const int P = h * w;
-  float* x = const_cast<float*>(src);
-  float* a = (float*)m->act[cur].p;
-  hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
-  hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
-                     (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
-  hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
-  hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 2), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
-                     (const float*)m->centers.p, P, D, K, (float*)m->vlad.p);
-  hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)m->vlad.p, D, K,
-                     (float*)m->pca_y.p);                                        // (pca_y doubles as the K norms)
-  hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(1024), 0, c->stream, (float*)m->vlad.p, D, K, (const float*)m->pca_y.p);
-  hipLaunchKernelGGL(k_wpca, dim3((m->pca_dim + 3) / 4), dim3(256), 0, c->stream, (const float*)m->pca_w.p,
-                     (const float*)m->pca_b.p, (const float*)m->vlad.p, m->pca_dim, D * K, (float*)m->pca_y.p);
-  hipLaunchKernelGGL(k_l2norm_vec, dim3(1), dim3(256), 0, c->stream, (const float*)m->pca_y.p, m->pca_dim, d_out, n_out);
   SF_HIP(c, hipGetLastError());
   return SF_OK;
+}
+
+int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out) {
+  return sf_netvlad_infer_batch_impl(c, d_image, 1, H, W, d_out, n_out);
 }

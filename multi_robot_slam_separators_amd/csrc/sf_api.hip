@@ -897,6 +897,13 @@ extern "C" int sf_netvlad_infer_device(sf_handle c, const float* d_image_rgb, in
   return sf_netvlad_infer_impl(c, d_image_rgb, height, width, d_out, n_out);
 }
 
+extern "C" int sf_netvlad_infer_batch_device(sf_handle c, const float* d_images_rgb, int32_t n_images, int32_t width,
+                                             int32_t height, float* d_out, int32_t n_out) {
+  if (!c || !d_images_rgb || !d_out) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_netvlad_infer_batch_impl(c, d_images_rgb, n_images, height, width, d_out, n_out);
+}
+
 extern "C" int sf_detect_corners_device(sf_handle c, const uint8_t* d_image, int32_t width, int32_t height, int32_t pitch,
                                         int32_t max_corners, double quality_level, double min_distance,
                                         sf_keypoint* d_kpts_out, int32_t cap, int32_t* n_out) {

@@ -328,6 +328,7 @@ struct sf_netvlad_model;
 void sf_netvlad_free(sf_context* c);
 int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w);
 int sf_netvlad_infer_impl(sf_context* c, const float* d_image, int H, int W, float* d_out, int n_out);
+int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img, int H, int W, float* d_out, int n_out);
 StoreView sf_store_view(const Store& s);
 void sf_prof_begin(sf_context* c, int kernel);
 void sf_prof_end(sf_context* c, int kernel);

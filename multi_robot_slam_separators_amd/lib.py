@@ -92,6 +92,7 @@ def load():
                                                        vp, vp, vp, vp]),
         "sf_netvlad_load": (C.c_int, [vp, P(_abi.NetvladWeights)]),
         "sf_netvlad_infer_device": (C.c_int, [vp, vp, i32, i32, vp, i32]),
+        "sf_netvlad_infer_batch_device": (C.c_int, [vp, vp, i32, i32, i32, vp, i32]),
         "sf_store_size": (C.c_int, [vp, P(i32)]),
         "sf_store_clear": (C.c_int, [vp]),
         "sf_estimate_transform": (C.c_int, [vp, P(_abi.Features), P(_abi.Features), vp]),
@@ -148,7 +149,7 @@ EXPORTED = [
     "sf_set_option",
     "sf_nn_find_matches", "sf_nn_last_row_minima", "sf_nn_last_filter_dims", "sf_nn_walk", "sf_store_add_keyframe",
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
-    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_estimate_transform",
+    "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_netvlad_infer_batch_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
@@ -337,6 +338,11 @@ class SeparatorFinder:
 
     def netvlad_infer_device(self, d_image_rgb, width, height, d_out, n_out):
         self._check(self._L.sf_netvlad_infer_device(self._h, C.c_void_p(d_image_rgb), width, height, C.c_void_p(d_out), n_out))
+
+    def netvlad_infer_batch_device(self, d_images_rgb, n_images, width, height, d_out, n_out):
+        """n_images images [H][W][3] float32 back to back on the device -> d_out [n_images][n_out] (data_handler.py:149-156)."""
+        self._check(self._L.sf_netvlad_infer_batch_device(self._h, C.c_void_p(d_images_rgb), n_images, width, height,
+                                                          C.c_void_p(d_out), n_out))
 
     def detect_corners_device(self, d_image, width, height, pitch, max_corners, quality_level, min_distance,
                               d_kpts_out, cap):

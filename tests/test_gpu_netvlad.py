@@ -58,3 +58,40 @@ def test_distinct_images_give_distinct_descriptors_and_errors(model):
         infer(f, torch, a[:8, :8], 16)                       # smaller than the four poolings need
     with pytest.raises(lib.SepfinderError):
         infer(f, torch, a, 4096)                             # more dimensions than the loaded WPCA has
+
+
+def test_batch_equals_single_images(model):
+    """sf_netvlad_infer_batch_device (data_handler.py:149-156: netvlad_batch_size = 3 images per call): every image's
+    descriptor carries the bits of its single-image call, for batches that fill one WPCA group and that span two."""
+    import torch
+    f, w = model
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    for n_img in (3, 5):
+        imgs = rng.uniform(0, 255, size=(n_img, 120, 160, 3)).astype(np.float32)
+        d_imgs = torch.from_numpy(imgs).to(dev)
+        d_out = torch.zeros((n_img, 128), dtype=torch.float32, device=dev)
+        f.netvlad_infer_batch_device(d_imgs.data_ptr(), n_img, 160, 120, d_out.data_ptr(), 128)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for i in range(n_img):
+            assert np.array_equal(got[i], infer(f, torch, imgs[i], 128)), i
+
+
+def test_published_wpca_width_at_camera_resolution():
+    """The network as the reference loads it -- 64 clusters, 4096-wide WPCA (data_handler.py:63 vgg16NetvladPca) -- on a
+    640 x 480 image, against the PyTorch fp32 CPU evaluation: 1e-4 on the unit-norm descriptor, and the 128-value
+    prefix the reference keeps (data_handler.py:157-158)."""
+    import torch
+    w = ref.random_weights(5, clusters=64, pca_dim=4096)
+    rng = np.random.default_rng(12)
+    image = rng.uniform(0, 255, size=(480, 640, 3)).astype(np.float32)
+    with lib.SeparatorFinder(synth.camera_params(), device=0) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.netvlad_load(w)
+        got = infer(f, torch, image, 4096)
+        pre = infer(f, torch, image, 128)
+    want = ref.netvlad(image, w)
+    assert got.shape == (4096,) and abs(float(np.linalg.norm(got)) - 1.0) < 1e-5
+    assert np.max(np.abs(got - want)) < 1e-4, float(np.max(np.abs(got - want)))
+    assert np.array_equal(pre, got[:128])
