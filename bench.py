@@ -308,37 +308,6 @@ def upload_store(f, feats, dev, n_kf, k, cols):
     return first["a"], first["b"]
 
 
-class GpuShardBackend:
-    """multi_robot_slam_separators_amd.sharded backend on one GPU: the handle holds THIS rank's block of local
-    NetVLAD rows, the whole received database and the whole (replicated) keyframe store of one robot pair."""
-
-    def __init__(self, f, lo, n_received, slot_a, slot_b, n_local_total, dev):
-        import torch
-        from multi_robot_slam_separators_amd import _abi
-        self.f, self.lo, self.n_r, self.slot_a, self.slot_b, self.dev = f, lo, n_received, slot_a, slot_b, dev
-        self.RB = _abi.RESULT_DTYPE.itemsize
-        self.d_res = torch.empty((max(n_local_total, 1), self.RB), dtype=torch.uint8, device=dev)
-        self.n_total = n_local_total
-
-    def row_minima(self, lo, hi):
-        if hi <= lo:
-            return np.zeros(0), np.zeros(0, np.int32)
-        self.f.nn_find_matches(cap=hi - lo)             # NN kernels of this block (its own walk is not used)
-        return self.f.nn_last_row_minima()
-
-    def walk(self, d, a):
-        return self.f.nn_walk(d, a, self.n_r, cap=self.n_total)
-
-    def verify(self, matches):
-        import torch
-        n = len(matches)
-        if n == 0:
-            return self.d_res[:0]
-        self.f.verify_matches_device(np.ascontiguousarray(matches), self.slot_a, self.slot_b, self.d_res.data_ptr())
-        torch.cuda.synchronize()
-        return self.d_res[:n]
-
-
 def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
     """the step(s) of R(R-1)/2 robot pairs cut over the ranks (strong scaling).  Prints its own
     JSON line (rank 0)."""
@@ -375,7 +344,7 @@ def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
             if hi > lo:
                 f.nn_append_local_device(tb.data_ptr(), hi - lo, dim)
         torch.cuda.synchronize()
-        be = GpuShardBackend(f, lo, n_kf, slot_a, slot_b, n_kf, dev)
+        be = sharded.GpuShardBackend(f, lo, n_kf, slot_a, slot_b, n_kf, dev, world)
         steps.append(sharded.ShardedStep(be, rank, world, n_kf, coll_dev, accept_cap=n_kf // (4 * world) + 256))
         truths.append(feats["is_true"])
         del feats
@@ -406,10 +375,10 @@ def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
     correct = total = accepted = 0
     for (m, flags, acc), truth in zip(last, truths):
         want = truth[m["idx_local"]] & (m["idx_local"] == m["idx_other"])
-        correct += int((flags.numpy() == want).sum())
+        correct += int((flags == want).sum())
         total += len(m)
         accepted += int(acc.shape[0])
-        rec = np.frombuffer(acc.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+        rec = np.frombuffer(acc.tobytes(), dtype=_abi.RESULT_DTYPE)
         assert bool(rec["success"].all()) and len(rec) == int(flags.sum())
     if rank == 0:
         print(json.dumps({
@@ -424,7 +393,8 @@ def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
                                    % (args.robots, n_rp, n_kf, dim, "fp16" if args.netvlad_f16 else "fp32", k, cols * 8,
                                       args.iterations, world, world),
                        "pairs_per_step": n_pairs / args.steps, "parallelism": "section 8(e): row-sharded NN, pairs p mod G"},
-            "check": {"decisions_matching_ground_truth": correct, "of": total, "accepted_last_step": accepted},
+            "check": {"decisions_matching_ground_truth": correct, "of": total, "accepted_last_step": accepted,
+                      "host_waits_per_robot_pair_step": steps[0].waits},
         }))
     for st in steps:
         st.b.f.close()

@@ -220,10 +220,18 @@ int  sf_nn_last_row_minima(sf_handle h, double* dist, int32_t* idx, int32_t cap)
 /* The sequential tail of DataHandler.find_matches (data_handler.py:191-205: rows sorted by their minimum, the
    walk with its "idx_other already taken" and break rules) on caller-provided per-row minima -- host work only.
    For a node that shards the LOCAL rows of one query over its GPUs: every rank searches its
-   block (sf_nn_find_matches + sf_nn_last_row_minima), the minima are all-gathered, and every rank runs this
+   block (sf_nn_row_minima_device below), the minima are all-gathered, and every rank runs this
    identical walk.  row_min: n_local float64 (+inf = no candidate under the threshold), row_arg: column of each. */
 int  sf_nn_walk(sf_handle h, const double* row_min, const int32_t* row_arg, int32_t n_local, int32_t n_received,
                 sf_match* out, int32_t cap, int32_t* n_out);
+/* The NN kernels of this handle's local rows (data_handler.py:166-189 on ONE rank's block of rows) WITHOUT the walk
+   and without a host round trip: d_row_min[n_local] (float64) and d_row_arg[n_local] (int32) are DEVICE buffers
+   (typically a slice of the all-gather's send block), filled asynchronously on the handle's stream; rows with no
+   column under netvlad_distance report (+inf, 0) on the filter path.  With nn_precision 1 the prefix filter runs at
+   the ladder level the handle last settled on; d_status[0] (device int32) = 1 when the candidate set was denser than
+   that level's sparse limit -- the minima are then undefined and the caller takes sf_nn_find_matches +
+   sf_nn_last_row_minima (which walks the ladder) -- and 0 otherwise.                                           */
+int  sf_nn_row_minima_device(sf_handle h, double* d_row_min, int32_t* d_row_arg, int32_t* d_status);
 /* Descriptor dimensions the fp16 filter contracted in the last find_matches call (0: exact path). */
 int  sf_nn_last_filter_dims(sf_handle h, int32_t* dims);
 
@@ -418,6 +426,9 @@ int  sf_allgather_separators(sf_handle h, const sf_separator* d_local, int32_t n
    is this rank's count STAMPED ON THE DEVICE (e.g. by sf_compact_accepted_device_async writing its count there),
    slots 1.. the records; d_all = world such blocks (block r = rank r).  ONE collective, asynchronous on the handle's
    stream; the caller reads the counts out of the gathered headers behind its own synchronisation.            */
+/* The same collective on an opaque block of bytes_per_rank bytes (device memory, asynchronous on the handle's
+   stream): the row minima of the row-sharded NN stage travel this way.  d_all: world * bytes_per_rank bytes.   */
+int  sf_allgather_bytes_device(sf_handle h, const void* d_send, void* d_all, size_t bytes_per_rank);
 int  sf_allgather_separators_device(sf_handle h, const sf_separator* d_send, sf_separator* d_all,
                                     int32_t cap_per_rank);
 

@@ -666,6 +666,48 @@ k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, 
   }
 }
 
+// ---- per-row minima of the candidate list, on the device (the row-sharded NN stage of SURVEY.md section 8(e): no
+// candidate list travels to the host).  Same rule as the host loop of nn_run_filter: smallest exact float64 distance,
+// ties to the lowest column, ignored pairs skipped, rows without a candidate = (+inf, 0).  Non-negative doubles order
+// like their bit patterns, so the minimum is an atomicMin on 64-bit integers; the column is settled in a second pass
+// over the candidates that hold their row's minimum.
+__global__ void k_nn_rowmin_init(unsigned long long* __restrict__ mn, int* __restrict__ arg, int n, int* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { mn[i] = 0x7FF0000000000000ull; arg[i] = 0x7FFFFFFF; }
+  if (i == 0) *status = 0;
+}
+
+__device__ __forceinline__ bool nn_pair_ignored(const int* __restrict__ ign_ptr, const int* __restrict__ ign_col, int r, int col) {
+  for (int e = ign_ptr[r]; e < ign_ptr[r + 1]; ++e)
+    if (ign_col[e] == col) return true;
+  return false;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_nn_rowmin(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned limit,
+            const double* __restrict__ cdist, const int* __restrict__ ign_ptr, const int* __restrict__ ign_col,
+            int n_l, int n_r, unsigned long long* __restrict__ mn, int* __restrict__ arg, int* status) {
+  unsigned n = *count;
+  if (n > limit) {              // denser than the refinement was sized for: the caller falls back (status 1)
+    if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) *status = 1;
+    return;
+  }
+  for (unsigned c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+    const uint2 rc = cand[c];
+    if ((int)rc.x >= n_l || (int)rc.y >= n_r) continue;
+    if (nn_pair_ignored(ign_ptr, ign_col, (int)rc.x, (int)rc.y)) continue;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(cdist[c]);
+    if (PASS == 0) atomicMin(&mn[rc.x], key);
+    else if (key == mn[rc.x]) atomicMin(&arg[rc.x], (int)rc.y);
+  }
+}
+
+__global__ void k_nn_rowmin_finish(int* __restrict__ arg, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && arg[i] == 0x7FFFFFFF) arg[i] = 0;
+}
+
 // nb_eff[j] = |b_j|^2, +inf for masked / padding columns; *nb_max_bits = the largest finite one (bit pattern; the
 // error band of k_nn_select).  The caller zeroes *nb_max_bits.
 __global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* mask_other, int n_r, int n_r_pad,
@@ -834,36 +876,19 @@ static int nn_pinned_reserve(sf_context* c, size_t need) {
   return SF_OK;
 }
 
-static int nn_run_filter(sf_context* c, int* done) {
-  *done = 0;
-  NnTrace tr;
-  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
-  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
-  const int ld16 = (dim + 63) / 64 * 64;
+struct NnFilterBufs {
+  unsigned cap = 0;
+  float2* rowc = nullptr;
+  float2* colc = nullptr;
+  unsigned* count = nullptr;     // the counter block of the LAST launch (two 64-byte blocks alternate)
+  uint2* cand = nullptr;
+  double* cdist = nullptr;
+};
+
+static int nn_filter_reserve(sf_context* c, NnFilterBufs& fb) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n;
   const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
   int rc;
-  // Stage 1 contracts only a PREFIX of the descriptor: the squared distance over the first k
-  // dimensions is a lower bound of the full squared distance, so "prefix distance (within the fp16
-  // error band) under the threshold" is a necessary condition.  PCA-whitened NetVLAD spreads its
-  // energy evenly (the reference itself ranks on a 128-dim prefix, data_handler.py:157-158), so an
-  // eighth of the dimensions already rejects everything but real neighbours.  If the candidate
-  // buffer overflows the full length is tried, and after that the exact fp32-ranking path.
-  const int kfull = ld16;
-  // prefix ladder: 128 and 512 dimensions when they are at most a quarter of the descriptor, then the
-  // full length.  The handle remembers the level that last produced a sparse candidate set.
-  int levels[3], n_levels = 0;
-  if (128 * 4 <= dim) levels[n_levels++] = 128;
-  if (512 * 4 <= dim) levels[n_levels++] = 512;
-  levels[n_levels++] = kfull;
-  int level = std::min(std::max(c->nn_level, 0), n_levels - 1);
-  if (c->nn_force_full) {
-    level = n_levels - 1;      // SF_OPT_NN_FULL_FILTER: no prefix level (the worst case of the adaptive ladder)
-  } else if (level > 0 && c->nn_level_cooldown == 0) {   // now and then re-try the cheaper level
-    --level;
-    c->nn_level_cooldown = 32;
-  } else if (c->nn_level_cooldown > 0) {
-    --c->nn_level_cooldown;
-  }
   const unsigned cap = (unsigned)std::max<size_t>((size_t)1 << 20, (size_t)64 * n_l);
   {
     const void* before = c->nn_cand.p;
@@ -871,21 +896,32 @@ static int nn_run_filter(sf_context* c, int* done) {
     if (c->nn_cand.p != before) c->nn_count_primed = false;      // (a fresh buffer: nobody zeroed its counter blocks)
   }
   if ((rc = sf_buf_reserve(c, c->nn_rowmin, (size_t)(n_l_pad + n_r_pad) * 8)) != SF_OK) return rc;
-  float2* rowc = (float2*)c->nn_rowmin.p;
-  float2* colc = rowc + n_l_pad;
-  unsigned* count = (unsigned*)c->nn_cand.p;      // (re-pointed per launch below: two 64-byte blocks alternate)
-  uint2* cand = (uint2*)((char*)c->nn_cand.p + 128);
-  double* cdist = (double*)((char*)c->nn_cand.p + 128 + (size_t)cap * 8);
+  fb.rowc = (float2*)c->nn_rowmin.p;
+  fb.colc = fb.rowc + n_l_pad;
+  fb.count = (unsigned*)c->nn_cand.p;
+  fb.cand = (uint2*)((char*)c->nn_cand.p + 128);
+  fb.cdist = (double*)((char*)c->nn_cand.p + 128 + (size_t)cap * 8);
+  fb.cap = cap;
 
+  return SF_OK;
+}
+
+// One launch of the stage-1 filter at prefix length `kdims` (ladder level `level`): fp16 copies, coefficients, kernel.
+// Leaves the candidate list in fb.cand and its length in *fb.count (device).
+static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdims, NnTrace* trp) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
+  const unsigned cap = fb.cap;
+  float2* const rowc = fb.rowc;
+  float2* const colc = fb.colc;
+  uint2* const cand = fb.cand;
+  unsigned* count;
+  NnTrace& tr = *trp;
   const double thr = c->params.netvlad_distance;
   float thr2 = (float)(thr * thr);
   thr2 = nextafterf(thr2, INFINITY);
-  unsigned n_cand = 0;
-  bool ok = false;
-  uint2* h_cand = nullptr;     // pinned staging of the candidate list (pageable D2H copies are staged and slow)
-  double* h_dist = nullptr;
-  for (; level < n_levels && !ok; ++level) {
-    const int kdims = levels[level];
+  int rc;
     // the fp16 copy of a prefix level is stored COMPACT (pitch = prefix length): a 128-row operand tile is
     // then one contiguous 32 / 128 KB block instead of 128 pieces 2 * dim bytes apart
     const int pitch16 = kdims;
@@ -944,6 +980,53 @@ static int nn_run_filter(sf_context* c, int* done) {
     }
     sf_prof_end(c, SF_K_NN_FILTER);
     SF_HIP(c, hipGetLastError());
+    fb.count = count;
+  return SF_OK;
+}
+
+static int nn_run_filter(sf_context* c, int* done) {
+  *done = 0;
+  NnTrace tr;
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int ld16 = (dim + 63) / 64 * 64;
+  int rc;
+  // Stage 1 contracts only a PREFIX of the descriptor: the squared distance over the first k
+  // dimensions is a lower bound of the full squared distance, so "prefix distance (within the fp16
+  // error band) under the threshold" is a necessary condition.  PCA-whitened NetVLAD spreads its
+  // energy evenly (the reference itself ranks on a 128-dim prefix, data_handler.py:157-158), so an
+  // eighth of the dimensions already rejects everything but real neighbours.  If the candidate
+  // buffer overflows the full length is tried, and after that the exact fp32-ranking path.
+  const int kfull = ld16;
+  // prefix ladder: 128 and 512 dimensions when they are at most a quarter of the descriptor, then the
+  // full length.  The handle remembers the level that last produced a sparse candidate set.
+  int levels[3], n_levels = 0;
+  if (128 * 4 <= dim) levels[n_levels++] = 128;
+  if (512 * 4 <= dim) levels[n_levels++] = 512;
+  levels[n_levels++] = kfull;
+  int level = std::min(std::max(c->nn_level, 0), n_levels - 1);
+  if (c->nn_force_full) {
+    level = n_levels - 1;      // SF_OPT_NN_FULL_FILTER: no prefix level (the worst case of the adaptive ladder)
+  } else if (level > 0 && c->nn_level_cooldown == 0) {   // now and then re-try the cheaper level
+    --level;
+    c->nn_level_cooldown = 32;
+  } else if (c->nn_level_cooldown > 0) {
+    --c->nn_level_cooldown;
+  }
+  NnFilterBufs fb;
+  if ((rc = nn_filter_reserve(c, fb)) != SF_OK) return rc;
+  const unsigned cap = fb.cap;
+  uint2* const cand = fb.cand;
+  double* const cdist = fb.cdist;
+  unsigned* count = fb.count;
+  unsigned n_cand = 0;
+  bool ok = false;
+  uint2* h_cand = nullptr;     // pinned staging of the candidate list (pageable D2H copies are staged and slow)
+  double* h_dist = nullptr;
+  for (; level < n_levels && !ok; ++level) {
+    const int kdims = levels[level];
+    if ((rc = nn_filter_launch(c, fb, level, kdims, &tr)) != SF_OK) return rc;
+    count = fb.count;
     const bool prefix_level = level < n_levels - 1;
     // a dense prefix result would make the exact refinement the expensive part: insist on a sparse
     // candidate set from a prefix level, accept anything that fits the buffer from the full-length level
@@ -1147,15 +1230,11 @@ int sf_nn_walk_host(sf_context* c, const double* rm, const int32_t* row_arg, int
   return SF_OK;
 }
 
-int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
-  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
-  if (c->params.nn_precision != 0 && c->params.nn_precision != 1)
-    return sf_fail(c, SF_EINVAL, "nn_precision %d unknown (0 = fp32 exact ranking, 1 = fp16 filter + exact refine)", c->params.nn_precision);
-  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+// masks / ignore CSR on the device (rebuilt only when they changed)
+static int nn_sync_masks(sf_context* c) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n;
   const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
-  const int n_strips = n_r_pad / 64;
   int rc;
-  // masks / ignore CSR (rebuilt only when they changed)
   c->mask_local.resize(n_l, 0);
   c->mask_other.resize(n_r, 0);
   if (c->masks_dirty) {
@@ -1178,6 +1257,18 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
     c->masks_dirty = false;
     c->nn_coef_level = -1;     // masks / database changed: the filter coefficients must be rebuilt
   }
+  return SF_OK;
+}
+
+int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  if (c->params.nn_precision != 0 && c->params.nn_precision != 1)
+    return sf_fail(c, SF_EINVAL, "nn_precision %d unknown (0 = fp32 exact ranking, 1 = fp16 filter + exact refine)", c->params.nn_precision);
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
+  const int n_strips = n_r_pad / 64;
+  int rc;
+  if ((rc = nn_sync_masks(c)) != SF_OK) return rc;
   int filtered = 0;
   c->nn_last_kdims = 0;
   if (c->params.nn_precision == 1) {
@@ -1226,3 +1317,81 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
                          c->params.netvlad_max_matches_nb, out, cap, n_out);
 }
 
+// The NN kernels of this handle's local rows WITHOUT the walk and without a host round trip: d_row_min[n_local]
+// (float64) and d_row_arg[n_local] (int32) in DEVICE memory, asynchronous on the handle's stream.  This is what one
+// rank of the row-sharded NN stage contributes to the all-gather (data_handler.py:166-189 on
+// a block of rows).  With nn_precision 1 the prefix filter runs at the ladder level the handle last settled on;
+// d_status[0] = 1 reports a candidate set denser than the sparse limit (the minima are then undefined and the caller
+// takes sf_nn_find_matches + sf_nn_last_row_minima, which walks the ladder), 0 otherwise.
+int sf_nn_row_minima_dev(sf_context* c, double* d_row_min, int32_t* d_row_arg, int32_t* d_status) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  if (n_l <= 0 || n_r <= 0) return sf_fail(c, SF_EINVAL, "sf_nn_row_minima_device on an empty database (%d x %d)", n_l, n_r);
+  if (c->params.nn_precision != 0 && c->params.nn_precision != 1)
+    return sf_fail(c, SF_EINVAL, "nn_precision %d unknown", c->params.nn_precision);
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
+  int rc;
+  if ((rc = nn_sync_masks(c)) != SF_OK) return rc;
+  c->spec.valid = false;
+  c->last_row_cand.clear();
+  c->last_row_min.clear();        // (sf_nn_last_row_minima has nothing to report after this call)
+  c->last_row_arg.clear();
+  if (c->params.nn_precision == 1) {
+    NnTrace tr;
+    const int ld16 = (dim + 63) / 64 * 64;
+    int levels[3], n_levels = 0;
+    if (128 * 4 <= dim) levels[n_levels++] = 128;
+    if (512 * 4 <= dim) levels[n_levels++] = 512;
+    levels[n_levels++] = ld16;
+    const int level = c->nn_force_full ? n_levels - 1 : std::min(std::max(c->nn_level, 0), n_levels - 1);
+    NnFilterBufs fb;
+    if ((rc = nn_filter_reserve(c, fb)) != SF_OK) return rc;
+    if ((rc = nn_filter_launch(c, fb, level, levels[level], &tr)) != SF_OK) return rc;
+    c->nn_last_kdims = levels[level];
+    const unsigned limit = level < n_levels - 1 ? (unsigned)(8 * (size_t)n_l + 4096) : fb.cap;
+    // the count stays on the device: the grids are sized for a typical sparse list and stride over a longer one
+    const unsigned typical = std::min<unsigned>(limit, (unsigned)(2 * (size_t)n_l + 1024));
+    sf_prof_begin(c, SF_K_NN_REFINE);
+    hipLaunchKernelGGL(k_nn_refine, dim3((typical + 3) / 4), dim3(256), 0, c->stream, fb.cand, fb.count, limit,
+                       (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, fb.cdist, 0u);
+    sf_prof_end(c, SF_K_NN_REFINE);
+    unsigned long long* mn = (unsigned long long*)d_row_min;
+    const int wgs = (int)std::min<unsigned>((typical + 255) / 256, 1024u);
+    hipLaunchKernelGGL(k_nn_rowmin_init, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, mn, d_row_arg, n_l, d_status);
+    hipLaunchKernelGGL(k_nn_rowmin<0>, dim3(wgs), dim3(256), 0, c->stream, fb.cand, fb.count, limit, fb.cdist,
+                       (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status);
+    hipLaunchKernelGGL(k_nn_rowmin<1>, dim3(wgs), dim3(256), 0, c->stream, fb.cand, fb.count, limit, fb.cdist,
+                       (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status);
+    hipLaunchKernelGGL(k_nn_rowmin_finish, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, d_row_arg, n_l);
+    SF_HIP(c, hipGetLastError());
+    return SF_OK;
+  }
+  // exact fp32-ranking path: its select kernel already leaves the minima in device memory
+  const int n_strips = n_r_pad / 64;
+  c->nn_last_kdims = 0;
+  c->nn_coef_level = -1;
+  const size_t part_bytes = (size_t)n_strips * n_l_pad * 16;
+  if ((rc = sf_buf_reserve(c, c->nn_scalar, 64)) != SF_OK) return rc;
+  unsigned* nb_max_bits = (unsigned*)((char*)c->nn_scalar.p + 16);
+  SF_HIP(c, hipMemsetAsync(nb_max_bits, 0, 4, c->stream));
+  SF_HIP(c, hipMemsetAsync(d_status, 0, 4, c->stream));
+  if ((rc = sf_buf_reserve(c, c->nn_rowmin, part_bytes + (size_t)n_r_pad * 4)) != SF_OK) return rc;
+  unsigned long long* part = (unsigned long long*)c->nn_rowmin.p;
+  float* nb_eff = (float*)((char*)c->nn_rowmin.p + part_bytes);
+  hipLaunchKernelGGL(k_nn_fill_norms, dim3((n_r_pad + 255) / 256), dim3(256), 0, c->stream, nb_eff,
+                     (const float*)c->nn_recv.norms.p, (const uint8_t*)c->d_mask_other.p, n_r, n_r_pad, nb_max_bits);
+  sf_prof_begin(c, SF_K_NN);
+  hipLaunchKernelGGL(k_nn_argmin, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
+                     (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p,
+                     (const float*)c->nn_local.norms.p, nb_eff, (const int*)c->d_ign_ptr.p,
+                     (const int*)c->d_ign_col.p, part, n_l_pad, ld, n_r_pad / NN_BN, n_l_pad / NN_BM);
+  sf_prof_end(c, SF_K_NN);
+  sf_prof_begin(c, SF_K_NN_SELECT);
+  hipLaunchKernelGGL(k_nn_select, dim3((n_l + 3) / 4), dim3(256), 0, c->stream, part, n_strips, n_l, n_l_pad,
+                     (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld,
+                     (const uint8_t*)c->d_mask_local.p, (const float*)c->nn_local.norms.p, nb_eff, nb_max_bits,
+                     (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_r, d_row_min, d_row_arg);
+  sf_prof_end(c, SF_K_NN_SELECT);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}

@@ -2057,6 +2057,12 @@ extern "C" int sf_nn_find_matches(sf_handle c, sf_match* out, int32_t cap, int32
   return sf_nn_run(c, out, cap, n_out);
 }
 
+extern "C" int sf_nn_row_minima_device(sf_handle c, double* d_row_min, int32_t* d_row_arg, int32_t* d_status) {
+  if (!c || !d_row_min || !d_row_arg || !d_status) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_nn_row_minima_dev(c, d_row_min, d_row_arg, d_status);
+}
+
 extern "C" int sf_nn_walk(sf_handle c, const double* row_min, const int32_t* row_arg, int32_t n_local, int32_t n_received,
                           sf_match* out, int32_t cap, int32_t* n_out) {
   if (!c || !n_out || n_local < 0 || n_received < 0 || cap < 0 || (cap > 0 && !out) || (n_local > 0 && (!row_min || !row_arg)))

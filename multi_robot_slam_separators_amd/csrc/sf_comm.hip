@@ -112,6 +112,16 @@ extern "C" int sf_allgather_separators_device(sf_handle c, const sf_separator* d
   return SF_OK;
 }
 
+extern "C" int sf_allgather_bytes_device(sf_handle c, const void* d_send, void* d_all, size_t bytes_per_rank) {
+  if (!c || !d_send || !d_all || bytes_per_rank == 0) return SF_EINVAL;
+  if (!c->comm) return sf_fail(c, SF_EINVAL, "sf_comm_init has not been called");
+  RcclApi* a = rccl();
+  SF_HIP(c, hipSetDevice(c->device));
+  const ncclResult_t r = a->AllGather(d_send, d_all, bytes_per_rank, ncclUint8, (ncclComm_t)c->comm, c->stream);
+  if (r != ncclSuccess) return fail_rccl(c, "ncclAllGather(bytes)", r);
+  return SF_OK;
+}
+
 // Host-count convenience form (synchronous): d_local: n_local records in device memory; d_all: world * cap_per_rank
 // records in device memory (rank r's records start at r * cap_per_rank); counts: world entries on the host.  Also ONE
 // collective: the count travels in the header slot of the block (uploaded with the records' staging copy), the

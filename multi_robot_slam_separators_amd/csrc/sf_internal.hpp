@@ -384,6 +384,7 @@ int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, 
                      const uint8_t* d_desc, const float* d_xyz, const sf_keypoint* d_kp);
 // NN stage
 int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out);
+int sf_nn_row_minima_dev(sf_context* c, double* d_row_min, int32_t* d_row_arg, int32_t* d_status);
 int sf_nn_walk_host(sf_context* c, const double* row_min, const int32_t* row_arg, int n_l, int n_r, double thr,
                     int max_matches_nb, sf_match* out, int cap, int* n_out);
 // Speculation hook (sf_api.hip), called by the NN filter right behind the refinement launch of a prefix level:

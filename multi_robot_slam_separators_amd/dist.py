@@ -29,7 +29,7 @@ def allgather_records(local, group=None):
     all_gather_into_tensor of the payload padded to the largest shard (a single direct exchange
     over xGMI for the few-MB shards this path produces)."""
     import torch
-    td = _dist()
+    td = collective(group)
     world = td.get_world_size(group)
     n_local, rec = int(local.shape[0]), int(local.shape[1])
     cnt = torch.tensor([n_local], dtype=torch.int64, device=local.device)
@@ -82,6 +82,31 @@ def allgather_records_fixed(local, cap, group=None):
     return torch.cat(parts, dim=0), counts
 
 
+class SelfCollective:
+    """torch.distributed's slice of interface the exchanges use, for ONE rank without a process group: the
+    all-gather is a copy (on the caller's current stream), so that the same step code runs with and without a node."""
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def get_world_size(self, group=None):
+        return 1
+
+    def get_rank(self, group=None):
+        return 0
+
+    def all_gather_into_tensor(self, recv, send, group=None, async_op=False):
+        recv.view(-1).copy_(send.reshape(-1), non_blocking=True)
+        return SelfCollective._Done() if async_op else None
+
+
+def collective(group=None):
+    """torch.distributed when a process group is up, SelfCollective otherwise."""
+    td = _dist()
+    return td if td.is_available() and td.is_initialized() else SelfCollective()
+
+
 class RecordExchange:
     """The per-step separator exchange with persistent buffers: ONE all_gather_into_tensor per call, no
     allocation, no host-to-device copy and no synchronisation of its own.
@@ -95,20 +120,34 @@ class RecordExchange:
     `all_gathered()` fetches the overflow with the two-phase allgather_records (correct for any input, one
     collective in the common case).  Works on CPU tensors too (gloo rehearsals and tests)."""
 
-    def __init__(self, record_bytes, max_rows, cap, device, group=None):
+    def __init__(self, record_bytes, max_rows, cap, device, group=None, extra_bytes=0, host_mirror=False):
+        """extra_bytes: an opaque per-rank byte region that travels in the same collective (rows 1..E of the block,
+        in front of the records; `extra` is this rank's view of it, `gathered_extra(r)` rank r's) -- the per-candidate
+        success flags of the section 8(e) step ride here.  host_mirror: finish() queues a copy of the WHOLE receive
+        buffer into pinned host memory (`host_gathered*`), so that the step's results are host-readable behind the
+        caller's one synchronisation."""
         import torch
-        self.td = _dist()
+        self.td = collective(group)
         self.group = group
         self.world = self.td.get_world_size(group)
         self.rec = int(record_bytes)
         self.cap = max(1, min(int(cap), int(max_rows)))
         self.device = torch.device(device)
         assert self.rec >= 8
-        self.send = torch.zeros((int(max_rows) + 1, self.rec), dtype=torch.uint8, device=self.device)
-        self.payload = self.send[1:]
+        self.extra_bytes = int(extra_bytes)
+        E = self.extra_rows = (self.extra_bytes + self.rec - 1) // self.rec
+        self.blk = self.cap + 1 + E                                 # rows per rank in the collective
+        self.send = torch.zeros((int(max_rows) + 1 + E, self.rec), dtype=torch.uint8, device=self.device)
+        self.extra = self.send[1: 1 + E].reshape(-1)[: self.extra_bytes]
+        self.payload = self.send[1 + E:]
         self._hdr = self.send[0, :8].view(torch.int64)           # this rank's record count
-        self.recv = torch.empty((self.world, self.cap + 1, self.rec), dtype=torch.uint8, device=self.device)
+        self.recv = torch.empty((self.world, self.blk, self.rec), dtype=torch.uint8, device=self.device)
         self._hdr_all = self.recv[:, 0, :8]                        # [world, 8] bytes, strided view
+        self.h_recv = None
+        if host_mirror:
+            self.h_recv = torch.zeros((self.world, self.blk, self.rec), dtype=torch.uint8)
+            if self.device.type == "cuda":
+                self.h_recv = self.h_recv.pin_memory()
         self._h_counts = torch.zeros((self.world, 8), dtype=torch.uint8)
         if self.device.type == "cuda":
             self._h_counts = self._h_counts.pin_memory()
@@ -131,8 +170,8 @@ class RecordExchange:
         else:
             self._n_local = int(n_local)
             self._hdr.fill_(self._n_local)
-        self._work = self.td.all_gather_into_tensor(self.recv.view(self.world * (self.cap + 1), self.rec),
-                                                    self.send[: self.cap + 1], group=self.group, async_op=True)
+        self._work = self.td.all_gather_into_tensor(self.recv.view(self.world * self.blk, self.rec),
+                                                    self.send[: self.blk], group=self.group, async_op=True)
         if finish:
             self.finish()
 
@@ -141,15 +180,30 @@ class RecordExchange:
         if self._work is not None:
             self._work.wait()
             self._work = None
-        self._h_counts.copy_(self._hdr_all, non_blocking=True)
+        if self.h_recv is not None:
+            self.h_recv.copy_(self.recv, non_blocking=True)
+        else:
+            self._h_counts.copy_(self._hdr_all, non_blocking=True)
 
     def counts(self):
         """Per-rank record counts; valid once the stream the exchange ran on has been synchronised."""
-        return [int(c) for c in self._h_counts.view(torch_int64()).reshape(-1).tolist()]
+        h = self._h_counts if self.h_recv is None else self.h_recv[:, 0, :8].contiguous()
+        return [int(c) for c in h.view(torch_int64()).reshape(-1).tolist()]
 
     def gathered(self, r, counts=None):
         c = (counts or self.counts())[r]
-        return self.recv[r, 1: 1 + min(c, self.cap)]
+        return self.recv[r, 1 + self.extra_rows: 1 + self.extra_rows + min(c, self.cap)]
+
+    def gathered_extra(self, r):
+        return self.recv[r, 1: 1 + self.extra_rows].reshape(-1)[: self.extra_bytes]
+
+    def host_gathered(self, r, counts=None):
+        """numpy view of rank r's records in the pinned mirror (host_mirror=True; valid behind the synchronisation)."""
+        c = (counts or self.counts())[r]
+        return self.h_recv[r, 1 + self.extra_rows: 1 + self.extra_rows + min(c, self.cap)].numpy()
+
+    def host_gathered_extra(self, r):
+        return self.h_recv[r, 1: 1 + self.extra_rows].reshape(-1)[: self.extra_bytes].numpy()
 
     def all_gathered(self):
         """(records [sum n, record_bytes] rank-major, counts) -- materialises a copy; the overflow of a rank

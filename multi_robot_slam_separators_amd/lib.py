@@ -122,6 +122,8 @@ def load():
         "sf_comm_destroy": (C.c_int, [vp]),
         "sf_allgather_separators": (C.c_int, [vp, vp, i32, vp, i32, vp]),
         "sf_allgather_separators_device": (C.c_int, [vp, vp, vp, i32]),
+        "sf_allgather_bytes_device": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "sf_nn_row_minima_device": (C.c_int, [vp, vp, vp, vp]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_select": (C.c_int, [vp, C.c_uint32]),
         "sf_prof_reset": (C.c_int, [vp]),
@@ -153,7 +155,7 @@ EXPORTED = [
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
-    "sf_allgather_separators", "sf_allgather_separators_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
+    "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
 
@@ -273,6 +275,15 @@ class SeparatorFinder:
         self._check(self._L.sf_nn_walk(self._h, _ptr(d), _ptr(a), d.size, int(n_received), out.ctypes.data, cap,
                                        C.byref(n)))
         return out[: n.value]
+
+    def nn_row_minima_device(self, d_row_min, d_row_arg, d_status):
+        """The NN kernels of this handle's local rows without the walk; results stay in device memory (raw pointers:
+        float64[n_local], int32[n_local], int32[1]); asynchronous on the handle's stream."""
+        self._check(self._L.sf_nn_row_minima_device(self._h, C.c_void_p(d_row_min), C.c_void_p(d_row_arg),
+                                                    C.c_void_p(d_status)))
+
+    def allgather_bytes_device(self, d_send, d_all, bytes_per_rank):
+        self._check(self._L.sf_allgather_bytes_device(self._h, C.c_void_p(d_send), C.c_void_p(d_all), int(bytes_per_rank)))
 
     def nn_last_filter_dims(self):
         d = C.c_int32()

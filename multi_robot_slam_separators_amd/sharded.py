@@ -11,12 +11,29 @@ writes it (the reference runs this step on one CPU core: find_separators.py:59-1
                  separator records (`dist.RecordExchange`); `interleave` puts the accepted records back into the
                  candidate order of the walk, so the node's output is byte-identical to a single GPU's.
 
-The compute is behind a small backend interface so that the SAME orchestration runs on the GPUs (bench.py, the
-library) and, in the CPU tests, on the oracle with gloo ranks:
+The step keeps its data on the device between the stages, like the single-GPU step (sf_step_issue / sf_step_retire):
 
-  backend.row_minima(lo, hi) -> (float64[hi-lo], int32[hi-lo])   minima of local rows [lo, hi) (+inf: none < thr)
+  * the rank's minima are written by the NN kernels straight into the all-gather's send block (GPU backend:
+    sf_nn_row_minima_device -- no walk that is thrown away, no candidate list on the host); the gathered block comes
+    back through pinned memory behind ONE event wait, because the walk is sequential host work
+    (data_handler.py:191-205), exactly as inside sf_step_issue;
+  * the verification's accepted records are compacted straight into the record exchange's payload, their count is
+    stamped into its header on the device, and the per-candidate success flags ride in the same block (the `extra`
+    region of dist.RecordExchange): ONE collective, mirrored into pinned host memory;
+  * the second and last wait of the step is the caller's synchronisation behind `finish`; the interleave is then host
+    arithmetic on the pinned mirror.
+
+The compute is behind a small backend interface so that the SAME orchestration runs on the GPUs (bench.py, the
+library) and, in the CPU tests, on the oracle with gloo ranks.  All tensors are on the collective device:
+
+  backend.row_minima_into(row_min f64[n], row_arg i32[n], status i32[1])   this rank's block, asynchronous;
+                                           status 1 = "too dense for the device path" (every rank then sees it)
+  backend.row_minima_sync() -> (float64[n], int32[n])   the synchronous form that cannot fail (taken on status 1)
   backend.walk(row_min, row_arg) -> structured MATCH_DTYPE array  the replicated walk
-  backend.verify(matches) -> uint8 tensor [len, RESULT bytes]     results of these candidates, on `device`
+  backend.verify_into(matches, payload u8[rows, RESULT bytes], count i32[1] view, flags u8[len])
+                                           results of these candidates: accepted records compacted into `payload` in
+                                           candidate order, their number into `count`, success flags into `flags`
+  backend.sync()                           wait for the work queued so far (the step's final synchronisation)
 
 N robot pairs (BASELINE configs[4]: 5 robots = 10 robot pairs) are flattened into one candidate list by
 `flatten_candidates` before the round-robin.
@@ -47,94 +64,158 @@ def flatten_candidates(per_robot_pair):
 
 def interleave(flags_by_rank, recs_by_rank, world):
     """Accepted records of every rank (each in its own candidate order) -> the global candidate order.
-    flags_by_rank[r]: success flags of rank r's candidates p = r, r + G, ...; recs_by_rank[r]: its accepted records.
-    Returns (flags [n] in candidate order, accepted records in candidate order)."""
-    import torch
-    n = sum(int(f.numel()) for f in flags_by_rank)
-    flags = torch.zeros(n, dtype=torch.bool)
+    flags_by_rank[r]: uint8/bool numpy, success flags of rank r's candidates p = r, r + G, ...; recs_by_rank[r]: numpy
+    uint8 [n_accepted_r, record bytes].  Returns (bool[n] in candidate order, accepted records in candidate order)."""
+    n = sum(int(f.size) for f in flags_by_rank)
+    flags = np.zeros(n, dtype=bool)
     for r in range(world):
-        flags[r::world] = flags_by_rank[r].cpu().bool()
+        flags[r::world] = flags_by_rank[r].astype(bool)
     rec_bytes = recs_by_rank[0].shape[1]
-    out = torch.empty((int(flags.sum()), rec_bytes), dtype=torch.uint8, device=recs_by_rank[0].device)
-    pos = torch.cumsum(flags.to(torch.int64), 0) - 1          # rank of every accepted candidate among the accepted
+    out = np.empty((int(flags.sum()), rec_bytes), dtype=np.uint8)
+    pos = np.cumsum(flags) - 1                          # rank of every accepted candidate among the accepted
     for r in range(world):
-        mine = flags[r::world]
-        dst = pos[r::world][mine]
-        if dst.numel():
-            out[dst.to(out.device)] = recs_by_rank[r][: dst.numel()]
+        dst = pos[r::world][flags[r::world]]
+        if dst.size:
+            out[dst] = recs_by_rank[r][: dst.size]
     return flags, out
 
 
 class ShardedStep:
     """Orchestration of one sharded step (see the module docstring).  `coll_device`: where the collectives run
-    (the GPU for RCCL, "cpu" for gloo)."""
+    (the GPU for RCCL, "cpu" for gloo).  Without a process group (one rank) the collectives are copies."""
 
     def __init__(self, backend, rank, world, n_local, coll_device, group=None, accept_cap=None):
         import torch
         self.b, self.rank, self.world, self.n_local = backend, rank, world, int(n_local)
         self.group = group
         self.dev = torch.device(coll_device)
+        self.td = dist.collective(group)
+        assert self.td.get_world_size(group) == world
         self.blocks = row_blocks(self.n_local, world)
         self.rec_bytes = _abi.RESULT_DTYPE.itemsize
-        self.max_block = max(hi - lo for lo, hi in self.blocks)
+        mb = self.max_block = max(1, max(hi - lo for lo, hi in self.blocks))
+        # the minima block of one rank: float64[mb] | int32[mb] | int32 status (+ padding to 16 bytes)
+        self.min_bytes = (mb * 12 + 4 + 15) // 16 * 16
+        self.min_send = torch.zeros(self.min_bytes, dtype=torch.uint8, device=self.dev)
+        self.min_recv = torch.empty(world * self.min_bytes, dtype=torch.uint8, device=self.dev)
+        self.h_min = torch.zeros(world * self.min_bytes, dtype=torch.uint8)
+        self.ev_min = None
+        if self.dev.type == "cuda":
+            self.h_min = self.h_min.pin_memory()
+            self.ev_min = torch.cuda.Event()
+        self.v_min = self.min_send[: mb * 8].view(torch.float64)
+        self.v_arg = self.min_send[mb * 8: mb * 12].view(torch.int32)
+        self.v_status = self.min_send[mb * 12: mb * 12 + 4].view(torch.int32)
+        self.max_mine = (self.n_local + world - 1) // world          # candidates of one rank, at most
         cap = accept_cap if accept_cap is not None else self.n_local // world + 256
-        self.exch = dist.RecordExchange(self.rec_bytes, max(self.n_local, 1), cap, self.dev, group) if world > 1 else None
-        self.off_success = _abi.RESULT_DTYPE.fields["success"][1]
+        self.exch = dist.RecordExchange(self.rec_bytes, max(self.max_mine, 1), cap, self.dev, group,
+                                        extra_bytes=max(self.max_mine, 1), host_mirror=True)
+        self.v_count = self.exch.send[0, :4].view(torch.int32)
+        self.waits = 0                                               # host waits of the last step (2 when all is well)
+
+    def _gather_minima(self):
+        """all-gather of the minima blocks -> pinned host copy; ONE wait.  Returns (d, a, statuses)."""
+        import torch
+        mb = self.max_block
+        self.td.all_gather_into_tensor(self.min_recv, self.min_send, group=self.group)
+        self.h_min.copy_(self.min_recv, non_blocking=True)
+        if self.ev_min is not None:
+            self.ev_min.record()
+            self.ev_min.synchronize()
+        self.waits += 1
+        h = self.h_min.numpy().reshape(self.world, self.min_bytes)
+        ds, as_, st = [], [], []
+        for r, (lo, hi) in enumerate(self.blocks):
+            ds.append(h[r, : mb * 8].view(np.float64)[: hi - lo])
+            as_.append(h[r, mb * 8: mb * 12].view(np.int32)[: hi - lo])
+            st.append(int(h[r, mb * 12: mb * 12 + 4].view(np.int32)[0]))
+        return np.concatenate(ds), np.concatenate(as_), st
 
     def find_matches(self):
         """Row-sharded NN stage -> the candidate list (identical on every rank)."""
         import torch
         lo, hi = self.blocks[self.rank]
-        d, a = self.b.row_minima(lo, hi)
-        if self.world > 1:
-            td = dist._dist()
-            # fixed-size blocks (padded to the largest) so that ONE all_gather_into_tensor carries the minima
-            send = torch.zeros((self.max_block, 12), dtype=torch.uint8)
-            send[: hi - lo, :8] = torch.from_numpy(np.ascontiguousarray(d)).view(torch.uint8).reshape(-1, 8)
-            send[: hi - lo, 8:] = torch.from_numpy(np.ascontiguousarray(a)).view(torch.uint8).reshape(-1, 4)
-            send = send.to(self.dev)
-            recv = torch.empty((self.world * self.max_block, 12), dtype=torch.uint8, device=self.dev)
-            td.all_gather_into_tensor(recv, send, group=self.group)
-            recv = recv.cpu().view(self.world, self.max_block, 12)
-            ds, as_ = [], []
-            for r, (l, h) in enumerate(self.blocks):
-                ds.append(recv[r, : h - l, :8].contiguous().view(torch.float64).reshape(-1).numpy())
-                as_.append(recv[r, : h - l, 8:].contiguous().view(torch.int32).reshape(-1).numpy())
-            d, a = np.concatenate(ds), np.concatenate(as_)
+        n = hi - lo
+        self.waits = 0
+        if n:
+            self.b.row_minima_into(self.v_min[:n], self.v_arg[:n], self.v_status)
+        else:
+            self.v_status.zero_()
+        d, a, st = self._gather_minima()
+        if any(st):
+            # some rank's candidate set was too dense for its device path: EVERY rank sees that in the gathered
+            # block, the ranks concerned recompute synchronously, and all of them gather once more
+            if st[self.rank]:
+                dd, aa = self.b.row_minima_sync()
+                self.v_min[:n].copy_(torch.from_numpy(np.ascontiguousarray(dd)))
+                self.v_arg[:n].copy_(torch.from_numpy(np.ascontiguousarray(aa)))
+                self.v_status.zero_()
+            d, a, st = self._gather_minima()
+            assert not any(st)
         return self.b.walk(d, a)
 
     def verify(self, matches):
-        """Candidates p mod G -> (flags [n] bool in candidate order, accepted records in candidate order on the
-        collective device).  `matches`: the full candidate list (identical on every rank)."""
-        import torch
+        """Candidates p mod G -> (flags bool[n] in candidate order, accepted records uint8[n_acc, RESULT bytes] in
+        candidate order), host arrays.  `matches`: the full candidate list (identical on every rank)."""
         n = len(matches)
+        assert n <= self.max_mine * self.world
         mine = dist.shard_pairs(n, self.rank, self.world)
-        res = self.b.verify(matches[mine])                           # uint8 [len(mine), rec_bytes]
-        ok = res[:, self.off_success] != 0 if len(mine) else torch.zeros(0, dtype=torch.bool, device=res.device)
-        acc = res[ok]
-        if self.world == 1:
-            return ok.cpu(), acc
-        td = dist._dist()
-        per = (n + self.world - 1) // self.world
-        fs = torch.zeros(per, dtype=torch.uint8, device=self.dev)
-        fs[: len(mine)] = ok.to(self.dev).to(torch.uint8)
-        fr = torch.empty(self.world * per, dtype=torch.uint8, device=self.dev)
-        td.all_gather_into_tensor(fr, fs, group=self.group)
-        n_acc = int(acc.shape[0])
-        self.exch.payload[:n_acc].copy_(acc.to(self.dev))
-        self.exch.exchange(n_acc)
-        if self.dev.type == "cuda":
-            torch.cuda.synchronize()
-        allrec, counts = self.exch.all_gathered()
-        fr = fr.view(self.world, per)
-        flags_by_rank = [fr[r, : len(dist.shard_pairs(n, r, self.world))] for r in range(self.world)]
-        recs_by_rank, off = [], 0
-        for r in range(self.world):
-            recs_by_rank.append(allrec[off: off + counts[r]])
-            off += counts[r]
-        return interleave(flags_by_rank, recs_by_rank, self.world)
+        self.b.verify_into(matches[mine], self.exch.payload, self.v_count, self.exch.extra[: len(mine)])
+        self.exch.exchange(None, finish=True)
+        self.b.sync()                                   # the step's final wait
+        self.waits += 1
+        counts = self.exch.counts()
+        if max(counts) > self.exch.cap:                 # (rare) some rank accepted more than the block holds
+            allrec, counts = self.exch.all_gathered()
+            allrec = allrec.cpu().numpy()
+            recs, off = [], 0
+            for r in range(self.world):
+                recs.append(allrec[off: off + counts[r]])
+                off += counts[r]
+        else:
+            recs = [self.exch.host_gathered(r, counts) for r in range(self.world)]
+        flags_by_rank = [self.exch.host_gathered_extra(r)[: len(dist.shard_pairs(n, r, self.world))]
+                         for r in range(self.world)]
+        return interleave(flags_by_rank, recs, self.world)
 
     def step(self):
         m = self.find_matches()
         flags, acc = self.verify(m)
         return m, flags, acc
+
+
+class GpuShardBackend:
+    """multi_robot_slam_separators_amd.sharded backend on one GPU: the handle holds THIS rank's block of local
+    NetVLAD rows, the whole received database and the whole (replicated) keyframe store of one robot pair.  Nothing
+    is staged through the host: the NN kernels write the minima into the all-gather's send block, the compaction
+    writes the accepted records, their count and the flags into the record exchange's block."""
+
+    def __init__(self, f, lo, n_received, slot_a, slot_b, n_local_total, dev, world=1):
+        import torch
+        self.f, self.lo, self.n_r, self.slot_a, self.slot_b, self.dev = f, lo, n_received, slot_a, slot_b, dev
+        self.RB = _abi.RESULT_DTYPE.itemsize
+        self.d_res = torch.empty((max((n_local_total + world - 1) // world, 1), self.RB), dtype=torch.uint8, device=dev)
+        self.n_total = n_local_total
+
+    def row_minima_into(self, row_min, row_arg, status):
+        self.f.nn_row_minima_device(row_min.data_ptr(), row_arg.data_ptr(), status.data_ptr())
+
+    def row_minima_sync(self):
+        n_l, _ = self.f.nn_sizes()
+        self.f.nn_find_matches(cap=n_l)                 # walks the filter ladder; its own walk is not used
+        return self.f.nn_last_row_minima()
+
+    def walk(self, d, a):
+        return self.f.nn_walk(d, a, self.n_r, cap=self.n_total)
+
+    def verify_into(self, matches, payload, count, flags):
+        n = len(matches)
+        if n == 0:
+            count.zero_()
+            return
+        self.f.verify_matches_device(np.ascontiguousarray(matches), self.slot_a, self.slot_b, self.d_res.data_ptr())
+        self.f.compact_accepted_device_async(self.d_res.data_ptr(), n, payload.data_ptr(), flags.data_ptr(), count.data_ptr())
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 """Worker of tests/test_sharded_step.py: one gloo rank running multi_robot_slam_separators_amd.sharded.ShardedStep
 (the section 8(e) partition the multi-GPU bench uses) with the CPU ORACLE as the compute backend -- the tests may use
 the oracle; the orchestration (row blocks, all-gather of minima, replicated walk, p mod G, flag + record exchange,
-interleave) is the product's.  usage: sharded_worker.py RANK WORLD PORT OUT_PREFIX"""
+interleave) is the product's.  usage: sharded_worker.py RANK WORLD PORT OUT_PREFIX [dense]"""
 import os
 import sys
 
@@ -13,17 +13,34 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 class OracleShardBackend:
-    def __init__(self, params, local, received, feats_other, feats_local):
+    """The backend interface of sharded.ShardedStep on CPU tensors.  `dense_once`: report "too dense for the device
+    path" on the first query, so that the synchronous fallback (and its second all-gather) runs too."""
+
+    def __init__(self, params, local, received, feats_other, feats_local, lo, hi, dense_once=False):
         self.p, self.local, self.received = params, local, received
         self.fo, self.fl = feats_other, feats_local
+        self.lo, self.hi, self.dense = lo, hi, dense_once
+        self.sync_calls = 0
 
-    def row_minima(self, lo, hi):
+    def row_minima_sync(self):
         from oracle import pyoracle
-        if hi <= lo:
-            return np.zeros(0), np.zeros(0, np.int32)
-        _, d, a = pyoracle.find_matches(self.local[lo:hi], self.received, (), (), (), self.p.netvlad_distance,
+        _, d, a = pyoracle.find_matches(self.local[self.lo:self.hi], self.received, (), (), (), self.p.netvlad_distance,
                                         self.p.netvlad_max_matches_nb)
+        self.sync_calls += 1
         return np.asarray(d, dtype=np.float64), np.asarray(a, dtype=np.int32)
+
+    def row_minima_into(self, row_min, row_arg, status):
+        import torch
+        if self.dense:
+            self.dense = False
+            row_min.fill_(float("nan"))
+            status.fill_(1)
+            return
+        d, a = self.row_minima_sync()
+        self.sync_calls -= 1
+        row_min.copy_(torch.from_numpy(d))
+        row_arg.copy_(torch.from_numpy(a))
+        status.zero_()
 
     def walk(self, d, a):
         from multi_robot_slam_separators_amd import _abi, dist
@@ -33,16 +50,24 @@ class OracleShardBackend:
             m[k] = (il, io, d[il])
         return m
 
-    def verify(self, matches):
+    def verify_into(self, matches, payload, count, flags):
         import torch
-        from multi_robot_slam_separators_amd import _abi
         from oracle import pyoracle
+        count.zero_()
         if len(matches) == 0:
-            return torch.zeros((0, _abi.RESULT_DTYPE.itemsize), dtype=torch.uint8)
+            return
         A = [self.fo[int(r["idx_other"])] for r in matches]      # "from" = the querying robot's frame
         B = [self.fl[int(r["idx_local"])] for r in matches]      # "to"   = the computing robot's frame
         res = pyoracle.estimate_transform_batch(self.p, A, B, 1)
-        return torch.from_numpy(np.frombuffer(res.tobytes(), dtype=np.uint8).reshape(len(matches), -1).copy())
+        ok = torch.from_numpy(np.asarray(res["success"] != 0))
+        raw = torch.from_numpy(np.frombuffer(res.tobytes(), dtype=np.uint8).reshape(len(matches), -1).copy())
+        acc = raw[ok]
+        payload[: acc.shape[0]].copy_(acc)
+        count.fill_(int(acc.shape[0]))
+        flags.copy_(ok.to(torch.uint8))
+
+    def sync(self):
+        pass
 
 
 def make_problem(seed=4711, n=36):
@@ -71,12 +96,17 @@ def main():
         os.environ["MASTER_PORT"] = port
         td.init_process_group("gloo", rank=rank, world_size=world)
     p, local, received, A, B = make_problem()
-    st = sharded.ShardedStep(OracleShardBackend(p, local, received, A, B), rank, world, len(local), "cpu",
+    dense = len(sys.argv) > 5 and sys.argv[5] == "dense" and rank == world - 1
+    lo, hi = sharded.row_blocks(len(local), world)[rank]
+    be = OracleShardBackend(p, local, received, A, B, lo, hi, dense_once=dense)
+    st = sharded.ShardedStep(be, rank, world, len(local), "cpu",
                              accept_cap=3)      # small capacity: the overflow path of the record exchange runs too
     m, flags, acc = st.step()
+    assert st.waits == (3 if len(sys.argv) > 5 and sys.argv[5] == "dense" else 2), st.waits
+    assert be.sync_calls == (1 if dense else 0)
     np.save(prefix + "_m_%d.npy" % rank, m)
-    np.save(prefix + "_flags_%d.npy" % rank, flags.numpy())
-    np.save(prefix + "_acc_%d.npy" % rank, acc.cpu().numpy())
+    np.save(prefix + "_flags_%d.npy" % rank, flags)
+    np.save(prefix + "_acc_%d.npy" % rank, acc)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

@@ -22,9 +22,9 @@ def _free_port():
     return port
 
 
-def _run(world, prefix):
+def _run(world, prefix, *extra):
     port = str(_free_port())
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, prefix],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), port, prefix, *extra],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     for r, p in enumerate(procs):
         try:
@@ -49,6 +49,19 @@ def test_sharded_step_equals_single_rank(tmp_path, oracle, world):
         assert np.load(out + "_m_%d.npy" % r).tobytes() == m0.tobytes(), "candidate list differs on rank %d" % r
         assert np.array_equal(np.load(out + "_flags_%d.npy" % r), f0)
         assert np.load(out + "_acc_%d.npy" % r).tobytes() == a0.tobytes(), "accepted records differ on rank %d" % r
+
+
+def test_sharded_step_dense_fallback(tmp_path, oracle):
+    """One rank reports "candidate set too dense for the device path": every rank sees it in the gathered block, that
+    rank recomputes synchronously, the minima are gathered once more (three waits instead of two, asserted in the
+    worker) and the result is the same."""
+    ref = str(tmp_path / "ref")
+    _run(1, ref)
+    out = str(tmp_path / "dense")
+    _run(2, out, "dense")
+    for r in range(2):
+        for part in ("m", "flags", "acc"):
+            assert np.load(out + "_%s_%d.npy" % (part, r)).tobytes() == np.load(ref + "_%s_0.npy" % part).tobytes()
 
 
 def test_row_blocks_and_flatten():
