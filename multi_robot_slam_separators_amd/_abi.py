@@ -54,6 +54,8 @@ class Params(C.Structure):
         ("ba_robust_kernel_delta", C.c_float),
         ("ba_pixel_variance", C.c_float),
         ("stereo_baseline", C.c_float),
+        ("force_3dof", C.c_int32),
+        ("forward_est_only", C.c_int32),
     ]
 
 
@@ -215,7 +217,7 @@ class StepResult(C.Structure):
                 ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32)]
 
 
-SF_ABI_VERSION = 2      # include/sepfinder.h
+SF_ABI_VERSION = 3      # include/sepfinder.h
 
 
 def default_params() -> Params:
@@ -254,6 +256,8 @@ def default_params() -> Params:
     p.ba_robust_kernel_delta = 8.0
     p.ba_pixel_variance = 1.0
     p.stereo_baseline = 0.0
+    p.force_3dof = 0
+    p.forward_est_only = 1
     return p
 
 

@@ -617,7 +617,10 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     ps.var = v;
     ps.var_ang = v;
   }
-  if (tid == 0) pass[pair] = ps;
+  if (tid == 0) {
+    if (P.force_3dof && !ps.is_null) sfd::to3dof_canon(ps.T);     // myRegistrationVis.cpp:1100-1102
+    pass[pair] = ps;
+  }
   if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 4);
   return PnpTail{L.obj, L.cidx, inl, m, true};
 }
@@ -627,7 +630,7 @@ __global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
 k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
-      PassState* __restrict__ pass, DeviceParams P) {
+      PassState* __restrict__ pass, int extra_3dof, DeviceParams P) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = list[blockIdx.x];
@@ -638,6 +641,9 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
       ba_body(st, pair_from[pair], pair_to[pair], tail.obj, tail.cidx, tail.inl, tail.m, pass[pair], P,
               smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15));
   }
+  // myRegistration.cpp:269-276, and for pass 1 the application its result meets as the guess of pass 2 (:245-248)
+  if (extra_3dof && threadIdx.x == 0 && !pass[pair].is_null)
+    for (int t = 0; t < extra_3dof; ++t) sfd::to3dof_canon(pass[pair].T);
 }
 
 }  // namespace
@@ -663,7 +669,8 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
                        (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
                        (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
                        (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
-                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p),
+                       c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0, c->dparams);
   };
   if (ba) launch(k_pnp<true>); else launch(k_pnp<false>);
   sf_prof_end(c, kid);

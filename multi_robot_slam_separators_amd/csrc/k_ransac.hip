@@ -392,10 +392,12 @@ __device__ __forceinline__ void write_null_pass(PassState& out, int matches) {
 // correspondences (from | to << 16, ascending "from"; LDS in the fused kernel, global in the stage kernel);
 // `lds` = this stage's region of the workgroup's dynamic LDS (sf_ransac_lds_bytes).  The result is written to
 // `out` by thread 0.
-template <bool BA = false>
+// DIR = 1: the backward estimate of Vis/ForwardEstOnly = false (myRegistrationVis.cpp:936-978: A = "to", B = "from");
+// `mask_out` (stage kernel, DIR form only): one byte per "from" feature of the pair, set for this estimate's inliers.
+template <bool BA = false, int DIR = 0>
 __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int sF, int sT, const uint32_t* cl, int n_corr,
                                             PassState& out, const DeviceParams& P, unsigned char* lds,
-                                            int trace_base = 2) {
+                                            int trace_base = 2, uint8_t* mask_out = nullptr) {
   constexpr int NT = SF_BLOCK;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -414,8 +416,8 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
     if (i < n_corr) {
       const uint32_t c = cl[i];
-      const float* a = xF + 3 * (c & 0xFFFFu);
-      const float* b = xT + 3 * (c >> 16);
+      const float* a = DIR ? xT + 3 * (c >> 16) : xF + 3 * (c & 0xFFFFu);
+      const float* b = DIR ? xF + 3 * (c & 0xFFFFu) : xT + 3 * (c >> 16);
       ax = a[0]; ay = a[1]; az = a[2];
       bx = b[0]; by = b[1]; bz = b[2];
       ok = sfd::finite3(ax, ay, az) && sfd::finite3(bx, by, bz) && (ax != 0.f || ay != 0.f || az != 0.f) &&
@@ -650,6 +652,9 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   if (P.dbg_stop == 5) { if (tid_b == 0) write_null_pass(out, m); return; }
   SF_TRACE_MARK(P, pair, trace_base + 4);
   if (n_inl >= 3) {
+    if (mask_out)
+      for (int i = tid; i < m; i += NT)
+        if (inl[i]) mask_out[L.cidx[i] & 0xFFFFu] = 1;
     const double variance = variance_of(L, m, n_last, tid_b);
     if (tid_b == 0) {
       PassState ps;
@@ -679,6 +684,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
 #pragma unroll
         for (int i = 0; i < 12; ++i) allz = allz && (ps.T[i] == 0.f);
         ps.is_null = allz ? 1 : 0;
+        if (P.force_3dof && !allz) sfd::to3dof_canon(ps.T);     // :1141-1143
       }
       out = ps;
     }
@@ -693,17 +699,65 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   SF_TRACE_MARK(P, pair, trace_base + 5);
 }
 
-template <bool BA>
+// The end-of-pass to3DoF of myRegistration.cpp:269-276 and, for pass 1, the one its result meets as the guess of
+// pass 2 (:245-248): `times` applications by the thread that wrote the pass state.
+__device__ inline void pass_to3dof(PassState& ps, int times) {
+  if (ps.is_null) return;
+  for (int t = 0; t < times; ++t) sfd::to3dof_canon(ps.T);
+}
+
+template <bool BA, int DIR>
 __global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
 k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
          const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
          const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
-         PassState* __restrict__ pass, DeviceParams P) {
+         PassState* __restrict__ pass, uint8_t* __restrict__ mask, int extra_3dof, DeviceParams P) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = list[blockIdx.x];
-  ransac_body<BA>(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr, pass[pair],
-                  P, smem_raw);
+  ransac_body<BA, DIR>(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr,
+                       pass[pair], P, smem_raw, 2, mask ? mask + (size_t)pair * st.kcap : nullptr);
+  if (extra_3dof && threadIdx.x == 0) pass_to3dof(pass[pair], extra_3dof);
+}
+
+// Vis/ForwardEstOnly = false: the two directions' estimates of a pass merged as myRegistrationVis.cpp:1155-1189
+// (union of the inlier ids; the matches are the same ids in both directions) and :1376-1394 (inverse of the backward
+// transform; interpolate(0.5) when both exist, covariance their mean).  One wavefront per pair.
+__global__ void __launch_bounds__(64)
+k_merge_directions(const int32_t* __restrict__ list, const int32_t* __restrict__ counter, PassState* __restrict__ fwd,
+                   const PassState* __restrict__ back, const uint8_t* __restrict__ mask_f,
+                   const uint8_t* __restrict__ mask_b, int kcap, int extra_3dof) {
+  if ((int)blockIdx.x >= *counter) return;
+  const int pair = list[blockIdx.x], lane = threadIdx.x;
+  int uni = 0;
+  for (int i = lane; i < kcap; i += 64) uni += (mask_f[(size_t)pair * kcap + i] | mask_b[(size_t)pair * kcap + i]) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) uni += __shfl_xor(uni, off);
+  if (lane != 0) return;
+  PassState a = fwd[pair];
+  const PassState b = back[pair];
+  a.inliers = uni;
+  a.matches = a.matches > b.matches ? a.matches : b.matches;
+  if (!b.is_null) {
+    float inv[12];
+    sfd::rigid_inverse_canon(b.T, inv);
+    if (a.is_null) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.T[i] = inv[i];
+      a.is_null = 0;
+      a.var = b.var;
+      a.var_ang = b.var_ang;
+    } else {
+      float mid[12];
+      sfd::interpolate_half_canon(a.T, inv, mid);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.T[i] = mid[i];
+      a.var = (a.var + b.var) / 2.0;
+      a.var_ang = (a.var_ang + b.var_ang) / 2.0;
+    }
+  }
+  pass_to3dof(a, extra_3dof);
+  fwd[pair] = a;
 }
 
 }  // namespace
@@ -718,23 +772,47 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
   const bool ba = c->dparams.bundle_adjustment != 0;
   const size_t lds = ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
+  const bool bidir = c->dparams.bidirectional != 0;       // (never together with bundle adjustment: sf_create)
   bool& attr = ba ? c->ransac_ba_attr_set : c->ransac_attr_set;
   if (!attr) {   // per handle = per device
-    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else {
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
+  const int32_t* list = (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p);
+  const int32_t* counter = counters + (pass == 1 ? 0 : 2);
+  PassState* ps = (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p);
+  // Reg/Force3DoF: the end-of-pass application, and for pass 1 the one its result meets as the guess of pass 2
+  const int end_3dof = c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0;
+  uint8_t *mask_f = nullptr, *mask_b = nullptr;
+  if (bidir) {
+    int rc;
+    const size_t mb = (size_t)n * st.kcap;
+    if ((rc = sf_buf_reserve(c, c->dir_mask, 2 * mb)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->pass_back, (size_t)n * sizeof(PassState))) != SF_OK) return rc;
+    mask_f = (uint8_t*)c->dir_mask.p;
+    mask_b = mask_f + mb;
+    SF_HIP(c, hipMemsetAsync(mask_f, 0, 2 * mb, c->stream));
+  }
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
-  auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                       (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
+  auto launch = [&](auto kern, PassState* out, uint8_t* mask, int extra) {
+    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter,
                        (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
-                       (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
-                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p), c->dparams);
+                       (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p), out, mask, extra, c->dparams);
   };
-  if (ba) launch(k_ransac<true>); else launch(k_ransac<false>);
+  if (ba) launch(k_ransac<true, 0>, ps, nullptr, end_3dof);
+  else if (!bidir) launch(k_ransac<false, 0>, ps, nullptr, end_3dof);
+  else {
+    launch(k_ransac<false, 0>, ps, mask_f, 0);
+    launch(k_ransac<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    hipLaunchKernelGGL(k_merge_directions, dim3(n), dim3(64), 0, c->stream, list, counter, ps,
+                       (const PassState*)c->pass_back.p, (const uint8_t*)mask_f, (const uint8_t*)mask_b, st.kcap, end_3dof);
+  }
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
   return SF_OK;

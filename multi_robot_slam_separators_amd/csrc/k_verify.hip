@@ -47,6 +47,7 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
   __builtin_amdgcn_s_setprio(3);
   if (est1) {
     ransac_body<BA>(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2);
+    if (P.force_3dof && tid == 0) pass_to3dof(T.pass1, 2);      // myRegistration.cpp:269-276, then :245-248 as pass 2's guess
     __syncthreads();
   }
   // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
@@ -60,6 +61,7 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
   }
   if (est2) {
     ransac_body<BA>(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11);
+    if (P.force_3dof && tid == 0) pass_to3dof(T.pass2, 1);
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);
@@ -222,7 +224,7 @@ size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_mat
 // Dynamic LDS of the fused kernel = the largest stage + the hand-over tail; 0 when the fused pipeline does not
 // apply (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
-  if (!c->fused || c->dparams.estimation_type != 0) return 0;
+  if (!c->fused || c->dparams.estimation_type != 0 || c->dparams.bidirectional) return 0;   // (both directions: stage kernels)
   const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
@@ -278,6 +280,7 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
       if (P.bundle_adjustment && tail.ran)
         ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass1[pair], P, ba_lds);
     }
+    if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass1[pair], 2);
   }
   __syncthreads();     // pass1[pair] (written by thread 0) is read by every lane below
   const bool est2 = guided_body<W>(st, pair, sF, sT, pass1[pair], pass2[pair], guided_flag[pair],
@@ -291,6 +294,7 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
       if (P.bundle_adjustment && tail.ran)
         ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass2[pair], P, ba_lds);
     }
+    if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass2[pair], 1);
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);

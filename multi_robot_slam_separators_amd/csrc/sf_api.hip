@@ -629,6 +629,8 @@ extern "C" void sf_default_params(sf_params* p) {
   p->ba_robust_kernel_delta = 8.f;   // g2o/RobustKernelDelta
   p->ba_pixel_variance = 1.f;        // g2o/PixelVariance
   p->stereo_baseline = 0.f;
+  p->force_3dof = 0;                 // Reg/Force3DoF
+  p->forward_est_only = 1;           // Vis/ForwardEstOnly
 }
 
 static int fill_device_params(sf_context* c) {
@@ -653,8 +655,12 @@ static int fill_device_params(sf_context* c) {
     if (p.ba_iterations < 0 || !(p.ba_pixel_variance > 0.f) || !(p.ba_robust_kernel_delta > 0.f) || !(p.stereo_baseline >= 0.f))
       return sf_fail(c, SF_EINVAL, "bundle adjustment: ba_iterations >= 0, ba_pixel_variance > 0, ba_robust_kernel_delta > 0, stereo_baseline >= 0");
   }
+  if (p.forward_est_only == 0 && (p.estimation_type != 0 || p.bundle_adjustment != 0))
+    return sf_fail(c, SF_EINVAL, "forward_est_only = 0 is implemented for estimation_type 0 without bundle adjustment");
   DeviceParams& d = c->dparams;
   memset(&d, 0, sizeof(d));
+  d.force_3dof = p.force_3dof != 0;
+  d.bidirectional = p.forward_est_only == 0;
   d.nndr = p.nndr;
   d.min_inliers = p.min_inliers;
   d.iterations = p.iterations;

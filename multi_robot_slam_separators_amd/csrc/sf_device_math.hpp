@@ -392,4 +392,79 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
 
+// ---- Transform::to3DoF / inverse / interpolate(0.5) in their canonical forms (oracle/sf_oracle.c sfo_to3dof,
+// sfo_rigid_inverse, sfo_interpolate_half: the same operations in the same order, -ffp-contract=off on both sides).
+// to3DoF: Transform(x, y, 0, 0, 0, yaw), yaw = atan2(r21, r11) -> the rotation (r11, r21) / |(r11, r21)| about z.
+__device__ inline void to3dof_canon(float* T) {
+  const double r11 = (double)T[0], r21 = (double)T[4];
+  const double h = sqrt(r11 * r11 + r21 * r21);
+  float c = 1.0f, s = 0.0f;
+  if (h > 0.0) { c = (float)(r11 / h); s = (float)(r21 / h); }
+  const float x = T[3], y = T[7];
+  T[0] = c; T[1] = -s; T[2] = 0.0f; T[3] = x;
+  T[4] = s; T[5] = c; T[6] = 0.0f; T[7] = y;
+  T[8] = 0.0f; T[9] = 0.0f; T[10] = 1.0f; T[11] = 0.0f;
+}
+
+__device__ inline void quat_from_rot_canon(const float* T, double (&q)[4]) {
+  double m[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m[i][j] = (double)T[4 * i + j];
+  const double tr = (m[0][0] + m[1][1]) + m[2][2];
+  if (tr > 0.0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(((m[i][i] - m[j][j]) - m[k][k]) + 1.0);
+    double qv[3];
+    qv[i] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t;
+    qv[j] = (m[j][i] + m[i][j]) * t;
+    qv[k] = (m[k][i] + m[i][k]) * t;
+    q[0] = qv[0]; q[1] = qv[1]; q[2] = qv[2];
+  }
+}
+
+__device__ inline void rigid_inverse_canon(const float* T, float* out) {
+  double R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = (double)T[4 * i + j];
+    t[i] = (double)T[4 * i + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)R[3 * j + i];
+    out[4 * i + 3] = (float)(-((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]));
+  }
+}
+
+__device__ inline void interpolate_half_canon(const float* A, const float* B, float* out) {
+  double qa[4], qb[4], q[4];
+  quat_from_rot_canon(A, qa);
+  quat_from_rot_canon(B, qb);
+  const double d = ((qa[0] * qb[0] + qa[1] * qb[1]) + qa[2] * qb[2]) + qa[3] * qb[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = d < 0.0 ? qa[i] - qb[i] : qa[i] + qb[i];
+  const double n = sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  out[0] = (float)(1.0 - (tyy + tzz)); out[1] = (float)(txy - twz);         out[2] = (float)(txz + twy);
+  out[4] = (float)(txy + twz);         out[5] = (float)(1.0 - (txx + tzz)); out[6] = (float)(tyz - twx);
+  out[8] = (float)(txz - twy);         out[9] = (float)(tyz + twx);         out[10] = (float)(1.0 - (txx + tyy));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[4 * i + 3] = A[4 * i + 3] + 0.5f * (B[4 * i + 3] - A[4 * i + 3]);
+}
+
 }  // namespace sfd

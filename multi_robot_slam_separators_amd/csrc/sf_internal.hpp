@@ -83,6 +83,8 @@ struct DeviceParams {
   int32_t bundle_adjustment;  // two-view BA after each pass's estimate (k_ba.hip)
   int32_t ba_iterations;
   float ba_robust_kernel_delta, ba_pixel_variance, stereo_baseline;
+  int32_t force_3dof;         // Reg/Force3DoF
+  int32_t bidirectional;      // Vis/ForwardEstOnly = false (stage pipeline only)
   int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
                               // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
   const struct AcceptStream* accept;   // fused kernel: accepted results also stream to the host as they are produced (or null)
@@ -172,6 +174,7 @@ struct sf_context {
   Buf corr1, corr2;             // uint32[n][kcap]
   Buf hdr1, hdr2;               // CorrHeader[n]
   Buf pass1, pass2;             // PassState[n]
+  Buf pass_back, dir_mask;      // Vis/ForwardEstOnly = false: the backward estimate's PassState[n], inlier masks [2][n][kcap]
   Buf list1, list3;             // int32[n] work lists (RANSAC pass 1, RANSAC pass 2)
   Buf counters;                 // int32[8]
   Buf results;                  // sf_result[n]

@@ -845,8 +845,79 @@ static int sfo_validate(const sf_features* f) {
   return SF_OK;
 }
 
+/* Transform::to3DoF [upstream rtabmap Transform.cpp]: Transform(x, y, 0, 0, 0, yaw) with (roll, pitch, yaw) from
+ * pcl::getEulerAngles, i.e. yaw = atan2(r21, r11).  Canonical form shared with the device (csrc/sf_device_math.hpp
+ * to3dof_canon): the rotation about z by that angle is (r11, r21) / |(r11, r21)| -- no trigonometric call, so the two
+ * sides agree to the bit; against the reference's float atan2f / cosf / sinf it differs by a few 1e-8.             */
+void sfo_to3dof(float* T) {
+  const double r11 = (double)T[0], r21 = (double)T[4];
+  const double h = sqrt(r11 * r11 + r21 * r21);
+  float c = 1.0f, s = 0.0f;
+  if (h > 0.0) { c = (float)(r11 / h); s = (float)(r21 / h); }
+  const float x = T[3], y = T[7];
+  T[0] = c; T[1] = -s; T[2] = 0.0f; T[3] = x;
+  T[4] = s; T[5] = c; T[6] = 0.0f; T[7] = y;
+  T[8] = 0.0f; T[9] = 0.0f; T[10] = 1.0f; T[11] = 0.0f;
+}
+
+/* Eigen::Quaternionf(rotation) [upstream Eigen Quaternion.h quaternionbase_assign_impl], in double on the float
+ * entries; no sign convention applied. */
+static void sfo_quat_from_rot(const float* T, double q[4]) {
+  double m[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = (double)T[4 * i + j];
+  const double tr = (m[0][0] + m[1][1]) + m[2][2];
+  if (tr > 0.0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(((m[i][i] - m[j][j]) - m[k][k]) + 1.0);
+    q[i] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t;
+    q[j] = (m[j][i] + m[i][j]) * t;
+    q[k] = (m[k][i] + m[i][k]) * t;
+  }
+}
+
+/* Transform::inverse() of a rigid transform, in the form the estimators already use for their own result. */
+static void sfo_rigid_inverse(const float* T, float* out) {
+  double R[9], t[3];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[3 * i + j] = (double)T[4 * i + j]; t[i] = (double)T[4 * i + 3]; }
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) out[4 * i + j] = (float)R[3 * j + i];
+    out[4 * i + 3] = (float)(-((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]));
+  }
+}
+
+/* a.interpolate(0.5f, b) [upstream rtabmap Transform::interpolate]: qa.slerp(0.5, qb), translation a + 0.5 (b - a),
+ * then Transform(x, y, z, qx, qy, qz, qw), which NORMALISES the quaternion before toRotationMatrix().  At t = 0.5
+ * Eigen's slerp weights are equal (sin(theta / 2) / sin(theta) each; 0.5 each for nearly parallel quaternions) with
+ * the second negated when qa . qb < 0, so the normalised result is (qa +- qb) / |qa +- qb|: no trigonometry needed. */
+void sfo_interpolate_half(const float* A, const float* B, float* out) {
+  double qa[4], qb[4], q[4];
+  sfo_quat_from_rot(A, qa);
+  sfo_quat_from_rot(B, qb);
+  const double d = ((qa[0] * qb[0] + qa[1] * qb[1]) + qa[2] * qb[2]) + qa[3] * qb[3];
+  for (int i = 0; i < 4; ++i) q[i] = d < 0.0 ? qa[i] - qb[i] : qa[i] + qb[i];
+  const double n = sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  out[0] = (float)(1.0 - (tyy + tzz)); out[1] = (float)(txy - twz);         out[2] = (float)(txz + twy);
+  out[4] = (float)(txy + twz);         out[5] = (float)(1.0 - (txx + tzz)); out[6] = (float)(tyz - twx);
+  out[8] = (float)(txz - twy);         out[9] = (float)(tyz + twx);         out[10] = (float)(1.0 - (txx + tyy));
+  for (int i = 0; i < 3; ++i) out[4 * i + 3] = A[4 * i + 3] + 0.5f * (B[4 * i + 3] - A[4 * i + 3]);
+}
+
 /* One computeTransformationFromFeats call (myRegistration.cpp:225-303 ->
- * myRegistrationVis.cpp:441-1410) with estimation type 0 or 1 and forward-only estimation. */
+ * myRegistrationVis.cpp:441-1410) with estimation type 0 or 1; forward-only estimation, or (estimation type 0 without
+ * bundle adjustment) both directions merged as :1155-1189 and :1376-1394 do.  Reg/Force3DoF: :245-248, :1100-1102 /
+ * :1141-1143 and myRegistration.cpp:269-276. */
 static int sfo_registration_pass(const sf_params* p, const sf_features* from, const sf_features* to,
                                  const float* guess, int guess_is_null, sfo_pass* out, int* guided,
                                  uint16_t* cf, uint16_t* ct, int* nc) {
@@ -856,6 +927,12 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
   out->cov_diag_ang = 1.0;
   *guided = 0;
   *nc = 0;
+  float guess3[12];
+  if (!guess_is_null && p->force_3dof) {     /* myRegistration.cpp:245-248 */
+    memcpy(guess3, guess, sizeof(guess3));
+    sfo_to3dof(guess3);
+    guess = guess3;
+  }
   int kf = from->rows, kt = to->rows;
   int n_words_from = 0, n_words_to = 0, n_words_to_2d = 0, all_outside = 0, rc;
   if (kf > 0 && kt > 0) {
@@ -894,7 +971,43 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
       out->cov_diag_ang = mo.variance_ang;
       out->inliers = mo.inliers;
       out->matches = mo.matches;
-      if (!mo.is_null) { memcpy(out->transform, mo.transform, sizeof(out->transform)); out->is_null = 0; }
+      if (!mo.is_null) {
+        memcpy(out->transform, mo.transform, sizeof(out->transform));
+        out->is_null = 0;
+        if (p->force_3dof) sfo_to3dof(out->transform);      /* :1100-1102, :1141-1143 */
+      }
+      if (!p->forward_est_only && p->estimation_type == 0) {
+        /* dir = 1 (:936-978, :1113-1152): A = to, B = from; same words, same id order */
+        sfo_motion m1;
+        uint8_t* imask1 = (uint8_t*)calloc((size_t)(*nc > 0 ? *nc : 1), 1);
+        if (!imask1) { free(imask); return SF_ENOMEM; }
+        rc = sfo_estimate_motion_3d3d(p, to->xyz, from->xyz, ct, cf, *nc, &m1, imask1);
+        if (rc != SF_OK) { free(imask); free(imask1); return rc; }
+        if (!m1.is_null && p->force_3dof) sfo_to3dof(m1.transform);
+        /* :1155-1189 union of the two directions' inlier ids (matches: the same ids in both directions) */
+        int uni = 0;
+        for (int i = 0; i < *nc; ++i) uni += (imask[i] | imask1[i]) ? 1 : 0;
+        out->inliers = uni;
+        out->matches = mo.matches > m1.matches ? mo.matches : m1.matches;
+        /* :1376-1394 */
+        if (!m1.is_null) {
+          float inv[12];
+          sfo_rigid_inverse(m1.transform, inv);
+          if (out->is_null) {
+            memcpy(out->transform, inv, sizeof(inv));
+            out->is_null = 0;
+            out->cov_diag = m1.variance;
+            out->cov_diag_ang = m1.variance_ang;
+          } else {
+            float mid[12];
+            sfo_interpolate_half(out->transform, inv, mid);
+            memcpy(out->transform, mid, sizeof(mid));
+            out->cov_diag = (mo.variance + m1.variance) / 2.0;
+            out->cov_diag_ang = (mo.variance_ang + m1.variance_ang) / 2.0;
+          }
+        }
+        free(imask1);
+      }
       /* :1192-1197 bundle adjustment of the forward transform (the covariance keeps the motion estimate's value) */
       if (p->bundle_adjustment > 0 && !mo.is_null && mo.inliers > 0 && n_words_from > 0 && n_words_to_2d > 0) {
         int n_inl = mo.inliers, null2 = 0;
@@ -907,6 +1020,7 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
       free(imask);
     }
   }
+  if (!out->is_null && p->force_3dof) sfo_to3dof(out->transform);   /* myRegistration.cpp:269-276 */
   return SF_OK;
 }
 
@@ -947,6 +1061,7 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if ((rc = sfo_validate(from)) != SF_OK) return rc;
   if ((rc = sfo_validate(to)) != SF_OK) return rc;
   if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
+  if (!p->forward_est_only && (p->estimation_type != 0 || p->bundle_adjustment != 0)) return SF_EINVAL;
   if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations < 0)) return SF_EINVAL;
   if (p->bundle_adjustment != 0 &&
       (p->bundle_adjustment != 1 || !(p->image_width > 0 && p->image_height > 0 && p->fx > 0.0 && p->fy > 0.0) ||

@@ -116,6 +116,8 @@ int sfo_estimate_transform_batch(const sf_params* p, const sf_features* from,
 /* Building blocks exposed for unit tests */
 void   sfo_fit_rigid(const double* src, const double* dst, int n, double R[9], double t[3]);
 double sfo_canon_log(double x);
+void sfo_to3dof(float* T);
+void sfo_interpolate_half(const float* A, const float* B, float* out);
 void   sfo_sample_triplet(uint64_t seed, uint32_t iteration, uint32_t attempt, uint32_t m,
                           uint32_t out[3]);
 int    sfo_num_threads(void);

@@ -289,3 +289,119 @@ def test_verification_regression_vectors(oracle):
             got = oracle.estimate_transform(p, A[i], B[i])
             assert got.tobytes() == want[i].tobytes(), "estimation_type %d pair %d" % (est, i)
             assert bool(got["success"]) == bool(z["is_true"][i])
+
+
+# ---- Reg/Force3DoF and Vis/ForwardEstOnly = false (the adjacent branches of myRegistration.cpp:245-276 and
+# myRegistrationVis.cpp:936-978 / 1155-1189 / 1376-1394) -----------------------------------------------------------
+def _rot(axis, ang):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_rotvec(np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis) * ang).as_matrix()
+
+
+def _T(Rm, t):
+    T = np.zeros((3, 4), dtype=np.float32)
+    T[:, :3] = Rm
+    T[:, 3] = t
+    return T
+
+
+def test_to3dof_is_x_y_yaw(oracle):
+    """Transform::to3DoF [upstream]: Transform(x, y, 0, 0, 0, yaw), yaw = atan2(r21, r11) (pcl::getEulerAngles)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.sfo_to3dof.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        Rm = _rot(rng.normal(size=3), rng.uniform(0, 3.0))
+        T = _T(Rm, rng.normal(size=3))
+        yaw = np.arctan2(np.float32(Rm[1, 0]), np.float32(Rm[0, 0]))
+        want = _T(_rot([0, 0, 1], yaw), [T[0, 3], T[1, 3], 0.0])
+        got = T.copy()
+        L.sfo_to3dof(got.ctypes.data)
+        assert np.abs(got - want).max() < 5e-7
+        assert got[2, 3] == 0 and got[2, 2] == 1 and got[0, 3] == T[0, 3] and got[1, 3] == T[1, 3]
+    I = _T(np.eye(3), [0, 0, 0])
+    got = I.copy()
+    L.sfo_to3dof(got.ctypes.data)
+    assert np.array_equal(got, I)                 # the identity guess of pass 1 stays the identity (isIdentity, :477)
+
+
+def test_interpolate_half_is_slerp(oracle):
+    """Transform::interpolate(0.5, other) [upstream]: Eigen slerp of the two rotations, midpoint of the translations."""
+    import ctypes as C
+    from scipy.spatial.transform import Rotation, Slerp
+    L = oracle.lib()
+    L.sfo_interpolate_half.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for k in range(60):
+        Ra = _rot(rng.normal(size=3), rng.uniform(0, 3.1))
+        Rb = Ra @ _rot(rng.normal(size=3), rng.uniform(0, 0.5 if k % 2 else 3.0))
+        A, B = _T(Ra, rng.normal(size=3)), _T(Rb, rng.normal(size=3))
+        out = np.zeros((3, 4), dtype=np.float32)
+        L.sfo_interpolate_half(A.ctypes.data, B.ctypes.data, out.ctypes.data)
+        mid = Slerp([0, 1], Rotation.from_matrix(np.stack([A[:, :3], B[:, :3]]).astype(np.float64)))(0.5).as_matrix()
+        assert np.abs(out[:, :3] - mid).max() < 2e-6
+        assert np.abs(out[:, 3] - 0.5 * (A[:, 3] + B[:, 3])).max() < 1e-6
+
+
+def test_force_3dof_results_are_planar(oracle):
+    A, B, is_true, Ts = synth.make_pairs(77, 12, k=300, true_frac=0.75)
+    for est in (0, 1):
+        p = synth.camera_params()
+        p.iterations = 200
+        p.estimation_type = est
+        p.force_3dof = 1
+        n_ok = 0
+        for a, b in zip(A, B):
+            r = oracle.estimate_transform(p, a, b)
+            if r["success"]:
+                n_ok += 1
+                assert r["position"][2] == 0.0
+                assert abs(r["orientation"][0]) < 1e-7 and abs(r["orientation"][1]) < 1e-7     # rotation about z
+        # (a general 6-DoF motion squeezed into 3 DoF as the guess of pass 2 usually loses the pair: that is the
+        #  reference's behaviour for a non-planar robot; at least the calls run and decide)
+        assert n_ok >= 0
+
+
+def test_planar_motion_survives_force_3dof(oracle):
+    """Pairs whose true motion IS planar (yaw + x, y): with Reg/Force3DoF the result stays close to the 6-DoF estimate."""
+    rng = np.random.default_rng(12)
+    p0 = synth.camera_params()
+    p0.iterations = 300
+    p1 = _abi.copy_params(p0)
+    p1.force_3dof = 1
+    hits = 0
+    for _ in range(8):
+        a = synth.make_keyframe(rng, 300, 32)
+        T = np.eye(4)
+        T[:3, :3] = _rot([0, 0, 1], rng.uniform(-0.4, 0.4))
+        T[:2, 3] = rng.uniform(-1, 1, size=2)
+        b, _ = synth.make_true_partner(rng, a, T, 0.5, 0.01, 0.03)
+        r0, r1 = oracle.estimate_transform(p0, a, b), oracle.estimate_transform(p1, a, b)
+        if r0["success"] and r1["success"]:
+            hits += 1
+            assert np.linalg.norm(r0["position"] - r1["position"]) < 0.05
+    assert hits >= 5
+
+
+def test_bidirectional_estimate(oracle):
+    """Vis/ForwardEstOnly = false: inliers = union of both directions' (>= the forward estimate's), the pose stays
+    within the noise of the forward-only one; PnP / bundle adjustment with it are refused."""
+    A, B, is_true, Ts = synth.make_pairs(78, 16, k=300, true_frac=0.75)
+    p0 = synth.camera_params()
+    p0.iterations = 200
+    p1 = _abi.copy_params(p0)
+    p1.forward_est_only = 0
+    both = 0
+    for a, b in zip(A, B):
+        r0, r1 = oracle.estimate_transform(p0, a, b), oracle.estimate_transform(p1, a, b)
+        assert r1["matches_pass1"] == r0["matches_pass1"]
+        assert r1["inliers_pass1"] >= r0["inliers_pass1"]
+        if r0["success"] and r1["success"]:
+            both += 1
+            assert np.linalg.norm(r0["position"] - r1["position"]) < 0.05
+    assert both >= 6
+    p2 = _abi.copy_params(p1)
+    p2.estimation_type = 1
+    with pytest.raises(RuntimeError):
+        oracle.estimate_transform(p2, A[0], B[0])
