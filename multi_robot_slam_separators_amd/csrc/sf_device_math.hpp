@@ -392,8 +392,9 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }
 
-// ---- Transform::to3DoF / inverse / interpolate(0.5) in their canonical forms (oracle/sf_oracle.c sfo_to3dof,
-// sfo_rigid_inverse, sfo_interpolate_half: the same operations in the same order, -ffp-contract=off on both sides).
+// ---- Transform::to3DoF / inverse / interpolate(0.5) [upstream rtabmap Transform.cpp] in canonical forms: fixed
+// operation order in double on the float entries, -ffp-contract=off, no trigonometric call (the
+// test suite's CPU restatement performs the same operations in the same order).
 // to3DoF: Transform(x, y, 0, 0, 0, yaw), yaw = atan2(r21, r11) -> the rotation (r11, r21) / |(r11, r21)| about z.
 __device__ inline void to3dof_canon(float* T) {
   const double r11 = (double)T[0], r21 = (double)T[4];
