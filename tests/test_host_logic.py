@@ -209,3 +209,20 @@ def test_multi_rank_exchange_gloo(tmp_path, world):
         outs.append(o.decode())
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o[-3000:]
+
+
+def test_ros_shims_use_only_the_declared_abi():
+    """ros/ is not compiled here (no ROS in the image): at least every sf_* name the shim sources use must be declared
+    in the drop-in header, and the services they advertise must be the reference's."""
+    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
+    declared = set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\}\s*(sf_[a-z0-9_]+);", hdr))
+    declared |= {"sf_handle"}
+    src = open(os.path.join(ROOT, "ros", "src", "sepfinder_geometric_tools_node.cpp")).read()
+    used = set(re.findall(r"\b(sf_[a-z0-9_]+)\b", src)) - {"sf_"}
+    assert used and used <= declared, sorted(used - declared)
+    for service in ("get_features_and_descriptor", "estimate_transformation"):
+        assert '"%s"' % service in src
+    py = open(os.path.join(ROOT, "ros", "scripts", "sepfinder_find_matches.py")).read()
+    for service in ("find_matches_compute", "receive_separators_py"):
+        assert '"%s"' % service in py
+    assert "NOT COMPILED" in src and "NOT RUN" in py and "NOT COMPILED HERE" in open(os.path.join(ROOT, "ros", "README.md")).read()
