@@ -189,7 +189,28 @@ def measure_next_rows(dev):
         t3 = time.perf_counter()
         d0, p0, k0 = pyoracle.extract_keyframe(left, kp0, np.ascontiguousarray(xy0[:, 0]), st0, cam, tests)
         t4 = time.perf_counter()
+        # a batch of 64 keyframes in one launch sequence (counts on the device, no host wait between the stages)
+        nb = 64
+        stride = ((h * w + 255) // 256) * 256
+        Lb = torch.zeros((nb, stride), dtype=torch.uint8, device=dev)
+        Rb = torch.zeros((nb, stride), dtype=torch.uint8, device=dev)
+        for i in range(nb):
+            li, ri, _ = ec.make_stereo_pair(100 + i % 8, pad=0)
+            Lb[i, : h * w] = torch.from_numpy(np.ascontiguousarray(li).reshape(-1)).to(dev)
+            Rb[i, : h * w] = torch.from_numpy(np.ascontiguousarray(ri).reshape(-1)).to(dev)
+        d_rows = torch.zeros(nb, dtype=torch.int32, device=dev)
+        batch_ms = None
+        for rep in range(4):
+            g.store_clear()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            g.get_features_and_descriptor_batch_device(Lb.data_ptr(), Rb.data_ptr(), nb, w, h, w, stride, cam, None, None,
+                                                       d_rows.data_ptr())
+            torch.cuda.synchronize()
+            if rep:
+                batch_ms = min(batch_ms or 1e9, (time.perf_counter() - t5) / nb * 1e3)
         out["keyframe_features"] = {
+            "ms_per_keyframe_in_a_batch_of_64": batch_ms, "batch_features_kept_mean": float(d_rows.float().mean().item()),
             "what": "752 x 480 stereo pair -> 1000 corners (goodFeaturesToTrack) -> pyramidal LK -> BRIEF-32 + stereo 3D, "
                     "written into the device-resident store; synchronous calls, pixels resident in HBM",
             "ms_per_keyframe": gpu_ms, "features_kept": int(rows), "rows_equal_cpu_restatement": bool(rows == len(d0)),

@@ -51,7 +51,7 @@ extern "C" {
       indexed compactions moved to sf_experimental.h.  A binding checks sf_abi_version() against the header it was
       written for (multi_robot_slam_separators_amd/lib.py does).                                                   */
 /* 3: sf_params grew force_3dof / forward_est_only (appended), sf_nn_row_minima_device, sf_allgather_bytes_device,
-      sf_netvlad_infer_batch_device added.                                                                          */
+      sf_netvlad_infer_batch_device, sf_get_features_and_descriptor_batch_device added.                                                                          */
 #define SF_ABI_VERSION 3
 
 /* ---- status codes ---------------------------------------------------------------------- */
@@ -372,6 +372,21 @@ int  sf_get_features_and_descriptor(sf_handle h, const uint8_t* left, const uint
                                     int32_t pitch, const sf_stereo_camera* cam, const sf_detector_params* det,
                                     const sf_stereo_flow_params* flow, uint8_t* desc_out, float* xyz_out,
                                     sf_keypoint* kpts_out, int32_t cap_rows, int32_t* rows_out, int32_t* slot_out);
+
+/* A batch of keyframes: n_keyframes rectified MONO8 pairs of one size already in DEVICE memory
+   (pair i at d_left / d_right + i * image_stride bytes), through the same three stages as sf_get_features_and_descriptor
+   in ONE launch sequence -- every stage runs once over the whole batch, the corner counts stay in device memory between
+   the stages, and the host is never waited for (asynchronous on the handle's stream).  The keyframes land in the store
+   slots *first_slot_out .. + n_keyframes - 1; per keyframe the results are the single call's, byte for byte.  Optional
+   device outputs, each sized for n_keyframes x det->max_features rows (keyframe i at row i * max_features; any may be
+   NULL): d_rows_out [n_keyframes] features kept, d_desc_out, d_xyz_out, d_kpts_out as in the single call.  Images up to
+   about 1.2 Mpixel (the corner selection keeps its bitmap in LDS).                                                 */
+int  sf_get_features_and_descriptor_batch_device(sf_handle h, const uint8_t* d_left, const uint8_t* d_right,
+                                                 int32_t n_keyframes, int32_t width, int32_t height, int32_t pitch,
+                                                 size_t image_stride, const sf_stereo_camera* cam,
+                                                 const sf_detector_params* det, const sf_stereo_flow_params* flow,
+                                                 int32_t* first_slot_out, int32_t* d_rows_out, uint8_t* d_desc_out,
+                                                 float* d_xyz_out, sf_keypoint* d_kpts_out);
 
 /* ---- geometric verification (stereoCamGeometricTools.cpp:122-178) ---------------------------- */
 /* One estimate_transformation service call on host buffers.                                  */

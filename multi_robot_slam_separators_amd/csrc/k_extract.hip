@@ -35,10 +35,21 @@ constexpr int BRIEF_PATCH = 48;
 constexpr int BRIEF_KERNEL = 9;
 constexpr int BRIEF_BORDER = BRIEF_PATCH / 2 + BRIEF_KERNEL / 2;   // KeyPointsFilter::runByImageBorder margin
 
+// A batch of keyframes in one launch sequence (blockIdx.y = image, except k_extract_commit: blockIdx.x): images
+// img_stride bytes apart, integral images s_stride entries apart, per-corner arrays per_image entries apart, the corner
+// count of every image in d_n (device; null = the scalar n of the single-image call).
+struct ExtractBatch {
+  size_t img_stride, s_stride;
+  int per_image;
+  const int32_t* d_n;
+};
+
 // S is (h + 1) x (w + 1); this pass leaves ROW prefix sums in rows 1..h and zeroes row 0 / column 0.
 __global__ void __launch_bounds__(256)
-k_integral_rows(const uint8_t* __restrict__ img, int w, int h, int pitch, int32_t* __restrict__ S) {
+k_integral_rows(const uint8_t* __restrict__ img, int w, int h, int pitch, int32_t* __restrict__ S, ExtractBatch B) {
   __shared__ int wave_sum[4];
+  img += blockIdx.y * B.img_stride;
+  S += blockIdx.y * B.s_stride;
   const int y = blockIdx.x;          // 0..h: row y of S
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int32_t* row = S + (size_t)y * (w + 1);
@@ -75,9 +86,10 @@ k_integral_rows(const uint8_t* __restrict__ img, int w, int h, int pitch, int32_
 // One thread per column; the rows are taken 16 at a time so that 16 loads are in flight per dependent step (a
 // load-add-store per row was ~480 serial L2 round trips: 120 of the call's 154 us at 752 x 480).
 __global__ void __launch_bounds__(64)
-k_integral_cols(int w, int h, int32_t* __restrict__ S) {
+k_integral_cols(int w, int h, int32_t* __restrict__ S, ExtractBatch B) {
   const int x = blockIdx.x * 64 + threadIdx.x;   // column 1..w of S
   if (x < 1 || x > w) return;
+  S += blockIdx.y * B.s_stride;
   const size_t pitch = (size_t)(w + 1);
   int32_t run = 0;
   int y = 1;
@@ -117,10 +129,19 @@ __global__ void __launch_bounds__(256)
 k_extract_points(const int32_t* __restrict__ S, int w, int h, const sf_keypoint* __restrict__ kpts,
                  const float* __restrict__ right_x, const uint8_t* __restrict__ status, int n, int bytes,
                  const int8_t* __restrict__ tests, ExtractCam cam, uint8_t* __restrict__ desc_tmp,
-                 float* __restrict__ xyz_tmp, uint8_t* __restrict__ keep) {
+                 float* __restrict__ xyz_tmp, uint8_t* __restrict__ keep, ExtractBatch B) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   const int i = g / bytes, b = g - i * bytes;
+  if (B.d_n) n = min(n, B.d_n[blockIdx.y]);
   if (i >= n) return;
+  {
+    const size_t o = (size_t)blockIdx.y * B.per_image;
+    S += blockIdx.y * B.s_stride;
+    kpts += o;
+    if (right_x) right_x += o;
+    if (status) status += o;
+    desc_tmp += o * bytes; xyz_tmp += 3 * o; keep += o;
+  }
   const sf_keypoint k = kpts[i];
   const bool inside = k.x >= (float)BRIEF_BORDER && k.x < (float)(w - BRIEF_BORDER) && k.y >= (float)BRIEF_BORDER &&
                       k.y < (float)(h - BRIEF_BORDER);
@@ -166,9 +187,20 @@ k_extract_commit(const sf_keypoint* __restrict__ kpts, const uint8_t* __restrict
                  const float* __restrict__ xyz_tmp, const uint8_t* __restrict__ keep, int n, int bytes, int has3d,
                  uint32_t* __restrict__ st_desc, float* __restrict__ st_xyz, float4* __restrict__ st_kp,
                  int4* __restrict__ st_meta, int kcap, int w_dwords, int slot, uint8_t* __restrict__ desc_out,
-                 float* __restrict__ xyz_out, sf_keypoint* __restrict__ kp_out, int32_t* __restrict__ rows_out) {
+                 float* __restrict__ xyz_out, sf_keypoint* __restrict__ kp_out, int32_t* __restrict__ rows_out,
+                 ExtractBatch B) {
   __shared__ int wave_cnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (B.d_n) n = min(n, B.d_n[blockIdx.x]);
+  {
+    const size_t o = (size_t)blockIdx.x * B.per_image;
+    slot += blockIdx.x;
+    kpts += o; desc_tmp += o * bytes; xyz_tmp += 3 * o; keep += o;
+    if (desc_out) desc_out += o * bytes;
+    if (xyz_out) xyz_out += 3 * o;
+    if (kp_out) kp_out += o;
+    if (rows_out) rows_out += blockIdx.x;
+  }
   uint8_t* d8 = reinterpret_cast<uint8_t*>(st_desc + (size_t)slot * kcap * w_dwords);
   float* dx = st_xyz + (size_t)slot * kcap * 3;
   float4* dk = st_kp + (size_t)slot * kcap;
@@ -231,20 +263,26 @@ void sf_brief_default_pattern(int8_t* tests, int bytes) {
 }
 
 // Launch sequence on the handle's stream; the store slot (kcap >= n, w dwords) has been reserved by the caller.
-int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int height, int pitch, const sf_keypoint* d_kpts,
-                      const float* d_right_x, const uint8_t* d_status, int n, const sf_stereo_camera* cam, int bytes,
-                      const int8_t* d_tests, uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap,
-                      int w_dwords, int slot, uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out,
-                      int32_t* d_rows_out) {
+// n_img > 1: a batch -- image i at d_left + i * img_stride, its corners / right_x / status / optional copies at + i * n
+// entries, its corner count in d_n[i] (device; `n` is then the per-image capacity), its store slot = slot + i.
+int sf_launch_extract_batch(sf_context* c, const uint8_t* d_left, size_t img_stride, int n_img, int width, int height,
+                            int pitch, const sf_keypoint* d_kpts, const float* d_right_x, const uint8_t* d_status, int n,
+                            const int32_t* d_n, const sf_stereo_camera* cam, int bytes, const int8_t* d_tests,
+                            uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap, int w_dwords,
+                            int slot, uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out,
+                            int32_t* d_rows_out) {
   int rc;
-  const size_t s_bytes = (size_t)(width + 1) * (height + 1) * sizeof(int32_t);
-  if ((rc = sf_buf_reserve(c, c->ex_integral, s_bytes)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->ex_desc, (size_t)std::max(n, 1) * bytes)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->ex_xyz, (size_t)std::max(n, 1) * 12)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->ex_keep, (size_t)std::max(n, 1))) != SF_OK) return rc;
+  const size_t s_entries = (size_t)(width + 1) * (height + 1);
+  const size_t rows_all = (size_t)std::max(n, 1) * n_img;
+  if ((rc = sf_buf_reserve(c, c->ex_integral, s_entries * sizeof(int32_t) * n_img)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ex_desc, rows_all * bytes)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ex_xyz, rows_all * 12)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ex_keep, rows_all)) != SF_OK) return rc;
   int32_t* S = (int32_t*)c->ex_integral.p;
-  hipLaunchKernelGGL(k_integral_rows, dim3(height + 1), dim3(256), 0, c->stream, d_left, width, height, pitch, S);
-  hipLaunchKernelGGL(k_integral_cols, dim3((width + 1 + 63) / 64), dim3(64), 0, c->stream, width, height, S);
+  ExtractBatch B;
+  B.img_stride = img_stride; B.s_stride = s_entries; B.per_image = n; B.d_n = d_n;
+  hipLaunchKernelGGL(k_integral_rows, dim3(height + 1, n_img), dim3(256), 0, c->stream, d_left, width, height, pitch, S, B);
+  hipLaunchKernelGGL(k_integral_cols, dim3((width + 1 + 63) / 64, n_img), dim3(64), 0, c->stream, width, height, S, B);
   ExtractCam ec;
   ec.fx = cam->fx; ec.fy = cam->fy; ec.cx = cam->cx; ec.cy = cam->cy; ec.cx_right = cam->cx_right;
   ec.baseline = cam->baseline; ec.min_depth = cam->min_depth; ec.max_depth = cam->max_depth;
@@ -256,13 +294,23 @@ int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int heigh
   ec.filter = cam->min_depth > 0.0f || cam->max_depth > 0.0f;
   if (n > 0) {
     const long long threads = (long long)n * bytes;
-    hipLaunchKernelGGL(k_extract_points, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, S, width,
+    hipLaunchKernelGGL(k_extract_points, dim3((unsigned)((threads + 255) / 256), n_img), dim3(256), 0, c->stream, S, width,
                        height, d_kpts, d_right_x, d_status, n, bytes, d_tests, ec, (uint8_t*)c->ex_desc.p,
-                       (float*)c->ex_xyz.p, (uint8_t*)c->ex_keep.p);
+                       (float*)c->ex_xyz.p, (uint8_t*)c->ex_keep.p, B);
   }
-  hipLaunchKernelGGL(k_extract_commit, dim3(1), dim3(256), 0, c->stream, d_kpts, (const uint8_t*)c->ex_desc.p,
+  hipLaunchKernelGGL(k_extract_commit, dim3(n_img), dim3(256), 0, c->stream, d_kpts, (const uint8_t*)c->ex_desc.p,
                      (const float*)c->ex_xyz.p, (const uint8_t*)c->ex_keep.p, n, bytes, d_right_x != nullptr, st_desc,
-                     st_xyz, st_kp, st_meta, kcap, w_dwords, slot, d_desc_out, d_xyz_out, d_kpts_out, d_rows_out);
+                     st_xyz, st_kp, st_meta, kcap, w_dwords, slot, d_desc_out, d_xyz_out, d_kpts_out, d_rows_out, B);
   SF_HIP(c, hipGetLastError());
   return SF_OK;
+}
+
+int sf_launch_extract(sf_context* c, const uint8_t* d_left, int width, int height, int pitch, const sf_keypoint* d_kpts,
+                      const float* d_right_x, const uint8_t* d_status, int n, const sf_stereo_camera* cam, int bytes,
+                      const int8_t* d_tests, uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap,
+                      int w_dwords, int slot, uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out,
+                      int32_t* d_rows_out) {
+  return sf_launch_extract_batch(c, d_left, 0, 1, width, height, pitch, d_kpts, d_right_x, d_status, n, nullptr, cam, bytes,
+                                 d_tests, st_desc, st_xyz, st_kp, st_meta, kcap, w_dwords, slot, d_desc_out, d_xyz_out,
+                                 d_kpts_out, d_rows_out);
 }

@@ -39,9 +39,12 @@ __device__ __forceinline__ int refl101(int i, int n) {
 
 __global__ void __launch_bounds__(256)
 k_gftt_products(const uint8_t* __restrict__ img, int w, int h, int pitch, float s1, float s2, float* __restrict__ dxx,
-                float* __restrict__ dxy, float* __restrict__ dyy) {
+                float* __restrict__ dxy, float* __restrict__ dyy, size_t img_stride, size_t plane_stride) {
+  // (blockIdx.z = image of a batch: images img_stride bytes apart, every image's planes plane_stride floats apart)
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
+  img += blockIdx.z * img_stride;
+  dxx += blockIdx.z * plane_stride; dxy += blockIdx.z * plane_stride; dyy += blockIdx.z * plane_stride;
   const int xm = refl101(x - 1, w), xp = refl101(x + 1, w);
   const uint8_t* ru = img + (size_t)refl101(y - 1, h) * pitch;
   const uint8_t* r0 = img + (size_t)y * pitch;
@@ -64,8 +67,11 @@ __device__ __forceinline__ float box3(const float* __restrict__ p, int w, int yu
 
 __global__ void __launch_bounds__(256)
 k_gftt_eig(const float* __restrict__ dxx, const float* __restrict__ dxy, const float* __restrict__ dyy, int w, int h,
-           float* __restrict__ eig, int* __restrict__ max_bits) {
+           float* __restrict__ eig, int* __restrict__ max_bits, size_t plane_stride) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  dxx += blockIdx.z * plane_stride; dxy += blockIdx.z * plane_stride; dyy += blockIdx.z * plane_stride;
+  eig += blockIdx.z * plane_stride;
+  max_bits += blockIdx.z;
   float e = 0.f;
   if (x < w && y < h) {
     const int xm = refl101(x - 1, w), xp = refl101(x + 1, w), yu = refl101(y - 1, h), yd = refl101(y + 1, h);
@@ -91,7 +97,11 @@ k_gftt_eig(const float* __restrict__ dxx, const float* __restrict__ dxy, const f
 constexpr int GFTT_CAND_TILES = 4;      // 64 x 4 pixel tiles per workgroup of k_gftt_candidates
 __global__ void __launch_bounds__(256)
 k_gftt_candidates(const float* __restrict__ eig, int w, int h, const int* __restrict__ max_bits, double quality,
-                  unsigned long long* __restrict__ keys, unsigned* __restrict__ count, unsigned cap) {
+                  unsigned long long* __restrict__ keys, unsigned* __restrict__ count, unsigned cap, size_t plane_stride) {
+  eig += blockIdx.z * plane_stride;
+  max_bits += blockIdx.z;
+  keys += (size_t)blockIdx.z * cap;
+  count += blockIdx.z;
   // (the counter is ONE address: a returning atomic per 64 x 4 tile was most of this kernel's 20 us -- four tiles
   // per workgroup share one)
   __shared__ unsigned long long s_keys[256 * GFTT_CAND_TILES];
@@ -192,8 +202,15 @@ k_gftt_select(const unsigned long long* __restrict__ keys, int n, int w, int cel
 constexpr int GFTT_MAX_RADIUS = 64;
 __global__ void __launch_bounds__(256)
 k_gftt_select_lds(const unsigned long long* __restrict__ keys, int n, int w, int h, int wpr, float md2, int radius,
-                  int max_corners, sf_keypoint* __restrict__ kp_out, int cap, int32_t* __restrict__ n_out) {
+                  int max_corners, sf_keypoint* __restrict__ kp_out, int cap, int32_t* __restrict__ n_out,
+                  const unsigned* __restrict__ d_count = nullptr, unsigned key_cap = 0) {
   extern __shared__ unsigned gf_bm[];
+  if (d_count) {     // batch: one workgroup per image, the candidate count read on the device
+    keys += (size_t)blockIdx.x * key_cap;
+    n = (int)min(d_count[blockIdx.x], key_cap);
+    kp_out += (size_t)blockIdx.x * cap;
+    n_out += blockIdx.x;
+  }
   __shared__ int span[2 * GFTT_MAX_RADIUS + 1];
   for (int i = threadIdx.x; i < wpr * h; i += 256) gf_bm[i] = 0u;
   if ((int)threadIdx.x <= 2 * radius) {
@@ -298,12 +315,12 @@ int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, i
   const double scale = 1.0 / ((double)(1 << 2) * 3.0 * 255.0);
   const dim3 grid((width + 63) / 64, (height + 3) / 4), block(256);
   hipLaunchKernelGGL(k_gftt_products, grid, block, 0, c->stream, d_image, width, height, pitch, (float)(1.0 * scale),
-                     (float)(2.0 * scale), dxx, dxy, dyy);
+                     (float)(2.0 * scale), dxx, dxy, dyy, (size_t)0, (size_t)0);
   hipLaunchKernelGGL(k_gftt_eig, grid, block, 0, c->stream, (const float*)dxx, (const float*)dxy, (const float*)dyy, width,
-                     height, eig, max_bits);
+                     height, eig, max_bits, (size_t)0);
   const dim3 grid_c((width + 63) / 64, (height + 4 * GFTT_CAND_TILES - 1) / (4 * GFTT_CAND_TILES));
   hipLaunchKernelGGL(k_gftt_candidates, grid_c, block, 0, c->stream, (const float*)eig, width, height, (const int*)max_bits,
-                     quality_level, keys, count, key_cap);
+                     quality_level, keys, count, key_cap, (size_t)0);
   SF_HIP(c, hipGetLastError());
   unsigned h_count = 0;
   SF_HIP(c, hipMemcpyAsync(&h_count, count, 4, hipMemcpyDeviceToHost, c->stream));
@@ -344,5 +361,73 @@ int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, i
     SF_HIP(c, hipMemcpyAsync(n_out, d_n_out, 4, hipMemcpyDeviceToHost, c->stream));
     SF_HIP(c, hipStreamSynchronize(c->stream));
   }
+  return SF_OK;
+}
+
+
+namespace {
+__global__ void k_gftt_segments(const unsigned* __restrict__ count, unsigned key_cap, int n, unsigned* __restrict__ begin,
+                                unsigned* __restrict__ end) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { begin[i] = (unsigned)i * key_cap; end[i] = (unsigned)i * key_cap + min(count[i], key_cap); }
+}
+}  // namespace
+
+// The detector on a batch of images of one size, no host round trip: candidate counts stay on the device (a segmented
+// sort takes the place of the sort sized by the host), one selection workgroup per image.  d_kpts_out [n_img][cap],
+// d_n_out [n_img] (device).  Needs the LDS bitmap form of the selection (images up to about 1.2 Mpixel).
+int sf_launch_detect_corners_batch(sf_context* c, const uint8_t* d_images, size_t img_stride, int n_img, int width, int height,
+                                   int pitch, int max_corners, double quality_level, double min_distance,
+                                   sf_keypoint* d_kpts_out, int cap, int32_t* d_n_out) {
+  const size_t np = (size_t)width * height;
+  const int wpr = (width + 31) / 32;
+  const size_t bm_bytes = (size_t)wpr * height * sizeof(unsigned);
+  const int radius = min_distance >= 1.0 ? (int)std::ceil(min_distance) : 0;
+  if (bm_bytes > 150 * 1024 || radius > GFTT_MAX_RADIUS)
+    return sf_fail(c, SF_ERANGE, "batched corner detection: %d x %d image does not fit the LDS selection bitmap", width, height);
+  if (np * (size_t)n_img > 0xFFFFFFFFull) return sf_fail(c, SF_ERANGE, "batched corner detection: %d images of %zu pixels", n_img, np);
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->gf_planes, np * 4 * sizeof(float) * n_img)) != SF_OK) return rc;
+  const unsigned key_cap = (unsigned)np;
+  if ((rc = sf_buf_reserve(c, c->gf_keys, (size_t)key_cap * 2 * sizeof(unsigned long long) * n_img)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->gf_scalar, 64 + (size_t)n_img * 16)) != SF_OK) return rc;
+  float* dxx = (float*)c->gf_planes.p;                    // image i: planes at + i * 4 np (dxx, dxy, dyy, eig)
+  float* dxy = dxx + np;
+  float* dyy = dxy + np;
+  float* eig = dyy + np;
+  const size_t plane_stride = 4 * np;
+  unsigned long long* keys = (unsigned long long*)c->gf_keys.p;
+  unsigned long long* keys_sorted = keys + (size_t)key_cap * n_img;
+  int* max_bits = (int*)((char*)c->gf_scalar.p + 64);
+  unsigned* count = (unsigned*)(max_bits + n_img);
+  unsigned* seg_begin = count + n_img;
+  unsigned* seg_end = seg_begin + n_img;
+  SF_HIP(c, hipMemsetAsync(max_bits, 0, (size_t)n_img * 8, c->stream));
+  const double scale = 1.0 / ((double)(1 << 2) * 3.0 * 255.0);
+  const dim3 grid((width + 63) / 64, (height + 3) / 4, n_img), block(256);
+  hipLaunchKernelGGL(k_gftt_products, grid, block, 0, c->stream, d_images, width, height, pitch, (float)(1.0 * scale),
+                     (float)(2.0 * scale), dxx, dxy, dyy, img_stride, plane_stride);
+  hipLaunchKernelGGL(k_gftt_eig, grid, block, 0, c->stream, (const float*)dxx, (const float*)dxy, (const float*)dyy, width,
+                     height, eig, max_bits, plane_stride);
+  const dim3 grid_c((width + 63) / 64, (height + 4 * GFTT_CAND_TILES - 1) / (4 * GFTT_CAND_TILES), n_img);
+  hipLaunchKernelGGL(k_gftt_candidates, grid_c, block, 0, c->stream, (const float*)eig, width, height, (const int*)max_bits,
+                     quality_level, keys, count, key_cap, plane_stride);
+  hipLaunchKernelGGL(k_gftt_segments, dim3((n_img + 63) / 64), dim3(64), 0, c->stream, (const unsigned*)count, key_cap, n_img,
+                     seg_begin, seg_end);
+  SF_HIP(c, hipGetLastError());
+  size_t tmp_bytes = 0;
+  SF_HIP(c, rocprim::segmented_radix_sort_keys_desc(nullptr, tmp_bytes, keys, keys_sorted, (unsigned)((size_t)key_cap * n_img),
+                                                    (unsigned)n_img, seg_begin, seg_end, 0, 64, c->stream));
+  if ((rc = sf_buf_reserve(c, c->gf_tmp, std::max<size_t>(tmp_bytes, 16))) != SF_OK) return rc;
+  SF_HIP(c, rocprim::segmented_radix_sort_keys_desc(c->gf_tmp.p, tmp_bytes, keys, keys_sorted, (unsigned)((size_t)key_cap * n_img),
+                                                    (unsigned)n_img, seg_begin, seg_end, 0, 64, c->stream));
+  if (!c->gf_select_attr) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_gftt_select_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    c->gf_select_attr = true;
+  }
+  hipLaunchKernelGGL(k_gftt_select_lds, dim3(n_img), dim3(256), bm_bytes, c->stream, (const unsigned long long*)keys_sorted, 0,
+                     width, height, wpr, (float)(min_distance * min_distance), radius, max_corners, d_kpts_out, cap, d_n_out,
+                     (const unsigned*)count, key_cap);
+  SF_HIP(c, hipGetLastError());
   return SF_OK;
 }

@@ -38,6 +38,9 @@ struct LkLevel {
 struct LkLevels {
   LkLevel v[LK_MAX_LEVELS];
   int n;
+  int per_image;                  // batch (blockIdx.y = image): corners / outputs of consecutive images this many apart
+  size_t stride0, stride_pyr;     // bytes between consecutive images at level 0 / between their pyramid blocks
+  const int32_t* d_n;             // batch: corners of every image (device); null: the scalar n
 };
 
 __device__ __forceinline__ int border_101(int p, int len) {       // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
@@ -51,11 +54,13 @@ __device__ __forceinline__ int border_101(int p, int len) {       // cv::borderI
 
 __global__ __launch_bounds__(256) void k_lk_pyr_down(const uint8_t* __restrict__ src_l, const uint8_t* __restrict__ src_r,
                                                      int w, int h, int pitch, uint8_t* __restrict__ dst_l,
-                                                     uint8_t* __restrict__ dst_r, int dw, int dh) {
+                                                     uint8_t* __restrict__ dst_r, int dw, int dh, size_t src_stride,
+                                                     size_t dst_stride) {
+  // blockIdx.z = 2 * image + (0: left, 1: right)
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
-  const uint8_t* src = blockIdx.z ? src_r : src_l;
-  uint8_t* dst = blockIdx.z ? dst_r : dst_l;
+  const uint8_t* src = ((blockIdx.z & 1) ? src_r : src_l) + (blockIdx.z >> 1) * src_stride;
+  uint8_t* dst = ((blockIdx.z & 1) ? dst_r : dst_l) + (blockIdx.z >> 1) * dst_stride;
   int cx[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) cx[i] = border_101(2 * x + i - 2, w);
@@ -106,7 +111,15 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
                                                  float* __restrict__ rx_out, float* __restrict__ err_out) {
   extern __shared__ unsigned char lk_smem[];
   const int p = blockIdx.x;
+  const int img = blockIdx.y;
+  if (P.d_n) n = min(n, P.d_n[img]);
   if (p >= n) return;
+  {
+    const size_t o = (size_t)img * P.per_image;
+    kp += o; xy_out += 2 * o; st_out += o;
+    if (rx_out) rx_out += o;
+    if (err_out) err_out += o;
+  }
   const int lane = threadIdx.x;
   const int pw = ww + 3, ph = wh + 3;          // patch of the first image: window + bilinear tap + derivative ring
   const int dw = ww + 1, dh = wh + 1;          // positions the bilinear taps touch
@@ -131,7 +144,11 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
   int st = 1;
   float er = 0.0f, nx = 0.0f, ny = 0.0f;
   for (int level = max_level; level >= 0; --level) {
-    const LkLevel L = P.v[level];
+    LkLevel L = P.v[level];
+    {
+      const size_t o = (size_t)img * (level == 0 ? P.stride0 : P.stride_pyr);
+      L.l += o; L.r += o;
+    }
     const float sc = (float)(1. / (double)(1 << level));
     float px = kx * sc, py = ky * sc;
     float qx, qy;
@@ -276,9 +293,12 @@ __global__ __launch_bounds__(64) void k_lk_track(const LkLevels P, const sf_keyp
 
 }  // namespace
 
-int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d_right, int width, int height, int pitch,
-                          const sf_keypoint* d_kpts, int n, const sf_stereo_flow_params* prm, float* d_right_xy,
-                          uint8_t* d_status, float* d_right_x, float* d_err) {
+// n_img > 1: a batch -- image i at d_left / d_right + i * img_stride, its corners / outputs at + i * n entries, its corner
+// count in d_n[i] (device; `n` is then the per-image capacity the grid is sized for).
+int sf_launch_stereo_flow_batch(sf_context* c, const uint8_t* d_left, const uint8_t* d_right, size_t img_stride, int n_img,
+                                int width, int height, int pitch, const sf_keypoint* d_kpts, int n, const int32_t* d_n,
+                                const sf_stereo_flow_params* prm, float* d_right_xy, uint8_t* d_status, float* d_right_x,
+                                float* d_err) {
   const int ww = prm->win_width, wh = prm->win_height;
   // buildOpticalFlowPyramid: the level whose successor would be <= winSize in either direction is the last
   int lw[LK_MAX_LEVELS], lh[LK_MAX_LEVELS];
@@ -297,20 +317,25 @@ int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d
     }
   }
   int rc;
-  if ((rc = sf_buf_reserve(c, c->lk_pyr, std::max<size_t>(2 * bytes, 16))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->lk_pyr, std::max<size_t>(2 * bytes * n_img, 16))) != SF_OK) return rc;
   uint8_t* base_l = (uint8_t*)c->lk_pyr.p;
-  uint8_t* base_r = base_l + bytes;
+  uint8_t* base_r = base_l + bytes * n_img;
   LkLevels P;
   P.n = nl;
+  P.per_image = n;
+  P.stride0 = img_stride;
+  P.stride_pyr = bytes;
+  P.d_n = d_n;
   for (int l = 0; l < nl; ++l) {
     P.v[l].l = l == 0 ? d_left : base_l + off[l];
     P.v[l].r = l == 0 ? d_right : base_r + off[l];
     P.v[l].w = lw[l]; P.v[l].h = lh[l]; P.v[l].pitch = l == 0 ? pitch : lw[l]; P.v[l].pad_ = 0;
   }
   for (int l = 1; l < nl; ++l) {
-    const dim3 grid((lw[l] + 63) / 64, (lh[l] + 3) / 4, 2);
+    const dim3 grid((lw[l] + 63) / 64, (lh[l] + 3) / 4, 2 * n_img);
     hipLaunchKernelGGL(k_lk_pyr_down, grid, dim3(256), 0, c->stream, P.v[l - 1].l, P.v[l - 1].r, lw[l - 1], lh[l - 1],
-                       P.v[l - 1].pitch, (uint8_t*)P.v[l].l, (uint8_t*)P.v[l].r, lw[l], lh[l]);
+                       P.v[l - 1].pitch, (uint8_t*)P.v[l].l, (uint8_t*)P.v[l].r, lw[l], lh[l],
+                       l == 1 ? img_stride : bytes, bytes);
   }
   const int max_count = std::min(std::max(prm->iterations, 0), 100);
   double eps = std::min(std::max(prm->epsilon, 0.0), 10.0);
@@ -320,11 +345,18 @@ int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d
                       (((size_t)(ww + 3) * (wh + 3) + 3) & ~(size_t)3) +
                       (size_t)(ww + 1 + 2 * LK_REGION_X) * (wh + 1 + 2 * LK_REGION_Y);
   if (area <= 64)
-    hipLaunchKernelGGL(k_lk_track<true>, dim3(n), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
+    hipLaunchKernelGGL(k_lk_track<true>, dim3(n, n_img), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
                        prm->min_eig_threshold, prm->min_disparity, prm->max_disparity, d_right_xy, d_status, d_right_x, d_err);
   else
-    hipLaunchKernelGGL(k_lk_track<false>, dim3(n), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
+    hipLaunchKernelGGL(k_lk_track<false>, dim3(n, n_img), dim3(64), smem, c->stream, P, d_kpts, n, ww, wh, max_count, eps,
                        prm->min_eig_threshold, prm->min_disparity, prm->max_disparity, d_right_xy, d_status, d_right_x, d_err);
   SF_HIP(c, hipGetLastError());
   return SF_OK;
+}
+
+int sf_launch_stereo_flow(sf_context* c, const uint8_t* d_left, const uint8_t* d_right, int width, int height, int pitch,
+                          const sf_keypoint* d_kpts, int n, const sf_stereo_flow_params* prm, float* d_right_xy,
+                          uint8_t* d_status, float* d_right_x, float* d_err) {
+  return sf_launch_stereo_flow_batch(c, d_left, d_right, 0, 1, width, height, pitch, d_kpts, n, nullptr, prm, d_right_xy,
+                                     d_status, d_right_x, d_err);
 }

@@ -1051,6 +1051,63 @@ extern "C" int sf_get_features_and_descriptor(sf_handle c, const uint8_t* left, 
   return SF_OK;
 }
 
+// n keyframes from device images to n store slots in ONE launch sequence: detector, stereo correspondence and
+// extraction each run once over the batch (blockIdx = image), the corner counts stay in device memory between them, the
+// host never waits.  Same per-keyframe results as sf_get_features_and_descriptor.
+extern "C" int sf_get_features_and_descriptor_batch_device(sf_handle c, const uint8_t* d_left, const uint8_t* d_right,
+                                                           int32_t n_keyframes, int32_t width, int32_t height, int32_t pitch,
+                                                           size_t image_stride, const sf_stereo_camera* cam,
+                                                           const sf_detector_params* det, const sf_stereo_flow_params* flow,
+                                                           int32_t* first_slot_out, int32_t* d_rows_out, uint8_t* d_desc_out,
+                                                           float* d_xyz_out, sf_keypoint* d_kpts_out) {
+  if (!c || !cam || n_keyframes < 0) return SF_EINVAL;
+  if (n_keyframes == 0) { if (first_slot_out) *first_slot_out = c->store.slots; return SF_OK; }
+  if (!d_left || !d_right || width < 3 || height < 3 || pitch < width || image_stride < (size_t)pitch * height)
+    return sf_fail(c, SF_EINVAL, "stereo pairs missing or malformed (%d x %d, pitch %d, stride %zu)", width, height, pitch, image_stride);
+  sf_detector_params dp;
+  if (det) dp = *det; else sf_detector_defaults(&dp);
+  if (dp.max_features <= 0 || dp.max_features > SF_MAX_FEATURES)
+    return sf_fail(c, SF_ERANGE, "max_features %d outside 1 .. %d (KeyPointVec.size is an int16)", dp.max_features, SF_MAX_FEATURES);
+  if (!(dp.quality_level > 0.0) || !(dp.min_distance >= 0.0))
+    return sf_fail(c, SF_EINVAL, "qualityLevel must be > 0 and minDistance >= 0 (cv::goodFeaturesToTrack asserts the same)");
+  sf_stereo_flow_params prm;
+  if (flow) prm = *flow; else sf_stereo_flow_defaults(&prm);
+  if (prm.win_width <= 2 || prm.win_height <= 2 || (long long)prm.win_width * prm.win_height > 1024 || prm.max_level < 0 ||
+      prm.max_level > 15 || !(prm.epsilon == prm.epsilon))
+    return sf_fail(c, SF_EINVAL, "stereo flow parameters out of range (see sf_stereo_correspondences_device)");
+  if ((long long)(width + 1) * (height + 1) * 255 > 0x7FFFFFFFll) return sf_fail(c, SF_ERANGE, "image too large for a 32-bit integral image");
+  SF_HIP(c, hipSetDevice(c->device));
+  int rc = brief_ensure(c);
+  if (rc != SF_OK) return rc;
+  const int maxf = dp.max_features, n = n_keyframes;
+  const size_t rows_all = (size_t)maxf * n;
+  if ((rc = sf_buf_reserve(c, c->ft_kpts, rows_all * sizeof(sf_keypoint))) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ft_flow, rows_all * 16)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->ft_counts, (size_t)n * 4)) != SF_OK) return rc;
+  if ((rc = store_reserve(c, c->store, c->store.slots + n, maxf, c->brief_bytes)) != SF_OK) return rc;
+  sf_keypoint* d_kpts = (sf_keypoint*)c->ft_kpts.p;
+  int32_t* d_n = (int32_t*)c->ft_counts.p;
+  if ((rc = sf_launch_detect_corners_batch(c, d_left, image_stride, n, width, height, pitch, maxf, dp.quality_level,
+                                           dp.min_distance, d_kpts, maxf, d_n)) != SF_OK)
+    return rc;
+  float* d_xy = (float*)c->ft_flow.p;                    // [n][maxf][2], then x [n][maxf], then status [n][maxf]
+  float* d_rx = d_xy + 2 * rows_all;
+  uint8_t* d_status = (uint8_t*)(d_rx + rows_all);
+  if ((rc = sf_launch_stereo_flow_batch(c, d_left, d_right, image_stride, n, width, height, pitch, d_kpts, maxf, d_n, &prm,
+                                        d_xy, d_status, d_rx, nullptr)) != SF_OK)
+    return rc;
+  Store& st = c->store;
+  const int slot = st.slots;
+  if ((rc = sf_launch_extract_batch(c, d_left, image_stride, n, width, height, pitch, d_kpts, d_rx, d_status, maxf, d_n, cam,
+                                    c->brief_bytes, (const int8_t*)c->brief_tests.p, (uint32_t*)st.desc.p, (float*)st.xyz.p,
+                                    (float4*)st.kp.p, (int4*)st.meta.p, st.kcap, st.w, slot, d_desc_out, d_xyz_out,
+                                    d_kpts_out, d_rows_out)) != SF_OK)
+    return rc;
+  st.slots += n;
+  if (first_slot_out) *first_slot_out = slot;
+  return SF_OK;
+}
+
 extern "C" int sf_store_size(sf_handle c, int32_t* n_slots) {
   if (!c || !n_slots) return SF_EINVAL;
   *n_slots = c->store.slots;

@@ -174,6 +174,7 @@ struct sf_context {
   Buf corr1, corr2;             // uint32[n][kcap]
   Buf hdr1, hdr2;               // CorrHeader[n]
   Buf pass1, pass2;             // PassState[n]
+  Buf ft_counts;                // batched feature extraction: corners per image (device)
   Buf pass_back, dir_mask;      // Vis/ForwardEstOnly = false: the backward estimate's PassState[n], inlier masks [2][n][kcap]
   Buf list1, list3;             // int32[n] work lists (RANSAC pass 1, RANSAC pass 2)
   Buf counters;                 // int32[8]
@@ -369,6 +370,19 @@ size_t sf_ba_lds_bytes(int kcap);
 size_t sf_pnp_lds_bytes(int kcap, int iterations);
 size_t sf_guided_lds_bytes(int kcap, int n_cells);
 void sf_brief_default_pattern(int8_t* tests, int bytes);
+int sf_launch_detect_corners_batch(sf_context* c, const uint8_t* d_images, size_t img_stride, int n_img, int width, int height,
+                                   int pitch, int max_corners, double quality_level, double min_distance,
+                                   sf_keypoint* d_kpts_out, int cap, int32_t* d_n_out);
+int sf_launch_stereo_flow_batch(sf_context* c, const uint8_t* d_left, const uint8_t* d_right, size_t img_stride, int n_img,
+                                int width, int height, int pitch, const sf_keypoint* d_kpts, int n, const int32_t* d_n,
+                                const sf_stereo_flow_params* prm, float* d_right_xy, uint8_t* d_status, float* d_right_x,
+                                float* d_err);
+int sf_launch_extract_batch(sf_context* c, const uint8_t* d_left, size_t img_stride, int n_img, int width, int height,
+                            int pitch, const sf_keypoint* d_kpts, const float* d_right_x, const uint8_t* d_status, int n,
+                            const int32_t* d_n, const sf_stereo_camera* cam, int bytes, const int8_t* d_tests,
+                            uint32_t* st_desc, float* st_xyz, float4* st_kp, int4* st_meta, int kcap, int w_dwords,
+                            int slot, uint8_t* d_desc_out, float* d_xyz_out, sf_keypoint* d_kpts_out,
+                            int32_t* d_rows_out);
 int sf_launch_detect_corners(sf_context* c, const uint8_t* d_image, int width, int height, int pitch, int max_corners,
                              double quality_level, double min_distance, sf_keypoint* d_kpts_out, int cap,
                              int32_t* n_out);

@@ -124,6 +124,8 @@ def load():
         "sf_allgather_separators_device": (C.c_int, [vp, vp, vp, i32]),
         "sf_allgather_bytes_device": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "sf_nn_row_minima_device": (C.c_int, [vp, vp, vp, vp]),
+        "sf_get_features_and_descriptor_batch_device": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, C.c_size_t, vp, vp, vp,
+                                                                   P(i32), vp, vp, vp, vp]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_select": (C.c_int, [vp, C.c_uint32]),
         "sf_prof_reset": (C.c_int, [vp]),
@@ -155,7 +157,8 @@ EXPORTED = [
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
-    "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
+    "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device",
+    "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
 
@@ -392,6 +395,18 @@ class SeparatorFinder:
             C.byref(slot)))
         n = min(rows.value, cap)
         return desc[:n].copy(), xyz[:n].copy(), kp[:n].copy(), slot.value
+
+    def get_features_and_descriptor_batch_device(self, d_left, d_right, n_keyframes, width, height, pitch, image_stride,
+                                                 cam, det=None, flow=None, d_rows_out=None, d_desc_out=None,
+                                                 d_xyz_out=None, d_kpts_out=None):
+        """n keyframes from device images (raw pointers) to n store slots in one launch sequence, no host wait; optional
+        device outputs sized for n_keyframes x max_features rows.  Returns the first slot."""
+        first = C.c_int32()
+        self._check(self._L.sf_get_features_and_descriptor_batch_device(
+            self._h, C.c_void_p(d_left), C.c_void_p(d_right), n_keyframes, width, height, pitch, int(image_stride),
+            C.byref(cam), C.byref(det) if det is not None else None, C.byref(flow) if flow is not None else None,
+            C.byref(first), C.c_void_p(d_rows_out), C.c_void_p(d_desc_out), C.c_void_p(d_xyz_out), C.c_void_p(d_kpts_out)))
+        return first.value
 
     def extract_keyframe_device(self, d_left, width, height, pitch, d_kpts, d_right_x, d_status, n, cam,
                                 d_desc_out=None, d_xyz_out=None, d_kpts_out=None, want_rows=True):

@@ -215,3 +215,53 @@ def test_keyframes_from_pixels_verify_like_wire_features(finder):
     assert r_slots.tobytes() == r_wire.tobytes()
     assert r_slots["success"] and np.abs(r_slots["position"]).max() < 1e-3 and r_slots["inliers"] > 100
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape,n_kf,det", [((480, 752), 5, None), ((240, 320), 9, (300, 0.01, 5.0)), ((100, 140), 3, (2000, 0.001, 1.0))])
+def test_batched_keyframes_equal_the_single_calls(finder, shape, n_kf, det):
+    """sf_get_features_and_descriptor_batch_device: n stereo pairs in device memory -> n store slots in one launch
+    sequence with the corner counts left on the device; per keyframe the rows kept, descriptors, 3D points and
+    keypoints are the single call's byte for byte, and the store slots verify like the single call's."""
+    import torch
+    dev = torch.device("cuda:0")
+    tests = ec.brief_tests(6, 32)
+    finder.brief_set_pattern(tests)
+    det = _abi.detector_params(*det) if det else None
+    maxf = det.max_features if det else 1000
+    h, w = shape
+    cam = _abi.stereo_camera(460.0, 458.0, w / 2.0, h / 2.0, 0.11)
+    pairs = [ec.make_stereo_pair(600 + i, width=w, height=h, max_disp=min(40.0, w / 6))[:2] for i in range(n_kf)]
+    pairs[1] = (np.full((h, w), 90, np.uint8), np.full((h, w), 90, np.uint8))       # a keyframe without a single corner
+    singles = [finder.get_features_and_descriptor(l, r, cam, det) for l, r in pairs]
+    stride = ((h * w + 255) // 256) * 256 + 512                                      # images need not be back to back
+    L = torch.zeros((n_kf, stride), dtype=torch.uint8, device=dev)
+    R = torch.zeros((n_kf, stride), dtype=torch.uint8, device=dev)
+    for i, (l, r) in enumerate(pairs):
+        L[i, : h * w] = torch.from_numpy(np.ascontiguousarray(l).reshape(-1)).to(dev)
+        R[i, : h * w] = torch.from_numpy(np.ascontiguousarray(r).reshape(-1)).to(dev)
+    rows = torch.full((n_kf,), -1, dtype=torch.int32, device=dev)
+    desc = torch.zeros((n_kf, maxf, 32), dtype=torch.uint8, device=dev)
+    xyz = torch.zeros((n_kf, maxf, 3), dtype=torch.float32, device=dev)
+    kp = torch.zeros((n_kf, maxf, _abi.KEYPOINT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    finder.set_stream(torch.cuda.current_stream().cuda_stream)
+    before = finder.store_size()
+    first = finder.get_features_and_descriptor_batch_device(L.data_ptr(), R.data_ptr(), n_kf, w, h, w, stride, cam, det,
+                                                            None, rows.data_ptr(), desc.data_ptr(), xyz.data_ptr(),
+                                                            kp.data_ptr())
+    torch.cuda.synchronize()
+    assert first == before and finder.store_size() == before + n_kf
+    rows = rows.cpu().numpy()
+    assert rows[1] == 0 and len(singles[1][0]) == 0
+    for i, (d0, p0, k0, s0) in enumerate(singles):
+        n = len(d0)
+        assert rows[i] == n, "keyframe %d: %d rows, the single call kept %d" % (i, rows[i], n)
+        assert desc[i, :n].cpu().numpy().tobytes() == d0.tobytes()
+        assert kp[i, :n].cpu().numpy().tobytes() == k0.tobytes()
+        got = xyz[i, :n].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(p0)) and got[~np.isnan(got)].tobytes() == p0[~np.isnan(p0)].tobytes()
+    # the store slots of the batch hold what the single calls' slots hold: verifying (single slot -> batch slot) finds
+    # the identity with every feature matched
+    big = [i for i in range(n_kf) if len(singles[i][0]) >= 60]
+    res = finder.verify_pairs([singles[i][3] for i in big], [first + i for i in big])
+    same = finder.verify_pairs([singles[i][3] for i in big], [singles[i][3] for i in big])
+    assert res.tobytes() == same.tobytes() and len(big) >= 1
