@@ -1259,6 +1259,10 @@ def main():
         out["self_warmup_steps"] = len(warm_ts)
         out["steps_overlap"] = bool(pipelined)
         out["timed_step_entry_points"] = "sf_step_issue + sf_step_retire" if pipelined else "sf_experimental.h building blocks"
+        # SF_OPT_STEP_OVERLAP (the library's default, SF_STEP_OVERLAP=0 turns it off): the two steps in flight on two
+        # streams -- unless the separators are mirrored into an exchange buffer (N > 1), where one stream orders the
+        # collective behind the step
+        out["steps_on_two_streams"] = bool(pipelined and not dist_cuda and os.environ.get("SF_STEP_OVERLAP", "1") != "0")
         out["accepted_separators_streamed_from_the_kernel"] = bool(state.get("streamed_last", False))
         if alt_sync is not None:
             out["value_one_synchronisation_per_step"] = alt_sync

@@ -86,7 +86,7 @@ void parallel_rows(int n, F body) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  int n = 10000, k = 500, dim = 4096, iterations = 500, steps = 200, warmup = 20, est = 0;
+  int n = 10000, k = 500, dim = 4096, iterations = 500, steps = 200, warmup = 20, est = 0, overlap_steps = 1;
   double true_frac = 0.2;
   uint64_t seed = 12345;
   for (int i = 1; i + 1 < argc; i += 2) {
@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
     else if (a == "--true-frac") true_frac = atof(argv[i + 1]);
     else if (a == "--seed") seed = strtoull(argv[i + 1], nullptr, 10);
     else if (a == "--estimator") est = std::string(argv[i + 1]) == "pnp" ? 1 : 0;
+    else if (a == "--overlap-steps") { overlap_steps = atoi(argv[i + 1]); }
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
   }
   constexpr int COLS = 32;
@@ -191,6 +192,8 @@ int main(int argc, char** argv) {
   {
     const int rc = sf_create(&p, 0, &h);
     if (rc != SF_OK) { fprintf(stderr, "sf_create -> %d: %s\n", rc, sf_last_error(nullptr)); return 3; }
+    // --overlap-steps 0: both steps in flight on the handle's stream (SF_OPT_STEP_OVERLAP, default 1: two streams)
+    CHECK_SF(sf_set_option(h, SF_OPT_STEP_OVERLAP, overlap_steps));
   }
   // ---- make everything resident in HBM (untimed) -----------------------------------------------------------
   int32_t slot[2] = {-1, -1};
@@ -270,12 +273,12 @@ int main(int argc, char** argv) {
   }
   printf("{\"metric\": \"candidate keyframe-pair verifications/sec (NetVLAD NN + ORB match + RANSAC) @1/2/4/8 GPU\", "
          "\"value\": %.1f, \"unit\": \"pairs/s\", \"n_gpus\": 1, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.6f, "
-         "\"host\": \"C++ (examples/bench_cli.cpp): sf_step_issue + sf_step_retire over include/sepfinder.h, no torch\", "
+         "\"host\": \"C++ (examples/bench_cli.cpp): sf_step_issue + sf_step_retire over include/sepfinder.h, no torch\", \"overlap_steps\": %d, "
          "\"config\": {\"workload\": \"BASELINE configs[1] shape: 2 robots x %d keyframes, %d-D fp32 NetVLAD, %d x %d-bit "
          "ORB per keyframe, <= %d RANSAC hypotheses per pass (%s), %.0f %% true revisits\"}, "
          "\"check\": {\"matches_last_step\": %d, \"accepted_last_step\": %d, \"decisions_matching_ground_truth\": %d, "
          "\"streamed\": %d}, \"input_generation_s\": %.2f}\n",
-         (double)pairs / elapsed, steps, warmup, elapsed / steps * 1e3, n, dim, k, COLS * 8, iterations,
+         (double)pairs / elapsed, steps, warmup, elapsed / steps * 1e3, overlap_steps, n, dim, k, COLS * 8, iterations,
          est ? "PnP" : "3D-3D", 100.0 * true_frac, r.n_matches, accepted, correct, r.streamed, t_gen);
   sf_destroy(h);
   return correct == r.n_matches ? 0 : 4;

@@ -480,6 +480,9 @@ int  sf_find_matches_and_verify_device(sf_handle h, int32_t slot_base_other, int
                        PoseWithCovariance -- the rows of the ReceiveSeparators request (sf_pack_separators packs them).
    Up to TWO steps may be in flight, so a host issues step k before it retires step k - 1 and the device never waits for
    the host (bench.py, examples/bench_cli.cpp):  issue(0); for k = 1..: issue(k); retire(k - 1); ...; retire(last).
+   The two steps in flight run on two streams (SF_OPT_STEP_OVERLAP): work the caller queued on the handle's stream before
+   sf_step_issue is waited for, and database calls (sf_store_*, sf_nn_append_*, sf_nn_reset) made while steps are in
+   flight are ordered against them by the library.
    Accepted results leave the verification kernel for host-pinned memory the moment they are final (no compaction
    launch, no copy); a query the speculative verification does not cover (netvlad_max_matches_nb < local rows, as in the
    reference's default of 20; nn_precision 0; very large batches) takes sf_nn_find_matches + sf_verify_matches_device +
@@ -537,6 +540,12 @@ enum {
   SF_OPT_NN_FULL_FILTER = 5, /* 1: the fp16 NN filter (nn_precision = 1) always contracts the FULL descriptor length
                              instead of climbing its adaptive prefix ladder (128 / 512 / full): the cost of a data set
                              whose prefixes are uninformative; matches are identical either way                        */
+  SF_OPT_STEP_OVERLAP = 6, /* 1 (default): the two steps sf_step_issue keeps in flight run on two streams (the odd ones on a
+                              stream and workspace of the handle's own), so that the emptying tail of one step's
+                              verification overlaps the NN stage and the first workgroups of the next: +9-12 % steps per
+                              second (3D-3D), +14 % (PnP), results unchanged.  0: every step on the handle's stream.
+                              Ignored while sf_step_mirror is set (the caller's collective is ordered on the handle's
+                              stream).  Either way a step's results are complete when sf_step_retire returns.            */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never
                              leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */

@@ -776,6 +776,7 @@ static int nn_stage_reserve(sf_context* c, size_t bytes) {
 
 // src_kind 0: host float64 rows ; 1: device float32 rows
 int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int src_kind) {
+  (void)sf_lanes_touch(c, false);     // rows are written through the handle's stream: the second step lane waits for them
   if (n < 0 || dim <= 0) return sf_fail(c, SF_EINVAL, "bad descriptor block %d x %d", n, dim);
   if (n == 0) return SF_OK;
   if (!src) return sf_fail(c, SF_EINVAL, "null descriptor pointer");

@@ -323,7 +323,9 @@ static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, in
   if (s.slots > 0 && s.w != w) return sf_fail(c, SF_EINVAL, "descriptor width %d B differs from the store's (%d dwords)", cols, s.w);
   int cap = s.cap_slots;
   if (cap < slots_needed) cap = std::max(slots_needed, std::max(cap * 2, &s == &c->store ? c->params.store_capacity : 64));
+  if (&s == &c->store) (void)sf_lanes_touch(c, false);     // (a slot of the store is about to be written)
   if (kcap == s.kcap && cap == s.cap_slots && s.w == w) return SF_OK;
+  if (&s == &c->store) (void)sf_lanes_touch(c, true);      // the old buffers are freed below: nothing may still read them
   // (re)allocate; keep old contents slot by slot (pitch copy when kcap grew)
   Store n;
   n.kcap = kcap; n.w = w; n.cap_slots = cap; n.slots = s.slots;
@@ -732,6 +734,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
+  if (const char* v = getenv("SF_STEP_OVERLAP")) c->step_overlap = atoi(v) != 0;   // 1: SF_OPT_STEP_OVERLAP from the start
   if (const char* v = getenv("SF_OVERLAP_MIN")) c->overlap_min_pairs = std::max(2, atoi(v));
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
   *out = c;
@@ -765,8 +768,19 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
                  &c->ex_integral, &c->ex_desc, &c->ex_xyz, &c->ex_keep, &c->ex_rows, &c->brief_tests,
-                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr, &c->ft_images, &c->ft_kpts, &c->ft_flow, &c->ft_wire};
+                 &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr, &c->ft_images, &c->ft_kpts, &c->ft_flow, &c->ft_wire,
+                 &c->ft_counts, &c->pass_back, &c->dir_mask};
   for (Buf* b : bufs) buf_free(*b);
+  {
+    sf_context::StepLane& L = c->lane1;
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    Buf* lb[] = {&L.pair_from, &L.pair_to, &L.corr1, &L.corr2, &L.hdr1, &L.hdr2, &L.pass1, &L.pass2, &L.pass_back, &L.dir_mask,
+                 &L.list1, &L.list3, &L.counters, &L.results, &L.flags, &L.nn_cand, &L.spec_from, &L.spec_to, &L.spec_results,
+                 &L.spec_index, &L.compact_scratch};
+    for (Buf* b : lb) buf_free(*b);
+    if (L.ev_main) (void)hipEventDestroy(L.ev_main);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
   sf_netvlad_free(c);
   sf_ingest_pool_destroy(c);
   if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
@@ -814,6 +828,7 @@ extern "C" int sf_get_params(sf_handle c, sf_params* out) {
 
 extern "C" int sf_set_stream(sf_handle c, void* hip_stream) {
   if (!c) return SF_EINVAL;
+  (void)sf_lanes_touch(c, true);
   SF_HIP(c, hipStreamSynchronize(c->stream));
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->stream = (hipStream_t)hip_stream;
@@ -824,6 +839,7 @@ extern "C" int sf_set_stream(sf_handle c, void* hip_stream) {
 extern "C" int sf_synchronize(sf_handle c) {
   if (!c) return SF_EINVAL;
   SF_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->lane1.stream) SF_HIP(c, hipStreamSynchronize(c->lane1.stream));
   return SF_OK;
 }
 
@@ -1116,6 +1132,7 @@ extern "C" int sf_store_size(sf_handle c, int32_t* n_slots) {
 
 extern "C" int sf_store_clear(sf_handle c) {
   if (!c) return SF_EINVAL;
+  (void)sf_lanes_touch(c, true);
   SF_HIP(c, hipStreamSynchronize(c->stream));
   c->store.slots = 0;
   return SF_OK;
@@ -1668,12 +1685,61 @@ extern "C" int sf_step_mirror(sf_handle c, sf_result* d_records2, uint32_t* d_co
   return SF_OK;
 }
 
+// ---- SF_OPT_STEP_OVERLAP: the second lane of the step pipeline ------------------------------------------------------
+static void lane_swap(sf_context* c) {
+  sf_context::StepLane& L = c->lane1;
+  std::swap(c->stream, L.stream);
+#define SF_SWAP(m) std::swap(c->m, L.m)
+  SF_SWAP(pair_from); SF_SWAP(pair_to); SF_SWAP(corr1); SF_SWAP(corr2); SF_SWAP(hdr1); SF_SWAP(hdr2); SF_SWAP(pass1);
+  SF_SWAP(pass2); SF_SWAP(pass_back); SF_SWAP(dir_mask); SF_SWAP(list1); SF_SWAP(list3); SF_SWAP(counters);
+  SF_SWAP(results); SF_SWAP(flags); SF_SWAP(nn_cand); SF_SWAP(spec_from); SF_SWAP(spec_to); SF_SWAP(spec_results);
+  SF_SWAP(spec_index); SF_SWAP(compact_scratch); SF_SWAP(ws_pairs); SF_SWAP(ws_kcap); SF_SWAP(nn_count_idx);
+  SF_SWAP(nn_count_primed); SF_SWAP(compact_epoch); SF_SWAP(compact_state_chunks); SF_SWAP(compact_state_ptr);
+#undef SF_SWAP
+}
+
+int sf_lanes_touch(sf_context* c, bool drain) {
+  c->db_epoch += 1;
+  if (drain && c->lane1.stream && c->step_blocks[1].issued) SF_HIP(c, hipStreamSynchronize(c->lane1.stream));
+  return SF_OK;
+}
+
+static int lane1_enter(sf_context* c) {
+  sf_context::StepLane& L = c->lane1;
+  if (!L.stream) {
+    SF_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    SF_HIP(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
+    int rc = sf_buf_reserve(c, L.counters, 64);      // (the work-list counters of the stage kernels; the handle's own
+    if (rc != SF_OK) return rc;                      //  are reserved at sf_create)
+  }
+  if (L.seen_db_epoch != c->db_epoch) {
+    // the databases were written through the handle's stream since this lane last looked: wait for that work once
+    SF_HIP(c, hipEventRecord(L.ev_main, c->stream));
+    SF_HIP(c, hipStreamWaitEvent(L.stream, L.ev_main, 0));
+    L.seen_db_epoch = c->db_epoch;
+  }
+  lane_swap(c);
+  return SF_OK;
+}
+
+static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_base_local);
+
 extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_base_local) {
   if (!c) return SF_EINVAL;
   if (c->step_inflight >= 2) return sf_fail(c, SF_EINVAL, "two steps are in flight: call sf_step_retire first");
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
+  const bool lane1 = c->step_overlap && c->step_head == 1 && !c->step_mirror_records && !c->overlap;
+  if (!lane1) return step_issue_body(c, slot_base_other, slot_base_local);
+  int rc = lane1_enter(c);
+  if (rc != SF_OK) return rc;
+  rc = step_issue_body(c, slot_base_other, slot_base_local);
+  lane_swap(c);
+  return rc;
+}
+
+static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_base_local) {
   const int which = c->step_head;
   sf_context::StepBlock& b = c->step_blocks[which];
   const int n_l = c->nn_local.n;
@@ -2019,6 +2085,10 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
     case SF_OPT_CHAIN_WAVES: return SF_OK;   // (round 1's narrower chains are gone: accepted, no effect)
     case SF_OPT_DEBUG_CORR: c->debug_corr = value != 0; return SF_OK;
     case SF_OPT_NN_FULL_FILTER: c->nn_force_full = value != 0; c->nn_coef_level = -1; return SF_OK;
+    case SF_OPT_STEP_OVERLAP:
+      if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_OVERLAP cannot change while steps are in flight");
+      c->step_overlap = value != 0;
+      return SF_OK;
     default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
   }
 }
@@ -2086,6 +2156,7 @@ extern "C" int sf_nn_ignore_pair(sf_handle c, int32_t il, int32_t io) {
 
 extern "C" int sf_nn_reset(sf_handle c) {
   if (!c) return SF_EINVAL;
+  (void)sf_lanes_touch(c, true);
   SF_HIP(c, hipStreamSynchronize(c->stream));
   // the row buffers are sized, pitched and zero-padded for the old dimension: release them, the next append
   // re-allocates for its own (nn_reserve); the fp16 copies and cached filter coefficients go with them

@@ -308,6 +308,24 @@ struct sf_context {
     hipEvent_t done = nullptr;
   } step_blocks[2];
   int step_head = 0, step_inflight = 0;
+  // SF_OPT_STEP_OVERLAP: the two steps in flight run on two streams -- the odd steps on `lane1.stream` with their own copy
+  // of every device buffer a step writes (parked in `lane1` while an even step owns the handle's members of the same
+  // names, swapped in for the duration of sf_step_issue) -- so that the tail of one step's verification (its last
+  // motion-estimation chains on an emptying chip) and the NN filter of the next overlap.
+  struct StepLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_main = nullptr;          // "the handle's stream up to here": awaited when the databases changed
+    Buf pair_from, pair_to, corr1, corr2, hdr1, hdr2, pass1, pass2, pass_back, dir_mask, list1, list3, counters, results,
+        flags, nn_cand, spec_from, spec_to, spec_results, spec_index, compact_scratch;
+    int ws_pairs = 0, ws_kcap = 0, nn_count_idx = 0;
+    bool nn_count_primed = false;
+    unsigned compact_epoch = 0;
+    int compact_state_chunks = 0;
+    void* compact_state_ptr = nullptr;
+    uint64_t seen_db_epoch = ~0ull;
+  } lane1;
+  bool step_overlap = true;                // the option (SF_STEP_OVERLAP=0 / sf_set_option turn it off)
+  uint64_t db_epoch = 0;                   // bumped by every call that writes a database through the handle's stream
   sf_result* step_mirror_records = nullptr;   // sf_step_mirror: second (device) destination of every accepted record
   uint32_t* step_mirror_counter = nullptr;    // ... and the caller's slot counter
   int32_t step_mirror_cap = 0;
@@ -326,6 +344,8 @@ struct sf_context {
 
 // ---- helpers implemented in sf_api.hip ---------------------------------------------------------
 int sf_fail(sf_context* c, int code, const char* fmt, ...);
+// a database is about to change (SF_OPT_STEP_OVERLAP): `drain` also waits for the step in flight on the second stream
+int sf_lanes_touch(sf_context* c, bool drain);
 int sf_buf_reserve(sf_context* c, Buf& b, size_t bytes, bool keep = false);
 void sf_buf_free(Buf& b);
 struct sf_netvlad_model;

@@ -61,8 +61,9 @@ def _check_step(out, m_ref, res_ref, want_streamed):
     assert recs["success"].all()          # only accepted results are ever delivered
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("est", [0, 1])
-def test_step_pair_equals_the_separate_calls(est):
+def test_step_pair_equals_the_separate_calls(est, overlap):
     """Batch mode (the walk may return every local row: speculative verification, separators streamed out of the kernel)
     and the reference's cadence (netvlad_max_matches_nb = 20: no speculation, ordered compaction), both estimators, with
     masked rows / columns and ignored pairs; steps overlapped two deep as a host would run them."""
@@ -77,6 +78,7 @@ def test_step_pair_equals_the_separate_calls(est):
         p.max_features = k
         with lib.SeparatorFinder(p) as f:
             f.set_stream(torch.cuda.current_stream().cuda_stream)
+            f.set_option(_abi.SF_OPT_STEP_OVERLAP, overlap)       # the two steps in flight on two streams / on one
             sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
             f.nn_mark_local_used(3); f.nn_mark_other_used(5); f.nn_ignore_pair(20, 20); f.nn_ignore_pair(21, 22)
             m_ref, res_ref = _two_calls(f, sa, sb, max_nb)
@@ -158,3 +160,40 @@ def test_step_on_an_empty_candidate_list_and_an_empty_database():
         f.step_issue(sa, sb)
         m, rom, recs, info = f.step_retire()
         assert info["n_matches"] == 0 and info["n_accepted"] == 0 and len(m) == 0 and len(rom) == 0
+
+
+def test_overlapped_steps_and_a_growing_store():
+    """SF_OPT_STEP_OVERLAP: keyframes appended (the store re-allocated) and descriptors appended while two steps are in
+    flight on two streams; the steps in flight and the steps after see consistent databases."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(477, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = 4 * n_kf
+    p.max_features = k
+    p.store_capacity = 2 * n_kf                       # exactly full after _fill: the next keyframe re-allocates
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.set_option(_abi.SF_OPT_STEP_OVERLAP, 1)
+        sa, sb, T = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, 4 * n_kf)
+        f.step_issue(sa, sb)
+        f.step_issue(sa, sb)                          # on the second stream
+        extra = f.store_add_keyframes_device(8, k, 32, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+        assert extra == 2 * n_kf
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        for _ in range(4):                            # steps after the re-allocation, both lanes
+            f.step_issue(sa, sb)
+            f.step_issue(sa, sb)
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        # new received descriptors (written through the handle's stream) are seen by a step on the second stream
+        f.step_issue(sa, sb)                          # lane 0
+        more = nv_a[:5] + 1e-4
+        f.nn_append_received(more / np.linalg.norm(more, axis=1, keepdims=True))
+        m2, res2 = _two_calls(f, sa, sb, 4 * n_kf)
+        f.step_issue(sa, sb)                          # lane 1
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        _check_step(f.step_retire(copy=True), m2, res2, True)
