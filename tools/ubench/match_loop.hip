@@ -77,6 +77,76 @@ __global__ void __launch_bounds__(1024) kA(unsigned long long* out, float* sink,
   if (threadIdx.x == 0) out[0] = t1 - t0;
 }
 
+// (b, s) <- the two largest of {b, s, v[i0..i0+3]}: one quarter of top2_16, so that the merge of a finished chain can be
+// spread between the MFMAs of the next chain (variant D)
+__device__ __forceinline__ void top2_q(float v0, float v1, float v2, float v3, float& b, float& s, bool first) {
+  float x0 = first ? __builtin_amdgcn_fmed3f(b, v0, v1) : 0.f;
+  float t;
+  if (first)
+    asm("v_max3_f32 %0, %0, %3, %4\n\tv_med3_f32 %2, %0, %5, %6\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %1, %1, %7, %2"
+        : "+v"(b), "+v"(s), "=&v"(t) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(x0));
+  else
+    asm("v_med3_f32 %2, %0, %3, %4\n\tv_max3_f32 %0, %0, %3, %4\n\tv_med3_f32 %7, %0, %5, %6\n\tv_max3_f32 %0, %0, %5, %6\n\t"
+        "v_max3_f32 %1, %1, %2, %7"
+        : "+v"(b), "+v"(s), "=&v"(t), "=&v"(x0) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+}
+
+// D: A's arithmetic with the instruction order chosen by hand: chain 0's four MFMAs first, then chain 1's with the merge
+// of chain 0 spread between them (a quarter behind each), the next tile's rows requested and spread behind chain 1's last
+// MFMA, the merge of chain 1 last -- a wavefront then feeds the matrix pipe for all but ~36 VALU instructions per tile.
+__global__ void __launch_bounds__(1024) kD(unsigned long long* out, float* sink, const unsigned* g, int iters) {
+  extern __shared__ unsigned lds[];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = g[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  unsigned m88, c22;
+  asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+  v8i Bf[2][4];
+  for (int j = 0; j < 2; ++j) for (int k = 0; k < 4; ++k) Bf[j][k] = spread_from(g[lane * 8 + j * 4 + k] ^ 0x5a5a5a5au, m88, c22);
+  float cin[16], b[2] = {-1e30f, -1e30f}, s[2] = {-1e30f, -1e30f};
+  for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) / 2048.f;
+  uint4 rw = *reinterpret_cast<const uint4*>(lds + r * 8 + 4 * h);
+  v8i Af[4];
+  Af[0] = spread_from(rw.x, m88, c22); Af[1] = spread_from(rw.y, m88, c22);
+  Af[2] = spread_from(rw.z, m88, c22); Af[3] = spread_from(rw.w, m88, c22);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    const int mt = (it + 1) & 15;
+    v16f c0;
+    for (int i = 0; i < 16; ++i) c0[i] = cin[i];
+    for (int j = 0; j < 2; ++j) { b[j] += 32.f / 2048.f; s[j] += 32.f / 2048.f; }
+    v16f a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[0], Bf[0][0], c0, 4, 4, 0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[1], Bf[0][1], a0, 4, 4, 0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[2], Bf[0][2], a0, 4, 4, 0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[3], Bf[0][3], a0, 4, 4, 0, 0, 0, 0);
+    v16f a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[0], Bf[1][0], c0, 4, 4, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    top2_q(a0[0], a0[1], a0[2], a0[3], b[0], s[0], true);
+    __builtin_amdgcn_sched_barrier(0);
+    a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[1], Bf[1][1], a1, 4, 4, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    top2_q(a0[4], a0[5], a0[6], a0[7], b[0], s[0], false);
+    __builtin_amdgcn_sched_barrier(0);
+    a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[2], Bf[1][2], a1, 4, 4, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    top2_q(a0[8], a0[9], a0[10], a0[11], b[0], s[0], false);
+    __builtin_amdgcn_sched_barrier(0);
+    a1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[3], Bf[1][3], a1, 4, 4, 0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    top2_q(a0[12], a0[13], a0[14], a0[15], b[0], s[0], false);
+    // the next tile: rows out of LDS and their spread, while chain 1 finishes
+    rw = *reinterpret_cast<const uint4*>(lds + (mt * 32 + r) * 8 + 4 * h);
+    Af[0] = spread_from(rw.x, m88, c22); Af[1] = spread_from(rw.y, m88, c22);
+    Af[2] = spread_from(rw.z, m88, c22); Af[3] = spread_from(rw.w, m88, c22);
+    __builtin_amdgcn_sched_barrier(0);
+    top2_16(a1, b[1], s[1]);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  sink[threadIdx.x] = b[0] + s[0] + b[1] + s[1] + (float)Af[0][0];
+  if (threadIdx.x == 0) out[0] = t1 - t0;
+}
+
 // NB resident 16-column blocks per wavefront (4: 64 columns, 8: 128 columns)
 template <int NB>
 __global__ void __launch_bounds__(1024) kB(unsigned long long* out, float* sink, const unsigned* g, int iters) {
@@ -172,6 +242,7 @@ int main() {
   (void)hipMemcpy(g, hbuf, 65536 * 4, hipMemcpyHostToDevice);
   for (int w = 1; w <= 4; ++w) run("M 8 MFMAs only", kM, w, 8 * 32.0, 32.0 * 64, g);
   for (int w = 1; w <= 4; ++w) run("A 32x32x64, 32 x 64 cells", kA, w, 8 * 32.0, 32.0 * 64, g);
+  for (int w = 1; w <= 4; ++w) run("D = A, hand-ordered", kD, w, 8 * 32.0, 32.0 * 64, g);
   for (int w = 1; w <= 4; ++w) run("B 16x16x128, 16 x 64 cells", kB<4>, w, 8 * 16.0, 16.0 * 64, g);
   for (int w = 1; w <= 4; ++w) run("C 16x16x128, 16 x 128 cells", kB<8>, w, 16 * 16.0, 16.0 * 128, g);
   return 0;
