@@ -979,10 +979,11 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n_alt = 0
-            for _ in range(5):
+            for _ in range(20):
                 n_alt += step()
             torch.cuda.synchronize()
-            alt_full = {"value": n_alt / (time.perf_counter() - t1) * world, "contracted_dims": f.nn_last_filter_dims()}
+            alt_full = {"value": n_alt / (time.perf_counter() - t1) * world, "contracted_dims": f.nn_last_filter_dims(),
+                        "steps": 20, "one_synchronisation_per_step": True}
         except Exception as e:
             print("bench: full-length filter comparison run failed: %r" % (e,), file=sys.stderr)
         f.set_option(_abi.SF_OPT_NN_FULL_FILTER, 0)
@@ -1010,11 +1011,11 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             n_alt = 0
-            for _ in range(5):
+            for _ in range(20):
                 n_alt += step_fixed()[0]
             torch.cuda.synchronize()
             alt_fixed = {"value": n_alt / (time.perf_counter() - t1) * world, "accepted_last_step": step_fixed()[1],
-                         "hypotheses_per_pass": args.iterations + 1}
+                         "hypotheses_per_pass": args.iterations + 1, "steps": 20}
             f2.close()
         except Exception as e:
             print("bench: fixed-iteration comparison run failed: %r" % (e,), file=sys.stderr)
