@@ -35,6 +35,11 @@ for rd in range(rounds):
         p.pnp_refine_iterations = int(rng.choice([0, 0, 1, 3, 5]))
         if rng.random() < 0.1:
             p.image_width = 0        # uncalibrated: the estimation never runs
+    # the adjacent branches (Reg/Force3DoF, Vis/ForwardEstOnly = false) in a third of the rounds each
+    if rng.random() < 0.33:
+        p.force_3dof = 1
+    if p.estimation_type == 0 and rng.random() < 0.33:
+        p.forward_est_only = 0
     A, B = [], []
     for i in range(npairs):
         k = int(rng.choice([0, 1, 3, 9, 64, 100, 255, 256, 257, 500, 777, 1024]))
