@@ -23,7 +23,7 @@
 // Kernels:
 //   k_conv3x3_first   Cin = 3 (27 MACs per output): direct, one thread per (pixel, 4 output channels)
 //   k_conv_igemm_h    every other convolution as an implicit GEMM with SPLIT fp16 operands (x = hi + lo, three
-//                     v_mfma_f32_32x32x8f16 per product term: fp32-grade results, 3.1e-7 on the descriptor like the
+//                     v_mfma_f32_32x32x16_f16 per product term: fp32-grade results, 3.1e-7 on the descriptor like the
 //                     fp32 kernel, at a third of its matrix-pipe time); tile / tap split per layer MEASURED at the
 //                     first inference of an image size (conv_autotune).  SF_CNN_FP32=1: k_conv_igemm below.
 //   k_conv_igemm      the same on the fp32 matrix cores (v_mfma_f32_32x32x2f32, the
@@ -193,15 +193,18 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
   }
 }
 
-// The same implicit GEMM with SPLIT fp16 operands on the fp16 matrix cores (v_mfma_f32_32x32x8f16, 16 x the rate of the
-// fp32 form): x = hi + lo with hi = fp16(x), lo = fp16(x - hi) -- 22 significant bits -- and
-//   a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi   (the dropped a_lo b_lo is 2^-22 of the product),
-// three MFMAs where the fp32 form needs four, each a quarter as long; products are exact in the fp32 accumulator.  The
+// The same implicit GEMM with SPLIT fp16 operands on the fp16 matrix cores: x = hi + lo with hi = fp16(x),
+// lo = fp16(x - hi) -- 22 significant bits -- and
+//   a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi   (the dropped a_lo b_lo is 2^-22 of the product);
+// products are exact in the fp32 accumulator.  The MFMA is CDNA4's v_mfma_f32_32x32x16_f16: 16 k per instruction in the
+// 32 cycles the CDNA3-era v_mfma_f32_32x32x8_f16 takes for 8 (tools/ubench/mfma_f16_rate.hip: 32.2 against 32.4 cycles
+// -- the old opcode runs at HALF the fp16 rate of the chip; rounds 2 built this kernel on it).  The
 // weights are split once at load time (and scaled by a power of two so that the largest is about 8: small weights keep
 // their low part out of the subnormals), the activations when a tile is staged into LDS (scaled by 2^-4: headroom for
 // activations up to 10^6); both scalings are undone exactly in the epilogue.  The lane layout is the fp32 kernel's:
-// the float4 a lane used for four x2 MFMAs is the 4-half operand of ONE x8 MFMA.
+// a lane's two float4 of the fp32 form (k = 8 h .. 8 h + 7 of a 16-wide slice) are the 8-half operand of ONE x16 MFMA.
 typedef _Float16 ch16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
 constexpr int CPH = 40;            // LDS pitch in halves (32 + 8)
 constexpr float CONV_ACT_SCALE = 0.0625f;
 
@@ -291,27 +294,27 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
     __syncthreads();
     if (k0 + CK < k_hi) fetch(k0 + CK);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ch16x4 ah[NI], al[NI], bh[NJ], bl[NJ];
+    for (int q = 0; q < 2; ++q) {   // 16 of the step's 32 k per MFMA: lane (l31, h) holds k = 16 q + 8 h .. + 7
+      ch16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int o = ((TM / 2) * wr + 32 * i + l31) * CPH + 8 * q + 4 * h;
-        ah[i] = *reinterpret_cast<const ch16x4*>(&sAh[o]);
-        al[i] = *reinterpret_cast<const ch16x4*>(&sAl[o]);
+        const int o = ((TM / 2) * wr + 32 * i + l31) * CPH + 16 * q + 8 * h;
+        ah[i] = *reinterpret_cast<const ch16x8*>(&sAh[o]);
+        al[i] = *reinterpret_cast<const ch16x8*>(&sAl[o]);
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int o = ((TN / 2) * wc + 32 * j + l31) * CPH + 8 * q + 4 * h;
-        bh[j] = *reinterpret_cast<const ch16x4*>(&sBh[o]);
-        bl[j] = *reinterpret_cast<const ch16x4*>(&sBl[o]);
+        const int o = ((TN / 2) * wc + 32 * j + l31) * CPH + 16 * q + 8 * h;
+        bh[j] = *reinterpret_cast<const ch16x8*>(&sBh[o]);
+        bl[j] = *reinterpret_cast<const ch16x8*>(&sBl[o]);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
   }
