@@ -1147,7 +1147,7 @@ def main():
                        "queries_per_s": n_kf * reps / dtn, "ms_per_query_block": dtn / reps * 1e3,
                        "matches_found": int(len(mm)), "planted": int((planted >= 0).sum()),
                        "contracted_dims": kd,
-                       "kernel": kern + ("_k128" if kern == "k_nn_filter_f16" and kd == 128 else ""), "kernel_ms": kms,
+                       "kernel": kern + ("_k128r" if kern == "k_nn_filter_f16" and kd == 128 else ""), "kernel_ms": kms,
                        "kernel_tflops": 2.0 * n_kf * n_kf * kd / (kms * 1e-3) / 1e12 if kms > 0 else 0.0}
             del tl, to
         except Exception as e:
@@ -1242,7 +1242,7 @@ def main():
                 "launches_per_step": nm / args.steps,
             },
             "roofline_nn": {
-                "kernel": nn_kernel + ("_k128" if nn_kernel == "k_nn_filter_f16" and k_eff == 128 else ""),
+                "kernel": nn_kernel + ("_k128r" if nn_kernel == "k_nn_filter_f16" and k_eff == 128 else ""),
                 "bound": "mfma", "achieved": nn_tf, "peak": nn_peak,
                 "unit": "TFLOP/s", "frac": nn_tf / nn_peak, "avg_launch_ms": nn_ms, "contracted_dims": k_eff,
             },
