@@ -688,10 +688,14 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
 // Tap split of a layer: a FIXED function of its shape.  The split decides the order in which a pixel's taps are summed
 // (S partial sums, then their sum), i.e. the low bits of the descriptor; it must not depend on a timing, or two robots
 // -- or two handles of one -- would produce descriptors that differ in the last bits and near-tie NetVLAD matches could
-// flip.  Rule: split the nine taps three ways when 64 x 64 tiles of the unsplit layer would not even give every compute
-// unit one workgroup (the 40 x 30 layers of a 640 x 480 image), and only while the partial outputs stay small.
+// flip.  Rule: split the nine taps three ways when 128 x 128 tiles of the unsplit layer would not give every compute unit
+// one workgroup (the 80 x 60 and 40 x 30 layers of a 640 x 480 image: with the split the 80 x 60 layers run wider tiles on
+// more workgroups -- NetVLAD inference 1.49 -> 1.36 ms), and only while the partial outputs stay small.
+// (Tried in round 3 and dropped: two LDS stages with ONE barrier per K step instead of one stage with two -- 1.41-1.44
+//  against 1.36 ms on the same box: the second stage halves the workgroups a CU holds, and these kernels hide their
+//  operand latency with occupancy.)
 static int conv_split_rule(int P, int co) {
-  const long wgs = (long)((P + 63) / 64) * ((co + 63) / 64);
+  const long wgs = (long)((P + 127) / 128) * ((co + 127) / 128);
   return (wgs < 256 && (size_t)P * co * 3 <= ((size_t)9 << 20)) ? 3 : 1;
 }
 
