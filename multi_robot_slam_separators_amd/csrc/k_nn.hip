@@ -666,19 +666,22 @@ typedef __attribute__((address_space(3))) void* nn_lds_vp;
 typedef __attribute__((address_space(1))) const void* nn_glb_vp;
 constexpr int NN_K128R_ROWS = NN_BN * 64;            // dwords of the rows of one column tile (128 rows x 256 B)
 constexpr int NN_K128R_TILE = NN_K128R_ROWS + 256;   // + the tile's 128 column coefficients (one more 1 KiB piece)
-constexpr int NN_K128R_LDS = 2 * NN_K128R_TILE * 4 + NN_K128_HITS * 8 + 16;
 
-template <int ABL>     // ABL != 0: timing-only ablations (tools/ab_nn_k128.sh), never launched by the product path
+template <int ABL>     // ABL != 0: timing-only ablations (tools/nn_filter_time.py), never launched by the product path
 __global__ void __launch_bounds__(256, 2)
 k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float2* __restrict__ rowc,
                       const float2* __restrict__ colc, int gx, int gy, int tiles_per_strip,
                       uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap,
                       unsigned* __restrict__ next_count) {
-  extern __shared__ __attribute__((aligned(16))) float nn_lds[];
+  // The two tile buffers are two OBJECTS, and the tile loop below is unrolled by two so that every access names its
+  // buffer statically: the compiler orders a ds_read behind an outstanding LDS-DMA (s_waitcnt vmcnt(0)) whenever it cannot
+  // prove that the two do not alias -- with one array and a runtime buffer index it waited for the next tile's DMA
+  // right after issuing it, in front of the current tile's first operand read (no overlap at all).
+  __shared__ __attribute__((aligned(16))) float sB0[NN_K128R_TILE];   // [128 rows][16 chunks of 16 B], swizzled, + coefficients
+  __shared__ __attribute__((aligned(16))) float sB1[NN_K128R_TILE];
+  __shared__ uint2 s_hits[NN_K128_HITS];
+  __shared__ unsigned s_nhits[2];                                      // [0] count, [1] global base
   if (blockIdx.x == 0 && threadIdx.x < 16 && next_count) next_count[threadIdx.x] = 0u;
-  float* sB = nn_lds;                                                    // [2][128 rows][16 chunks of 16 B], swizzled
-  uint2* s_hits = reinterpret_cast<uint2*>(nn_lds + 2 * NN_K128R_TILE);   // [NN_K128_HITS]
-  unsigned* s_nhits = reinterpret_cast<unsigned*>(s_hits + NN_K128_HITS);  // [0] count, [1] global base
   const int tid = threadIdx.x;
   if (tid == 0) s_nhits[0] = 0;               // (visible after the first barrier)
   const int lane = tid & 63, wave = tid >> 6;
@@ -690,69 +693,63 @@ k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict
   const int t_last = min(gx, t_first + tiles_per_strip);
   const int row0 = tile_y * NN_BM;
 
-  // LDS-DMA of one column tile: 32 pieces of 1 KiB (4 rows), 8 per wavefront; lane l of piece p fills row
+  // LDS-DMA of one 128-row block: 32 pieces of 1 KiB (4 rows), 8 per wavefront; lane l of piece p fills row
   // 4 p + (l >> 4), physical chunk l & 15, i.e. fetches logical chunk (l & 15) ^ (row & 15)
   // (pieces u and u + 4 of a wavefront are 16 rows apart: same swizzle, 4096 bytes further)
-  unsigned dma_off[4];                       // byte offset of this lane's source inside a column tile, per piece & 3
+  unsigned dma_off[4];                       // byte offset of this lane's source inside a block, per piece & 3
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int row = 4 * (8 * wave + u) + (lane >> 4);
     dma_off[u] = (unsigned)(row * 256 + (((lane & 15) ^ (row & 15)) << 4));
   }
   // one 128-row block (rows at `rows_g`, 256 B each; its 128 coefficient pairs at `coef_g`) -> LDS buffer `buf`
-  auto dma_block = [&](const void* rows_g, const float2* coef_g, int buf) {
+  auto dma_block = [&](const void* rows_g, const float2* coef_g, float* buf) {
     const char* Bg = reinterpret_cast<const char*>(rows_g);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       __builtin_amdgcn_global_load_lds((nn_glb_vp)(Bg + (u >> 2) * 4096 + dma_off[u & 3]),
-                                       (nn_lds_vp)(sB + buf * NN_K128R_TILE + (8 * wave + u) * 256), 16, 0, 0);
+                                       (nn_lds_vp)(buf + (8 * wave + u) * 256), 16, 0, 0);
     // the block's coefficients ride along (an ordinary load in the tile loop would make the compiler wait for
     // ALL outstanding vector-memory operations, the DMA included, at its first use)
     if (wave == 0)
       __builtin_amdgcn_global_load_lds((nn_glb_vp)(reinterpret_cast<const char*>(coef_g) + lane * 16),
-                                       (nn_lds_vp)(sB + buf * NN_K128R_TILE + NN_K128R_ROWS), 16, 0, 0);
+                                       (nn_lds_vp)(buf + NN_K128R_ROWS), 16, 0, 0);
   };
-  auto dma_tile = [&](int t, int buf) { dma_block(B + (size_t)t * NN_BN * 128, colc + (size_t)t * NN_BN, buf); };
   // prologue: the first column tile into buffer 0 and the ROW panel, with its coefficients, into buffer 1 -- by the
   // same coalesced 1 KiB pieces; fragment-shaped loads straight from global memory (32 rows x 32 B per instruction)
   // and 32 scalar coefficient loads per lane made the prologue a third of the kernel at 10 000 x 10 000
-  dma_tile(t_first, 0);
-  dma_block(A + (size_t)row0 * 128, rowc + row0, 1);
+  dma_block(B + (size_t)t_first * NN_BN * 128, colc + (size_t)t_first * NN_BN, sB0);
+  dma_block(A + (size_t)row0 * 128, rowc + row0, sB1);
   __syncthreads();                                    // (vmcnt(0) in front of it: both blocks have landed)
   // this wavefront's rows of the panel, in operand layout: lane (l31, h) holds halfs 16 q + 8 h .. + 7 of row
   // 64 wr + 32 i + l31 for q = 0 .. 7
   half8 a[2][8];
   f32x16 cinit[2];
   _Float16 ci16[2];                                // the row half of the ninth step (k = 0 lives in lanes 0..31)
-  {
-    const float* pan = sB + NN_K128R_TILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = 64 * wr + 32 * i + l31;
+  for (int i = 0; i < 2; ++i) {
+    const int row = 64 * wr + 32 * i + l31;
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        a[i][q] = *reinterpret_cast<const half8*>(&pan[row * 64 + (((2 * q + h) ^ (l31 & 15)) << 2)]);
-      // accumulator start values -A_i of this lane's 16 rows: four groups of four consecutive rows
+    for (int q = 0; q < 8; ++q)
+      a[i][q] = *reinterpret_cast<const half8*>(&sB1[row * 64 + (((2 * q + h) ^ (l31 & 15)) << 2)]);
+    // accumulator start values -A_i of this lane's 16 rows: four groups of four consecutive rows
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4* cp = reinterpret_cast<const float4*>(&pan[NN_K128R_ROWS + 2 * (64 * wr + 32 * i + 8 * g + 4 * h)]);
-        const float4 c01 = cp[0], c23 = cp[1];
-        cinit[i][4 * g] = -c01.x; cinit[i][4 * g + 1] = -c01.z; cinit[i][4 * g + 2] = -c23.x; cinit[i][4 * g + 3] = -c23.z;
-      }
-      const float cy = pan[NN_K128R_ROWS + 2 * row + 1];
-      ci16[i] = h == 0 ? (_Float16)cy : (_Float16)0.f;
+    for (int g = 0; g < 4; ++g) {
+      const float4* cp = reinterpret_cast<const float4*>(&sB1[NN_K128R_ROWS + 2 * (64 * wr + 32 * i + 8 * g + 4 * h)]);
+      const float4 c01 = cp[0], c23 = cp[1];
+      cinit[i][4 * g] = -c01.x; cinit[i][4 * g + 1] = -c01.z; cinit[i][4 * g + 2] = -c23.x; cinit[i][4 * g + 3] = -c23.z;
     }
+    const float cy = sB1[NN_K128R_ROWS + 2 * row + 1];
+    ci16[i] = h == 0 ? (_Float16)cy : (_Float16)0.f;
   }
   // ds_read address of this lane inside a tile: row 64 wc + 32 j + l31 (row & 15 = l31 & 15), chunk (2 q + h) ^ (l31 & 15)
   const int rd_row = (64 * wc + l31) * 64;            // dwords
   const int rd_sw = l31 & 15;
   __syncthreads();                                    // every wavefront has its panel rows: buffer 1 is free
 
-  for (int t = t_first; t < t_last; ++t) {
+  // one column tile out of `cur`
+  auto contract = [&](const float* cur, int t) {
     const int col0 = t * NN_BN;
-    const int cb = (t - t_first) & 1;
-    const float* cur = sB + cb * NN_K128R_TILE;
-    if (t + 1 < t_last && !(ABL & 4)) dma_tile(t + 1, cb ^ 1);      // its buffer's last reads ended before the barrier above
     // the two 32-column halves of the wavefront's tile one after the other: 32 accumulator registers live, not 64
     // (two independent chains of dependent MFMAs keep the pipe full)
 #pragma unroll
@@ -761,7 +758,7 @@ k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict
 #pragma unroll
       for (int q = 0; q < 8; ++q) {   // 16 halfs of K per MFMA: lane holds k = 16 q + 8 h + 0..7
         const half8 b = (ABL & 2) ? a[1][q ^ 1]
-                                 : *reinterpret_cast<const half8*>(&cur[rd_row + 32 * 64 * j + (((2 * q + h) ^ rd_sw) << 2)]);
+                                  : *reinterpret_cast<const half8*>(&cur[rd_row + 32 * 64 * j + (((2 * q + h) ^ rd_sw) << 2)]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][q], b, q == 0 ? cinit[i] : acc[i], 0, 0, 0);
@@ -805,7 +802,18 @@ k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict
         }
       }
     }
+  };
+  auto dma_tile = [&](int t, float* buf) {
+    if (!(ABL & 4)) dma_block(B + (size_t)t * NN_BN * 128, colc + (size_t)t * NN_BN, buf);
+  };
+  for (int t = t_first; t < t_last; t += 2) {
+    if (t + 1 < t_last) dma_tile(t + 1, sB1);       // (its last reads ended before the previous barrier)
+    contract(sB0, t);
     __syncthreads();            // vmcnt(0) + barrier: the next tile has landed, this tile's reads are complete
+    if (t + 1 >= t_last) break;
+    if (t + 2 < t_last) dma_tile(t + 2, sB0);
+    contract(sB1, t + 1);
+    __syncthreads();
   }
   const unsigned nh = min(s_nhits[0], (unsigned)NN_K128_HITS);
   if (tid == 0 && nh) s_nhits[1] = atomicAdd(cand_count, nh);
@@ -1141,15 +1149,14 @@ static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdim
       if (!c->nn_k128_attr) {
         SF_HIP(c, hipFuncSetAttribute((const void*)k_nn_filter_f16_k128, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       NN_K128_LDS));
-        SF_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NN_K128R_LDS));
         c->nn_k128_attr = true;
       }
       if (k128_lds_panel)
         hipLaunchKernelGGL(k_nn_filter_f16_k128, dim3(gy * ((gx + tps - 1) / tps)), dim3(256), NN_K128_LDS, c->stream,
                            (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc, gx,
                            gy, tps, cand, count, cap, count_next);
-      else
-        hipLaunchKernelGGL(kern, dim3(gy * ((gx + tps - 1) / tps)), dim3(256), NN_K128R_LDS, c->stream,
+      else      // (static LDS: two tile buffers + the hit list, 74 KB)
+        hipLaunchKernelGGL(kern, dim3(gy * ((gx + tps - 1) / tps)), dim3(256), 0, c->stream,
                            (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc, gx,
                            gy, tps, cand, count, cap, count_next);
       c->nn_count_primed = true;                 // (this launch zeroes the other block for the next one)
