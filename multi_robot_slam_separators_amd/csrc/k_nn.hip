@@ -718,8 +718,10 @@ k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict
   // prologue: the first column tile into buffer 0 and the ROW panel, with its coefficients, into buffer 1 -- by the
   // same coalesced 1 KiB pieces; fragment-shaped loads straight from global memory (32 rows x 32 B per instruction)
   // and 32 scalar coefficient loads per lane made the prologue a third of the kernel at 10 000 x 10 000
-  dma_block(B + (size_t)t_first * NN_BN * 128, colc + (size_t)t_first * NN_BN, sB0);
-  dma_block(A + (size_t)row0 * 128, rowc + row0, sB1);
+  if (!(ABL & 16)) {
+    dma_block(B + (size_t)t_first * NN_BN * 128, colc + (size_t)t_first * NN_BN, sB0);
+    dma_block(A + (size_t)row0 * 128, rowc + row0, sB1);
+  }
   __syncthreads();                                    // (vmcnt(0) in front of it: both blocks have landed)
   // this wavefront's rows of the panel, in operand layout: lane (l31, h) holds halfs 16 q + 8 h .. + 7 of row
   // 64 wr + 32 i + l31 for q = 0 .. 7
@@ -806,7 +808,7 @@ k_nn_filter_f16_k128r(const _Float16* __restrict__ A, const _Float16* __restrict
   auto dma_tile = [&](int t, float* buf) {
     if (!(ABL & 4)) dma_block(B + (size_t)t * NN_BN * 128, colc + (size_t)t * NN_BN, buf);
   };
-  for (int t = t_first; t < t_last; t += 2) {
+  for (int t = t_first; t < ((ABL & 8) ? t_first : t_last); t += 2) {
     if (t + 1 < t_last) dma_tile(t + 1, sB1);       // (its last reads ended before the previous barrier)
     contract(sB0, t);
     __syncthreads();            // vmcnt(0) + barrier: the next tile has landed, this tile's reads are complete
@@ -1142,9 +1144,10 @@ static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdim
       const int tps = (gx + strips - 1) / strips;
       static const int k128_abl = getenv("SF_NN_K128_ABL") ? atoi(getenv("SF_NN_K128_ABL")) : 0;   // timing-only forms
       static const bool k128_lds_panel = getenv("SF_NN_K128_LDS_PANEL") != nullptr;   // (round-2 form, for A/B runs)
-      // bit 0: no hit scan, bit 1: no LDS operand reads, bit 2: no DMA of the next tile
+      // bit 0: no hit scan, bit 1: no LDS operand reads, bit 2: no DMA of the next tile, bit 3: no tile loop, bit 4: no prologue DMA
       auto kern = k128_abl == 1 ? k_nn_filter_f16_k128r<1> : k128_abl == 3 ? k_nn_filter_f16_k128r<3>
                   : k128_abl == 5 ? k_nn_filter_f16_k128r<5> : k128_abl == 7 ? k_nn_filter_f16_k128r<7>
+                  : k128_abl == 8 ? k_nn_filter_f16_k128r<8> : k128_abl == 24 ? k_nn_filter_f16_k128r<24>
                   : k_nn_filter_f16_k128r<0>;
       if (!c->nn_k128_attr) {
         SF_HIP(c, hipFuncSetAttribute((const void*)k_nn_filter_f16_k128, hipFuncAttributeMaxDynamicSharedMemorySize,
