@@ -53,10 +53,58 @@ namespace {
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
 constexpr int CK = 32, CP = 36;    // K step 32 floats, LDS pitch 36 floats
 
-// in: [H][W][3] float, wgt: [64][27] (tap-major, channel-minor), out: [H][W][64]; mean subtraction fused
+// ---- packed split activations ("hl4") --------------------------------------------------------------------------
+// Between the layers of the split-fp16 trunk an activation is stored ALREADY SPLIT: the four channels 4 g .. 4 g + 3 of a
+// pixel occupy the 16 bytes a float4 would, as {hi[0..3], lo[0..3]} halves of x * CONV_ACT_SCALE (hi = fp16(x s),
+// lo = fp16(x s - hi)).  Same strides as the fp32 tensor, so every index computation is unchanged; the consuming
+// convolution's staging is then a copy (round 2 split every element again in every workgroup that read it -- 9 taps x
+// Cout / TN times, 24 vector instructions per float4, more issue time than the MFMAs of a 64 x 64 tile's step).  The
+// operands the matrix cores see are what they were: the producer does the split the consumer did; the 2 x 2 pooling
+// takes the maximum of hi + lo (exact in fp32; the rounding is monotone, so it picks what max(x) would) and splits it
+// again -- into the same pair except in rare ties at an fp16 rounding midpoint or binade edge, where it may choose the
+// other 22-bit representation of the same value (descriptors of the two forms differ by <= 2e-8, a twentieth of their
+// distance to a CPU fp32 evaluation).  conv5_3 (the VLAD layer's input) stays fp32.
+// Measured on one box (tools/cnn_ab.sh): convolutions 10-17 % faster each, NetVLAD inference 1.34 -> 1.20 ms.
+typedef _Float16 ch16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
+constexpr float CONV_ACT_SCALE = 0.0625f;
+
+__device__ __forceinline__ void split4(const float4 v, float s, ch16x4& hi, ch16x4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(x[i] - (float)h);
+  }
+}
+// (all in registers: a union or an indexed vector here becomes a private array that the compiler moves to LDS -- 2 KB per
+//  workgroup and an LDS round trip per element, which tripled the run time of the pooling kernel)
+typedef _Float16 ch16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float hl_word(_Float16 a, _Float16 b) {
+  const ch16x2 v = {a, b};
+  return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ float4 hl4_repack(const float4 x) {          // x * CONV_ACT_SCALE -> packed
+  const _Float16 h0 = (_Float16)x.x, h1 = (_Float16)x.y, h2 = (_Float16)x.z, h3 = (_Float16)x.w;
+  const _Float16 l0 = (_Float16)(x.x - (float)h0), l1 = (_Float16)(x.y - (float)h1), l2 = (_Float16)(x.z - (float)h2),
+                 l3 = (_Float16)(x.w - (float)h3);
+  return make_float4(hl_word(h0, h1), hl_word(h2, h3), hl_word(l0, l1), hl_word(l2, l3));
+}
+__device__ __forceinline__ float4 hl4_pack(const float4 v) {             // true-scale values -> packed
+  return hl4_repack(make_float4(v.x * CONV_ACT_SCALE, v.y * CONV_ACT_SCALE, v.z * CONV_ACT_SCALE, v.w * CONV_ACT_SCALE));
+}
+__device__ __forceinline__ float4 hl4_values(const float4 p) {           // packed -> hi + lo (x * CONV_ACT_SCALE, exact sums)
+  const ch16x2 h01 = __builtin_bit_cast(ch16x2, p.x), h23 = __builtin_bit_cast(ch16x2, p.y);
+  const ch16x2 l01 = __builtin_bit_cast(ch16x2, p.z), l23 = __builtin_bit_cast(ch16x2, p.w);
+  return make_float4((float)h01[0] + (float)l01[0], (float)h01[1] + (float)l01[1], (float)h23[0] + (float)l23[0],
+                     (float)h23[1] + (float)l23[1]);
+}
+
+// in: [H][W][3] float, wgt: [64][27] (tap-major, channel-minor), out: [H][W][64] (fp32, or packed split halves when `packed`); mean subtraction fused
 __global__ void __launch_bounds__(256)
 k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restrict__ wgt, const float* __restrict__ bias,
-                const float* __restrict__ mean, float* __restrict__ out, int relu) {
+                const float* __restrict__ mean, float* __restrict__ out, int relu, int packed) {
   __shared__ __attribute__((aligned(16))) float sw[64 * 27];
   __shared__ __attribute__((aligned(16))) float sb[64];
   // (tap-major in LDS: sw[k][channel], so that four channels' weights of a tap come in one 16-byte broadcast read)
@@ -85,7 +133,7 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
       a.x = fmaf(v[k], w4.x, a.x); a.y = fmaf(v[k], w4.y, a.y); a.z = fmaf(v[k], w4.z, a.z); a.w = fmaf(v[k], w4.w, a.w);
     }
     if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    *reinterpret_cast<float4*>(out + (size_t)p * 64 + c16 + c4) = a;
+    *reinterpret_cast<float4*>(out + (size_t)p * 64 + c16 + c4) = packed ? hl4_pack(a) : a;
   }
 }
 
@@ -203,26 +251,14 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
 // their low part out of the subnormals), the activations when a tile is staged into LDS (scaled by 2^-4: headroom for
 // activations up to 10^6); both scalings are undone exactly in the epilogue.  The lane layout is the fp32 kernel's:
 // a lane's two float4 of the fp32 form (k = 8 h .. 8 h + 7 of a 16-wide slice) are the 8-half operand of ONE x16 MFMA.
-typedef _Float16 ch16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
 constexpr int CPH = 40;            // LDS pitch in halves (32 + 8)
-constexpr float CONV_ACT_SCALE = 0.0625f;
-
-__device__ __forceinline__ void split4(const float4 v, float s, ch16x4& hi, ch16x4& lo) {
-  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const _Float16 h = (_Float16)x[i];
-    hi[i] = h;
-    lo[i] = (_Float16)(x[i] - (float)h);
-  }
-}
 
 template <int TM, int TN>
 __global__ void __launch_bounds__(256)
 k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float16* __restrict__ wgt_hi,
                const _Float16* __restrict__ wgt_lo, float out_scale, int Cout, const float* __restrict__ bias,
-               float* __restrict__ out, int relu) {
+               float* __restrict__ out, int relu, int out_packed) {
+  // `in`: packed split activations (above); `out`: fp32, or packed when out_packed
   constexpr int TAPS = 9;
   constexpr int NI = TM / 64, NJ = TN / 64, QA = TM / 32, QB = TN / 32;
   __shared__ __attribute__((aligned(16))) _Float16 sAh[TM * CPH];
@@ -280,11 +316,9 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
   for (int k0 = k_lo; k0 < k_hi; k0 += CK) {
     __syncthreads();                                  // the previous step's LDS reads are complete
 #pragma unroll
-    for (int q = 0; q < QA; ++q) {
-      ch16x4 ah, al;
-      split4(ra[q], CONV_ACT_SCALE, ah, al);
-      *reinterpret_cast<ch16x4*>(&sAh[(srow + 32 * q) * CPH + sk4]) = ah;
-      *reinterpret_cast<ch16x4*>(&sAl[(srow + 32 * q) * CPH + sk4]) = al;
+    for (int q = 0; q < QA; ++q) {   // the activations arrive split: a copy (words 0, 1 = hi, words 2, 3 = lo)
+      *reinterpret_cast<float2*>(&sAh[(srow + 32 * q) * CPH + sk4]) = make_float2(ra[q].x, ra[q].y);
+      *reinterpret_cast<float2*>(&sAl[(srow + 32 * q) * CPH + sk4]) = make_float2(ra[q].z, ra[q].w);
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
@@ -318,19 +352,39 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
         }
     }
   }
+  // Packed output: a lane holds ONE channel of 16 pixels; the four channels of a 16-byte group sit in the four lanes of a
+  // quad.  Each lane splits its value into P = hi | lo << 16, takes P of two quad neighbours (DPP quad permutes) and
+  // assembles the 32-bit word of the group that lands at ITS channel's address: words 0 / 1 = hi of channels (0, 1) /
+  // (2, 3), words 2 / 3 = lo of the same -- the store pattern is the fp32 one.
+  const int kq = l31 & 3;
+  const unsigned perm_sel = kq < 2 ? 0x05040100u : 0x07060302u;     // low halves of (Pa, Pb) / high halves
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n = col0 + (TN / 2) * wc + 32 * j + l31;
-    if (n >= Cout) continue;
-    const float bn = bias ? bias[n] : 0.f;
+    const bool n_ok = n < Cout;                                      // (uniform over a quad: Cout % 4 == 0)
+    const float bn = (bias && n_ok) ? bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = row0 + (TM / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (p < P) {
-          const float v = acc[i][j][r] * out_scale + bn;
-          out[(size_t)p * Cout + n] = relu ? fmaxf(v, 0.f) : v;
+        float v = acc[i][j][r] * out_scale + bn;
+        v = relu ? fmaxf(v, 0.f) : v;
+        if (out_packed) {
+          const float xs = v * CONV_ACT_SCALE;
+          const _Float16 hh = (_Float16)xs;
+          const _Float16 ll = (_Float16)(xs - (float)hh);
+          unsigned short hb, lb;
+          __builtin_memcpy(&hb, &hh, 2);
+          __builtin_memcpy(&lb, &ll, 2);
+          const int Pw = (int)((unsigned)hb | ((unsigned)lb << 16));
+          // quad_perm [0, 2, 0, 2] and [1, 3, 1, 3]: lanes 0 / 2 of a quad read lanes (0, 1), lanes 1 / 3 read (2, 3)
+          const unsigned Pa = (unsigned)__builtin_amdgcn_update_dpp(0, Pw, 0x88, 0xF, 0xF, false);
+          const unsigned Pb = (unsigned)__builtin_amdgcn_update_dpp(0, Pw, 0xDD, 0xF, 0xF, false);
+          const unsigned word = __builtin_amdgcn_perm(Pb, Pa, perm_sel);
+          if (p < P && n_ok) reinterpret_cast<unsigned*>(out)[(size_t)p * Cout + n] = word;
+        } else if (p < P && n_ok) {
+          out[(size_t)p * Cout + n] = v;
         }
       }
   }
@@ -338,7 +392,7 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
 
 // 2 x 2 max pooling (stride 2, 'valid') + ReLU; in [H][W][C] -> out [H/2][W/2][C], 4 channels per thread
 __global__ void __launch_bounds__(256)
-k_pool2_relu(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out) {
+k_pool2_relu(const float* __restrict__ in, int H, int W, int C, float* __restrict__ out, int packed) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= (size_t)Ho * Wo * C4) return;
@@ -346,14 +400,15 @@ k_pool2_relu(const float* __restrict__ in, int H, int W, int C, float* __restric
   const size_t p = g / C4;
   const int xo = (int)(p % Wo), yo = (int)(p / Wo);
   const float4* src = reinterpret_cast<const float4*>(in);
-  const float4 a = src[((size_t)(2 * yo) * W + 2 * xo) * C4 + c4], b = src[((size_t)(2 * yo) * W + 2 * xo + 1) * C4 + c4];
-  const float4 c = src[((size_t)(2 * yo + 1) * W + 2 * xo) * C4 + c4], d = src[((size_t)(2 * yo + 1) * W + 2 * xo + 1) * C4 + c4];
+  float4 a = src[((size_t)(2 * yo) * W + 2 * xo) * C4 + c4], b = src[((size_t)(2 * yo) * W + 2 * xo + 1) * C4 + c4];
+  float4 c = src[((size_t)(2 * yo + 1) * W + 2 * xo) * C4 + c4], d = src[((size_t)(2 * yo + 1) * W + 2 * xo + 1) * C4 + c4];
+  if (packed) { a = hl4_values(a); b = hl4_values(b); c = hl4_values(c); d = hl4_values(d); }   // (scaled: max and ReLU do not care)
   float4 m;
   m.x = fmaxf(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), 0.f);
   m.y = fmaxf(fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)), 0.f);
   m.z = fmaxf(fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), 0.f);
   m.w = fmaxf(fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)), 0.f);
-  reinterpret_cast<float4*>(out)[g] = m;
+  reinterpret_cast<float4*>(out)[g] = packed ? hl4_repack(m) : m;
 }
 
 // tf.nn.l2_normalize over the channels of every pixel: x / sqrt(max(sum x^2, 1e-12)); one wavefront per pixel
@@ -372,7 +427,7 @@ k_l2norm_rows(float* __restrict__ x, int rows, int C) {
 // out[i] = act(bias[i % C] + (part[0][i] + part[1][i]) + ... ), 4 values per thread
 __global__ void __launch_bounds__(256)
 k_sum_partials(const float* __restrict__ part, int S, size_t n, int C, const float* __restrict__ bias, float* __restrict__ out,
-               int relu) {
+               int relu, int packed) {
   const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (g >= n) return;
   float4 a = *reinterpret_cast<const float4*>(part + g);
@@ -383,7 +438,7 @@ k_sum_partials(const float* __restrict__ part, int S, size_t n, int C, const flo
   const float4 bz = *reinterpret_cast<const float4*>(bias + (g % C));
   a.x += bz.x; a.y += bz.y; a.z += bz.z; a.w += bz.w;
   if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-  *reinterpret_cast<float4*>(out + g) = a;
+  *reinterpret_cast<float4*>(out + g) = packed ? hl4_pack(a) : a;
 }
 
 // softmax over the K clusters of every pixel (in place); one wavefront per pixel, lane = cluster, K <= 64
@@ -651,6 +706,8 @@ int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
 // One 3 x 3 convolution layer (i >= 1) in a given configuration: tile tm x tn, S-way tap split (S > 1: partial outputs,
 // summed -- with bias and ReLU -- by k_sum_partials in a fixed order).
 static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* src, int h, int w, float* dst, ConvCfg cfg) {
+  // split-fp16 trunk: activations travel packed (hl4) except the last layer's output, the VLAD head's fp32 input
+  const int pk = (m->split_f16 && i != 12) ? 1 : 0;
   const int P = h * w, co = VGG_COUT[i], S = cfg.split, tm = cfg.tm, tn = cfg.tn;
   int rc;
   float* cdst = dst;
@@ -665,7 +722,7 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
                          c->stream, src, h, w, VGG_CIN[i], (const _Float16*)m->conv_wh[i].p,                          \
                          (const _Float16*)m->conv_wl[i].p, m->conv_out_scale[i], co,                                  \
                          S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                          \
-                         S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0));                                                          \
+                         S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0), S > 1 ? 0 : pk);                                          \
     else                                                                                                            \
       hipLaunchKernelGGL((k_conv_igemm<9, TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
                          c->stream, src, h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, co,                          \
@@ -680,7 +737,7 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
   if (S > 1) {
     const size_t n = (size_t)P * co;
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, c->stream,
-                       (const float*)cdst, S, n, co, (const float*)m->conv_b[i].p, dst, VGG_RELU[i] ? 1 : 0);
+                       (const float*)cdst, S, n, co, (const float*)m->conv_b[i].p, dst, VGG_RELU[i] ? 1 : 0, pk);
   }
   return SF_OK;
 }
@@ -779,7 +836,7 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
         if (i == 0) {
           hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
                              (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
-                             VGG_RELU[0] ? 1 : 0);
+                             VGG_RELU[0] ? 1 : 0, m->split_f16 ? 1 : 0);
         } else {
           if ((rc = conv_layer(c, m, i, src, h, w, dst, m->cfg[i])) != SF_OK) return rc;
         }
@@ -788,7 +845,8 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
         if (VGG_POOL[i]) {
           float* pd = (float*)m->act[cur].p;
           const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
-          hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd);
+          hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd,
+                             m->split_f16 ? 1 : 0);
           h /= 2; w /= 2;
           src = pd;
           cur ^= 1;
