@@ -252,6 +252,7 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
 // activations up to 10^6); both scalings are undone exactly in the epilogue.  The lane layout is the fp32 kernel's:
 // a lane's two float4 of the fp32 form (k = 8 h .. 8 h + 7 of a 16-wide slice) are the 8-half operand of ONE x16 MFMA.
 constexpr int CPH = 40;            // LDS pitch in halves (32 + 8)
+constexpr int CONV_ZERO_PAGE = 1024;   // floats of zeros the host keeps in front of every activation buffer
 
 template <int TM, int TN>
 __global__ void __launch_bounds__(256)
@@ -280,39 +281,56 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int srow = tid >> 3, sk4 = (tid & 7) * 4;     // staging: 32 rows x 8 groups of 4 k per pass
-  int py[QA], px[QA];
-  bool pv[QA];
+  // Operand addresses of a K step (one tap, 32 channels) = a UNIFORM base that moves with the step + a 32-bit lane offset
+  // that does not: global_load saddr + voffset, no 64-bit multiplies, no divisions, no branches in the loop (round 2
+  // recomputed tap = k0 / Cin, the shifted pixel's address and a bounds test per row and step, and branched around
+  // every load: ~100 vector instructions per step beside 12-24 MFMAs).  A tap that falls outside the image (or a row
+  // past the last pixel) reads ZEROS from the 4 KB page the host keeps in front of every activation buffer
+  // (CONV_ZERO_PAGE floats): its lane offset is swapped for one inside that page, the data needs no masking.
+  unsigned oa[QA], vmask[QA];                        // byte offset of the row's centre pixel from in - page; valid taps
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
     const int p = row0 + srow + 32 * q;
-    pv[q] = p < P;
-    py[q] = pv[q] ? p / W : 0;
-    px[q] = pv[q] ? p - py[q] * W : 0;
+    const bool pv = p < P;
+    const int py = pv ? p / W : 0, px = pv ? p - py * W : 0;
+    oa[q] = (unsigned)(CONV_ZERO_PAGE * 4) + ((unsigned)(py * W + px) * (unsigned)Cin + (unsigned)sk4) * 4u;
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      mk |= (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (1u << t) : 0u;
+    }
+    vmask[q] = mk;
   }
+  const unsigned zoff = (unsigned)sk4 * 4u;           // (16-byte aligned, inside the zero page)
+  unsigned ob[QB];                                    // byte offset of the weight row (clamped: columns >= Cout are never stored)
+#pragma unroll
+  for (int q = 0; q < QB; ++q) ob[q] = ((unsigned)min(col0 + srow + 32 * q, Cout - 1) * (unsigned)K + (unsigned)sk4) * 2u;
+  const char* in_page = reinterpret_cast<const char*>(in) - CONV_ZERO_PAGE * 4;
   float4 ra[QA];
   ch16x4 rbh[QB], rbl[QB];
-  auto fetch = [&](int k0) {
-    const int tap = k0 / Cin, c0 = k0 - tap * Cin;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  int f_tap = k_lo / Cin, f_c0 = 0;                   // the step the NEXT fetch loads (k_lo is a multiple of Cin)
+  auto fetch = [&]() {
+    const int dy = ((f_tap * 11) >> 5) - 1, dx = f_tap - 3 * (dy + 1) - 1;      // tap / 3 - 1, tap % 3 - 1 for tap < 9
+    const unsigned step = (unsigned)(((dy * W + dx) * Cin + f_c0) * 4);          // (wraps; offset + step >= 0 where valid)
+    const unsigned bit = 1u << f_tap;
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
-      const int yy = py[q] + dy, xx = px[q] + dx;
-      ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pv[q] && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        ra[q] = *reinterpret_cast<const float4*>(in + ((size_t)yy * W + xx) * Cin + c0 + sk4);
+      const unsigned off = (vmask[q] & bit) ? oa[q] + step : zoff;
+      ra[q] = *reinterpret_cast<const float4*>(in_page + off);
     }
+    const size_t kb = (size_t)(f_tap * Cin + f_c0) * 2;
+    const char* bh = reinterpret_cast<const char*>(wgt_hi) + kb;
+    const char* bl = reinterpret_cast<const char*>(wgt_lo) + kb;
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      rbh[q] = ch16x4{0, 0, 0, 0};
-      rbl[q] = ch16x4{0, 0, 0, 0};
-      if (col0 + srow + 32 * q < Cout) {
-        const size_t o = (size_t)(col0 + srow + 32 * q) * K + k0 + sk4;
-        rbh[q] = *reinterpret_cast<const ch16x4*>(wgt_hi + o);
-        rbl[q] = *reinterpret_cast<const ch16x4*>(wgt_lo + o);
-      }
+      rbh[q] = *reinterpret_cast<const ch16x4*>(bh + ob[q]);
+      rbl[q] = *reinterpret_cast<const ch16x4*>(bl + ob[q]);
     }
+    f_c0 += CK;
+    if (f_c0 == Cin) { f_c0 = 0; ++f_tap; }
   };
-  fetch(k_lo);
+  fetch();
   for (int k0 = k_lo; k0 < k_hi; k0 += CK) {
     __syncthreads();                                  // the previous step's LDS reads are complete
 #pragma unroll
@@ -326,7 +344,7 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
       *reinterpret_cast<ch16x4*>(&sBl[(srow + 32 * q) * CPH + sk4]) = rbl[q];
     }
     __syncthreads();
-    if (k0 + CK < k_hi) fetch(k0 + CK);
+    if (k0 + CK < k_hi) fetch();
 #pragma unroll
     for (int q = 0; q < 2; ++q) {   // 16 of the step's 32 k per MFMA: lane (l31, h) holds k = 16 q + 8 h .. + 7
       ch16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
@@ -601,6 +619,8 @@ struct sf_netvlad_model {
   Buf conv_wh[13], conv_wl[13];     // fp16 high / low parts of the scaled weights (k_conv_igemm_h)
   float conv_out_scale[13] = {};    // 1 / (weight scale x activation scale): exact powers of two
   bool split_f16 = true;            // SF_CNN_FP32=1: the fp32 matrix-core kernels
+  const void* act_zeroed[2] = {nullptr, nullptr};   // the allocations whose leading zero page has been written
+  size_t act_zeroed_bytes[2] = {0, 0};
   ConvCfg cfg[13] = {};             // tile / split of every layer, measured for ...
   int tuned_h = 0, tuned_w = 0;     // ... this image size (conv_autotune)
   Buf act[2], vlad, pca_y, partial;
@@ -766,8 +786,8 @@ static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
   if (hipEventCreate(&e0) != hipSuccess) return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed");
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed"); }
   int h = H, w = W, rc = SF_OK;
-  const float* src = (const float*)m->act[0].p;
-  float* dst = (float*)m->act[1].p;
+  const float* src = (const float*)m->act[0].p + CONV_ZERO_PAGE;
+  float* dst = (float*)m->act[1].p + CONV_ZERO_PAGE;
   for (int i = 0; i < 13 && rc == SF_OK; ++i) {
     if (i > 0) {
       const int P = h * w, co = VGG_COUT[i];
@@ -813,8 +833,15 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
   if (n_out < 1 || n_out > m->pca_dim) return sf_fail(c, SF_ERANGE, "%d output dimensions of %d", n_out, m->pca_dim);
   int rc;
   const size_t act_max = (size_t)H * W * 64;
-  if ((rc = sf_buf_reserve(c, m->act[0], act_max * sizeof(float))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, m->act[1], act_max * sizeof(float))) != SF_OK) return rc;
+  // every activation buffer starts with a page of zeros: what k_conv_igemm_h reads for a tap outside the image
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = sf_buf_reserve(c, m->act[i], (act_max + CONV_ZERO_PAGE) * sizeof(float))) != SF_OK) return rc;
+    if (m->act[i].p != m->act_zeroed[i] || m->act[i].bytes != m->act_zeroed_bytes[i]) {   // (a new allocation)
+      SF_HIP(c, hipMemsetAsync(m->act[i].p, 0, CONV_ZERO_PAGE * sizeof(float), c->stream));
+      m->act_zeroed[i] = m->act[i].p;
+      m->act_zeroed_bytes[i] = m->act[i].bytes;
+    }
+  }
   const int K = m->clusters, D = 512;
   const int group = std::min(n_img, 4);
   const int y_pitch = std::max(m->pca_dim, 64);
@@ -831,7 +858,7 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
       int h = H, w = W, cur = 0;
       const float* src = d_image;
       for (int i = 0; i < 13; ++i) {
-        float* dst = (float*)m->act[cur].p;
+        float* dst = (float*)m->act[cur].p + CONV_ZERO_PAGE;
         const int P = h * w;
         if (i == 0) {
           hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
@@ -843,7 +870,7 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
         src = dst;
         cur ^= 1;
         if (VGG_POOL[i]) {
-          float* pd = (float*)m->act[cur].p;
+          float* pd = (float*)m->act[cur].p + CONV_ZERO_PAGE;
           const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
           hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd,
                              m->split_f16 ? 1 : 0);
@@ -855,7 +882,7 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
       // src = conv5_3 output [h][w][512] (in act[cur ^ 1]); normalise in place, assignment into act[cur]
       const int P = h * w;
       float* x = const_cast<float*>(src);
-      float* a = (float*)m->act[cur].p;
+      float* a = (float*)m->act[cur].p + CONV_ZERO_PAGE;
       float* norms = (float*)m->pca_y.p + (size_t)b * y_pitch;                     // (the slot doubles as the K norms)
       hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
       hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
