@@ -251,17 +251,20 @@ k_conv_igemm(const float* __restrict__ in, int H, int W, int Cin, const float* _
 // their low part out of the subnormals), the activations when a tile is staged into LDS (scaled by 2^-4: headroom for
 // activations up to 10^6); both scalings are undone exactly in the epilogue.  The lane layout is the fp32 kernel's:
 // a lane's two float4 of the fp32 form (k = 8 h .. 8 h + 7 of a 16-wide slice) are the 8-half operand of ONE x16 MFMA.
-constexpr int CPH = 40;            // LDS pitch in halves (32 + 8)
 constexpr int CONV_ZERO_PAGE = 1024;   // floats of zeros the host keeps in front of every activation buffer
 
-template <int TM, int TN>
+// CKT = channels of a tap per K step (32 or 64; 64: half the barriers per MFMA, twice the LDS -- the choice is measured per
+// layer with the tile, it does not change the order of a pixel's sum)
+template <int TM, int TN, int CKT>
 __global__ void __launch_bounds__(256)
 k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float16* __restrict__ wgt_hi,
                const _Float16* __restrict__ wgt_lo, float out_scale, int Cout, const float* __restrict__ bias,
                float* __restrict__ out, int relu, int out_packed) {
   // `in`: packed split activations (above); `out`: fp32, or packed when out_packed
   constexpr int TAPS = 9;
-  constexpr int NI = TM / 64, NJ = TN / 64, QA = TM / 32, QB = TN / 32;
+  constexpr int GK = CKT / 4, RP = 256 / GK;            // staging: RP rows x GK groups of 4 k per pass
+  constexpr int CPH = CKT + 8;                          // LDS pitch in halves (80 / 144 bytes: conflict-free ds_read_b128)
+  constexpr int NI = TM / 64, NJ = TN / 64, QA = TM / RP, QB = TN / RP;
   __shared__ __attribute__((aligned(16))) _Float16 sAh[TM * CPH];
   __shared__ __attribute__((aligned(16))) _Float16 sAl[TM * CPH];
   __shared__ __attribute__((aligned(16))) _Float16 sBh[TN * CPH];
@@ -280,7 +283,7 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int srow = tid >> 3, sk4 = (tid & 7) * 4;     // staging: 32 rows x 8 groups of 4 k per pass
+  const int srow = tid / GK, sk4 = (tid % GK) * 4;
   // Operand addresses of a K step (one tap, 32 channels) = a UNIFORM base that moves with the step + a 32-bit lane offset
   // that does not: global_load saddr + voffset, no 64-bit multiplies, no divisions, no branches in the loop (round 2
   // recomputed tap = k0 / Cin, the shifted pixel's address and a bounds test per row and step, and branched around
@@ -290,7 +293,7 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
   unsigned oa[QA], vmask[QA];                        // byte offset of the row's centre pixel from in - page; valid taps
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
-    const int p = row0 + srow + 32 * q;
+    const int p = row0 + srow + RP * q;
     const bool pv = p < P;
     const int py = pv ? p / W : 0, px = pv ? p - py * W : 0;
     oa[q] = (unsigned)(CONV_ZERO_PAGE * 4) + ((unsigned)(py * W + px) * (unsigned)Cin + (unsigned)sk4) * 4u;
@@ -305,7 +308,7 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
   const unsigned zoff = (unsigned)sk4 * 4u;           // (16-byte aligned, inside the zero page)
   unsigned ob[QB];                                    // byte offset of the weight row (clamped: columns >= Cout are never stored)
 #pragma unroll
-  for (int q = 0; q < QB; ++q) ob[q] = ((unsigned)min(col0 + srow + 32 * q, Cout - 1) * (unsigned)K + (unsigned)sk4) * 2u;
+  for (int q = 0; q < QB; ++q) ob[q] = ((unsigned)min(col0 + srow + RP * q, Cout - 1) * (unsigned)K + (unsigned)sk4) * 2u;
   const char* in_page = reinterpret_cast<const char*>(in) - CONV_ZERO_PAGE * 4;
   float4 ra[QA];
   ch16x4 rbh[QB], rbl[QB];
@@ -327,26 +330,26 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
       rbh[q] = *reinterpret_cast<const ch16x4*>(bh + ob[q]);
       rbl[q] = *reinterpret_cast<const ch16x4*>(bl + ob[q]);
     }
-    f_c0 += CK;
+    f_c0 += CKT;
     if (f_c0 == Cin) { f_c0 = 0; ++f_tap; }
   };
   fetch();
-  for (int k0 = k_lo; k0 < k_hi; k0 += CK) {
+  for (int k0 = k_lo; k0 < k_hi; k0 += CKT) {
     __syncthreads();                                  // the previous step's LDS reads are complete
 #pragma unroll
     for (int q = 0; q < QA; ++q) {   // the activations arrive split: a copy (words 0, 1 = hi, words 2, 3 = lo)
-      *reinterpret_cast<float2*>(&sAh[(srow + 32 * q) * CPH + sk4]) = make_float2(ra[q].x, ra[q].y);
-      *reinterpret_cast<float2*>(&sAl[(srow + 32 * q) * CPH + sk4]) = make_float2(ra[q].z, ra[q].w);
+      *reinterpret_cast<float2*>(&sAh[(srow + RP * q) * CPH + sk4]) = make_float2(ra[q].x, ra[q].y);
+      *reinterpret_cast<float2*>(&sAl[(srow + RP * q) * CPH + sk4]) = make_float2(ra[q].z, ra[q].w);
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
-      *reinterpret_cast<ch16x4*>(&sBh[(srow + 32 * q) * CPH + sk4]) = rbh[q];
-      *reinterpret_cast<ch16x4*>(&sBl[(srow + 32 * q) * CPH + sk4]) = rbl[q];
+      *reinterpret_cast<ch16x4*>(&sBh[(srow + RP * q) * CPH + sk4]) = rbh[q];
+      *reinterpret_cast<ch16x4*>(&sBl[(srow + RP * q) * CPH + sk4]) = rbl[q];
     }
     __syncthreads();
-    if (k0 + CK < k_hi) fetch();
+    if (k0 + CKT < k_hi) fetch();
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {   // 16 of the step's 32 k per MFMA: lane (l31, h) holds k = 16 q + 8 h .. + 7
+    for (int q = 0; q < CKT / 16; ++q) {   // 16 of the step's k per MFMA: lane (l31, h) holds k = 16 q + 8 h .. + 7
       ch16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -612,7 +615,7 @@ const bool VGG_POOL[13] = {false, true, false, true, false, false, true, false, 
 
 }  // namespace
 
-struct ConvCfg { int tm, tn, split; };
+struct ConvCfg { int tm, tn, split, ck; };   // ck: channels per K step of the split-fp16 kernel (32 / 64)
 
 struct sf_netvlad_model {
   Buf conv_w[13], conv_b[13], mean, assign_w, centers, pca_w, pca_b;
@@ -735,15 +738,17 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
     if ((rc = sf_buf_reserve(c, m->partial, (size_t)S * P * co * sizeof(float))) != SF_OK) return rc;
     cdst = (float*)m->partial.p;
   }
+#define SF_CONV_H(TM_, TN_, CK_)                                                                                    \
+  hipLaunchKernelGGL((k_conv_igemm_h<TM_, TN_, CK_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
+                     c->stream, src, h, w, VGG_CIN[i], (const _Float16*)m->conv_wh[i].p,                              \
+                     (const _Float16*)m->conv_wl[i].p, m->conv_out_scale[i], co,                                      \
+                     S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                              \
+                     S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0), S > 1 ? 0 : pk)
 #define SF_CONV(TM_, TN_)                                                                                           \
   do {                                                                                                              \
-    if (m->split_f16)                                                                                               \
-      hipLaunchKernelGGL((k_conv_igemm_h<TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
-                         c->stream, src, h, w, VGG_CIN[i], (const _Float16*)m->conv_wh[i].p,                          \
-                         (const _Float16*)m->conv_wl[i].p, m->conv_out_scale[i], co,                                  \
-                         S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                          \
-                         S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0), S > 1 ? 0 : pk);                                          \
-    else                                                                                                            \
+    if (m->split_f16) {                                                                                             \
+      if (cfg.ck == 64) SF_CONV_H(TM_, TN_, 64); else SF_CONV_H(TM_, TN_, 32);                                       \
+    } else                                                                                                          \
       hipLaunchKernelGGL((k_conv_igemm<9, TM_, TN_>), dim3((P + TM_ - 1) / TM_, (co + TN_ - 1) / TN_, S), dim3(256), 0, \
                          c->stream, src, h, w, VGG_CIN[i], (const float*)m->conv_w[i].p, co,                          \
                          S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                          \
@@ -754,6 +759,7 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
   else if (tn == 128) SF_CONV(64, 128);
   else SF_CONV(64, 64);
 #undef SF_CONV
+#undef SF_CONV_H
   if (S > 1) {
     const size_t n = (size_t)P * co;
     hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, c->stream,
@@ -777,8 +783,8 @@ static int conv_split_rule(int P, int co) {
 }
 
 // Tile of every layer for one image size, MEASURED: the first inference at a new size times each layer with tiles
-// 64 / 128 x 64 / 128 (the tap split fixed by conv_split_rule: the tile does not change the order of a pixel's sum, so
-// the choice is invisible in the results) on the buffers it is about to use and keeps the fastest (HIP events, three
+// 64 / 128 x 64 / 128 and K steps of 32 / 64 channels (the tap split fixed by conv_split_rule: neither changes the order of
+// a pixel's sum, so the choice is invisible in the results) on the buffers it is about to use and keeps the fastest (HIP events, three
 // runs each; a few ms once per image size, synchronous).  The split-fp16 kernels are bound by the latency of their
 // operand fetches, where more, smaller workgroups often win, and a measurement is the honest way to choose.
 static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
@@ -793,11 +799,12 @@ static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
       const int P = h * w, co = VGG_COUT[i];
       const int S = conv_split_rule(P, co);
       float best = 1e30f;
-      ConvCfg pick = {64, 64, S};
+      ConvCfg pick = {64, 64, S, 32};
+      for (int ck = 32; ck <= (m->split_f16 ? 64 : 32) && rc == SF_OK; ck *= 2)
       for (int tm = 64; tm <= 128 && rc == SF_OK; tm *= 2)
         for (int tn = 64; tn <= 128 && rc == SF_OK; tn *= 2) {
           if (co == 64 && tn == 128) continue;
-          const ConvCfg cfg = {tm, tn, S};
+          const ConvCfg cfg = {tm, tn, S, ck};
           rc = conv_layer(c, m, i, src, h, w, dst, cfg);      // warm-up (and buffer growth)
           float t_min = 1e30f;
           for (int rep = 0; rep < 3 && rc == SF_OK; ++rep) {
