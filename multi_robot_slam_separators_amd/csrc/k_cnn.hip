@@ -104,7 +104,8 @@ __device__ __forceinline__ float4 hl4_values(const float4 p) {           // pack
 // in: [H][W][3] float, wgt: [64][27] (tap-major, channel-minor), out: [H][W][64] (fp32, or packed split halves when `packed`); mean subtraction fused
 __global__ void __launch_bounds__(256)
 k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restrict__ wgt, const float* __restrict__ bias,
-                const float* __restrict__ mean, float* __restrict__ out, int relu, int packed) {
+                const float* __restrict__ mean, float* __restrict__ out, int relu, int packed, int Himg) {
+  // (H = rows of the whole input, Himg = rows of ONE image: a batch is a stack of images, a tap never crosses into the next)
   __shared__ __attribute__((aligned(16))) float sw[64 * 27];
   __shared__ __attribute__((aligned(16))) float sb[64];
   // (tap-major in LDS: sw[k][channel], so that four channels' weights of a tap come in one 16-byte broadcast read)
@@ -114,12 +115,12 @@ k_conv3x3_first(const float* __restrict__ in, int H, int W, const float* __restr
   const int g = blockIdx.x * 256 + threadIdx.x;        // (pixel, group of 16 output channels)
   const int p = g >> 2, c16 = (g & 3) * 16;
   if (p >= H * W) return;
-  const int y = p / W, x = p - y * W;
+  const int y = p / W, x = p - y * W, yi = y % Himg;
   float v[27];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1, yyi = yi + t / 3 - 1;
+    const bool ok = yyi >= 0 && yyi < Himg && xx >= 0 && xx < W;
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[3 * t + c] = ok ? in[((size_t)yy * W + xx) * 3 + c] - mean[c] : 0.f;
   }
@@ -259,8 +260,8 @@ template <int TM, int TN, int CKT>
 __global__ void __launch_bounds__(256)
 k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float16* __restrict__ wgt_hi,
                const _Float16* __restrict__ wgt_lo, float out_scale, int Cout, const float* __restrict__ bias,
-               float* __restrict__ out, int relu, int out_packed) {
-  // `in`: packed split activations (above); `out`: fp32, or packed when out_packed
+               float* __restrict__ out, int relu, int out_packed, int Himg) {
+  // `in`: packed split activations (above); `out`: fp32, or packed when out_packed; H rows = a stack of images of Himg rows
   constexpr int TAPS = 9;
   constexpr int GK = CKT / 4, RP = 256 / GK;            // staging: RP rows x GK groups of 4 k per pass
   constexpr int CPH = CKT + 8;                          // LDS pitch in halves (80 / 144 bytes: conflict-free ds_read_b128)
@@ -295,13 +296,13 @@ k_conv_igemm_h(const float* __restrict__ in, int H, int W, int Cin, const _Float
   for (int q = 0; q < QA; ++q) {
     const int p = row0 + srow + RP * q;
     const bool pv = p < P;
-    const int py = pv ? p / W : 0, px = pv ? p - py * W : 0;
+    const int py = pv ? p / W : 0, px = pv ? p - py * W : 0, pyi = py % Himg;
     oa[q] = (unsigned)(CONV_ZERO_PAGE * 4) + ((unsigned)(py * W + px) * (unsigned)Cin + (unsigned)sk4) * 4u;
     unsigned mk = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      mk |= (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) ? (1u << t) : 0u;
+      const int yy = pyi + t / 3 - 1, xx = px + t % 3 - 1;          // (inside the row's own image)
+      mk |= (pv && yy >= 0 && yy < Himg && xx >= 0 && xx < W) ? (1u << t) : 0u;
     }
     vmask[q] = mk;
   }
@@ -624,8 +625,8 @@ struct sf_netvlad_model {
   bool split_f16 = true;            // SF_CNN_FP32=1: the fp32 matrix-core kernels
   const void* act_zeroed[2] = {nullptr, nullptr};   // the allocations whose leading zero page has been written
   size_t act_zeroed_bytes[2] = {0, 0};
-  ConvCfg cfg[13] = {};             // tile / split of every layer, measured for ...
-  int tuned_h = 0, tuned_w = 0;     // ... this image size (conv_autotune)
+  struct Tune { ConvCfg cfg[13] = {}; int h = 0, w = 0, n = 0; };   // tile / K step / split of every layer, measured for
+  Tune tune[2];                     // ... an image size and a stack of n images (conv_autotune): [0] n = 1, [1] the last n > 1
   Buf act[2], vlad, pca_y, partial;
   int clusters = 0, pca_dim = 0;
 };
@@ -728,7 +729,8 @@ int sf_netvlad_load_impl(sf_context* c, const sf_netvlad_weights* w) {
 
 // One 3 x 3 convolution layer (i >= 1) in a given configuration: tile tm x tn, S-way tap split (S > 1: partial outputs,
 // summed -- with bias and ReLU -- by k_sum_partials in a fixed order).
-static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* src, int h, int w, float* dst, ConvCfg cfg) {
+static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* src, int h, int w, float* dst, ConvCfg cfg,
+                      int himg) {   // h = rows of the stack, himg = rows of one image at this layer
   // split-fp16 trunk: activations travel packed (hl4) except the last layer's output, the VLAD head's fp32 input
   const int pk = (m->split_f16 && i != 12) ? 1 : 0;
   const int P = h * w, co = VGG_COUT[i], S = cfg.split, tm = cfg.tm, tn = cfg.tn;
@@ -743,7 +745,7 @@ static int conv_layer(sf_context* c, sf_netvlad_model* m, int i, const float* sr
                      c->stream, src, h, w, VGG_CIN[i], (const _Float16*)m->conv_wh[i].p,                              \
                      (const _Float16*)m->conv_wl[i].p, m->conv_out_scale[i], co,                                      \
                      S > 1 ? (const float*)nullptr : (const float*)m->conv_b[i].p, cdst,                              \
-                     S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0), S > 1 ? 0 : pk)
+                     S > 1 ? 0 : (VGG_RELU[i] ? 1 : 0), S > 1 ? 0 : pk, himg)
 #define SF_CONV(TM_, TN_)                                                                                           \
   do {                                                                                                              \
     if (m->split_f16) {                                                                                             \
@@ -787,17 +789,17 @@ static int conv_split_rule(int P, int co) {
 // a pixel's sum, so the choice is invisible in the results) on the buffers it is about to use and keeps the fastest (HIP events, three
 // runs each; a few ms once per image size, synchronous).  The split-fp16 kernels are bound by the latency of their
 // operand fetches, where more, smaller workgroups often win, and a measurement is the honest way to choose.
-static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
+static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W, int n_stack, sf_netvlad_model::Tune& T) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (hipEventCreate(&e0) != hipSuccess) return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed");
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return sf_fail(c, SF_EHIP, "autotune: hipEventCreate failed"); }
-  int h = H, w = W, rc = SF_OK;
+  int h = H * n_stack, himg = H, w = W, rc = SF_OK;   // (a batch runs as a vertical stack of its images)
   const float* src = (const float*)m->act[0].p + CONV_ZERO_PAGE;
   float* dst = (float*)m->act[1].p + CONV_ZERO_PAGE;
   for (int i = 0; i < 13 && rc == SF_OK; ++i) {
     if (i > 0) {
-      const int P = h * w, co = VGG_COUT[i];
-      const int S = conv_split_rule(P, co);
+      const int co = VGG_COUT[i];
+      const int S = conv_split_rule(himg * w, co);      // (of ONE image's shape: a batch gives the bits of single calls)
       float best = 1e30f;
       ConvCfg pick = {64, 64, S, 32};
       for (int ck = 32; ck <= (m->split_f16 ? 64 : 32) && rc == SF_OK; ck *= 2)
@@ -805,11 +807,11 @@ static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
         for (int tn = 64; tn <= 128 && rc == SF_OK; tn *= 2) {
           if (co == 64 && tn == 128) continue;
           const ConvCfg cfg = {tm, tn, S, ck};
-          rc = conv_layer(c, m, i, src, h, w, dst, cfg);      // warm-up (and buffer growth)
+          rc = conv_layer(c, m, i, src, h, w, dst, cfg, himg);      // warm-up (and buffer growth)
           float t_min = 1e30f;
           for (int rep = 0; rep < 3 && rc == SF_OK; ++rep) {
             (void)hipEventRecord(e0, c->stream);
-            rc = conv_layer(c, m, i, src, h, w, dst, cfg);
+            rc = conv_layer(c, m, i, src, h, w, dst, cfg, himg);
             (void)hipEventRecord(e1, c->stream);
             if (rc == SF_OK && hipEventSynchronize(e1) != hipSuccess) rc = sf_fail(c, SF_EHIP, "autotune: event wait failed");
             float ms = 0.f;
@@ -818,13 +820,13 @@ static int conv_autotune(sf_context* c, sf_netvlad_model* m, int H, int W) {
           }
           if (rc == SF_OK && t_min < best) { best = t_min; pick = cfg; }
         }
-      m->cfg[i] = pick;
+      T.cfg[i] = pick;
     }
-    if (VGG_POOL[i]) { h /= 2; w /= 2; }
+    if (VGG_POOL[i]) { h /= 2; himg /= 2; w /= 2; }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (rc == SF_OK) { m->tuned_h = H; m->tuned_w = W; }
+  if (rc == SF_OK) { T.h = H; T.w = W; T.n = n_stack; }
   return rc;
 }
 
@@ -839,7 +841,16 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
   if (H < 16 || W < 16) return sf_fail(c, SF_ERANGE, "image of %d x %d is smaller than the four poolings need", W, H);
   if (n_out < 1 || n_out > m->pca_dim) return sf_fail(c, SF_ERANGE, "%d output dimensions of %d", n_out, m->pca_dim);
   int rc;
-  const size_t act_max = (size_t)H * W * 64;
+  const int K = m->clusters, D = 512;
+  const int group = std::min(n_img, 4);
+  // The trunk of a group runs as ONE vertical stack of its images (split-fp16 kernels; heights that survive the four
+  // poolings as whole rows): the late layers of a camera image have too few pixels to fill the chip (40 x 30 at conv5),
+  // a stack of three has three times the workgroups.  A tap never crosses from one image of the stack into the next
+  // (the kernels take the image height), the tap split is the single image's, tiles and K steps do not enter the sums:
+  // per image the results are the bits of the single-image call.
+  const bool stackable = m->split_f16 && (H % 16) == 0;
+  const int ns_max = stackable ? group : 1;
+  const size_t act_max = (size_t)ns_max * H * W * 64;
   // every activation buffer starts with a page of zeros: what k_conv_igemm_h reads for a tap outside the image
   for (int i = 0; i < 2; ++i) {
     if ((rc = sf_buf_reserve(c, m->act[i], (act_max + CONV_ZERO_PAGE) * sizeof(float))) != SF_OK) return rc;
@@ -849,20 +860,19 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
       m->act_zeroed_bytes[i] = m->act[i].bytes;
     }
   }
-  const int K = m->clusters, D = 512;
-  const int group = std::min(n_img, 4);
   const int y_pitch = std::max(m->pca_dim, 64);
   if ((rc = sf_buf_reserve(c, m->vlad, (size_t)group * D * K * sizeof(float))) != SF_OK) return rc;
   if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)group * y_pitch * sizeof(float))) != SF_OK) return rc;
-  if (m->tuned_h != H || m->tuned_w != W) {
-    if ((rc = conv_autotune(c, m, H, W)) != SF_OK) return rc;
-  }
   for (int g0 = 0; g0 < n_img; g0 += group) {
     const int gb = std::min(group, n_img - g0);
-    for (int b = 0; b < gb; ++b) {
-      const float* d_image = d_images + (size_t)(g0 + b) * H * W * 3;
-      float* vlad = (float*)m->vlad.p + (size_t)b * D * K;
-      int h = H, w = W, cur = 0;
+    const int ns = (stackable && gb > 1) ? gb : 1;          // images per pass of the trunk
+    sf_netvlad_model::Tune& T = m->tune[ns == 1 ? 0 : 1];
+    if (T.h != H || T.w != W || T.n != ns) {
+      if ((rc = conv_autotune(c, m, H, W, ns, T)) != SF_OK) return rc;
+    }
+    for (int b0 = 0; b0 < gb; b0 += ns) {
+      const float* d_image = d_images + (size_t)(g0 + b0) * H * W * 3;
+      int h = H * ns, himg = H, w = W, cur = 0;
       const float* src = d_image;
       for (int i = 0; i < 13; ++i) {
         float* dst = (float*)m->act[cur].p + CONV_ZERO_PAGE;
@@ -870,9 +880,9 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
         if (i == 0) {
           hipLaunchKernelGGL(k_conv3x3_first, dim3((unsigned)(((size_t)P * 4 + 255) / 256)), dim3(256), 0, c->stream, src, h, w,
                              (const float*)m->conv_w[0].p, (const float*)m->conv_b[0].p, (const float*)m->mean.p, dst,
-                             VGG_RELU[0] ? 1 : 0, m->split_f16 ? 1 : 0);
+                             VGG_RELU[0] ? 1 : 0, m->split_f16 ? 1 : 0, himg);
         } else {
-          if ((rc = conv_layer(c, m, i, src, h, w, dst, m->cfg[i])) != SF_OK) return rc;
+          if ((rc = conv_layer(c, m, i, src, h, w, dst, T.cfg[i], himg)) != SF_OK) return rc;
         }
         src = dst;
         cur ^= 1;
@@ -881,24 +891,28 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
           const size_t n = (size_t)(h / 2) * (w / 2) * (VGG_COUT[i] / 4);
           hipLaunchKernelGGL(k_pool2_relu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, h, w, VGG_COUT[i], pd,
                              m->split_f16 ? 1 : 0);
-          h /= 2; w /= 2;
+          h /= 2; himg /= 2; w /= 2;
           src = pd;
           cur ^= 1;
         }
       }
-      // src = conv5_3 output [h][w][512] (in act[cur ^ 1]); normalise in place, assignment into act[cur]
-      const int P = h * w;
-      float* x = const_cast<float*>(src);
-      float* a = (float*)m->act[cur].p + CONV_ZERO_PAGE;
-      float* norms = (float*)m->pca_y.p + (size_t)b * y_pitch;                     // (the slot doubles as the K norms)
-      hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
-      hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, h, w, D,
-                         (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
-      hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
-      hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 2), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
-                         (const float*)m->centers.p, P, D, K, vlad);
-      hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)vlad, D, K, norms);
-      hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(1024), 0, c->stream, vlad, D, K, (const float*)norms);
+      // src = conv5_3 output of the stack [ns][himg][w][512] (in act[cur ^ 1]); per image: normalise in place, assignment
+      // into act[cur], aggregation
+      const int P = himg * w;
+      for (int j = 0; j < ns; ++j) {
+        float* vlad = (float*)m->vlad.p + (size_t)(b0 + j) * D * K;
+        float* x = const_cast<float*>(src) + (size_t)j * P * D;
+        float* a = (float*)m->act[cur].p + CONV_ZERO_PAGE;
+        float* norms = (float*)m->pca_y.p + (size_t)(b0 + j) * y_pitch;                     // (the slot doubles as the K norms)
+        hipLaunchKernelGGL(k_l2norm_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, x, P, D);
+        hipLaunchKernelGGL((k_conv_igemm<1, 64, 64>), dim3((P + 63) / 64, (K + 63) / 64), dim3(256), 0, c->stream, (const float*)x, himg, w, D,
+                           (const float*)m->assign_w.p, K, (const float*)nullptr, a, 0);
+        hipLaunchKernelGGL(k_softmax_rows, dim3((P + 3) / 4), dim3(256), 0, c->stream, a, P, K);
+        hipLaunchKernelGGL(k_vlad_aggregate, dim3(D / 2), dim3(256), 0, c->stream, (const float*)x, (const float*)a,
+                           (const float*)m->centers.p, P, D, K, vlad);
+        hipLaunchKernelGGL(k_vlad_cluster_norms, dim3(K), dim3(256), 0, c->stream, (const float*)vlad, D, K, norms);
+        hipLaunchKernelGGL(k_vlad_normalize, dim3(1), dim3(1024), 0, c->stream, vlad, D, K, (const float*)norms);
+      }
     }
     const dim3 wg((m->pca_dim + 3) / 4);
     const float* V = (const float*)m->vlad.p;

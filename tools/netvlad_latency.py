@@ -1,7 +1,9 @@
 """Time of one NetVLAD descriptor inference (csrc/k_cnn.hip) on a 640 x 480 RGB image with the reference's network size
 (64 clusters, 4096-D WPCA; random weights), per kernel through rocprofv3 if run under it, else wall time over `reps`.
 FLOPs of the VGG16 trunk at H x W: 2 * sum(9 Cin Cout H_l W_l).
-usage: python tools/netvlad_latency.py [width=640] [height=480] [reps=20] [pca_dim=4096]"""
+usage: python tools/netvlad_latency.py [width=640] [height=480] [reps=20] [pca_dim=4096] [batch=0]
+(batch > 0: also the time per image of sf_netvlad_infer_batch_device on `batch` images, and whether its rows are the
+bits of the single-image calls)"""
 import os
 import sys
 
@@ -17,6 +19,7 @@ def main():
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 480
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     pca = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     rng = np.random.default_rng(0)
     w = {"conv_kernel": [], "conv_bias": []}
     for ci, co in _abi.VGG16_CONVS:
@@ -51,6 +54,24 @@ def main():
             h, ww = h // 2, ww // 2
     print("%d x %d, WPCA %d: %.3f ms per image; VGG16 trunk %.1f GFLOP -> %.1f TFLOP/s over the whole call "
           "(fp32 matrix-core peak 157.3)" % (W, H, pca, ms, flops / 1e9, flops / (ms * 1e-3) / 1e12))
+    if batch > 0:
+        imgs = torch.from_numpy(rng.uniform(0, 255, size=(batch, H, W, 3)).astype(np.float32)).to(dev)
+        outs = torch.zeros(batch, pca, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            f.netvlad_infer_batch_device(imgs.data_ptr(), batch, W, H, outs.data_ptr(), pca)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            f.netvlad_infer_batch_device(imgs.data_ptr(), batch, W, H, outs.data_ptr(), pca)
+        e1.record()
+        torch.cuda.synchronize()
+        msb = e0.elapsed_time(e1) / reps / batch
+        single = torch.zeros(batch, pca, dtype=torch.float32, device=dev)
+        for b in range(batch):
+            f.netvlad_infer_device(imgs[b].data_ptr(), W, H, single[b].data_ptr(), pca)
+        torch.cuda.synchronize()
+        print("batch of %d: %.3f ms per image; rows equal the single-image calls bit for bit: %s"
+              % (batch, msb, bool(torch.equal(outs, single))))
     f.close()
 
 
