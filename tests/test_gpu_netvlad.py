@@ -67,15 +67,18 @@ def test_batch_equals_single_images(model):
     f, w = model
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(11)
-    for n_img in (3, 5):
-        imgs = rng.uniform(0, 255, size=(n_img, 120, 160, 3)).astype(np.float32)
-        d_imgs = torch.from_numpy(imgs).to(dev)
-        d_out = torch.zeros((n_img, 128), dtype=torch.float32, device=dev)
-        f.netvlad_infer_batch_device(d_imgs.data_ptr(), n_img, 160, 120, d_out.data_ptr(), 128)
-        torch.cuda.synchronize()
-        got = d_out.cpu().numpy()
-        for i in range(n_img):
-            assert np.array_equal(got[i], infer(f, torch, imgs[i], 128)), i
+    # heights that are a multiple of 16 run the trunk of a group as ONE vertical stack of its images (a tap must not see
+    # the neighbouring image's rows); the others image by image
+    for height, width, sizes in ((120, 160, (3, 5)), (128, 160, (2, 3, 4, 5)), (96, 64, (3,)), (16, 48, (4,))):
+        for n_img in sizes:
+            imgs = rng.uniform(0, 255, size=(n_img, height, width, 3)).astype(np.float32)
+            d_imgs = torch.from_numpy(imgs).to(dev)
+            d_out = torch.zeros((n_img, 128), dtype=torch.float32, device=dev)
+            f.netvlad_infer_batch_device(d_imgs.data_ptr(), n_img, width, height, d_out.data_ptr(), 128)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy()
+            for i in range(n_img):
+                assert np.array_equal(got[i], infer(f, torch, imgs[i], 128)), (height, width, n_img, i)
 
 
 def test_published_wpca_width_at_camera_resolution():
