@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """NN-stage soak: random database sizes, dimensions, thresholds, masks, ignored pairs and incremental
-appends; the matches of both GPU paths (fp16 filter and fp32 ranking) must equal the oracle's."""
+appends; the matches of both GPU paths (fp16 filter and fp32 ranking) must equal the oracle's.
+usage: tools/soak_nn.py [rounds=50] [n_max=500]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_robot_slam_separators_amd import lib, _abi
 from oracle import pyoracle
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+n_max = int(sys.argv[2]) if len(sys.argv) > 2 else 500      # database sizes are drawn from [1, n_max)
 t0 = time.time(); nq = 0
 for rd in range(rounds):
     rng = np.random.default_rng(7000 + rd)
     dim = int(rng.choice([8, 33, 100, 128, 512, 1100, 2048, 4096]))
-    n_l, n_r = int(rng.integers(1, 500)), int(rng.integers(1, 500))
+    n_l, n_r = int(rng.integers(1, n_max)), int(rng.integers(1, n_max))
     scale = float(rng.choice([1.0, 0.2, 30.0]))
     a = rng.normal(size=(n_l, dim)); a /= np.linalg.norm(a, axis=1, keepdims=True); a *= scale
     b = rng.normal(size=(n_r, dim)); b /= np.linalg.norm(b, axis=1, keepdims=True); b *= scale
