@@ -848,8 +848,14 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
   // a stack of three has three times the workgroups.  A tap never crosses from one image of the stack into the next
   // (the kernels take the image height), the tap split is the single image's, tiles and K steps do not enter the sums:
   // per image the results are the bits of the single-image call.
+  // (k_conv_igemm_h addresses its input with 32-bit byte offsets: the largest activation tensor of a pass, 64 channels at
+  //  full resolution, has to stay under 4 GB -- 16 Mpixel for a single image; a stack is cut down to what fits)
+  const size_t img_bytes = (size_t)H * W * 64 * sizeof(float);
+  const size_t off_limit = ((size_t)1 << 32) - 2 * CONV_ZERO_PAGE * sizeof(float);
+  if (m->split_f16 && img_bytes > off_limit)
+    return sf_fail(c, SF_ERANGE, "image of %d x %d is beyond the 32-bit activation offsets of the split-fp16 trunk", W, H);
   const bool stackable = m->split_f16 && (H % 16) == 0;
-  const int ns_max = stackable ? group : 1;
+  const int ns_max = stackable ? (int)std::max<size_t>(1, std::min<size_t>((size_t)group, off_limit / img_bytes)) : 1;
   const size_t act_max = (size_t)ns_max * H * W * 64;
   // every activation buffer starts with a page of zeros: what k_conv_igemm_h reads for a tap outside the image
   for (int i = 0; i < 2; ++i) {
@@ -865,7 +871,8 @@ int sf_netvlad_infer_batch_impl(sf_context* c, const float* d_images, int n_img,
   if ((rc = sf_buf_reserve(c, m->pca_y, (size_t)group * y_pitch * sizeof(float))) != SF_OK) return rc;
   for (int g0 = 0; g0 < n_img; g0 += group) {
     const int gb = std::min(group, n_img - g0);
-    const int ns = (stackable && gb > 1) ? gb : 1;          // images per pass of the trunk
+    int ns = (stackable && gb > 1) ? std::min(gb, ns_max) : 1;          // images per pass of the trunk
+    if (gb % ns != 0) ns = 1;                                          // (a stack cut down by the offset limit: whole passes only)
     sf_netvlad_model::Tune& T = m->tune[ns == 1 ? 0 : 1];
     if (T.h != H || T.w != W || T.n != ns) {
       if ((rc = conv_autotune(c, m, H, W, ns, T)) != SF_OK) return rc;
