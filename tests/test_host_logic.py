@@ -89,6 +89,22 @@ def test_product_never_imports_the_oracle():
     assert "oracle" not in hdr.lower()
 
 
+def test_kernels_use_no_half_rate_matrix_opcodes():
+    """gfx950 keeps the CDNA3-era fp16 / bf16 / int8 MFMA opcodes at their old cycle count, i.e. at HALF the rate of their
+    CDNA4 successors with twice the K (tools/ubench/mfma_f16_rate.hip: v_mfma_f32_32x32x8_f16 32.2 cycles against 32.4 for
+    v_mfma_f32_32x32x16_f16; the bf16 and int8 forms are listed by the same rule, "2 x K over CDNA3", unmeasured here); round
+    2's convolution kernel sat on one for a whole round.  No kernel source may use them."""
+    half_rate = ("mfma_f32_32x32x8f16", "mfma_f32_16x16x16f16", "mfma_f32_32x32x8bf16_1k", "mfma_f32_16x16x16bf16_1k",
+                 "mfma_f32_32x32x4bf16", "mfma_f32_16x16x8bf16", "mfma_i32_32x32x16_i8", "mfma_i32_16x16x32_i8",
+                 "mfma_i32_32x32x8i8", "mfma_i32_16x16x16i8")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "multi_robot_slam_separators_amd", "csrc")):
+        for fn in files:
+            if fn.endswith((".hip", ".hpp")):
+                for ln, line in enumerate(open(os.path.join(dirpath, fn)), 1):
+                    code = line.split("//")[0]
+                    assert not any("__builtin_amdgcn_" + h in code for h in half_rate), (fn, ln, line.strip())
+
+
 def test_pack_separators_rows():
     from multi_robot_slam_separators_amd import lib
     res = np.zeros(3, dtype=_abi.RESULT_DTYPE)
