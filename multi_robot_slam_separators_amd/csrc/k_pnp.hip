@@ -170,30 +170,53 @@ __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const u
   double* cand = L.ne_b;
   pnp_normal_eq(L, cam, m, mask, q, t, cur, tid);
   double lambda = 1e-3;
+  // The damped 6 x 6 solve and the candidate pose are a short scalar computation on the reduced sums: ONE wavefront
+  // does it and hands the candidate over through L.red (free between two reductions); round 2 had all four wavefronts
+  // issue the same ~300 fp64 instructions per evaluation, on all four SIMDs of the CU the chain shares with two others.
+  const int lm_wave = tid >> 6, lm_lane = tid & 63;
   for (int iter = 0; iter < 20; ++iter) {
-    double d[6];
-    if (!sfd::solve6(cur, lambda, d)) {
+    if (lm_wave == 0) {
+      double d[6];
+      const bool ok = sfd::solve6(cur, lambda, d);
+      double qc0[4], tc0[3], dd0 = 0.0, tt0 = 0.0;
+      if (ok) {
+        const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
+        const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
+        const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
+        qc0[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
+        qc0[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
+        qc0[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
+        qc0[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
+        const double qn = 1.0 / sqrt(((qc0[0] * qc0[0] + qc0[1] * qc0[1]) + qc0[2] * qc0[2]) + qc0[3] * qc0[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qc0[i] = qc0[i] * qn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tc0[i] = t[i] + d[3 + i];
+        // a step below float epsilon relative to the parameters ends the iteration either way
+        dd0 = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
+        tt0 = ((tc0[0] * tc0[0] + tc0[1] * tc0[1]) + tc0[2] * tc0[2]) + 1.0;
+      }
+      if (lm_lane == 0) {
+        L.red[0] = ok ? 1.0 : 0.0;
+        if (ok) {
+          L.red[1] = qc0[0]; L.red[2] = qc0[1]; L.red[3] = qc0[2]; L.red[4] = qc0[3];
+          L.red[5] = tc0[0]; L.red[6] = tc0[1]; L.red[7] = tc0[2];
+          L.red[8] = dd0; L.red[9] = tt0;
+        }
+      }
+    }
+    __syncthreads();
+    if (L.red[0] == 0.0) {                       // (uniform: the factorisation failed at this damping)
+      __syncthreads();                           // every wavefront has read the flag before the next hand-over
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
       continue;
     }
-    const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
-    const double dn = 1.0 / sqrt(((hx * hx + hy * hy) + hz * hz) + 1.0);
-    const double dw = dn, dx = hx * dn, dy = hy * dn, dz = hz * dn;
     double qc[4], tc[3];
-    qc[0] = ((dw * q[0] - dx * q[1]) - dy * q[2]) - dz * q[3];
-    qc[1] = ((dw * q[1] + dx * q[0]) + dy * q[3]) - dz * q[2];
-    qc[2] = ((dw * q[2] - dx * q[3]) + dy * q[0]) + dz * q[1];
-    qc[3] = ((dw * q[3] + dx * q[2]) - dy * q[1]) + dz * q[0];
-    const double qn = 1.0 / sqrt(((qc[0] * qc[0] + qc[1] * qc[1]) + qc[2] * qc[2]) + qc[3] * qc[3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
-    pnp_normal_eq(L, cam, m, mask, qc, tc, cand, tid);
-    // a step below float epsilon relative to the parameters ends the iteration either way
-    const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
-    const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
+    qc[0] = L.red[1]; qc[1] = L.red[2]; qc[2] = L.red[3]; qc[3] = L.red[4];
+    tc[0] = L.red[5]; tc[1] = L.red[6]; tc[2] = L.red[7];
+    const double dd = L.red[8], tt = L.red[9];
+    pnp_normal_eq(L, cam, m, mask, qc, tc, cand, tid);     // (its first barrier: the hand-over has been read by everyone)
     if (cand[27] < cur[27]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) q[i] = qc[i];
