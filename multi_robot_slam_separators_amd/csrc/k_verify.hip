@@ -93,8 +93,11 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
   }
 }
 
-template <int W, int NQ, bool BA>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
+// WIDE: the instantiation for frames whose LDS working set leaves room for at most two workgroups per CU anyway
+// (K = 1000 features: 60 KB for the guided pass): compiled for two workgroups per CU, i.e. 256 registers, it keeps FOUR
+// resident "to" tiles per wavefront in the scan (one spread of a "from" tile per four tiles instead of per two).
+template <int W, int NQ, bool BA, bool WIDE = false>
+__global__ void __launch_bounds__(SF_BLOCK, (BA || WIDE) ? 2 : 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
                uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
@@ -122,7 +125,7 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;        // RANSAC / guided working set behind it
   SF_TRACE_MARK(P, pair, 0);
   // pass 1: global matching (myRegistrationVis.cpp:826-895) and, for survivors, RANSAC (:1113-1152)
-  const bool est1 = match_v2_body<W, NQ, SF_BLOCK>(st, pair, sF, sT, P.nndr, P.min_inliers, 0, cl, T.hdr1, T.pass1,
+  const bool est1 = match_v2_body<W, NQ, SF_BLOCK, WIDE ? 4 : 2>(st, pair, sF, sT, P.nndr, P.min_inliers, 0, cl, T.hdr1, T.pass1,
                                                    nullptr, nullptr, reinterpret_cast<int*>(smem_raw),
                                                    P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
   __syncthreads();   // list / header / pass-1 defaults visible to the whole workgroup
@@ -193,16 +196,16 @@ k_chain(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __re
   chain_after_match<W, BA>(st, pair, sF, sT, true, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P);
 }
 
-template <int W, int NQ, bool BA>
+template <int W, int NQ, bool BA, bool WIDE = false>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds, int tail_off) {
-  bool& attr_set = c->fused_attr[W == 16][NQ == 0][BA];   // one flag per instantiation
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0][BA || WIDE];   // one flag per instantiation (WIDE only without BA)
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, BA>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, BA, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_verify_fused<W, NQ, BA>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_verify_fused<W, NQ, BA, WIDE>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
                      (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams,
                      tail_off, c->pair_src);
@@ -246,6 +249,12 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
 #define SF_FUSED_CASE(W_, NQ_)                                                               \
   rc = ba ? launch_fused<W_, NQ_, true>(c, st, d_from, d_to, n, d_out, lds, tail_off)         \
           : launch_fused<W_, NQ_, false>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+  // more than a third of a CU's LDS per workgroup: at most two fit, so the 256-register build with four resident tiles
+  static const bool wide_off = getenv("SF_FUSED_WIDE_OFF") != nullptr;      // (A/B runs)
+  static const bool wide_all = getenv("SF_FUSED_WIDE_ALL") != nullptr;    // (experiment: the wide build for every shape)
+  if (mf && !ba && st.w == 8 && (lds * 3 > 160 * 1024 || wide_all) && !wide_off)
+    rc = launch_fused<8, 0, false, true>(c, st, d_from, d_to, n, d_out, lds, tail_off);
+  else
   if (mf) { if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0); }
   else { if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2); }
 #undef SF_FUSED_CASE
