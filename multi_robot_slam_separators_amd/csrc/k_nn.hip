@@ -1142,13 +1142,18 @@ static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdim
       }
       const int strips = std::max(1, std::min(gx, (2 * c->cu_count) / std::max(1, gy)));
       const int tps = (gx + strips - 1) / strips;
-      static const int k128_abl = getenv("SF_NN_K128_ABL") ? atoi(getenv("SF_NN_K128_ABL")) : 0;   // timing-only forms
       static const bool k128_lds_panel = getenv("SF_NN_K128_LDS_PANEL") != nullptr;   // (round-2 form, for A/B runs)
-      // bit 0: no hit scan, bit 1: no LDS operand reads, bit 2: no DMA of the next tile, bit 3: no tile loop, bit 4: no prologue DMA
+#ifdef SF_NN_ABLATION
+      // timing-only forms (make NN_ABLATION=1; tools/nn_filter_time.py): bit 0 no hit scan, bit 1 no LDS operand reads,
+      // bit 2 no DMA of the next tile, bit 3 no tile loop, bit 4 no prologue DMA -- never compiled into the product build
+      static const int k128_abl = getenv("SF_NN_K128_ABL") ? atoi(getenv("SF_NN_K128_ABL")) : 0;
       auto kern = k128_abl == 1 ? k_nn_filter_f16_k128r<1> : k128_abl == 3 ? k_nn_filter_f16_k128r<3>
                   : k128_abl == 5 ? k_nn_filter_f16_k128r<5> : k128_abl == 7 ? k_nn_filter_f16_k128r<7>
                   : k128_abl == 8 ? k_nn_filter_f16_k128r<8> : k128_abl == 24 ? k_nn_filter_f16_k128r<24>
                   : k_nn_filter_f16_k128r<0>;
+#else
+      auto kern = k_nn_filter_f16_k128r<0>;
+#endif
       if (!c->nn_k128_attr) {
         SF_HIP(c, hipFuncSetAttribute((const void*)k_nn_filter_f16_k128, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       NN_K128_LDS));

@@ -4,7 +4,8 @@ N x N x 4096 unit rows with 20 % planted neighbours, the shape of BASELINE confi
 
 usage: tools/nn_filter_time.py [N] [reps] [full]
   full = 1: SF_OPT_NN_FULL_FILTER (the prefix ladder forced to the whole descriptor)
-Environment (timing experiments of k_nn.hip): SF_NN_K128_LDS_PANEL=1 (round-2 kernel), SF_NN_K128_ABL=1|3|5|7|8|24
+Environment (timing experiments of k_nn.hip): SF_NN_K128_LDS_PANEL=1 (round-2 kernel); with a library built by
+`make -C multi_robot_slam_separators_amd/csrc NN_ABLATION=1` (touch k_nn.hip first) also SF_NN_K128_ABL=1|3|5|7|8|24
 (bit 0 no hit scan, bit 1 no LDS reads, bit 2 no next-tile DMA, bit 3 no tile loop, bit 4 no prologue DMA: timing
 only, results are wrong)."""
 import os, sys
