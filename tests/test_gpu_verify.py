@@ -196,6 +196,50 @@ def test_octave_and_window_semantics(finder, oracle):
     assert np.array_equal(g2[0], c2[0]) and np.array_equal(g2[1], c2[1])
 
 
+@pytest.mark.parametrize("k", [300, 900])
+def test_guided_pass_with_more_candidates_than_its_list_holds(oracle, k):
+    """Every feature of both frames inside a 40-pixel spot: each projected point of the guess-guided pass has (almost)
+    every keypoint of the other frame inside its window -- tens of thousands of (from, to) combinations against the 2 048
+    the candidate-parallel search can record, so the per-lane search answers.  Same correspondences, same result."""
+    rng = np.random.default_rng(500 + k)
+
+    def narrow(f):
+        xyz = f.xyz.copy()
+        xyz[:, 1] *= 0.06
+        xyz[:, 2] *= 0.06                                   # (base frame: x forward) -> projections within ~20 px of the centre
+        u, v = synth.project_base_points(xyz)
+        kp = f.kpts.copy()
+        kp["x"], kp["y"] = u, v
+        return _abi.FeatureArrays(f.desc, xyz, kp)
+
+    a = narrow(synth.make_keyframe(rng, k))
+    T = synth.random_transform(rng, 0.5, 0.03)
+    b, _ = synth.make_true_partner(rng, a, T, overlap=0.7, noise=0.002, flip=0.02)
+    far = np.abs(b.kpts["x"] - synth.CX) > 40.0             # the partner's NEW points come from the whole image: squeeze them too
+    xyz = b.xyz.copy()
+    xyz[far, 1] *= 0.06
+    xyz[far, 2] *= 0.06
+    u, v = synth.project_base_points(xyz)
+    kp = b.kpts.copy()
+    kp["x"], kp["y"] = u, v
+    b = _abi.FeatureArrays(b.desc, xyz, kp)
+    # (the guess moves a projection by a few pixels at most: pairs within 12 px of each other are inside the 20 px window)
+    du = a.kpts["x"][:, None] - b.kpts["x"][None, :]
+    dv = a.kpts["y"][:, None] - b.kpts["y"][None, :]
+    assert int((du * du + dv * dv < 12.0 ** 2).sum()) > 4 * 2048
+    from multi_robot_slam_separators_amd import lib
+    p = synth.camera_params()
+    p.iterations = 300
+    with lib.SeparatorFinder(p) as f:
+        f.set_option(_abi.SF_OPT_DEBUG_CORR, 1)
+        got = f.estimate_transform(a, b)
+        o, c1, c2 = oracle.estimate_transform(f.params, a, b, debug=True)
+        assert_result_parity(got, o, "spot %d" % k)
+        g2 = f.debug_correspondences(0, 2)
+        assert np.array_equal(g2[0], c2[0]) and np.array_equal(g2[1], c2[1])
+        assert len(c2[0]) > 0                                # the guided pass ran and matched
+
+
 def test_size_independent_properties_full_config(finder):
     """BASELINE configs[1] sizes (K=500, 256-bit, 500 iterations) on a larger batch: properties that
     need no oracle -- planted transforms recovered, false pairs rejected, batch order irrelevant."""
