@@ -64,20 +64,23 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   int* misc = smem + 2 * kcap;     // [16]
   const int NC = P.grid_gx * P.grid_gy;
   int* cell_start = misc + 16;     // [NC + 1] CSR of "to" keypoints bucketed on a uniform grid
-  int* cell_fill = cell_start + NC + 1;   // [NC]
+  // [NC] fill counters of the bucketing: only alive until the keypoints are in their cells, so they live in `matched`
+  // (written by the decisions at the very end) when that is large enough -- round 3: the guided pass sizes the fused
+  // kernel's LDS, and K = 1000 frames were 10 KB over what lets three workgroups share a CU
+  const bool fill_in_matched = NC <= kcap;
+  int* cell_fill = fill_in_matched ? matched : cell_start + NC + 1;
   // [kcap] the "to" keypoints grouped by cell as {x, y, octave bits, index bits}: the window test never leaves
   // LDS and takes ONE 16-byte read per entry
   // (the 16-byte alignment is done on the int INDEX: rounding the pointer through uintptr_t, as round 1 did, hid the
   //  LDS address space from the compiler and turned every access behind it -- the window tests' entry reads, the
   //  key atomics -- into FLAT instructions)
-  float4* item4 = reinterpret_cast<float4*>(smem + ((2 * kcap + 16 + 2 * NC + 1 + 3) & ~3));
-  float2* proj = reinterpret_cast<float2*>(item4 + kcap);        // [kcap] projection of each "from" point (NaN: not searched)
-  uint32_t* oilast = reinterpret_cast<uint32_t*>(proj + kcap);   // [kcap] candidates of the point << 16 | highest one
+  float4* item4 = reinterpret_cast<float4*>(smem + ((2 * kcap + 16 + NC + 1 + (fill_in_matched ? 0 : NC) + 3) & ~3));
+  // (a point's projection is not kept: the per-lane search behind a candidate-list overflow recomputes it)
+  uint32_t* oilast = reinterpret_cast<uint32_t*>(item4 + kcap);  // [kcap] candidates of the point << 16 | highest one
   uint32_t* key1 = oilast + kcap;                                // [kcap] best (Hamming << 16 | to) of the point
   uint32_t* key2 = key1 + kcap;                                  // [kcap] second best
   uint32_t* cand = key2 + kcap;                                  // [GUIDED_CPT * 256] recorded combinations (from << 16 | to)
   for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
-  for (int i = tid; i < Kf; i += NT) matched[i] = -1;
   for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
   for (int i = tid; i < NC; i += NT) cell_fill[i] = 0;
   if (tid < 16) misc[tid] = 0;
@@ -140,7 +143,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   // in LDS for the second bucketing pass -- the region is the search's scratch, unused until then) and the first
   // 512 "from" points with their octaves (kept in registers until the search).  Round 1 re-read the keypoints from
   // HBM for the fill pass and loaded the "from" points inside the search loop.
-  float4* raw = reinterpret_cast<float4*>(proj);        // [kcap] (aliases proj / oilast / key1 / key2 / cand)
+  float4* raw = reinterpret_cast<float4*>(oilast);      // [kcap] (aliases oilast / key1 / key2 / cand: 3 kcap + 2048 words >= 4 kcap)
   float pre_x[2], pre_y[2], pre_z[2];
   int pre_o[2];
 #pragma unroll
@@ -232,10 +235,24 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     for (int c0 = tid; c0 < NC; c0 += NT) short_cells += (cell_fill[c0] != cell_start[c0 + 1] - cell_start[c0]) ? 1 : 0;
     if (short_cells) atomicAdd(&P.dbg_trace[0], (unsigned long long)short_cells);
     if (tid == 0) atomicAdd(&P.dbg_trace[1], 1ull);
+    __syncthreads();                                       // (the counters are about to be overwritten)
   }
 #endif
+  for (int i = tid; i < Kf; i += NT) matched[i] = -1;      // (the fill counters are dead; ordered before the decisions by
+                                                          //  the barrier behind the search's first pass)
   int n_finite = 0, n_proj = 0;
   const int cand_cap = GUIDED_CPT * NT;
+  // projection of a finite "from" point with the guess (:503-512): pixel position and "inside the image, in front"
+  auto project = [&](float x, float y, float z, float& u, float& v) -> bool {
+    const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
+    const double X = (((double)Rc[0] * (double)x + (double)Rc[1] * (double)y) + (double)Rc[2] * (double)z) + (double)tc[0];
+    const double Y = (((double)Rc[3] * (double)x + (double)Rc[4] * (double)y) + (double)Rc[5] * (double)z) + (double)tc[1];
+    const double Z = (((double)Rc[6] * (double)x + (double)Rc[7] * (double)y) + (double)Rc[8] * (double)z) + (double)tc[2];
+    const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;
+    u = (float)((X * iz) * P.fx + P.cx);
+    v = (float)((Y * iz) * P.fy + P.cy);
+    return isfinite(u) && isfinite(v) && !(u < 0.f) && !(u >= P.wlim) && !(v < 0.f) && !(v >= P.hlim) && (zf > 0.f);
+  };
   // pass A: projections, per-point candidate count / highest candidate (:751-764 needs it), candidate list
   for (int base = 0; base < Kf; base += NT) {
     const int i = base + tid;
@@ -254,15 +271,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     if (i < Kf) {
       if (sfd::finite3(x, y, z)) {
         ++n_finite;
-        const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
-        const double X = (((double)Rc[0] * (double)x + (double)Rc[1] * (double)y) + (double)Rc[2] * (double)z) + (double)tc[0];
-        const double Y = (((double)Rc[3] * (double)x + (double)Rc[4] * (double)y) + (double)Rc[5] * (double)z) + (double)tc[1];
-        const double Z = (((double)Rc[6] * (double)x + (double)Rc[7] * (double)y) + (double)Rc[8] * (double)z) + (double)tc[2];
-        const double iz = (Z != 0.0) ? 1.0 / Z : 1.0;
-        u = (float)((X * iz) * P.fx + P.cx);
-        v = (float)((Y * iz) * P.fy + P.cy);
-        inimg = isfinite(u) && isfinite(v) && !(u < 0.f) && !(u >= P.wlim) && !(v < 0.f) && !(v >= P.hlim) &&
-                (zf > 0.f);
+        inimg = project(x, y, z, u, v);
       }
     }
     // Window / octave tests of this lane's point against the 3x3 cells around its projection.  Combinations that
@@ -357,7 +366,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     }
 #endif
     if (i < Kf) {
-      proj[i] = make_float2(inimg ? u : __int_as_float(0x7FC00000), v);   // NaN u = "not searched"
       oilast[i] = ((uint32_t)min(oi, 0xFFFF) << 16) | (uint32_t)(last & 0xFFFF);
       key1[i] = 0xFFFFFFFFu;
       key2[i] = 0xFFFFFFFFu;
@@ -430,9 +438,9 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   } else {
     // more combinations than the list holds: the per-lane loop (same tests, same keys)
     for (int i = tid; i < Kf; i += NT) {
-      const float2 pr = proj[i];
-      if (!(pr.x == pr.x)) continue;
-      const float u = pr.x, v = pr.y;
+      const float px = xF[3 * i], py = xF[3 * i + 1], pz = xF[3 * i + 2];
+      float u = 0.f, v = 0.f;
+      if (!sfd::finite3(px, py, pz) || !project(px, py, pz, u, v)) continue;     // not searched
       const int octf = __float_as_int(kF[i].z);
       uint32_t q[W];
       {
@@ -660,7 +668,10 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 size_t sf_guided_lds_bytes(int kcap, int n_cells) {
   // claim, matched, misc, cell_start, cell_fill, (+3: 16-byte alignment of the item block) item4, then the search's
   // projections (2), candidate summaries, best / second-best keys (3) and the combination list
-  return (size_t)(6 * kcap + 16 + 2 * n_cells + 1 + 3 + 5 * kcap + GUIDED_CPT * SF_BLOCK) * sizeof(int);
+  // claim, matched, misc, cell_start (the fill counters live in `matched` when they fit), alignment, item4, candidate
+  // summaries, best / second-best keys and the combination list
+  return (size_t)(2 * kcap + 16 + n_cells + 1 + (n_cells <= kcap ? 0 : n_cells) + 3 + 4 * kcap + 3 * kcap +
+                  GUIDED_CPT * SF_BLOCK + (kcap > 2048 ? kcap - 2048 : 0)) * sizeof(int);   // (+ the raw keypoints' overhang)
 }
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {

@@ -93,9 +93,9 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
   }
 }
 
-// WIDE: the instantiation for frames whose LDS working set leaves room for at most two workgroups per CU anyway
-// (K = 1000 features: 60 KB for the guided pass): compiled for two workgroups per CU, i.e. 256 registers, it keeps FOUR
-// resident "to" tiles per wavefront in the scan (one spread of a "from" tile per four tiles instead of per two).
+// WIDE: the instantiation for frames whose LDS working set does not let four workgroups share a CU anyway (K = 1000
+// features: 52 KB, three per CU): compiled for two workgroups per CU it takes 162 registers -- three still fit -- and
+// keeps FOUR resident "to" tiles per wavefront in the scan (one spread of a "from" tile per four tiles instead of two).
 template <int W, int NQ, bool BA, bool WIDE = false>
 __global__ void __launch_bounds__(SF_BLOCK, (BA || WIDE) ? 2 : 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
@@ -249,10 +249,11 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
 #define SF_FUSED_CASE(W_, NQ_)                                                               \
   rc = ba ? launch_fused<W_, NQ_, true>(c, st, d_from, d_to, n, d_out, lds, tail_off)         \
           : launch_fused<W_, NQ_, false>(c, st, d_from, d_to, n, d_out, lds, tail_off)
-  // more than a third of a CU's LDS per workgroup: at most two fit, so the 256-register build with four resident tiles
+  // more than a quarter of a CU's LDS per workgroup: four do not fit, so the build for fewer workgroups (162 registers:
+  // up to three per CU) with four resident tiles
   static const bool wide_off = getenv("SF_FUSED_WIDE_OFF") != nullptr;      // (A/B runs)
   static const bool wide_all = getenv("SF_FUSED_WIDE_ALL") != nullptr;    // (experiment: the wide build for every shape)
-  if (mf && !ba && st.w == 8 && (lds * 3 > 160 * 1024 || wide_all) && !wide_off)
+  if (mf && !ba && st.w == 8 && (lds * 4 > 160 * 1024 || wide_all) && !wide_off)
     rc = launch_fused<8, 0, false, true>(c, st, d_from, d_to, n, d_out, lds, tail_off);
   else
   if (mf) { if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0); }
