@@ -78,7 +78,7 @@ def test_single_call_equals_batch_entry(finder, oracle):
         assert single.tobytes() == batch[i].tobytes()    # n = 1 reproduces one service call
 
 
-@pytest.mark.parametrize("k,cols,iters", [(1000, 32, 2000), (500, 64, 500), (200, 16, 300), (77, 32, 100)])
+@pytest.mark.parametrize("k,cols,iters", [(1000, 32, 2000), (500, 64, 500), (200, 16, 300), (77, 32, 100), (2000, 32, 300)])
 def test_other_configs(oracle, k, cols, iters):
     from multi_robot_slam_separators_amd import lib
     p = synth.camera_params()
