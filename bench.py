@@ -848,17 +848,23 @@ def main():
     # hipEventCreate of a process can cost milliseconds)
     f.prof_select(("k_verify_fused", "k_match_global"))
     f.prof_enable(True)
-    # bounded self-warm-up: the driver's few warm-up steps can leave the clocks un-ramped (round 2: 0.53 ms for a kernel
-    # that takes 0.47 once warm), so steps are run until three consecutive ones agree within 3 % (at most 50)
+    # bounded self-warm-up: the driver's few warm-up steps leave the clocks un-ramped (round 2: 0.53 ms for a kernel
+    # that takes 0.47 once warm).  Steps are run, in the PIPELINED form of the timed region, until three consecutive ones
+    # agree within 3 % -- but at least 100 (~50 ms of load) and at most 150: the device needs tens of milliseconds of the
+    # overlapped load to settle (a 20-step timed region behind 5-20 such steps: median step 0.52 ms, 18.6 M pairs/s;
+    # behind 100: 0.485 ms, 19.5 M; behind 400: the same -- round 3, one box), and host-side step times converge long
+    # before that
     warm_ts = []
-    for step_i in range(50):
+    sw_min = int(os.environ.get("BENCH_SELF_WARMUP_MIN", "100"))
+    sw_max = int(os.environ.get("BENCH_SELF_WARMUP_MAX", "150"))
+    for step_i in range(sw_max):
         ts = time.perf_counter()
         if pipelined:
             issue(step_i)
         else:
             step()
         warm_ts.append(time.perf_counter() - ts)
-        if len(warm_ts) >= 5 and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
+        if len(warm_ts) >= sw_min and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
             break
     if pipelined:
         torch.cuda.synchronize()
