@@ -864,7 +864,12 @@ def main():
         else:
             step()
         warm_ts.append(time.perf_counter() - ts)
-        if len(warm_ts) >= sw_min and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
+        # (with several ranks every step is a collective: all ranks must run the SAME number of warm-up steps, so the
+        #  count is fixed there -- a break decided by a rank's own timings would leave the others waiting in an all-gather)
+        if dist_on:
+            if len(warm_ts) >= sw_min:
+                break
+        elif len(warm_ts) >= sw_min and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
             break
     if pipelined:
         torch.cuda.synchronize()
