@@ -597,6 +597,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not args.no_extras:
+        # every step of a multi-rank run is a collective: the informational comparison runs behind the timed region
+        # (other NN precision, fixed iterations, VALU matcher, ...) would add hundreds of them, each a chance for the
+        # ranks to part ways on an error path; the N > 1 line carries the contract's fields only
+        args.no_extras = True
     import torch
     import torch.distributed as td
     from multi_robot_slam_separators_amd.hostinfo import cpu_share
