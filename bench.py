@@ -17,7 +17,8 @@ region.
 N > 1 (`python bench.py --gpus N` starts the N ranks itself when WORLD_SIZE is unset; under torchrun the
 environment's WORLD_SIZE must equal --gpus):
   --partition robot-pairs (default, "weak"): every rank owns an independent robot pair of the same size and the
-      accepted separators are all-gathered (one RCCL collective per step);
+      accepted separators are all-gathered (one RCCL collective per step, out of two alternating send buffers: the
+      collective of step k runs beside the verification of step k + 1);
   --partition 8e ("strong"): SURVEY.md section 8(e) as written -- ONE robot pair's step cut over the ranks: local NN
       rows in contiguous blocks against the replicated received database, all-gather of the per-row minima, the
       walk replicated, candidate p to rank p mod G over a replicated keyframe store, flags + accepted records
@@ -28,6 +29,7 @@ environment's WORLD_SIZE must equal --gpus):
       configs[1] shape round-robin over the ranks, accepted separators all-gathered.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -723,8 +725,28 @@ def main():
     # right behind the verification; it is retired with the step.
     dist_cuda = exch is not None and coll_dev.type == "cuda"
     pipelined = (exch is None or dist_cuda) and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
+    # Two exchanges (send + receive buffers) alternate with the steps (sf_step_mirror_pair): the all-gather of step k,
+    # on RCCL's stream, runs beside the verification of step k + 1; only the REUSE of a buffer -- the zeroing of its
+    # count header for step k + 2 -- is ordered behind the collective that read it.  BENCH_ONE_EXCHANGE_BUFFER=1: one
+    # buffer, every step's kernels behind the previous step's collective (up to round r03k).  With two buffers the odd
+    # steps also move to the handle's second stream as they do at N = 1 (sf_step_mirror_streams): everything that
+    # touches a buffer -- the fill, the step, the collective's hand-over -- is then queued on that buffer's stream
+    # (BENCH_EXCHANGE_ONE_STREAM=1: both on the handle's stream).
+    exchs = [exch]
+    lane_streams = [None]
+    issued = [0]
     if pipelined and dist_cuda:
-        f.step_mirror(exch.payload.data_ptr(), exch.count_ptr, int(exch.payload.shape[0]))
+        if os.environ.get("BENCH_ONE_EXCHANGE_BUFFER") is None:
+            exchs.append(dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf + n_kf // 8 + 256, n_kf // 4 + 256, coll_dev))
+            f.step_mirror_pair((exchs[0].payload.data_ptr(), exchs[0].count_ptr),
+                               (exchs[1].payload.data_ptr(), exchs[1].count_ptr), int(exch.payload.shape[0]))
+            lane_streams = [torch.cuda.current_stream()] * 2
+            if os.environ.get("BENCH_EXCHANGE_ONE_STREAM") is None:
+                s_even, s_odd = f.step_mirror_streams()
+                if s_odd != s_even:
+                    lane_streams[1] = torch.cuda.ExternalStream(s_odd)
+        else:
+            f.step_mirror(exch.payload.data_ptr(), exch.count_ptr, int(exch.payload.shape[0]))
     inflight = [0]
 
     def retire(copy=False):
@@ -732,17 +754,34 @@ def main():
         inflight[0] -= 1
         state["pairs"] += info["n_matches"]
         state["last"] = (m, rom, recs, info)
-        state["gathered"] = info["n_accepted"] if exch is None else sum(exch.counts())
+        if exch is None:
+            state["gathered"] = info["n_accepted"]
 
     def issue(k):
         if dist_cuda:
-            exch.send[0, :8].zero_()          # this rank's count header = the stream's slot counter
-        f.step_issue(slot_a, slot_b)
-        if dist_cuda:
-            exch.exchange(None, finish=True)  # (behind the verification in stream order)
+            b = issued[0] % len(exchs)           # (the library alternates its mirrors with the steps the same way)
+            ex, lane = exchs[b], lane_streams[b]
+            with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+                ex.finish()                   # the collective that last read this buffer (step k - 2, or k - 1 with one buffer)
+                ex.send[0, :8].zero_()        # this rank's count header = the stream's slot counter
+                f.step_issue(slot_a, slot_b)
+                ex.exchange(None, finish=False)   # (behind the verification in stream order, on the collective's own stream)
+            state["exch_last"] = ex
+            issued[0] += 1
+        else:
+            f.step_issue(slot_a, slot_b)
         if inflight[0]:
             retire()                          # step k - 1: its outputs were queued before this step's NN filter
         inflight[0] += 1
+
+    def drain_exchanges():
+        """Every collective in flight finished, its header rows on the host; `gathered` = the last step's node-wide count."""
+        if dist_cuda:
+            for ex, lane in zip(exchs, lane_streams):
+                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+                    ex.finish()
+            torch.cuda.synchronize()
+            state["gathered"] = sum(state["exch_last"].counts())
 
     def materialize_last():
         """The last retired step's separators in MATCH order + every match's flag, in the form the checks below take."""
@@ -880,6 +919,7 @@ def main():
         torch.cuda.synchronize()
         while inflight[0]:
             retire()
+        drain_exchanges()
     f.prof_enable(False)
     # HIP events over the timed region bracket ONLY the kernel the roofline prices (two timing events per launch
     # cost host time and a marker on the queue: with every kernel bracketed a step took 0.594 ms instead of 0.568);
@@ -900,8 +940,7 @@ def main():
             issue(step_i)                 # (retires step k - 1 once step k's candidates are walked)
             step_ms.append((time.perf_counter() - ts) * 1e3)
         retire(copy=True)                 # (waits for the last step's verification)
-        if dist_cuda:
-            torch.cuda.synchronize()    # (the collective's stream and the header copies too)
+        drain_exchanges()                 # (the collectives' stream and the header copies too)
     else:
         for _ in range(args.steps):
             ts = time.perf_counter()
@@ -916,6 +955,7 @@ def main():
         materialize_last()                # (check infrastructure: the last step's separators in match order)
         if dist_cuda:
             f.step_mirror(None, None, 0)
+            exch = state["exch_last"]     # (the checks below read the LAST step's exchange)
     if os.environ.get("BENCH_DEBUG_SPREAD"):
         order = np.argsort(step_ms)[::-1][:4]
         print("[bench] slowest steps: " + ", ".join("#%d %.3f ms" % (int(i), step_ms[int(i)]) for i in order), file=sys.stderr)
@@ -1279,7 +1319,10 @@ def main():
         # SF_OPT_STEP_OVERLAP (the library's default, SF_STEP_OVERLAP=0 turns it off): the two steps in flight on two
         # streams -- unless the separators are mirrored into an exchange buffer (N > 1), where one stream orders the
         # collective behind the step
-        out["steps_on_two_streams"] = bool(pipelined and not dist_cuda and os.environ.get("SF_STEP_OVERLAP", "1") != "0")
+        out["steps_on_two_streams"] = bool(pipelined and os.environ.get("SF_STEP_OVERLAP", "1") != "0" and
+                                           (not dist_cuda or lane_streams[0] is not lane_streams[-1]))
+        if dist_cuda:
+            out["exchange_buffers"] = len(exchs)
         out["accepted_separators_streamed_from_the_kernel"] = bool(state.get("streamed_last", False))
         if alt_sync is not None:
             out["value_one_synchronisation_per_step"] = alt_sync
@@ -1319,9 +1362,17 @@ def main():
             out["parity_in_this_run"] = {"accepted_separators_compared_with_the_oracle": int(inside.sum()),
                                          "byte_identical": int(ident)}
         print(json.dumps(out))
-    f.close()
+    # teardown order: the exchanges' tensors and the process group have seen the handle's second stream (collectives
+    # were handed over on it); they go first, while that stream still exists
+    exch = None
+    exchs.clear()
+    lane_streams.clear()
+    state.clear()
+    gc.collect()
+    torch.cuda.synchronize()
     if dist_on:
         td.destroy_process_group()
+    f.close()
 
 
 if __name__ == "__main__":

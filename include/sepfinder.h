@@ -512,6 +512,18 @@ int  sf_step_retire(sf_handle h, sf_step_result* out);      /* the OLDEST step i
    of verified candidates of a query (local rows * 9 / 8 + 256) switches that query to the compaction (nothing is ever
    dropped).  NULL, NULL, 0 removes the mirror.  Not while a step is in flight.                                    */
 int  sf_step_mirror(sf_handle h, sf_result* d_records2, uint32_t* d_counter, int32_t cap);
+/* The same with TWO destinations that alternate with the steps (the first sf_step_issue after this call writes the
+   even pair, the next one the odd pair, ...): with two send buffers the all-gather of step k runs beside the
+   verification of step k + 1 instead of in front of it -- the caller orders only the REUSE of a buffer (step k + 2)
+   behind the collective that read it.  Both pairs NULL removes the mirror.  Not while a step is in flight.        */
+int  sf_step_mirror_pair(sf_handle h, sf_result* d_records_even, uint32_t* d_counter_even,
+                         sf_result* d_records_odd, uint32_t* d_counter_odd, int32_t cap);
+/* After sf_step_mirror_pair: lets the odd steps run on the handle's second stream as they do without a mirror
+   (SF_OPT_STEP_OVERLAP) and returns the two hipStream_t.  From here on the caller orders everything it does with the
+   even pair -- zeroing the counter, the collective that reads the buffer -- on *stream_even and everything with the
+   odd pair on *stream_odd.  With SF_OPT_STEP_OVERLAP off both are the handle's stream.  Ends with the next
+   sf_step_mirror / sf_step_mirror_pair call.  Not while a step is in flight.                                     */
+int  sf_step_mirror_streams(sf_handle h, void** stream_even, void** stream_odd);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* Kernel ids for sf_prof_get */
@@ -548,7 +560,7 @@ enum {
                               verification overlaps the NN stage and the first workgroups of the next: +9-12 % steps per
                               second (3D-3D), +14 % (PnP), results unchanged.  0: every step on the handle's stream.
                               Ignored while sf_step_mirror is set (the caller's collective is ordered on the handle's
-                              stream).  Either way a step's results are complete when sf_step_retire returns.            */
+                              stream) unless sf_step_mirror_streams handed the two streams to the caller.  Either way a step's results are complete when sf_step_retire returns.            */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never
                              leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */

@@ -1675,14 +1675,25 @@ static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t c
   return SF_OK;
 }
 
-extern "C" int sf_step_mirror(sf_handle c, sf_result* d_records2, uint32_t* d_counter, int32_t cap) {
-  if (!c || cap < 0 || ((d_records2 == nullptr) != (d_counter == nullptr))) return SF_EINVAL;
+extern "C" int sf_step_mirror_pair(sf_handle c, sf_result* d_records_even, uint32_t* d_counter_even,
+                                   sf_result* d_records_odd, uint32_t* d_counter_odd, int32_t cap) {
+  if (!c || cap < 0 || ((d_records_even == nullptr) != (d_counter_even == nullptr)) ||
+      ((d_records_odd == nullptr) != (d_counter_odd == nullptr)) || ((d_records_even == nullptr) != (d_records_odd == nullptr)))
+    return SF_EINVAL;
   if (c->step_inflight) return sf_fail(c, SF_EINVAL, "sf_step_mirror: %d step(s) in flight, retire them first", c->step_inflight);
-  c->step_mirror_records = d_records2;
-  c->step_mirror_counter = d_counter;
-  c->step_mirror_cap = d_records2 ? cap : 0;
+  c->step_mirror_records[0] = d_records_even;
+  c->step_mirror_counter[0] = d_counter_even;
+  c->step_mirror_records[1] = d_records_odd;
+  c->step_mirror_counter[1] = d_counter_odd;
+  c->step_mirror_cap = d_records_even ? cap : 0;
+  c->step_mirror_lanes = false;
+  c->step_head = 0;                                                     // the next step is an even one
   for (auto& ab : c->accept_blocks) ab = sf_context::AcceptHost();      // (re-registered by the next sf_step_issue)
   return SF_OK;
+}
+
+extern "C" int sf_step_mirror(sf_handle c, sf_result* d_records2, uint32_t* d_counter, int32_t cap) {
+  return sf_step_mirror_pair(c, d_records2, d_counter, d_records2, d_counter, cap);
 }
 
 // ---- SF_OPT_STEP_OVERLAP: the second lane of the step pipeline ------------------------------------------------------
@@ -1704,14 +1715,18 @@ int sf_lanes_touch(sf_context* c, bool drain) {
   return SF_OK;
 }
 
+static int lane1_create(sf_context* c) {
+  sf_context::StepLane& L = c->lane1;
+  if (L.stream) return SF_OK;
+  SF_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  SF_HIP(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
+  return sf_buf_reserve(c, L.counters, 64);          // (the work-list counters of the stage kernels; the handle's own
+}                                                    //  are reserved at sf_create)
+
 static int lane1_enter(sf_context* c) {
   sf_context::StepLane& L = c->lane1;
-  if (!L.stream) {
-    SF_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-    SF_HIP(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
-    int rc = sf_buf_reserve(c, L.counters, 64);      // (the work-list counters of the stage kernels; the handle's own
-    if (rc != SF_OK) return rc;                      //  are reserved at sf_create)
-  }
+  int rc0 = lane1_create(c);
+  if (rc0 != SF_OK) return rc0;
   if (L.seen_db_epoch != c->db_epoch) {
     // the databases were written through the handle's stream since this lane last looked: wait for that work once
     SF_HIP(c, hipEventRecord(L.ev_main, c->stream));
@@ -1719,6 +1734,22 @@ static int lane1_enter(sf_context* c) {
     L.seen_db_epoch = c->db_epoch;
   }
   lane_swap(c);
+  return SF_OK;
+}
+
+extern "C" int sf_step_mirror_streams(sf_handle c, void** stream_even, void** stream_odd) {
+  if (!c || !stream_even || !stream_odd) return SF_EINVAL;
+  if (c->step_inflight) return sf_fail(c, SF_EINVAL, "sf_step_mirror_streams: %d step(s) in flight, retire them first", c->step_inflight);
+  if (!c->step_mirror_records[0] || c->step_mirror_records[0] == c->step_mirror_records[1])
+    return sf_fail(c, SF_EINVAL, "sf_step_mirror_streams: needs two distinct mirrors (sf_step_mirror_pair)");
+  SF_HIP(c, hipSetDevice(c->device));
+  *stream_even = *stream_odd = (void*)c->stream;
+  if (c->step_overlap && !c->overlap) {
+    int rc = lane1_create(c);
+    if (rc != SF_OK) return rc;
+    *stream_odd = (void*)c->lane1.stream;
+    c->step_mirror_lanes = true;
+  }
   return SF_OK;
 }
 
@@ -1730,7 +1761,8 @@ extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
-  const bool lane1 = c->step_overlap && c->step_head == 1 && !c->step_mirror_records && !c->overlap;
+  const bool lane1 = c->step_overlap && c->step_head == 1 && !c->overlap &&
+                     (!c->step_mirror_records[0] || c->step_mirror_lanes);
   if (!lane1) return step_issue_body(c, slot_base_other, slot_base_local);
   int rc = lane1_enter(c);
   if (rc != SF_OK) return rc;
@@ -1747,12 +1779,14 @@ static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_
   const int32_t need = n_l + n_l / 8 + 256;
   int rc;
   if ((rc = step_block_reserve(c, b, need)) != SF_OK) return rc;
-  const int32_t mirror_cap = c->step_mirror_records ? c->step_mirror_cap : b.cap;
+  sf_result* const mirror_rec = c->step_mirror_records[which];
+  uint32_t* const mirror_cnt = c->step_mirror_counter[which];
+  const int32_t mirror_cap = mirror_rec ? c->step_mirror_cap : b.cap;
   sf_context::AcceptHost& ab = c->accept_blocks[which];
   if (!ab.set || ab.s.records != b.records || ab.s.cap != std::min(b.cap, mirror_cap) ||
-      ab.s.records2 != c->step_mirror_records) {
+      ab.s.records2 != mirror_rec) {
     if ((rc = sf_accept_stream_set(c, which, b.records, b.index, nullptr, std::min(b.cap, mirror_cap),
-                                   c->step_mirror_records, c->step_mirror_counter)) != SF_OK) return rc;
+                                   mirror_rec, mirror_cnt)) != SF_OK) return rc;
   }
   b.matches.resize((size_t)std::max(n_l, 1));
   c->accept_sel = which;
@@ -1773,7 +1807,7 @@ static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_
     // the matches are compacted, in match order, straight into the block
     if (n > b.cap) return sf_fail(c, SF_ERANGE, "sf_step_issue: %d matches exceed the block's %d records", n, b.cap);
     if ((rc = compact_launch(c, c->last_results, n, b.records, b.flags, b.count, c->last_results_index,
-                             c->step_mirror_records, nullptr, (int32_t*)c->step_mirror_counter)) != SF_OK) return rc;
+                             mirror_rec, nullptr, (int32_t*)mirror_cnt)) != SF_OK) return rc;
   }
   SF_HIP(c, hipEventRecord(b.done, c->stream));
   b.issued = true;

@@ -326,9 +326,10 @@ struct sf_context {
   } lane1;
   bool step_overlap = true;                // the option (SF_STEP_OVERLAP=0 / sf_set_option turn it off)
   uint64_t db_epoch = 0;                   // bumped by every call that writes a database through the handle's stream
-  sf_result* step_mirror_records = nullptr;   // sf_step_mirror: second (device) destination of every accepted record
-  uint32_t* step_mirror_counter = nullptr;    // ... and the caller's slot counter
+  sf_result* step_mirror_records[2] = {nullptr, nullptr};   // sf_step_mirror[_pair]: second (device) destination of every
+  uint32_t* step_mirror_counter[2] = {nullptr, nullptr};    // accepted record and the caller's slot counter, per step block
   int32_t step_mirror_cap = 0;
+  bool step_mirror_lanes = false;             // sf_step_mirror_streams: the odd steps of a mirror pair run on lane 1
   void* spec_index_pinned = nullptr;
   size_t spec_index_pinned_bytes = 0;
   hipEvent_t spec_index_staged = nullptr;

@@ -106,6 +106,8 @@ def load():
         "sf_step_issue": (C.c_int, [vp, i32, i32]),
         "sf_step_retire": (C.c_int, [vp, P(_abi.StepResult)]),
         "sf_step_mirror": (C.c_int, [vp, vp, vp, i32]),
+        "sf_step_mirror_pair": (C.c_int, [vp, vp, vp, vp, vp, i32]),
+        "sf_step_mirror_streams": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "sf_accept_stream_set": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
         "sf_accept_stream_select": (C.c_int, [vp, i32]),
         "sf_accept_stream_status": (C.c_int, [vp, P(i32), P(i32)]),
@@ -155,7 +157,7 @@ EXPORTED = [
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_netvlad_infer_batch_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
-    "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
+    "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_step_mirror_pair", "sf_step_mirror_streams", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device",
     "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
@@ -501,6 +503,17 @@ class SeparatorFinder:
         """Second (device) destination of every accepted record + the caller's slot counter; (None, None, 0) removes it."""
         self._check(self._L.sf_step_mirror(self._h, C.c_void_p(d_records2) if d_records2 else None,
                                            C.c_void_p(d_counter) if d_counter else None, int(cap)))
+
+    def step_mirror_pair(self, even, odd, cap):
+        """Two alternating mirrors, (d_records2, d_counter) each: the first step issued after this call writes `even`."""
+        self._check(self._L.sf_step_mirror_pair(self._h, C.c_void_p(even[0]), C.c_void_p(even[1]),
+                                                C.c_void_p(odd[0]), C.c_void_p(odd[1]), int(cap)))
+
+    def step_mirror_streams(self):
+        """(stream_even, stream_odd) as integers: after step_mirror_pair, odd steps move to the handle's second stream."""
+        a, b = C.c_void_p(), C.c_void_p()
+        self._check(self._L.sf_step_mirror_streams(self._h, C.byref(a), C.byref(b)))
+        return a.value or 0, b.value or 0
 
     def last_match_results(self):
         """(d_results pointer, index pointer or None, n) of the last find_matches_and_verify_device call."""

@@ -144,6 +144,87 @@ def test_step_with_a_mirror_for_the_exchange():
         _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
 
 
+def test_step_with_two_alternating_mirrors():
+    """sf_step_mirror_pair: steps alternate between two device destinations (the first one issued after the call
+    writes the even pair), also with two steps in flight -- each buffer holds exactly its own step's records, and a
+    buffer is not touched by the step that uses the other one."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(281, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+        n_acc = int(res_ref["success"].sum())
+        assert n_acc > 0
+        cap = n_kf + n_kf // 8 + 256
+        send = [torch.zeros((cap + 1, RB), dtype=torch.uint8, device=DEV) for _ in range(2)]
+        f.step_issue(sa, sb)                        # an odd number of steps before the call: the call restarts the parity
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        f.step_mirror_pair((send[0][1:].data_ptr(), send[0].data_ptr()), (send[1][1:].data_ptr(), send[1].data_ptr()), cap)
+
+        def check_buffer(b, out):
+            cnt = int(send[b][0, :4].view(torch.int32).item())
+            assert cnt == out[3]["n_records"] >= n_acc
+            got = np.frombuffer(send[b][1: 1 + cnt].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+            assert got.tobytes() == out[2][:cnt].tobytes()
+
+        # one step at a time: even, odd, even; the other buffer stays as it was (all 0xEE)
+        for step in range(3):
+            b = step & 1
+            send[b].zero_()
+            send[b ^ 1].fill_(0xEE)
+            f.step_issue(sa, sb)
+            out = f.step_retire(copy=True)
+            _check_step(out, m_ref, res_ref, True)
+            torch.cuda.synchronize()
+            check_buffer(b, out)
+            assert bool((send[b ^ 1] == 0xEE).all())
+        # two in flight (the parity continues: this is step 3 -> odd)
+        send[1].zero_()
+        f.step_issue(sa, sb)
+        send[0].zero_()
+        f.step_issue(sa, sb)
+        out_odd = f.step_retire(copy=True)
+        out_even = f.step_retire(copy=True)
+        _check_step(out_odd, m_ref, res_ref, True)
+        _check_step(out_even, m_ref, res_ref, True)
+        torch.cuda.synchronize()
+        check_buffer(1, out_odd)
+        check_buffer(0, out_even)
+        with pytest.raises(lib.SepfinderError):
+            f.step_mirror_pair((send[0][1:].data_ptr(), send[0].data_ptr()), (0, 0), cap)     # both pairs or none
+        # sf_step_mirror_streams: the odd steps on the handle's second stream; the caller's fills go to the same streams
+        f.step_mirror_pair((send[0][1:].data_ptr(), send[0].data_ptr()), (send[1][1:].data_ptr(), send[1].data_ptr()), cap)
+        s_even, s_odd = f.step_mirror_streams()
+        assert s_odd != s_even                     # (SF_OPT_STEP_OVERLAP is the default)
+        lanes = [torch.cuda.current_stream(), torch.cuda.ExternalStream(s_odd)]
+        outs = []
+        for step in range(6):
+            b = step & 1
+            with torch.cuda.stream(lanes[b]):
+                send[b].zero_()
+                f.step_issue(sa, sb)
+            if step:
+                outs.append(f.step_retire(copy=True))      # the step before: two are in flight at this point
+        outs.append(f.step_retire(copy=True))
+        assert len(outs) == 6
+        for out in outs:
+            _check_step(out, m_ref, res_ref, True)
+        torch.cuda.synchronize()
+        check_buffer(0, outs[-2])                  # step 4 (even) and step 5 (odd): the last writers of the two buffers
+        check_buffer(1, outs[-1])
+        with pytest.raises(lib.SepfinderError):
+            f.step_mirror(send[0][1:].data_ptr(), send[0].data_ptr(), cap) or f.step_mirror_streams()   # one mirror: no lanes
+        f.step_mirror(None, None, 0)
+        f.step_issue(sa, sb)
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+
+
 def test_step_on_an_empty_candidate_list_and_an_empty_database():
     n_kf, k, dim = 32, 64, 128
     feats, nv_a, nv_b = _world(377, 48, k, dim)
