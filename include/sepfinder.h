@@ -52,7 +52,8 @@ extern "C" {
       written for (multi_robot_slam_separators_amd/lib.py does).                                                   */
 /* 3: sf_params grew force_3dof / forward_est_only (appended), sf_nn_row_minima_device, sf_allgather_bytes_device,
       sf_netvlad_infer_batch_device, sf_get_features_and_descriptor_batch_device added.                                                                          */
-#define SF_ABI_VERSION 3
+/* 4: sf_step_mirror_pair, sf_step_mirror_streams added (nothing existing changed).                                   */
+#define SF_ABI_VERSION 4
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {

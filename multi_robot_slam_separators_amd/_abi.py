@@ -217,7 +217,7 @@ class StepResult(C.Structure):
                 ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32)]
 
 
-SF_ABI_VERSION = 3      # include/sepfinder.h
+SF_ABI_VERSION = 4      # include/sepfinder.h
 
 
 def default_params() -> Params:
