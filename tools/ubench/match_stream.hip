@@ -158,6 +158,83 @@ __global__ void __launch_bounds__(256, 4) kG(const unsigned* __restrict__ raw, c
   sink[blockIdx.x * 256 + tid] = total;
 }
 
+
+// L: the spread shared by the workgroup through LDS.  Wavefront w spreads k-step w of every 32-row tile (one raw dword
+// per lane, straight from global memory: 4 vector instructions instead of 16) into a two-tile ring (8 KB; the 16 KB raw
+// staging block is gone); all four wavefronts read the whole tile back (4 ds_read_b128, in place, behind the MFMAs that
+// consumed the previous one).  One workgroup barrier per tile.
+template <int BAR>   // 1: the product-correct form; 0: no per-tile barrier (timing only: what the barrier costs)
+__global__ void __launch_bounds__(256, 4) kL(const unsigned* __restrict__ raw, int n_blocks, int pairs_per_wg, float* sink) {
+  __shared__ uint4 ring[2][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  unsigned m88, c22;
+  asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+  float total = 0.f;
+  auto spread4 = [&](unsigned x) {
+    uint4 o;
+    o.x = (x & m88) | c22; o.y = x & 0x44444444u; o.z = x & 0x22222222u; o.w = x & 0x11111111u;
+    return o;
+  };
+  for (int p = 0; p < pairs_per_wg; ++p) {
+    const int bf = (blockIdx.x + p * gridDim.x) % n_blocks, bt = (bf + 7919) % n_blocks;
+    const unsigned* src = raw + (size_t)bf * RAW_DW + r * 8 + 4 * h + wave;      // + 256 per tile
+    const unsigned* dT = raw + (size_t)bt * RAW_DW;
+    for (int g = 0; g < 2; ++g) {
+      v8i Bf[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = (wave + 4 * (2 * g + j)) * 32 + r;
+        const uint4 v = *reinterpret_cast<const uint4*>(dT + (size_t)t * 8 + 4 * h);
+        Bf[j][0] = spread_to(v.x, m88, c22); Bf[j][1] = spread_to(v.y, m88, c22);
+        Bf[j][2] = spread_to(v.z, m88, c22); Bf[j][3] = spread_to(v.w, m88, c22);
+      }
+      float cin[16], b[2] = {-1e30f, -1e30f}, s[2] = {-1e30f, -1e30f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) / 2048.f;
+      unsigned rw0 = src[0], rw1 = src[256], rw2 = src[512], rw3 = src[768];
+      __syncthreads();                                  // the ring is free (the previous group's reads have landed)
+      ring[0][wave][lane] = spread4(rw0);
+      ring[1][wave][lane] = spread4(rw1);
+      __syncthreads();
+      uint4 a0 = ring[0][0][lane], a1 = ring[0][1][lane], a2 = ring[0][2][lane], a3 = ring[0][3][lane];
+#pragma unroll 1
+      for (int mt = 0; mt < 16; ++mt) {
+        v16f c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c0[i] = cin[i];
+        const v8i A0 = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, 0, 0, 0, 0};
+        const v8i A1 = {(int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w, 0, 0, 0, 0};
+        const v8i A2 = {(int)a2.x, (int)a2.y, (int)a2.z, (int)a2.w, 0, 0, 0, 0};
+        const v8i A3 = {(int)a3.x, (int)a3.y, (int)a3.z, (int)a3.w, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { b[j] += 32.f / 2048.f; s[j] += 32.f / 2048.f; }
+        v16f acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, Bf[0][0], c0, 4, 4, 0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, Bf[0][1], acc0, 4, 4, 0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A2, Bf[0][2], acc0, 4, 4, 0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A3, Bf[0][3], acc0, 4, 4, 0, 0, 0, 0);
+        v16f acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, Bf[1][0], c0, 4, 4, 0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, Bf[1][1], acc1, 4, 4, 0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A2, Bf[1][2], acc1, 4, 4, 0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A3, Bf[1][3], acc1, 4, 4, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);            // the requests stay BEHIND the MFMAs that read the registers
+        const int sn = (mt + 1) & 1;                   // tile mt + 1: written one iteration ago, behind a barrier
+        a0 = ring[sn][0][lane]; a1 = ring[sn][1][lane]; a2 = ring[sn][2][lane]; a3 = ring[sn][3][lane];
+        __builtin_amdgcn_sched_barrier(0);
+        top2_16(acc0, b[0], s[0]);
+        // tile mt + 2 replaces tile mt (every wavefront's reads of it landed before the last barrier)
+        ring[mt & 1][wave][lane] = spread4(rw2);
+        rw2 = rw3;
+        rw3 = src[(size_t)min(mt + 4, 15) * 256];
+        top2_16(acc1, b[1], s[1]);
+        if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      total += (b[0] + s[0]) + (b[1] + s[1]);
+    }
+  }
+  sink[blockIdx.x * 256 + tid] = total;
+}
+
 int main(int argc, char** argv) {
   const int n_blocks = argc > 1 ? atoi(argv[1]) : 8192;     // 8192 x (16 + 64) KB = 640 MB: past the Infinity Cache
   const int ppw = argc > 2 ? atoi(argv[2]) : 16;
@@ -195,5 +272,7 @@ int main(int argc, char** argv) {
   timeit("S  raw rows in LDS, spread per wavefront", [&] { hipLaunchKernelGGL(kS, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
   timeit("G0 spread rows from global, in-place reload", [&] { hipLaunchKernelGGL(kG<0>, dim3(grid), dim3(256), 0, 0, raw, fp4, n_blocks, ppw, sink); });
   timeit("G1 spread rows from global, one tile ahead", [&] { hipLaunchKernelGGL(kG<1>, dim3(grid), dim3(256), 0, 0, raw, fp4, n_blocks, ppw, sink); });
+  timeit("L  spread shared through a two-tile LDS ring", [&] { hipLaunchKernelGGL(kL<1>, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
+  timeit("L' the same without its per-tile barrier", [&] { hipLaunchKernelGGL(kL<0>, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
   return 0;
 }
