@@ -117,7 +117,9 @@ def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
         flop = 2.0 * k * k * cols * 8          # one multiply-add per descriptor bit pair
         tf = pairs_per_launch * flop / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
         return {"note": "matching = v_mfma_f32_32x32x64_f8f6f4 over +-1-encoded descriptor bits (2*K*K*bits flop per pair, "
-                        "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan"
+                        "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan: per 32-row tile and SIMD the 8 MFMAs hold "
+                        "the fp4 pipe for 256 cycles and the scan's 63 vector instructions the issue port for 252 -- the two are "
+                        "balanced, removing vector instructions changes nothing (profiles/r03m_fewer_valu_no_gain.log)"
                         + ("; the launch also holds both motion-estimation chains of the surviving pairs, which are "
                            "latency-bound" if dom == "k_verify_fused" else ""),
                 "matrix_core": {"achieved": tf, "peak": MFMA_FP4_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_FP4_PEAK_TF},
