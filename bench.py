@@ -116,10 +116,14 @@ def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
     if os.environ.get("SF_MATCH_MFMA", "1") != "0":
         flop = 2.0 * k * k * cols * 8          # one multiply-add per descriptor bit pair
         tf = pairs_per_launch * flop / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        scan = ("four resident column tiles per wavefront (three workgroups per CU): per 32-row tile and SIMD the 16 MFMAs hold "
+                "the fp4 pipe for 512 cycles, the scan's 107 vector instructions the issue port for 428 -- the matrix pipe is the "
+                "longer of the two" if dom == "k_match_split" else
+                "per 32-row tile and SIMD the 8 MFMAs hold the fp4 pipe for 256 cycles and the scan's 63 vector instructions "
+                "the issue port for 252 -- the two are balanced, removing vector instructions changes nothing "
+                "(profiles/r03m_fewer_valu_no_gain.log)")
         return {"note": "matching = v_mfma_f32_32x32x64_f8f6f4 over +-1-encoded descriptor bits (2*K*K*bits flop per pair, "
-                        "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan: per 32-row tile and SIMD the 8 MFMAs hold "
-                        "the fp4 pipe for 256 cycles and the scan's 63 vector instructions the issue port for 252 -- the two are "
-                        "balanced, removing vector instructions changes nothing (profiles/r03m_fewer_valu_no_gain.log)"
+                        "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan: " + scan
                         + ("; the launch also holds both motion-estimation chains of the surviving pairs, which are "
                            "latency-bound" if dom == "k_verify_fused" else ""),
                 "matrix_core": {"achieved": tf, "peak": MFMA_FP4_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_FP4_PEAK_TF},
@@ -971,8 +975,18 @@ def main():
     f.prof_reset()
     f.prof_select(None)
     f.prof_enable(True)
-    for _ in range(survey_steps):
-        step()
+    if pipelined:
+        # (the form of the timed region: the library picks the verification's form per call -- inside overlapped steps the
+        #  split one, k_match_split + k_chain -- so the survey runs the step pair too)
+        for step_i in range(survey_steps):
+            issue(step_i)
+        torch.cuda.synchronize()
+        while inflight[0]:
+            retire()
+        drain_exchanges()
+    else:
+        for _ in range(survey_steps):
+            step()
     torch.cuda.synchronize()
     prof_all = f.prof_get()
     f.prof_enable(False)
@@ -1248,12 +1262,24 @@ def main():
         # result: the whole verification the 44 352 B/pair figure of SURVEY 8(d) describes), or the
         # matching kernel when the stage kernels run (PnP estimator, SF_FUSED=0)
         dom = "k_verify_fused" if prof.get("k_verify_fused", (0, 0.0))[0] > 0 else "k_match_global"
+        # the split form of the 3D-3D verification (the library's choice inside overlapped steps, SF_OPT_STEP_SPLIT; always
+        # with SF_FUSED=2): k_match_split over every candidate -- the dominant kernel, priced with ITS share of the
+        # 44 352 B (both keyframes' descriptors + the result record: 2*K*C + 352) -- and k_chain over the survivors (the
+        # 3D points, 2*K*12 B per surviving pair, and the latency-bound motion-estimation chains), reported beside it
+        split_form = (args.estimator == "3d3d" and prof.get("k_verify_fused", (0, 0.0))[0] > 0
+                      and prof.get("k_match_global", (0, 0.0))[0] > 0)
+        chain_ms = None
+        if split_form:
+            chain_ms = prof["k_verify_fused"][1] / max(prof["k_verify_fused"][0], 1)
+            dom = "k_match_global"
         nm, tm = prof[dom]
         match_ms = tm / max(nm, 1)
         # pairs one launch of the dominant kernel processes (big batches are cut in two halves on two streams)
         pairs_per_launch = pairs_per_step * args.steps / max(nm, 1)
-        pmc = pmc_traffic(dom, pairs_per_launch)
-        ach = pairs_per_launch * bpp / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+        dom_name = "k_match_split" if split_form else dom
+        bpp_dom = (2 * k * cols + 352) if split_form else bpp
+        pmc = pmc_traffic(dom_name, pairs_per_launch)
+        ach = pairs_per_launch * bpp_dom / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
         nn_kernel, nn_peak = (("k_nn_filter_f16", MFMA_F16_PEAK_TF) if args.nn_precision == 1
                               else ("k_nn_argmin", MFMA_F32_PEAK_TF))
         nn_n, nn_t = prof_all[nn_kernel]
@@ -1262,6 +1288,13 @@ def main():
         # (k_nn.hip, nn_run_filter: adaptive 128 / 512 / full), the fp32 ranking kernel all D dimensions
         k_eff = dim if args.nn_precision == 0 else (filter_dims or dim)
         nn_tf = 2.0 * n_kf * n_kf * k_eff / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+        def survey_name(kname):
+            if args.estimator == "pnp":
+                return kname.replace("k_ransac", "k_pnp")
+            if split_form and pipelined:      # (the profiling slots of the library keep the stage names)
+                return {"k_match_global": "k_match_split", "k_verify_fused": "k_chain"}.get(kname, kname)
+            return kname
+
         out = {
             "metric": METRIC,
             "value": total_pairs / elapsed,
@@ -1290,24 +1323,28 @@ def main():
                 "parallelism": "pairs sharded by robot pair, 1 rank per GPU" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "kernel": dom_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
                 "traffic": (pmc or {}).get("bytes"),
                 "traffic_measured_in_this_run": False,
                 "traffic_source": pmc,
-                "compute": compute_note(dom, k, cols, pairs_per_launch, match_ms),
-                "bytes_per_pair": bpp, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": match_ms,
+                "compute": compute_note(dom_name, k, cols, pairs_per_launch, match_ms),
+                "bytes_per_pair": bpp_dom, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": match_ms,
                 "launches_per_step": nm / args.steps,
             },
+            "verification_form": ("split: k_match_split over every candidate + k_chain over the survivors" if split_form
+                                  else "fused: k_verify_fused" if dom == "k_verify_fused" else "stage kernels"),
             "roofline_nn": {
                 "kernel": nn_kernel + ("_k128r" if nn_kernel == "k_nn_filter_f16" and k_eff == 128 else ""),
                 "bound": "mfma", "achieved": nn_tf, "peak": nn_peak,
                 "unit": "TFLOP/s", "frac": nn_tf / nn_peak, "avg_launch_ms": nn_ms, "contracted_dims": k_eff,
             },
-            "kernel_ms_per_step": {(kname.replace("k_ransac", "k_pnp") if args.estimator == "pnp" else kname):
-                                   (ms / survey_steps) for kname, (cnt, ms) in prof_all.items()},
-            "kernel_ms_per_step_source": "HIP events around every kernel in %d steps AFTER the timed region (the timed "
-                                         "region brackets only %s)" % (survey_steps, dom),
+            "kernel_ms_per_step": {survey_name(kname): (ms / survey_steps) for kname, (cnt, ms) in prof_all.items()},
+            "kernel_ms_per_step_source": "HIP events around every kernel in %d steps AFTER the timed region, in the timed "
+                                         "region's form (kernels of the two steps in flight run beside each other, so a "
+                                         "kernel's figure includes what it lost to its neighbour); the timed region "
+                                         "brackets only %s" % (survey_steps,
+                                                               "k_match_split and k_chain" if split_form else dom),
             "check": {"accepted_last_step": accepted, "decisions_matching_ground_truth": correct, "of": int(n),
                       "accepted_separators_gathered_per_step": state.get("gathered", 0),
                       "gathered_records_all_accepted": all_ok},
@@ -1315,6 +1352,18 @@ def main():
             "step_ms_spread": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
                                "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
         }
+        if split_form:
+            whole_ms = match_ms + chain_ms
+            out["roofline"]["chain_kernel"] = {
+                "kernel": "k_chain", "avg_launch_ms": chain_ms,
+                "note": "RANSAC, guess-guided matching, RANSAC and the result of the pairs whose matching found enough "
+                        "correspondences (a fifth of the candidates here): latency-bound fp64 chains, 2*K*12 B of 3D points "
+                        "per surviving pair"}
+            out["roofline"]["whole_verification"] = {
+                "bytes_per_pair": bpp, "ms_per_launch_pair": whole_ms,
+                "achieved": pairs_per_launch * bpp / (whole_ms * 1e-3) / 1e9 if whole_ms > 0 else 0.0, "unit": "GB/s",
+                "note": "SURVEY section 8(d)'s 44 352 B per pair over the two kernels' launch times added (they overlap the "
+                        "neighbouring step's kernels, not each other)"}
         out["self_warmup_steps"] = len(warm_ts)
         out["steps_overlap"] = bool(pipelined)
         out["timed_step_entry_points"] = "sf_step_issue + sf_step_retire" if pipelined else "sf_experimental.h building blocks"

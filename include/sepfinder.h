@@ -52,7 +52,7 @@ extern "C" {
       written for (multi_robot_slam_separators_amd/lib.py does).                                                   */
 /* 3: sf_params grew force_3dof / forward_est_only (appended), sf_nn_row_minima_device, sf_allgather_bytes_device,
       sf_netvlad_infer_batch_device, sf_get_features_and_descriptor_batch_device added.                                                                          */
-/* 4: sf_step_mirror_pair, sf_step_mirror_streams added (nothing existing changed).                                   */
+/* 4: sf_step_mirror_pair, sf_step_mirror_streams, SF_OPT_STEP_SPLIT added (nothing existing changed).                */
 #define SF_ABI_VERSION 4
 
 /* ---- status codes ---------------------------------------------------------------------- */
@@ -562,6 +562,11 @@ enum {
                               second (3D-3D), +14 % (PnP), results unchanged.  0: every step on the handle's stream.
                               Ignored while sf_step_mirror is set (the caller's collective is ordered on the handle's
                               stream) unless sf_step_mirror_streams handed the two streams to the caller.  Either way a step's results are complete when sf_step_retire returns.            */
+  SF_OPT_STEP_SPLIT = 7,  /* 1 (default): while the steps alternate between two streams (SF_OPT_STEP_OVERLAP) the 3D-3D
+                             verification of a step runs as one matching launch over all candidates + one chain launch
+                             over the survivors instead of the fused kernel (+5 % steps per second at the bench shape,
+                             +9 % at 40 000 keyframes; 256-bit descriptors, K <= 512 features, <= 65 536 candidates --
+                             other shapes keep the fused kernel).  0: always the fused kernel.  Results unchanged.    */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never
                              leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */

@@ -14,7 +14,7 @@ SF_MAX_DESC_BYTES = 64
 
 (SF_K_MATCH, SF_K_RANSAC1, SF_K_GUIDED, SF_K_RANSAC2, SF_K_NN, SF_K_NN_SELECT, SF_K_NN_FILTER,
  SF_K_NN_REFINE, SF_K_FUSED, SF_K_COUNT) = range(10)
-SF_OPT_MATCH_MFMA, SF_OPT_FUSED, SF_OPT_OVERLAP, SF_OPT_CHAIN_WAVES, SF_OPT_DEBUG_CORR, SF_OPT_NN_FULL_FILTER, SF_OPT_STEP_OVERLAP = range(7)      # sf_set_option
+SF_OPT_MATCH_MFMA, SF_OPT_FUSED, SF_OPT_OVERLAP, SF_OPT_CHAIN_WAVES, SF_OPT_DEBUG_CORR, SF_OPT_NN_FULL_FILTER, SF_OPT_STEP_OVERLAP, SF_OPT_STEP_SPLIT = range(8)      # sf_set_option
 
 STATUS_NAMES = {0: "SF_OK", 1: "SF_EINVAL", 2: "SF_EHIP", 3: "SF_ENOMEM", 4: "SF_ERANGE", 5: "SF_ENODEV", 6: "SF_ERCCL"}
 

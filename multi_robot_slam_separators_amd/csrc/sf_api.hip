@@ -730,6 +730,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
     c->fused = atoi(v) != 0;
     c->split = atoi(v) == 2;
   }
+  if (const char* v = getenv("SF_STEP_SPLIT")) c->split_auto = atoi(v) != 0;   // 0: overlapped steps keep the fused kernel
   if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;      // 0: PnP on the five stage launches
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
@@ -1179,6 +1180,21 @@ static int ws_reserve(sf_context* c, int n, int kcap, bool lists) {
 static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the workspace: ~4 KiB / pair at K = 500);
                                      // every launch ends with the latency tail of its last surviving pairs, so few, big chunks
 
+// Which form the 3D-3D verification of n pairs takes: the fused kernel (one workgroup carries a pair through matching
+// and both motion-estimation chains) or the split form (k_match_split over all pairs + k_chain over the survivors).
+// On one stream the fused kernel wins (its chains overlap other pairs' matching inside the launch: 19.5 against 17.1 M
+// pairs/s at the bench shape); when sf_step_issue alternates the steps between two streams the neighbouring step fills a
+// launch's tail anyway and the split form is faster (21.9 against 20.7 M pairs/s; 18.3 against 16.8 M at 40 000
+// keyframes): its matching kernel keeps four "to" tiles per wavefront at three workgroups per CU.  Frames that put
+// the fused kernel into its WIDE form (K = 1000), 512-bit descriptors and queries of more than 65 536 candidates
+// measured equal or slower in the split form and stay fused.  SF_FUSED=2 forces the split form everywhere.
+static bool sf_use_split(const sf_context* c, const StoreView& v, int n) {
+  if (c->split) return sf_split_applicable(c, v);
+  if (!c->split_auto || !c->in_overlapped_step) return false;
+  if (c->dparams.estimation_type != 0 || v.w != 8 || n > 65536 || !sf_split_applicable(c, v)) return false;
+  return sf_fused_lds_bytes(c, v) * 4 <= 160 * 1024;       // (not the WIDE form: sf_launch_verify_fused)
+}
+
 // One launch sequence for m <= SF_CHUNK pairs on ctx's stream and workspace.
 static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t* d_from, const int32_t* d_to, int m,
                            sf_result* d_out, bool allow_fused) {
@@ -1189,7 +1205,7 @@ static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t
     if ((rc = sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out)) != SF_OK) return rc;
     return SF_OK;
   }
-  if (allow_fused && ctx->split && sf_split_applicable(ctx, view)) {
+  if (allow_fused && sf_use_split(ctx, view, m)) {
     ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
     return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
   }
@@ -1283,7 +1299,7 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     return SF_OK;
   }
   if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap,
-                       c->debug_corr || c->split || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
+                       c->debug_corr || sf_use_split(c, view, n) || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
     return rc;
   c->ws_split = 0;
   for (int off = 0; off < n; off += SF_CHUNK) {
@@ -1368,7 +1384,8 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
   const unsigned grid = c->spec.grid;
   // one chunk on the fused kernel: it derives the pairs from the candidate list itself (one launch and its gap less
   // between the NN filter and the verification)
-  if (grid <= (unsigned)SF_CHUNK && !c->overlap && !c->split && c->store.slots > 0 &&
+  const bool split_form = c->store.slots > 0 && sf_use_split(c, sf_store_view(c->store), (int)grid);
+  if (grid <= (unsigned)SF_CHUNK && !c->overlap && !split_form && c->store.slots > 0 &&
       sf_fused_lds_bytes(c, sf_store_view(c->store)) != 0) {
     c->pair_src.cand = (const uint2*)d_cand;
     c->pair_src.count = d_count;
@@ -1388,8 +1405,11 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
                      (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
   SF_HIP(c, hipGetLastError());
   // the PnP estimator's chain kernel streams too (one chunk, one stream: a pair's index is its candidate slot)
-  if (grid <= (unsigned)SF_CHUNK && !c->overlap && c->store.slots > 0 && c->dparams.estimation_type == 1 && c->fused &&
-      c->chain_pnp && sf_split_pnp_applicable(c, sf_store_view(c->store))) {
+  // ... and so does the 3D-3D chain kernel of the split form (SF_FUSED=2: k_match_split + k_chain)
+  const bool pnp_chain = c->dparams.estimation_type == 1 && c->fused && c->chain_pnp &&
+                         sf_split_pnp_applicable(c, sf_store_view(c->store));
+  const bool split_chain = split_form && !pnp_chain;
+  if (grid <= (unsigned)SF_CHUNK && !c->overlap && c->store.slots > 0 && (pnp_chain || split_chain)) {
     int rc0 = arm_accept_stream(c, d_count);
     if (rc0 != SF_OK) return rc0;
   }
@@ -1761,13 +1781,17 @@ extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_
   if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
-  const bool lane1 = c->step_overlap && c->step_head == 1 && !c->overlap &&
-                     (!c->step_mirror_records[0] || c->step_mirror_lanes);
-  if (!lane1) return step_issue_body(c, slot_base_other, slot_base_local);
-  int rc = lane1_enter(c);
-  if (rc != SF_OK) return rc;
-  rc = step_issue_body(c, slot_base_other, slot_base_local);
-  lane_swap(c);
+  const bool lanes = c->step_overlap && !c->overlap && (!c->step_mirror_records[0] || c->step_mirror_lanes);
+  const bool lane1 = lanes && c->step_head == 1;
+  c->in_overlapped_step = lanes;            // (sf_use_split: the form the verification takes)
+  int rc;
+  if (!lane1) {
+    rc = step_issue_body(c, slot_base_other, slot_base_local);
+  } else if ((rc = lane1_enter(c)) == SF_OK) {
+    rc = step_issue_body(c, slot_base_other, slot_base_local);
+    lane_swap(c);
+  }
+  c->in_overlapped_step = false;
   return rc;
 }
 
@@ -2119,6 +2143,7 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
     case SF_OPT_CHAIN_WAVES: return SF_OK;   // (round 1's narrower chains are gone: accepted, no effect)
     case SF_OPT_DEBUG_CORR: c->debug_corr = value != 0; return SF_OK;
     case SF_OPT_NN_FULL_FILTER: c->nn_force_full = value != 0; c->nn_coef_level = -1; return SF_OK;
+    case SF_OPT_STEP_SPLIT: c->split_auto = value != 0; return SF_OK;
     case SF_OPT_STEP_OVERLAP:
       if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_OVERLAP cannot change while steps are in flight");
       c->step_overlap = value != 0;

@@ -108,6 +108,54 @@ def test_step_pair_equals_the_separate_calls(est, overlap):
             _check_step(f.step_retire(copy=True), m2, res2, want_streamed)
 
 
+@pytest.mark.parametrize("form", ["forced_two_streams", "forced_one_stream", "auto", "auto_one_stream", "off"])
+def test_step_pair_in_the_split_form(form, monkeypatch):
+    """The 3D-3D verification as one matching launch + one chain launch over the survivors (k_match_split + k_chain)
+    instead of the fused kernel: everywhere with SF_FUSED=2 (read at sf_create); by the library's own choice inside
+    overlapped steps (SF_OPT_STEP_SPLIT, default on) -- not when the steps share one stream, not with the option off.
+    The chain kernel streams the accepted separators like the fused one does, and a step's matches, flags and records
+    are the separate calls', byte for byte, in every form."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(577, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    monkeypatch.delenv("SF_FUSED", raising=False)
+    monkeypatch.delenv("SF_STEP_SPLIT", raising=False)
+    with lib.SeparatorFinder(p) as f:              # the reference results: the fused kernel through the separate calls
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+    assert res_ref["success"].sum() >= 3
+    if form.startswith("forced"):
+        monkeypatch.setenv("SF_FUSED", "2")
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.set_option(_abi.SF_OPT_STEP_OVERLAP, 0 if form.endswith("one_stream") else 1)
+        if form == "off":
+            f.set_option(_abi.SF_OPT_STEP_SPLIT, 0)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m2, res2 = _two_calls(f, sa, sb, n_kf)     # the separate calls in this handle's form: the same bytes
+        assert m2.tobytes() == m_ref.tobytes() and res2.tobytes() == res_ref.tobytes()
+        f.prof_reset()
+        f.prof_enable(True)
+        f.step_issue(sa, sb)
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        f.step_issue(sa, sb)
+        for _ in range(4):
+            f.step_issue(sa, sb)
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        torch.cuda.synchronize()
+        prof = f.prof_get()
+        f.prof_enable(False)
+        split_ran = prof["k_match_global"][0] > 0          # (the matching launch's profiling slot)
+        assert split_ran == (form in ("forced_two_streams", "forced_one_stream", "auto")), (form, prof)
+        assert prof["k_verify_fused"][0] == 6              # the fused kernel, or the chain launch in its slot
+
+
 def test_step_with_a_mirror_for_the_exchange():
     """sf_step_mirror: every accepted record also lands in a device buffer (an all-gather's send buffer) and the slot
     counter is the caller's device word; a mirror too small for the query's verified candidates switches the query to

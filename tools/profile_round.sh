@@ -22,7 +22,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_
 timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sqw -- $B > $out/sqw.log 2>&1
 python tools/summarize_prof.py $tag $out/stats $out/fetch $out/write > $out/summary.txt
 python tools/pmc_kernel.py $out/sq > $out/sq.txt
-python tools/sq_json.py $tag k_verify_fused $out/sq $out/sqw
+# (the verification's kernels: the fused form, or -- inside overlapped steps, the default since round 3's last session --
+#  the split form's matching and chain kernels; a kernel that did not run leaves no file)
+for kern in k_verify_fused k_match_split k_chain; do python tools/sq_json.py $tag $kern $out/sq $out/sqw; done
 cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv profiles/${tag}_sq_*.json $out/
 grep "^{" $out/stats.log > $out/${tag}_bench_stdout.log
-tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_global_mf" $out/sq.txt
+tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_split|k_chain|k_match_global_mf" $out/sq.txt
