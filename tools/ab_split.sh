@@ -10,6 +10,6 @@ tag,name=sys.argv[1:3]
 for line in open('gpurun_out/%s/%s.log'%(tag,name)):
     if line.startswith('{'):
         j=json.loads(line); k=j['kernel_ms_per_step']
-        print("%-14s value %.2f M  ms/step %.4f  fused/chain %.4f  match %.4f  filter %.4f  ok %s" % (name, j['value']/1e6, j['ms_per_step'], k.get('k_verify_fused',0), k.get('k_match_global',0), k.get('k_nn_filter_f16',0), j['check']['decisions_matching_ground_truth']))
+        print("%-14s value %.2f M  ms/step %.4f  fused/chain %.4f  match %.4f  filter %.4f  ok %s" % (name, j['value']/1e6, j['ms_per_step'], k.get('k_verify_fused',k.get('k_chain',0)), k.get('k_match_global',k.get('k_match_split',0)), k.get('k_nn_filter_f16',0), j['check']['decisions_matching_ground_truth']))
 PY
 done
