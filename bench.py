@@ -1333,6 +1333,8 @@ def main():
                 "launches_per_step": nm / args.steps,
             },
             "verification_form": ("split: k_match_split over every candidate + k_chain over the survivors" if split_form
+                                  else "split (PnP): k_match_split + k_chain_pnp (the library's k_verify_fused profiling slot)"
+                                  if args.estimator == "pnp" and dom == "k_verify_fused"
                                   else "fused: k_verify_fused" if dom == "k_verify_fused" else "stage kernels"),
             "roofline_nn": {
                 "kernel": nn_kernel + ("_k128r" if nn_kernel == "k_nn_filter_f16" and k_eff == 128 else ""),
