@@ -565,7 +565,7 @@ enum {
   SF_OPT_STEP_SPLIT = 7,  /* 1 (default): while the steps alternate between two streams (SF_OPT_STEP_OVERLAP) the 3D-3D
                              verification of a step runs as one matching launch over all candidates + one chain launch
                              over the survivors instead of the fused kernel (+5 % steps per second at the bench shape,
-                             +9 % at 40 000 keyframes; 256-bit descriptors, K <= 512 features, <= 65 536 candidates --
+                             +9 % at 40 000 keyframes; 256-bit descriptors, K <= 512 features, 2 048 .. 65 536 candidates --
                              other shapes keep the fused kernel).  0: always the fused kernel.  Results unchanged.    */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never

@@ -730,6 +730,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
     c->fused = atoi(v) != 0;
     c->split = atoi(v) == 2;
   }
+  if (const char* v = getenv("SF_STEP_SPLIT_MIN")) c->split_auto_min = std::max(1, atoi(v));
   if (const char* v = getenv("SF_STEP_SPLIT")) c->split_auto = atoi(v) != 0;   // 0: overlapped steps keep the fused kernel
   if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;      // 0: PnP on the five stage launches
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
@@ -1187,11 +1188,13 @@ static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the wo
 // launch's tail anyway and the split form is faster (21.9 against 20.7 M pairs/s; 18.3 against 16.8 M at 40 000
 // keyframes): its matching kernel keeps four "to" tiles per wavefront at three workgroups per CU.  Frames that put
 // the fused kernel into its WIDE form (K = 1000), 512-bit descriptors and queries of more than 65 536 candidates
-// measured equal or slower in the split form and stay fused.  SF_FUSED=2 forces the split form everywhere.
+// measured equal or slower in the split form and stay fused, and so do small queries (the reference's own cadence of 20
+// candidates per tick: one launch instead of three).  SF_FUSED=2 forces the split form everywhere.
 static bool sf_use_split(const sf_context* c, const StoreView& v, int n) {
   if (c->split) return sf_split_applicable(c, v);
   if (!c->split_auto || !c->in_overlapped_step) return false;
-  if (c->dparams.estimation_type != 0 || v.w != 8 || n > 65536 || !sf_split_applicable(c, v)) return false;
+  if (c->dparams.estimation_type != 0 || v.w != 8 || n > 65536 || n < c->split_auto_min || !sf_split_applicable(c, v))
+    return false;
   return sf_fused_lds_bytes(c, v) * 4 <= 160 * 1024;       // (not the WIDE form: sf_launch_verify_fused)
 }
 

@@ -231,6 +231,7 @@ struct sf_context {
   bool nn_k128_attr = false;   // k_nn_filter_f16_k128: dynamic LDS attribute set
   bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
   bool split_auto = true;   // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip)
+  int split_auto_min = 2048;   // ... for queries of at least this many candidates (SF_STEP_SPLIT_MIN): below, one launch wins
   bool in_overlapped_step = false;   // set around sf_step_issue's body while the steps alternate between two streams
   bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
   bool split_match_attr[2] = {};   // k_match_split [W == 16]

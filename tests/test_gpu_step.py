@@ -124,6 +124,7 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
     p.max_features = k
     monkeypatch.delenv("SF_FUSED", raising=False)
     monkeypatch.delenv("SF_STEP_SPLIT", raising=False)
+    monkeypatch.delenv("SF_STEP_SPLIT_MIN", raising=False)
     with lib.SeparatorFinder(p) as f:              # the reference results: the fused kernel through the separate calls
         f.set_stream(torch.cuda.current_stream().cuda_stream)
         sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
@@ -131,6 +132,7 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
     assert res_ref["success"].sum() >= 3
     if form.startswith("forced"):
         monkeypatch.setenv("SF_FUSED", "2")
+    monkeypatch.setenv("SF_STEP_SPLIT_MIN", "1")       # (by default only queries of >= 2048 candidates switch form)
     with lib.SeparatorFinder(p) as f:
         f.set_stream(torch.cuda.current_stream().cuda_stream)
         f.set_option(_abi.SF_OPT_STEP_OVERLAP, 0 if form.endswith("one_stream") else 1)
