@@ -242,3 +242,14 @@ def test_ros_shims_use_only_the_declared_abi():
     for service in ("find_matches_compute", "receive_separators_py"):
         assert '"%s"' % service in py
     assert "NOT COMPILED" in src and "NOT RUN" in py and "NOT COMPILED HERE" in open(os.path.join(ROOT, "ros", "README.md")).read()
+
+
+def test_option_constants_equal_the_header_enums():
+    """multi_robot_slam_separators_amd/_abi.py mirrors include/sepfinder.h by hand: every SF_OPT_* value must be the
+    header's (a binding that passes the wrong option number changes another switch silently)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "sepfinder.h")).read()
+    found = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\b(SF_OPT_[A-Z_0-9]+)\s*=\s*(\d+)", hdr))
+    assert len(found) >= 8 and len(set(found.values())) == len(found)
+    for name, value in found.items():
+        assert getattr(_abi, name) == value, name
