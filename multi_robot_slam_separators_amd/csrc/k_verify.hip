@@ -140,11 +140,13 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
 
 // ---- the split pipeline: ONE matching launch over all pairs, ONE chain launch over the survivors -------------
 // The fused kernel holds a latency-bound chain (~55 us alone, ~73 us beside matching workgroups) in a quarter of a
-// CU's slots while the matching of the other pairs (issue-bound, 7 us of a CU per pair whatever the occupancy)
-// queues behind it, and the chains born from the last matches run on an emptying chip.  Split, the matching of all
-// pairs runs at its issue bound with 4 "to" tiles resident per wavefront (2 workgroups per CU), the survivors'
-// lists / headers take one trip through HBM (~2 KB per survivor) and their chains run four to a CU with nothing
-// else on it.  Same bodies, same bytes.
+// CU's slots while the matching of the other pairs queues behind it, and the chains born from the last matches run on
+// an emptying chip.  Split, the matching of all pairs runs with 4 "to" tiles resident per wavefront at three workgroups
+// per CU (160 VGPRs: the spread of a "from" tile is shared by twice the columns of the fused kernel's scan), the
+// survivors' lists / headers take one trip through HBM (~2 KB per survivor) and their chains run four to a CU.  Same
+// bodies, same bytes.  On ONE stream the fused kernel is the faster form (its chains overlap other pairs' matching
+// inside the launch); since sf_step_issue alternates the steps between two streams the neighbouring step fills a
+// launch's tail anyway and the split form wins -- sf_use_split (sf_api.hip) picks it there (SF_OPT_STEP_SPLIT).
 template <int W, int NTL = 4, int MINW = 3>
 __global__ void __launch_bounds__(SF_BLOCK, MINW)
 k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
