@@ -351,6 +351,14 @@ __device__ __forceinline__ mf_v8i fp4_spread_to(uint32_t y, uint32_t m88, uint32
   return o;
 }
 
+// Dynamic LDS of the LDS-staged matching body: the staged "from" descriptors, the per-row counters / owners and 16 words.
+// The MFMA scan requests a tile's rows one tile ahead without clamping the row number, i.e. up to 32 rows past the
+// staged block: the words behind it must exist (they are the counters, or padding when kcap is small).
+static inline size_t sf_match_lds_bytes(int kcap, int w) {
+  const int behind = 2 * kcap + 16;
+  return (size_t)(kcap * w + (behind > 32 * w ? behind : 32 * w)) * sizeof(int);
+}
+
 template <int KS>
 __device__ __forceinline__ void load_raw(const uint32_t* p, uint32_t (&raw)[KS]) {
 #pragma unroll
@@ -401,7 +409,7 @@ template <int W, int NTL, bool TAIL>
 __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, int mt, int r, int h,
                                                const mf_v8i (&Bf)[NTL][W / 2], const float (&cin)[16],
                                                float (&b)[NTL], float (&s)[NTL], uint32_t m88, uint32_t c22,
-                                               uint32_t (&raw)[W / 2]) {
+                                               uint32_t (&raw)[W / 2], const uint32_t*& nxt) {
   constexpr int KS = W / 2;
   // every tile starts from the SAME accumulator tuple (the MFMA reads it as its C operand: no copy).  The ragged last
   // tile does too and masks its missing rows behind the products -- a second tuple with -inf in those rows was kept in
@@ -413,14 +421,29 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
 #pragma unroll
   for (int k = 0; k < KS; ++k) Af[k] = fp4_spread_from(raw[k], m88, c22);
   if (!TAIL) {
-    const int nrow = min((mt + 1) * 32 + r, Kf - 1);      // (the ragged last tile clamps its missing rows)
-    load_raw<KS>(fromD + (size_t)nrow * W + KS * h, raw);
+    // the next tile's rows: a running address, no clamp -- rows past Kf (the ragged last tile's missing ones, or a whole
+    // tile that is never used when Kf is a multiple of 32) lie inside the workgroup's LDS block (at most 32 rows past
+    // the staged descriptors: the counters behind them, sf_match_lds_bytes), spread to valid fp4 whatever their bits,
+    // and are masked behind the products
+    nxt += 32 * W;
+    load_raw<KS>(nxt, raw);
   }
+  // the scores kept so far move with the origin (the first row of the current tile); pairs of them in one packed add
+  if constexpr (NTL % 2 == 0) {
+    typedef float mf_v2f __attribute__((ext_vector_type(2)));
+    const mf_v2f step = {32.f * MF_FR, 32.f * MF_FR};
 #pragma unroll
-  for (int j = 0; j < NTL; ++j) {
-    // the scores kept so far move with the origin (the first row of the current tile)
-    b[j] += 32.f * MF_FR;
-    s[j] += 32.f * MF_FR;
+    for (int j = 0; j < NTL; j += 2) {
+      mf_v2f bb = {b[j], b[j + 1]}, ss = {s[j], s[j + 1]};
+      bb += step; ss += step;
+      b[j] = bb[0]; b[j + 1] = bb[1]; s[j] = ss[0]; s[j + 1] = ss[1];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      b[j] += 32.f * MF_FR;
+      s[j] += 32.f * MF_FR;
+    }
   }
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -474,8 +497,9 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
   const int n_full = Kf >> 5;
   uint32_t raw[KS];
   load_raw<KS>(fromD + (size_t)min(r, Kf - 1) * W + KS * h, raw);
-  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22, raw);
-  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22, raw);
+  const uint32_t* nxt = fromD + (size_t)r * W + KS * h;
+  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22, raw, nxt);
+  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22, raw, nxt);
   const float org = (float)(32 * (((Kf + 31) >> 5) - 1)) * MF_FR;
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -731,7 +755,7 @@ k_match_global_mf(StoreView st, const int32_t* __restrict__ pair_from, const int
 
 template <int W, int NQ, int NT>
 void launch_match_v2(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
-  size_t lds = (size_t)(st.kcap * W + 2 * st.kcap + 16) * sizeof(int);
+  size_t lds = sf_match_lds_bytes(st.kcap, W);
   if (const char* v = getenv("SF_MATCH_LDS_PAD")) lds += (size_t)atoi(v);   // occupancy experiment (diagnostic)
   int32_t* counters = (int32_t*)c->counters.p;
   if constexpr (NQ == 0)
@@ -761,7 +785,7 @@ int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, c
   int variant = c->match_variant;
   if (variant == 0) {
     // default: LDS + u16 variant while the staged "from" block keeps >= 2 workgroups per CU
-    const size_t lds_v2 = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+    const size_t lds_v2 = sf_match_lds_bytes(st.kcap, st.w);
     variant = lds_v2 <= 64 * 1024 ? (c->match_mfma && st.kcap <= MF_MAX_ROWS ? 10256 : 12256) : 2256;
   }
   sf_prof_begin(c, SF_K_MATCH);

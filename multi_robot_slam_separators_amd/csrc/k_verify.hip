@@ -217,7 +217,7 @@ int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32
 // offset of the FusedTail = the largest stage's working set (the chain stages sit behind the kcap-entry list)
 size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_match = true) {
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t match = with_match ? (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int) : 0;
+  const size_t match = with_match ? sf_match_lds_bytes(st.kcap, st.w) : 0;
   const size_t guided = (size_t)st.kcap * 4 + sf_guided_lds_bytes(st.kcap, nc);
   const size_t ransac = (size_t)st.kcap * 4 + ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
                         (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0);
@@ -230,7 +230,7 @@ size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_mat
 // apply (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
   if (!c->fused || c->dparams.estimation_type != 0 || c->dparams.bidirectional) return 0;   // (both directions: stage kernels)
-  const size_t match = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  const size_t match = sf_match_lds_bytes(st.kcap, st.w);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
   if (match > 64 * 1024 || c->match_variant != 0) return 0;
@@ -348,7 +348,7 @@ bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st) {
   const size_t lds = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
                                   (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0),
                               sf_guided_lds_bytes(st.kcap, nc));
-  return lds <= 160 * 1024 && (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int) <= 160 * 1024;
+  return lds <= 160 * 1024 && sf_match_lds_bytes(st.kcap, st.w) <= 160 * 1024;
 }
 
 namespace {
@@ -376,7 +376,7 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
   if (!(pnp ? sf_split_pnp_applicable(c, st) : sf_split_applicable(c, st)))
     return sf_fail(c, SF_EINVAL, "split verification pipeline not applicable");
   SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
-  const size_t lds_m = (size_t)(st.kcap * st.w + 2 * st.kcap + 16) * sizeof(int);
+  const size_t lds_m = sf_match_lds_bytes(st.kcap, st.w);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_MATCH);
   if (lds_m > 64 * 1024 && !c->split_match_attr[st.w == 16]) {
