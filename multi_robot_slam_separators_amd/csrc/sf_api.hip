@@ -1199,8 +1199,9 @@ static bool sf_use_split(const sf_context* c, const StoreView& v, int n) {
 }
 
 // One launch sequence for m <= SF_CHUNK pairs on ctx's stream and workspace.
+// `split`: the form decided ONCE for the whole call (sf_use_split over all its pairs: the workspace was reserved for it).
 static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t* d_from, const int32_t* d_to, int m,
-                           sf_result* d_out, bool allow_fused) {
+                           sf_result* d_out, bool allow_fused, bool split = false) {
   int rc;
   ctx->dparams.dbg_corr = ctx->debug_corr ? 1 : 0;
   if (allow_fused && ctx->chain_pnp && sf_split_pnp_applicable(ctx, view)) {
@@ -1208,7 +1209,7 @@ static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t
     if ((rc = sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out)) != SF_OK) return rc;
     return SF_OK;
   }
-  if (allow_fused && sf_use_split(ctx, view, m)) {
+  if (allow_fused && split) {
     ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
     return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
   }
@@ -1301,13 +1302,14 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     SF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return SF_OK;
   }
+  const bool split = sf_use_split(c, view, n);
   if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap,
-                       c->debug_corr || sf_use_split(c, view, n) || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
+                       c->debug_corr || split || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
     return rc;
   c->ws_split = 0;
   for (int off = 0; off < n; off += SF_CHUNK) {
     const int m = std::min(SF_CHUNK, n - off);
-    if ((rc = verify_sequence(c, view, d_from + off, d_to + off, m, d_out + off, true)) != SF_OK) return rc;
+    if ((rc = verify_sequence(c, view, d_from + off, d_to + off, m, d_out + off, true, split)) != SF_OK) return rc;
   }
   return SF_OK;
 }
