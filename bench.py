@@ -117,12 +117,12 @@ def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
         flop = 2.0 * k * k * cols * 8          # one multiply-add per descriptor bit pair
         tf = pairs_per_launch * flop / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
         scan = ("four resident column tiles per wavefront (three workgroups per CU): per 32-row tile and SIMD the 16 MFMAs hold "
-                "the fp4 pipe for 512 cycles; the issue port is held 4 cycles by each of the scan's 102 vector instructions and "
-                "~12-16 by each MFMA (operand reads): 600-664 cycles -- the port is the bound (87-93 % busy over the launch by "
-                "that count, DESIGN.md section 5)" if dom == "k_match_split" else
-                "per 32-row tile and SIMD the 8 MFMAs hold the fp4 pipe for 256 cycles; the issue port is held 4 cycles by each "
-                "of the scan's 60 vector instructions and ~12-16 by each MFMA: 336-368 cycles (DESIGN.md section 5; "
-                "profiles/r03m_fewer_valu_no_gain.log)")
+                "the fp4 pipe for 226 ns; the vector issue port is held 1.06 ns by each of the scan's 102 vector instructions and "
+                "9.3 ns by each MFMA (tools/ubench/mfma_port.hip): 257 ns -- over the launch the port is ~70 % busy, the pipe "
+                "~50 %, the rest is dependent latency at three wavefronts per SIMD (DESIGN.md section 5)" if dom == "k_match_split" else
+                "per 32-row tile and SIMD the 8 MFMAs hold the fp4 pipe for 113 ns; the vector issue port is held 1.06 ns by each "
+                "of the scan's 60 vector instructions and 9.3 ns by each MFMA (tools/ubench/mfma_port.hip): 138 ns "
+                "(DESIGN.md section 5; profiles/r03m_fewer_valu_no_gain.log)")
         return {"note": "matching = v_mfma_f32_32x32x64_f8f6f4 over +-1-encoded descriptor bits (2*K*K*bits flop per pair, "
                         "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan: " + scan
                         + ("; the launch also holds both motion-estimation chains of the surviving pairs, which are "
