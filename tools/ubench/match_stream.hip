@@ -96,6 +96,56 @@ __global__ void __launch_bounds__(256, 4) kS(const unsigned* __restrict__ raw, i
   sink[blockIdx.x * 256 + tid] = total;
 }
 
+// R: raw rows straight from global memory (L2), one tile ahead, no LDS staging and no barrier: every wavefront reads
+// the pair's 16 KB itself (1 KiB, perfectly coalesced, per tile).  raw: [blocks][KF][8] dwords
+__global__ void __launch_bounds__(256, 4) kR(const unsigned* __restrict__ raw, int n_blocks, int pairs_per_wg, float* sink) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  unsigned m88, c22;
+  asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
+  float total = 0.f;
+  for (int p = 0; p < pairs_per_wg; ++p) {
+    const int bf = (blockIdx.x + p * gridDim.x) % n_blocks, bt = (bf + 7919) % n_blocks;
+    const unsigned* dF = raw + (size_t)bf * RAW_DW;
+    const unsigned* dT = raw + (size_t)bt * RAW_DW;
+    for (int g = 0; g < 2; ++g) {
+      v8i Bf[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = (wave + 4 * (2 * g + j)) * 32 + r;
+        const uint4 v = *reinterpret_cast<const uint4*>(dT + (size_t)t * 8 + 4 * h);
+        Bf[j][0] = spread_to(v.x, m88, c22); Bf[j][1] = spread_to(v.y, m88, c22);
+        Bf[j][2] = spread_to(v.z, m88, c22); Bf[j][3] = spread_to(v.w, m88, c22);
+      }
+      float cin[16], b[2] = {-1e30f, -1e30f}, s[2] = {-1e30f, -1e30f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) / 2048.f;
+      uint4 rw = *reinterpret_cast<const uint4*>(dF + r * 8 + 4 * h);
+#pragma unroll 1
+      for (int mt = 0; mt < 16; ++mt) {
+        v16f c0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c0[i] = cin[i];
+        v8i Af[4];
+        Af[0] = spread_from(rw.x, m88, c22); Af[1] = spread_from(rw.y, m88, c22);
+        Af[2] = spread_from(rw.z, m88, c22); Af[3] = spread_from(rw.w, m88, c22);
+        rw = *reinterpret_cast<const uint4*>(dF + (min(mt + 1, 15) * 32 + r) * 8 + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { b[j] += 32.f / 2048.f; s[j] += 32.f / 2048.f; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[0], Bf[j][0], c0, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+          for (int k = 1; k < 4; ++k) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(Af[k], Bf[j][k], acc, 4, 4, 0, 0, 0, 0);
+          top2_16(acc, b[j], s[j]);
+        }
+      }
+      total += (b[0] + s[0]) + (b[1] + s[1]);
+    }
+  }
+  sink[blockIdx.x * 256 + tid] = total;
+}
+
 // G: the "from" operand already spread, from global memory.  fp4: [blocks][16 tiles][4 k-steps][64 lanes][4 dwords]
 template <int AHEAD>   // 0: a tile's operands are requested when the previous tile's MFMAs have consumed the registers
                        // (no extra registers); 1: one tile ahead in a second register set (+16 VGPRs)
@@ -270,6 +320,7 @@ int main(int argc, char** argv) {
            pairs, pairs / best / 1e3, best * 1e3 * cus / pairs);
   };
   timeit("S  raw rows in LDS, spread per wavefront", [&] { hipLaunchKernelGGL(kS, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
+  timeit("R  raw rows from global per wavefront, no LDS", [&] { hipLaunchKernelGGL(kR, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
   timeit("G0 spread rows from global, in-place reload", [&] { hipLaunchKernelGGL(kG<0>, dim3(grid), dim3(256), 0, 0, raw, fp4, n_blocks, ppw, sink); });
   timeit("G1 spread rows from global, one tile ahead", [&] { hipLaunchKernelGGL(kG<1>, dim3(grid), dim3(256), 0, 0, raw, fp4, n_blocks, ppw, sink); });
   timeit("L  spread shared through a two-tile LDS ring", [&] { hipLaunchKernelGGL(kL<1>, dim3(grid), dim3(256), 0, 0, raw, n_blocks, ppw, sink); });
