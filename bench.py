@@ -756,8 +756,15 @@ def main():
             f.step_mirror(exch.payload.data_ptr(), exch.count_ptr, int(exch.payload.shape[0]))
     inflight = [0]
 
+    # steps kept in flight: the library's ring (SF_OPT_STEP_DEPTH, default 6); with the RCCL exchange a step's buffer is
+    # reused two steps later, so two
+    depth = 2 if dist_cuda else int(os.environ.get("SF_STEP_DEPTH", "6"))
+    t_issue, t_retire = [], []
+
     def retire(copy=False):
+        ts = time.perf_counter()
         m, rom, recs, info = f.step_retire(copy=copy)
+        t_retire.append((time.perf_counter() - ts) * 1e3)
         inflight[0] -= 1
         state["pairs"] += info["n_matches"]
         state["last"] = (m, rom, recs, info)
@@ -765,6 +772,11 @@ def main():
             state["gathered"] = info["n_accepted"]
 
     def issue(k):
+        """Step k enters the pipeline; the oldest step is retired first when the ring is full (its outputs were queued
+        `depth` steps ago: the device has `depth - 1` steps of work queued while the host looks at them)."""
+        if inflight[0] >= depth:
+            retire()
+        ts = time.perf_counter()
         if dist_cuda:
             b = issued[0] % len(exchs)           # (the library alternates its mirrors with the steps the same way)
             ex, lane = exchs[b], lane_streams[b]
@@ -777,8 +789,7 @@ def main():
             issued[0] += 1
         else:
             f.step_issue(slot_a, slot_b)
-        if inflight[0]:
-            retire()                          # step k - 1: its outputs were queued before this step's NN filter
+        t_issue.append((time.perf_counter() - ts) * 1e3)
         inflight[0] += 1
 
     def drain_exchanges():
@@ -923,7 +934,6 @@ def main():
         elif len(warm_ts) >= sw_min and max(warm_ts[-3:]) < 1.03 * min(warm_ts[-3:]):
             break
     if pipelined:
-        torch.cuda.synchronize()
         while inflight[0]:
             retire()
         drain_exchanges()
@@ -936,6 +946,10 @@ def main():
     f.prof_select(None if os.environ.get("BENCH_PROF_ALL") else dominant)
     f.prof_enable(os.environ.get("BENCH_NO_PROF") is None)
     state["pairs"] = 0
+    del t_issue[:], t_retire[:]
+    # The contract's bracket: barrier + synchronize, then EXACTLY K steps issued and retired, then synchronize + barrier.
+    # Nothing else sits between the warm-up's last retire and t0 (round 3 drained, re-armed the profiler and collected
+    # here: the device idled long enough for its first timed step to take 7 ms on the driver's box).
     if dist_on:
         td.barrier()
     torch.cuda.synchronize()
@@ -944,8 +958,10 @@ def main():
     if pipelined:
         for step_i in range(args.steps):
             ts = time.perf_counter()
-            issue(step_i)                 # (retires step k - 1 once step k's candidates are walked)
+            issue(step_i)                 # (retires step k - depth first when the ring is full)
             step_ms.append((time.perf_counter() - ts) * 1e3)
+        while inflight[0] > 1:
+            retire()
         retire(copy=True)                 # (waits for the last step's verification)
         drain_exchanges()                 # (the collectives' stream and the header copies too)
     else:
@@ -963,9 +979,7 @@ def main():
         if dist_cuda:
             f.step_mirror(None, None, 0)
             exch = state["exch_last"]     # (the checks below read the LAST step's exchange)
-    if os.environ.get("BENCH_DEBUG_SPREAD"):
-        order = np.argsort(step_ms)[::-1][:4]
-        print("[bench] slowest steps: " + ", ".join("#%d %.3f ms" % (int(i), step_ms[int(i)]) for i in order), file=sys.stderr)
+    timed_issue_ms, timed_retire_ms = list(t_issue), list(t_retire)
     prof = f.prof_get()
     f.prof_enable(False)
     # survey of every kernel (not timed): per-kernel HIP-event times of `survey_steps` further steps
@@ -981,7 +995,6 @@ def main():
         #  split one, k_match_split + k_chain -- so the survey runs the step pair too)
         for step_i in range(survey_steps):
             issue(step_i)
-        torch.cuda.synchronize()
         while inflight[0]:
             retire()
         drain_exchanges()
@@ -1352,8 +1365,17 @@ def main():
                       "accepted_separators_gathered_per_step": state.get("gathered", 0),
                       "gathered_records_all_accepted": all_ok},
             "input_generation_s": t_gen,
+            # host wall time of each timed step's issue (which first retires the oldest step once the ring is full); the
+            # slowest step is named, with what its issue and the retire inside it took
             "step_ms_spread": {"min": float(np.min(step_ms)), "median": float(np.median(step_ms)),
-                               "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms))},
+                               "p90": float(np.percentile(step_ms, 90)), "max": float(np.max(step_ms)),
+                               "argmax": int(np.argmax(step_ms)),
+                               "issue_ms_of_argmax": (timed_issue_ms[int(np.argmax(step_ms))]
+                                                      if pipelined and len(timed_issue_ms) > int(np.argmax(step_ms)) else None),
+                               "issue_ms_median": float(np.median(timed_issue_ms)) if pipelined and timed_issue_ms else None,
+                               "retire_ms_median": float(np.median(timed_retire_ms)) if pipelined and timed_retire_ms else None,
+                               "retire_ms_max": float(np.max(timed_retire_ms)) if pipelined and timed_retire_ms else None,
+                               "steps_in_flight": depth if pipelined else 1},
         }
         if split_form:
             whole_ms = match_ms + chain_ms

@@ -53,7 +53,9 @@ extern "C" {
 /* 3: sf_params grew force_3dof / forward_est_only (appended), sf_nn_row_minima_device, sf_allgather_bytes_device,
       sf_netvlad_infer_batch_device, sf_get_features_and_descriptor_batch_device added.                                                                          */
 /* 4: sf_step_mirror_pair, sf_step_mirror_streams, SF_OPT_STEP_SPLIT added (nothing existing changed).                */
-#define SF_ABI_VERSION 4
+/* 5: sf_step_issue no longer waits for the device (SF_OPT_STEP_DEVICE_WALK, _DEPTH, _LANES), sf_nn_walk_device added; 
+      sf_step_result pointers stay valid until the next sf_step_retire.                                             */
+#define SF_ABI_VERSION 5
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -244,6 +246,13 @@ int  sf_nn_walk(sf_handle h, const double* row_min, const int32_t* row_arg, int3
    that level's sparse limit -- the minima are then undefined and the caller takes sf_nn_find_matches +
    sf_nn_last_row_minima (which walks the ladder) -- and 0 otherwise.                                           */
 int  sf_nn_row_minima_device(sf_handle h, double* d_row_min, int32_t* d_row_arg, int32_t* d_status);
+/* The walk of sf_nn_walk ON THE DEVICE (data_handler.py:191-205), asynchronous on the handle's stream, for minima that
+   are already there: d_row_min / d_row_arg as sf_nn_row_minima_device leaves them (or the all-gathered minima of a node
+   that shards the local rows), d_status (may be NULL) a device int32 that voids the walk (0 matches) when non-zero.
+   Writes up to `cap` matches, walk order, to d_matches and their number to d_n_matches[0]; both may be device memory
+   or host-pinned memory the device can write.  netvlad_distance and netvlad_max_matches_nb are the handle's.     */
+int  sf_nn_walk_device(sf_handle h, const double* d_row_min, const int32_t* d_row_arg, const int32_t* d_status,
+                       int32_t n_local, int32_t n_received, sf_match* d_matches, int32_t cap, int32_t* d_n_matches);
 /* Descriptor dimensions the fp16 filter contracted in the last find_matches call (0: exact path). */
 int  sf_nn_last_filter_dims(sf_handle h, int32_t* dims);
 
@@ -477,21 +486,26 @@ int  sf_find_matches_and_verify_device(sf_handle h, int32_t slot_base_other, int
 /* ---- the caller's loop body as a begin / retire pair ------------------------------------------------------------ */
 /* replaces: one iteration of find_separators.py:59-133 when both robots' keyframes live in this handle --
      sf_step_issue   = s_find_matches_query (:63) + one s_ans_est_transform per returned candidate (:83-95), QUEUED: the
-                       call returns when the candidate list is known (the NN stage has been walked on the host) and the
-                       verification of every candidate is running on the device;
+                       NN kernels, the argsort + walk of DataHandler.find_matches (data_handler.py:187-205) ON THE DEVICE
+                       and the verification of the walk's matches are all queued on one stream and the call returns
+                       without waiting for any of it (SF_OPT_STEP_DEVICE_WALK);
      sf_step_retire  = what the loop then does with the outcomes (:97-133): for every match, in the order
                        DataHandler.find_matches returned them, whether the estimation succeeded and, if so, its
                        PoseWithCovariance -- the rows of the ReceiveSeparators request (sf_pack_separators packs them).
-   Up to TWO steps may be in flight, so a host issues step k before it retires step k - 1 and the device never waits for
-   the host (bench.py, examples/bench_cli.cpp):  issue(0); for k = 1..: issue(k); retire(k - 1); ...; retire(last).
-   The two steps in flight run on two streams (SF_OPT_STEP_OVERLAP): work the caller queued on the handle's stream before
-   sf_step_issue is waited for, and database calls (sf_store_*, sf_nn_append_*, sf_nn_reset) made while steps are in
-   flight are ordered against them by the library.
+                       It is the only call of the pair that waits for the device.
+   Up to SF_OPT_STEP_DEPTH steps (default 6) may be in flight, so the device never waits for the host (bench.py,
+   examples/bench_cli.cpp):  issue(0) .. issue(D-1); then retire(k), issue(k + D) ...; retire the rest.
+   The steps in flight are dealt over SF_OPT_STEP_LANES streams (SF_OPT_STEP_OVERLAP): work the caller queued on the
+   handle's stream before sf_step_issue is waited for, and every call that changes a database or a mask
+   (sf_store_*, sf_nn_append_*, sf_nn_mark_*, sf_nn_ignore_pair, sf_nn_reset) first waits for the steps in flight:
+   a step sees the databases and masks as they were when it was issued.
    Accepted results leave the verification kernel for host-pinned memory the moment they are final (no compaction
-   launch, no copy); a query the speculative verification does not cover (netvlad_max_matches_nb < local rows, as in the
-   reference's default of 20; nn_precision 0; very large batches) takes sf_nn_find_matches + sf_verify_matches_device +
-   an ordered compaction inside the same two calls.  Results are identical either way.
-   Pointers in sf_step_result are owned by the handle and stay valid until the second-next sf_step_issue.          */
+   launch, no copy); launch shapes the stream does not cover (stage kernels, more than 131 072 matches) end with an
+   ordered compaction inside the same two calls.  With nn_precision 1 the NN filter runs at the prefix level the
+   handle last settled on; a candidate set too dense for that level is detected on the device, and sf_step_retire then
+   runs that one query again through the prefix ladder (sf_nn_find_matches' path) before it returns -- results are
+   identical either way; only with a mirror set (below) such a step returns SF_ERANGE, since the mirror missed it.
+   Pointers in sf_step_result are owned by the handle and stay valid until the next sf_step_retire.               */
 typedef struct sf_step_result {
   const sf_match*  matches;          /* n_matches candidates, walk order (data_handler.py:191-205)                   */
   const int32_t*   record_of_match;  /* n_matches: index into `records` of the match's result, -1 = estimation failed
@@ -538,7 +552,8 @@ enum {
   SF_K_NN_FILTER = 6,  /* fp16 MFMA candidate filter (nn_precision = 1)                       */
   SF_K_NN_REFINE = 7,  /* exact f64 distance of every filter survivor                         */
   SF_K_FUSED = 8,      /* fused per-pair pipeline: match + RANSAC + guided + RANSAC + result    */
-  SF_K_COUNT = 9
+  SF_K_NN_WALK = 9,    /* argsort of the row minima + the walk (data_handler.py:191-205), on the device */
+  SF_K_COUNT = 10
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);
@@ -562,11 +577,25 @@ enum {
                               second (3D-3D), +14 % (PnP), results unchanged.  0: every step on the handle's stream.
                               Ignored while sf_step_mirror is set (the caller's collective is ordered on the handle's
                               stream) unless sf_step_mirror_streams handed the two streams to the caller.  Either way a step's results are complete when sf_step_retire returns.            */
-  SF_OPT_STEP_SPLIT = 7,  /* 1 (default): while the steps alternate between two streams (SF_OPT_STEP_OVERLAP) the 3D-3D
-                             verification of a step runs as one matching launch over all candidates + one chain launch
-                             over the survivors instead of the fused kernel (+5 % steps per second at the bench shape,
-                             +9 % at 40 000 keyframes; 256-bit descriptors, K <= 512 features, 2 048 .. 65 536 candidates --
-                             other shapes keep the fused kernel).  0: always the fused kernel.  Results unchanged.    */
+  SF_OPT_STEP_SPLIT = 7,  /* 1: while the steps are dealt over several streams (SF_OPT_STEP_OVERLAP) the 3D-3D verification
+                             of a step runs as one matching launch over all candidates + one chain launch over the
+                             survivors instead of the fused kernel (256-bit descriptors, K <= 512 features, 2 048 .. 65 536
+                             candidates -- other shapes keep the fused kernel).  Round 3's default (two streams whose
+                             launches fell into step: +5 %); 0 (default since round 4): always the fused kernel -- with
+                             three streams and no host in the step it is the faster form (22.0 against 20.3 M pairs/s,
+                             profiles/r04g).  Results unchanged.                                                     */
+  SF_OPT_STEP_DEPTH = 8,  /* steps sf_step_issue keeps in flight, 1 .. 16 (default 6).  Not while a step is in flight.  */
+  SF_OPT_STEP_LANES = 9,  /* streams the steps in flight are dealt over, 1 .. 4 (default 3; step k runs on stream
+                             k mod lanes; with a mirror set at most 2).  Not while a step is in flight.              */
+  SF_OPT_STEP_DEVICE_WALK = 10, /* 1 (default): sf_step_issue never waits for the device -- the argsort + walk of
+                             data_handler.py:191-205 run on the device between the NN kernels and the verification;
+                             0: round 3's form (the call returns once the host has walked the row minima).  Results
+                             unchanged.  Not while a step is in flight.                                              */
+  SF_OPT_STEP_SPECULATE = 11, /* 1 (default): a device-resident step whose walk may return every local row
+                             (netvlad_max_matches_nb >= local rows, nn_precision 1) queues the verification of EVERY NN
+                             filter candidate straight behind the filter and runs the exact re-evaluation, the row
+                             minima and the walk on a second stream beside it; 0: always NN -> walk -> verification of
+                             the walk's matches on one stream.  Results unchanged.  Not while a step is in flight.   */
   SF_OPT_DEBUG_CORR = 4   /* 1: the fused kernel also copies every pair's correspondence lists, headers and pass states
                              to the global workspace, which sf_debug_correspondences reads (default 0: they never
                              leave the workgroup's LDS; the stage kernels always keep them in the workspace)       */

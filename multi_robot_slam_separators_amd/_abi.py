@@ -13,8 +13,10 @@ SF_MAX_FEATURES = 32767
 SF_MAX_DESC_BYTES = 64
 
 (SF_K_MATCH, SF_K_RANSAC1, SF_K_GUIDED, SF_K_RANSAC2, SF_K_NN, SF_K_NN_SELECT, SF_K_NN_FILTER,
- SF_K_NN_REFINE, SF_K_FUSED, SF_K_COUNT) = range(10)
-SF_OPT_MATCH_MFMA, SF_OPT_FUSED, SF_OPT_OVERLAP, SF_OPT_CHAIN_WAVES, SF_OPT_DEBUG_CORR, SF_OPT_NN_FULL_FILTER, SF_OPT_STEP_OVERLAP, SF_OPT_STEP_SPLIT = range(8)      # sf_set_option
+ SF_K_NN_REFINE, SF_K_FUSED, SF_K_NN_WALK, SF_K_COUNT) = range(11)
+(SF_OPT_MATCH_MFMA, SF_OPT_FUSED, SF_OPT_OVERLAP, SF_OPT_CHAIN_WAVES, SF_OPT_DEBUG_CORR, SF_OPT_NN_FULL_FILTER,
+ SF_OPT_STEP_OVERLAP, SF_OPT_STEP_SPLIT, SF_OPT_STEP_DEPTH, SF_OPT_STEP_LANES, SF_OPT_STEP_DEVICE_WALK,
+ SF_OPT_STEP_SPECULATE) = range(12)      # sf_set_option
 
 STATUS_NAMES = {0: "SF_OK", 1: "SF_EINVAL", 2: "SF_EHIP", 3: "SF_ENOMEM", 4: "SF_ERANGE", 5: "SF_ENODEV", 6: "SF_ERCCL"}
 
@@ -217,7 +219,7 @@ class StepResult(C.Structure):
                 ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32)]
 
 
-SF_ABI_VERSION = 4      # include/sepfinder.h
+SF_ABI_VERSION = 5      # include/sepfinder.h
 
 
 def default_params() -> Params:

@@ -848,9 +848,10 @@ k_nn_refine(const uint2* __restrict__ cand, const unsigned* __restrict__ count, 
 // ties to the lowest column, ignored pairs skipped, rows without a candidate = (+inf, 0).  Non-negative doubles order
 // like their bit patterns, so the minimum is an atomicMin on 64-bit integers; the column is settled in a second pass
 // over the candidates that hold their row's minimum.
-__global__ void k_nn_rowmin_init(unsigned long long* __restrict__ mn, int* __restrict__ arg, int n, int* status) {
+__global__ void k_nn_rowmin_init(unsigned long long* __restrict__ mn, int* __restrict__ arg, int n, int* status,
+                                 unsigned long long* __restrict__ arg64 = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { mn[i] = 0x7FF0000000000000ull; arg[i] = 0x7FFFFFFF; }
+  if (i < n) { mn[i] = 0x7FF0000000000000ull; arg[i] = 0x7FFFFFFF; if (arg64) arg64[i] = ~0ull; }
   if (i == 0) *status = 0;
 }
 
@@ -860,11 +861,15 @@ __device__ __forceinline__ bool nn_pair_ignored(const int* __restrict__ ign_ptr,
   return false;
 }
 
+// arg64 (optional, PASS 1): (column << 32 | candidate index) of each row's minimum -- the lowest column among the
+// candidates that hold the minimum, and WHICH entry of the list it is (the speculative step maps a match to the
+// verification slot of its candidate through it).  A (row, column) pair occurs at most once in the list.
 template <int PASS>
 __global__ void __launch_bounds__(256)
 k_nn_rowmin(const uint2* __restrict__ cand, const unsigned* __restrict__ count, unsigned limit,
             const double* __restrict__ cdist, const int* __restrict__ ign_ptr, const int* __restrict__ ign_col,
-            int n_l, int n_r, unsigned long long* __restrict__ mn, int* __restrict__ arg, int* status) {
+            int n_l, int n_r, unsigned long long* __restrict__ mn, int* __restrict__ arg, int* status,
+            unsigned long long* __restrict__ arg64 = nullptr) {
   unsigned n = *count;
   if (n > limit) {              // denser than the refinement was sized for: the caller falls back (status 1)
     if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) *status = 1;
@@ -876,13 +881,24 @@ k_nn_rowmin(const uint2* __restrict__ cand, const unsigned* __restrict__ count, 
     if (nn_pair_ignored(ign_ptr, ign_col, (int)rc.x, (int)rc.y)) continue;
     const unsigned long long key = (unsigned long long)__double_as_longlong(cdist[c]);
     if (PASS == 0) atomicMin(&mn[rc.x], key);
-    else if (key == mn[rc.x]) atomicMin(&arg[rc.x], (int)rc.y);
+    else if (key == mn[rc.x]) {
+      if (arg64) atomicMin(&arg64[rc.x], ((unsigned long long)rc.y << 32) | (unsigned long long)c);
+      else atomicMin(&arg[rc.x], (int)rc.y);
+    }
   }
 }
 
-__global__ void k_nn_rowmin_finish(int* __restrict__ arg, int n) {
+__global__ void k_nn_rowmin_finish(int* __restrict__ arg, int n, const unsigned long long* __restrict__ arg64 = nullptr,
+                                   int* __restrict__ row_cand = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && arg[i] == 0x7FFFFFFF) arg[i] = 0;
+  if (i >= n) return;
+  if (arg64) {
+    const unsigned long long v = arg64[i];
+    arg[i] = v == ~0ull ? 0 : (int)(v >> 32);
+    if (row_cand) row_cand[i] = v == ~0ull ? -1 : (int)(unsigned)(v & 0xFFFFFFFFull);
+  } else if (arg[i] == 0x7FFFFFFF) {
+    arg[i] = 0;
+  }
 }
 
 // nb_eff[j] = |b_j|^2, +inf for masked / padding columns; *nb_max_bits = the largest finite one (bit pattern; the
@@ -898,6 +914,146 @@ __global__ void k_nn_fill_norms(float* nb_eff, const float* nb, const uint8_t* m
   }
   for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
   if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(nb_max_bits, __float_as_uint(v));
+}
+
+
+// ---- data_handler.py:191-205 on the device: argsort of the row minima + the sequential walk --------------------------
+// Same rule as sf_nn_walk_host below, in three launches and without the host: (1) every 2048-row tile of the minima is
+// sorted in LDS on the composite key (float64 bit pattern, row) -- rows at or over the threshold carry the sentinel key
+// and sort behind the tile's live rows; (2) a live row's position in the global order = its position in its tile + the
+// number of smaller keys in every other tile (a binary search per tile; keys are unique, so the order is the stable
+// sort's: ties keep the lowest row first), and the first min(N_l, max_matches_nb) positions claim their column with an
+// atomicMin of the position -- the walk's "idx_other already taken" rule (:199-200) keeps exactly the FIRST position of
+// each column; (3) one workgroup emits the kept positions in order (an ordered compaction), up to `cap`.
+constexpr int WALK_TILE = 2048;
+constexpr unsigned long long WALK_SENTINEL = ~0ull;
+
+__device__ __forceinline__ bool walk_less(unsigned long long ka, int ra, unsigned long long kb, int rb) {
+  return ka < kb || (ka == kb && ra < rb);
+}
+
+__global__ void __launch_bounds__(1024)
+k_walk_tile_sort(const double* __restrict__ rm, int n_l, double thr, unsigned long long* __restrict__ keys,
+                 int* __restrict__ rows, int* __restrict__ tile_cnt, int* __restrict__ minpos, int n_r) {
+  __shared__ unsigned long long sk[WALK_TILE];
+  __shared__ int sr[WALK_TILE];
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x, base = blockIdx.x * WALK_TILE;
+  for (int j = blockIdx.x * 1024 + tid; j < n_r; j += gridDim.x * 1024) minpos[j] = 0x7FFFFFFF;
+  if (tid == 0) s_cnt = 0;
+  for (int e = tid; e < WALK_TILE; e += 1024) {
+    const int i = base + e;
+    unsigned long long k = WALK_SENTINEL;
+    if (i < n_l) {
+      const double v = rm[i];
+      if (v < thr) k = (unsigned long long)__double_as_longlong(v == 0.0 ? 0.0 : v);      // (-0.0 -> +0.0)
+    }
+    sk[e] = k;
+    sr[e] = i;
+  }
+  __syncthreads();
+  for (int k = 2; k <= WALK_TILE; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int i = 2 * tid - (tid & (j - 1)), l = i + j;       // i has bit j clear
+      const bool up = (i & k) == 0;
+      const unsigned long long ka = sk[i], kb = sk[l];
+      const int ra = sr[i], rb = sr[l];
+      if (walk_less(kb, rb, ka, ra) == up) { sk[i] = kb; sk[l] = ka; sr[i] = rb; sr[l] = ra; }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < WALK_TILE; e += 1024) {
+    keys[base + e] = sk[e];
+    rows[base + e] = sr[e];
+    if (sk[e] != WALK_SENTINEL && (e + 1 == WALK_TILE || sk[e + 1] == WALK_SENTINEL)) s_cnt = e + 1;
+  }
+  __syncthreads();
+  if (tid == 0) tile_cnt[blockIdx.x] = s_cnt;
+}
+
+__global__ void __launch_bounds__(256)
+k_walk_rank(const unsigned long long* __restrict__ keys, const int* __restrict__ rows, const int* __restrict__ tile_cnt,
+            int n_tiles, int lim, const int* __restrict__ row_arg, int n_r, int* __restrict__ sorted_rows,
+            int* __restrict__ minpos, int* __restrict__ nu_out) {
+  __shared__ int s_part[4];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x / (WALK_TILE / 256), p = (blockIdx.x % (WALK_TILE / 256)) * 256 + tid;
+  int part = 0;
+  for (int j = tid; j < n_tiles; j += 256) part += tile_cnt[j];
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  if ((tid & 63) == 0) s_part[tid >> 6] = part;
+  __syncthreads();
+  const int nu = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  if (blockIdx.x == 0 && tid == 0) *nu_out = nu;
+  if (p >= tile_cnt[t]) return;
+  const unsigned long long key = keys[(size_t)t * WALK_TILE + p];
+  const int row = rows[(size_t)t * WALK_TILE + p];
+  int s = p;
+  for (int u = 0; u < n_tiles; ++u) {
+    if (u == t) continue;
+    const unsigned long long* ku = keys + (size_t)u * WALK_TILE;
+    const int* ru = rows + (size_t)u * WALK_TILE;
+    int lo = 0, hi = tile_cnt[u];                 // number of entries of tile u below (key, row)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (walk_less(ku[mid], ru[mid], key, row)) lo = mid + 1; else hi = mid;
+    }
+    s += lo;
+  }
+  if (s < min(lim, nu)) {
+    sorted_rows[s] = row;
+    const int io = row_arg[row];
+    if ((unsigned)io < (unsigned)n_r) atomicMin(&minpos[io], s);
+  }
+}
+
+// out_rc / count_block: the match list in the candidate list's layout ((row, column) pairs behind a 64-byte counter
+// block: word 0 = matches, word 4 = the accepted-result stream's slot counter, zeroed here) -- what the verification
+// kernels take their pairs from; out_matches / out_n / out_status: the same for the caller (host-pinned or device).
+__global__ void __launch_bounds__(1024)
+k_walk_emit(const int* __restrict__ sorted_rows, const int* __restrict__ nu_p, int lim, const double* __restrict__ rm,
+            const int* __restrict__ row_arg, int n_r, const int* __restrict__ minpos, const int* __restrict__ status,
+            int cap, uint2* __restrict__ out_rc, unsigned* __restrict__ count_block, sf_match* __restrict__ out_matches,
+            int32_t* __restrict__ out_n, int32_t* __restrict__ out_status, const int* __restrict__ row_cand,
+            int32_t* __restrict__ out_slot, const unsigned* __restrict__ cand_count, unsigned cand_grid) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int st = status ? *status : 0;
+  // (speculative step: more candidates than verification slots were launched for -- status 2, the caller falls back)
+  if (st == 0 && cand_count && *cand_count > cand_grid) st = 2;
+  const int S = st ? 0 : min(lim, *nu_p);
+  int base = 0;
+  for (int s0 = 0; s0 < S && base < cap; s0 += 1024) {
+    const int s = s0 + tid;
+    bool ok = false;
+    int il = 0, io = 0;
+    if (s < S) {
+      il = sorted_rows[s];
+      io = row_arg[il];
+      ok = (unsigned)io < (unsigned)n_r && minpos[io] == s;
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { woff += (w < wave) ? s_w[w] : 0; tot += s_w[w]; }
+    const int j = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok && j < cap) {
+      if (out_rc) out_rc[j] = make_uint2((unsigned)il, (unsigned)io);
+      if (out_matches) { sf_match m; m.idx_local = il; m.idx_other = io; m.distance = rm[il]; out_matches[j] = m; }
+      if (out_slot) out_slot[j] = row_cand ? row_cand[il] : j;
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int n = min(base, cap);
+    if (count_block) { count_block[0] = (unsigned)n; count_block[4] = 0u; }       // (null for a speculative step: the
+                                                                              //  verification runs on the candidate list)
+    if (out_n) *out_n = n;
+    if (out_status) *out_status = st;
+  }
 }
 
 }  // namespace
@@ -993,6 +1149,7 @@ int sf_nn_append(sf_context* c, NNDb& db, const void* src, int n, int dim, int s
 static int nn_prepare_f16(sf_context* c, NNDb& db, int ld, int ld16, int kprefix) {
   if (db.h_n == db.n && db.h_ld == ld16 && db.h_kprefix == kprefix) return SF_OK;
   int rc;
+  c->prep_count += 1;          // (state every step lane reads is being rebuilt: sf_step_issue orders the lanes behind it)
   if ((rc = sf_buf_reserve(c, c->nn_scalar, 64)) != SF_OK) return rc;
   SF_HIP(c, hipMemsetAsync(c->nn_scalar.p, 0, 64, c->stream));
   hipLaunchKernelGGL(k_nn_maxabs, dim3(1024), dim3(256), 0, c->stream, (const float*)db.rows.p, (size_t)db.n * ld,
@@ -1119,6 +1276,7 @@ static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdim
     const bool coef_ok = c->nn_coef_level == level && c->nn_coef_nl == n_l && c->nn_coef_nr == n_r &&
                          c->nn_coef_thr == thr && c->nn_coef_ptr == (const void*)rowc && c->nn_coef_scale == scale;
     const float delta = 2e-6f + (float)((double)(kdims + 8) * ldexp(1.0, -24));
+    if (!coef_ok) c->prep_count += 1;
     if (!coef_ok)
     hipLaunchKernelGGL(k_nn_filter_row_coef, dim3((n_l_pad + 255) / 256), dim3(256), 0, c->stream, rowc,
                        (const float*)c->nn_local.norms_k.p, (const uint8_t*)c->d_mask_local.p, n_l, n_l_pad,
@@ -1425,6 +1583,42 @@ int sf_nn_walk_host(sf_context* c, const double* rm, const int32_t* row_arg, int
   return SF_OK;
 }
 
+// The same walk on the device (kernels above), asynchronous on the handle's stream: d_row_min / d_row_arg are DEVICE
+// arrays (sf_nn_row_minima_dev's outputs, or the all-gathered minima of a row-sharded node), d_status (or null) a device
+// word that voids the walk when non-zero (the filter's "too dense" report).  Scratch belongs to the handle (per step lane).
+int sf_nn_walk_dev(sf_context* c, const double* d_row_min, const int32_t* d_row_arg, const int32_t* d_status, int n_l,
+                   int n_r, double thr_d, int max_matches_nb, int cap, void* d_match_rc, unsigned* d_count_block,
+                   sf_match* out_matches, int32_t* out_n, int32_t* out_status, const int32_t* d_row_cand,
+                   int32_t* out_slot, const unsigned* d_cand_count, unsigned cand_grid) {
+  if (n_l <= 0 || n_r <= 0 || cap < 0) return sf_fail(c, SF_EINVAL, "device walk over %d x %d minima, cap %d", n_l, n_r, cap);
+  const int n_tiles = (n_l + WALK_TILE - 1) / WALK_TILE;
+  const size_t n_pad = (size_t)n_tiles * WALK_TILE;
+  // keys | rows | sorted rows | minpos | tile counts | nu
+  const size_t off_rows = n_pad * 8, off_sorted = off_rows + n_pad * 4, off_minpos = off_sorted + n_pad * 4,
+               off_cnt = off_minpos + (((size_t)n_r * 4 + 63) & ~(size_t)63), off_nu = off_cnt + (((size_t)n_tiles * 4 + 63) & ~(size_t)63);
+  int rc;
+  if ((rc = sf_buf_reserve(c, c->walk_scratch, off_nu + 64)) != SF_OK) return rc;
+  char* w = (char*)c->walk_scratch.p;
+  unsigned long long* keys = (unsigned long long*)w;
+  int* rows = (int*)(w + off_rows);
+  int* sorted = (int*)(w + off_sorted);
+  int* minpos = (int*)(w + off_minpos);
+  int* tile_cnt = (int*)(w + off_cnt);
+  int* nu = (int*)(w + off_nu);
+  const int lim = std::min(n_l, max_matches_nb);
+  sf_prof_begin(c, SF_K_NN_WALK);
+  hipLaunchKernelGGL(k_walk_tile_sort, dim3(n_tiles), dim3(1024), 0, c->stream, d_row_min, n_l, thr_d, keys, rows, tile_cnt,
+                     minpos, n_r);
+  hipLaunchKernelGGL(k_walk_rank, dim3(n_tiles * (WALK_TILE / 256)), dim3(256), 0, c->stream, keys, rows, tile_cnt, n_tiles,
+                     lim, d_row_arg, n_r, sorted, minpos, nu);
+  hipLaunchKernelGGL(k_walk_emit, dim3(1), dim3(1024), 0, c->stream, sorted, nu, lim, d_row_min, d_row_arg, n_r, minpos,
+                     d_status, cap, (uint2*)d_match_rc, d_count_block, out_matches, out_n, out_status, d_row_cand, out_slot,
+                     d_cand_count, cand_grid);
+  sf_prof_end(c, SF_K_NN_WALK);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
 // masks / ignore CSR on the device (rebuilt only when they changed)
 static int nn_sync_masks(sf_context* c) {
   const int n_l = c->nn_local.n, n_r = c->nn_recv.n;
@@ -1433,6 +1627,7 @@ static int nn_sync_masks(sf_context* c) {
   c->mask_local.resize(n_l, 0);
   c->mask_other.resize(n_r, 0);
   if (c->masks_dirty) {
+    c->prep_count += 1;
     if ((rc = sf_buf_reserve(c, c->d_mask_local, (size_t)n_l_pad)) != SF_OK) return rc;
     if ((rc = sf_buf_reserve(c, c->d_mask_other, (size_t)n_r_pad)) != SF_OK) return rc;
     std::vector<int> ptr(n_l_pad + 1, 0), col(std::max<size_t>(1, c->ignored.size() / 2));
@@ -1518,6 +1713,69 @@ int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out) {
 // a block of rows).  With nn_precision 1 the prefix filter runs at the ladder level the handle last settled on;
 // d_status[0] = 1 reports a candidate set denser than the sparse limit (the minima are then undefined and the caller
 // takes sf_nn_find_matches + sf_nn_last_row_minima, which walks the ladder), 0 otherwise.
+// The filter path of the row minima in its two halves (the speculative step puts the verification of every candidate
+// between them, on another stream): the stage-1 filter at the ladder level the handle last settled on ...
+int sf_nn_filter_dev(sf_context* c, NnFilterOut* out) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  if (n_l <= 0 || n_r <= 0) return sf_fail(c, SF_EINVAL, "NN filter on an empty database (%d x %d)", n_l, n_r);
+  int rc;
+  if ((rc = nn_sync_masks(c)) != SF_OK) return rc;
+  c->spec.valid = false;
+  c->last_row_cand.clear();
+  c->last_row_min.clear();        // (sf_nn_last_row_minima has nothing to report after this call)
+  c->last_row_arg.clear();
+  NnTrace tr;
+  const int ld16 = (dim + 63) / 64 * 64;
+  int levels[3], n_levels = 0;
+  if (128 * 4 <= dim) levels[n_levels++] = 128;
+  if (512 * 4 <= dim) levels[n_levels++] = 512;
+  levels[n_levels++] = ld16;
+  const int level = c->nn_force_full ? n_levels - 1 : std::min(std::max(c->nn_level, 0), n_levels - 1);
+  NnFilterBufs fb;
+  if ((rc = nn_filter_reserve(c, fb)) != SF_OK) return rc;
+  if ((rc = nn_filter_launch(c, fb, level, levels[level], &tr)) != SF_OK) return rc;
+  c->nn_last_kdims = levels[level];
+  out->cand = fb.cand; out->count = fb.count; out->cdist = fb.cdist;
+  out->limit = level < n_levels - 1 ? (unsigned)(8 * (size_t)n_l + 4096) : fb.cap;
+  // the count stays on the device: the grids are sized for a typical sparse list and stride over a longer one
+  out->typical = std::min<unsigned>(out->limit, (unsigned)(2 * (size_t)n_l + 1024));
+  return SF_OK;
+}
+
+// ... and the exact re-evaluation of its candidates + their per-row minima, on the handle's CURRENT stream.
+// d_row_cand / d_arg64 (both or neither): also the candidate-list index of each row's minimum.
+int sf_nn_minima_of_candidates_dev(sf_context* c, const NnFilterOut& fo, double* d_row_min, int32_t* d_row_arg,
+                                   int32_t* d_status, int32_t* d_row_cand, unsigned long long* d_arg64, bool throttle) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
+  const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
+  const uint2* cand = (const uint2*)fo.cand;
+  unsigned refine_wgs = (fo.typical + 3) / 4;
+  if (throttle) {
+    // beside a verification launch the re-evaluation has several times its own run time of slack: one workgroup per CU
+    // walks the list (grid-stride) and leaves the HBM and the dispatcher to the verification kernel's first third
+    if (c->n_cus <= 0) {
+      int v = 0;
+      c->n_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) ? v : 256;
+    }
+    refine_wgs = std::min(refine_wgs, (unsigned)c->n_cus);
+  }
+  sf_prof_begin(c, SF_K_NN_REFINE);
+  hipLaunchKernelGGL(k_nn_refine, dim3(refine_wgs), dim3(256), 0, c->stream, cand, fo.count, fo.limit,
+                     (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, fo.cdist, 0u);
+  sf_prof_end(c, SF_K_NN_REFINE);
+  unsigned long long* mn = (unsigned long long*)d_row_min;
+  const int wgs = (int)std::min<unsigned>((fo.typical + 255) / 256, 1024u);
+  hipLaunchKernelGGL(k_nn_rowmin_init, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, mn, d_row_arg, n_l, d_status, d_arg64);
+  hipLaunchKernelGGL(k_nn_rowmin<0>, dim3(wgs), dim3(256), 0, c->stream, cand, fo.count, fo.limit, fo.cdist,
+                     (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status, d_arg64);
+  hipLaunchKernelGGL(k_nn_rowmin<1>, dim3(wgs), dim3(256), 0, c->stream, cand, fo.count, fo.limit, fo.cdist,
+                     (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status, d_arg64);
+  hipLaunchKernelGGL(k_nn_rowmin_finish, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, d_row_arg, n_l,
+                     (const unsigned long long*)d_arg64, d_row_cand);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
+}
+
 int sf_nn_row_minima_dev(sf_context* c, double* d_row_min, int32_t* d_row_arg, int32_t* d_status) {
   const int n_l = c->nn_local.n, n_r = c->nn_recv.n, dim = c->nn_dim;
   if (n_l <= 0 || n_r <= 0) return sf_fail(c, SF_EINVAL, "sf_nn_row_minima_device on an empty database (%d x %d)", n_l, n_r);
@@ -1526,41 +1784,16 @@ int sf_nn_row_minima_dev(sf_context* c, double* d_row_min, int32_t* d_row_arg, i
   const int ld = (dim + NN_BK - 1) / NN_BK * NN_BK;
   const int n_l_pad = (n_l + NN_BM - 1) / NN_BM * NN_BM, n_r_pad = (n_r + NN_BN - 1) / NN_BN * NN_BN;
   int rc;
+  if (c->params.nn_precision == 1) {
+    NnFilterOut fo;
+    if ((rc = sf_nn_filter_dev(c, &fo)) != SF_OK) return rc;
+    return sf_nn_minima_of_candidates_dev(c, fo, d_row_min, d_row_arg, d_status, nullptr, nullptr, false);
+  }
   if ((rc = nn_sync_masks(c)) != SF_OK) return rc;
   c->spec.valid = false;
   c->last_row_cand.clear();
   c->last_row_min.clear();        // (sf_nn_last_row_minima has nothing to report after this call)
   c->last_row_arg.clear();
-  if (c->params.nn_precision == 1) {
-    NnTrace tr;
-    const int ld16 = (dim + 63) / 64 * 64;
-    int levels[3], n_levels = 0;
-    if (128 * 4 <= dim) levels[n_levels++] = 128;
-    if (512 * 4 <= dim) levels[n_levels++] = 512;
-    levels[n_levels++] = ld16;
-    const int level = c->nn_force_full ? n_levels - 1 : std::min(std::max(c->nn_level, 0), n_levels - 1);
-    NnFilterBufs fb;
-    if ((rc = nn_filter_reserve(c, fb)) != SF_OK) return rc;
-    if ((rc = nn_filter_launch(c, fb, level, levels[level], &tr)) != SF_OK) return rc;
-    c->nn_last_kdims = levels[level];
-    const unsigned limit = level < n_levels - 1 ? (unsigned)(8 * (size_t)n_l + 4096) : fb.cap;
-    // the count stays on the device: the grids are sized for a typical sparse list and stride over a longer one
-    const unsigned typical = std::min<unsigned>(limit, (unsigned)(2 * (size_t)n_l + 1024));
-    sf_prof_begin(c, SF_K_NN_REFINE);
-    hipLaunchKernelGGL(k_nn_refine, dim3((typical + 3) / 4), dim3(256), 0, c->stream, fb.cand, fb.count, limit,
-                       (const float*)c->nn_local.rows.p, (const float*)c->nn_recv.rows.p, dim, ld, fb.cdist, 0u);
-    sf_prof_end(c, SF_K_NN_REFINE);
-    unsigned long long* mn = (unsigned long long*)d_row_min;
-    const int wgs = (int)std::min<unsigned>((typical + 255) / 256, 1024u);
-    hipLaunchKernelGGL(k_nn_rowmin_init, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, mn, d_row_arg, n_l, d_status);
-    hipLaunchKernelGGL(k_nn_rowmin<0>, dim3(wgs), dim3(256), 0, c->stream, fb.cand, fb.count, limit, fb.cdist,
-                       (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status);
-    hipLaunchKernelGGL(k_nn_rowmin<1>, dim3(wgs), dim3(256), 0, c->stream, fb.cand, fb.count, limit, fb.cdist,
-                       (const int*)c->d_ign_ptr.p, (const int*)c->d_ign_col.p, n_l, n_r, mn, d_row_arg, d_status);
-    hipLaunchKernelGGL(k_nn_rowmin_finish, dim3((n_l + 255) / 256), dim3(256), 0, c->stream, d_row_arg, n_l);
-    SF_HIP(c, hipGetLastError());
-    return SF_OK;
-  }
   // exact fp32-ranking path: its select kernel already leaves the minima in device memory
   const int n_strips = n_r_pad / 64;
   c->nn_last_kdims = 0;

@@ -69,10 +69,10 @@ __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair,
     if (P.dbg_corr) { pass1[pair] = T.pass1; pass2[pair] = T.pass2; guided_flag[pair] = T.guided_flag; }
     finalize_one(T.pass1, T.pass2, T.guided_flag, out[pair]);
   }
-  if (P.accept) {
+  if (P.accept_on) {
     // the accepted result leaves for the host NOW (posted PCIe writes beside the other pairs' work) instead of through
     // a compaction kernel behind the launch: thread 0 takes the slot, 23 lanes move the 368 bytes
-    const AcceptStream S = *P.accept;
+    const AcceptStream& S = P.accept;
     if (tid == 0) {
       const bool ok = out[pair].success != 0;
       if (S.flags) S.flags[pair] = ok ? 1 : 0;
@@ -170,7 +170,7 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
       hdr2[pair] = h; pass2[pair] = p; guided_flag[pair] = 0;
     }
     finalize_one(p, p, 0, out[pair]);
-    if (P.accept && P.accept->flags) P.accept->flags[pair] = 0;      // (accepted-result stream: not accepted)
+    if (P.accept_on && P.accept.flags) P.accept.flags[pair] = 0;      // (accepted-result stream: not accepted)
   }
 }
 
@@ -311,10 +311,10 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
   }
   SF_TRACE_MARK(P, pair, 17);
   if (threadIdx.x == 0) finalize_one(pass1[pair], pass2[pair], guided_flag[pair], out[pair]);
-  if (P.accept) {                 // accepted-result stream (see chain_after_match)
+  if (P.accept_on) {              // accepted-result stream (see chain_after_match)
     __syncthreads();              // (the bodies are done with the LDS: its first word carries the slot)
     int& s_slot = *reinterpret_cast<int*>(smem_raw);
-    const AcceptStream S = *P.accept;
+    const AcceptStream& S = P.accept;
     if (threadIdx.x == 0) {
       const bool ok = out[pair].success != 0;
       if (S.flags) S.flags[pair] = ok ? 1 : 0;

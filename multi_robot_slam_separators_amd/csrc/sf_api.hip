@@ -73,7 +73,7 @@ StoreView sf_store_view(const Store& s) {
 // ---- profiling ------------------------------------------------------------------------------
 static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "k_guided",
                                           "k_ransac(pass2)", "k_nn_argmin", "k_nn_select",
-                                          "k_nn_filter_f16", "k_nn_refine", "k_verify_fused"};
+                                          "k_nn_filter_f16", "k_nn_refine", "k_verify_fused", "k_nn_walk"};
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
 // Brackets that have completed are booked and their events reused without waiting for anything: a long profiled
@@ -738,6 +738,10 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
   if (const char* v = getenv("SF_STEP_OVERLAP")) c->step_overlap = atoi(v) != 0;   // 1: SF_OPT_STEP_OVERLAP from the start
   if (const char* v = getenv("SF_OVERLAP_MIN")) c->overlap_min_pairs = std::max(2, atoi(v));
+  if (const char* v = getenv("SF_STEP_DEPTH")) c->step_depth = std::max(1, std::min(SF_STEP_MAX_DEPTH, atoi(v)));
+  if (const char* v = getenv("SF_STEP_LANES")) c->step_lanes = std::max(1, std::min(SF_STEP_MAX_LANES, atoi(v)));
+  if (const char* v = getenv("SF_STEP_SPECULATE")) c->step_speculate = atoi(v) != 0;   // 0: every device step in the serial form
+  if (const char* v = getenv("SF_STEP_DEVICE_WALK")) c->step_device_walk = atoi(v) != 0;   // 0: round 3's host walk inside sf_step_issue
   if ((rc = sf_buf_reserve(c, c->counters, 64)) != SF_OK) { g_create_error = c->err; sf_destroy(c); return rc; }
   *out = c;
   return SF_OK;
@@ -765,7 +769,7 @@ extern "C" void sf_destroy(sf_handle c) {
   for (hipEvent_t e : c->prof_event_pool) (void)hipEventDestroy(e);
   Buf* bufs[] = {&c->store.desc, &c->store.xyz, &c->store.kp, &c->store.meta, &c->scratch.desc, &c->scratch.xyz,
                  &c->scratch.kp, &c->scratch.meta, &c->pair_from, &c->pair_to, &c->corr1, &c->corr2, &c->hdr1,
-                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->accept_dev, &c->results,
+                 &c->hdr2, &c->pass1, &c->pass2, &c->list1, &c->list3, &c->counters, &c->results,
                  &c->flags, &c->nn_local.rows, &c->nn_local.norms, &c->nn_local.rows_h, &c->nn_local.norms_k, &c->nn_recv.norms_k, &c->nn_recv.rows,
                  &c->nn_recv.norms, &c->nn_recv.rows_h, &c->d_mask_local, &c->d_mask_other, &c->d_ign_ptr,
                  &c->d_ign_col, &c->nn_rowmin, &c->nn_exact, &c->nn_cand, &c->nn_scalar, &c->comm_scratch, &c->compact_scratch, &c->trace, &c->stage_desc, &c->stage_xyz, &c->stage_kp,
@@ -773,16 +777,24 @@ extern "C" void sf_destroy(sf_handle c) {
                  &c->gf_planes, &c->gf_keys, &c->gf_tmp, &c->gf_lists, &c->gf_scalar, &c->lk_pyr, &c->ft_images, &c->ft_kpts, &c->ft_flow, &c->ft_wire,
                  &c->ft_counts, &c->pass_back, &c->dir_mask};
   for (Buf* b : bufs) buf_free(*b);
-  {
-    sf_context::StepLane& L = c->lane1;
+  for (sf_context::StepLane& L : c->lanes) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     Buf* lb[] = {&L.pair_from, &L.pair_to, &L.corr1, &L.corr2, &L.hdr1, &L.hdr2, &L.pass1, &L.pass2, &L.pass_back, &L.dir_mask,
                  &L.list1, &L.list3, &L.counters, &L.results, &L.flags, &L.nn_cand, &L.spec_from, &L.spec_to, &L.spec_results,
-                 &L.spec_index, &L.compact_scratch};
+                 &L.spec_index, &L.compact_scratch, &L.step_nn, &L.walk_scratch};
     for (Buf* b : lb) buf_free(*b);
     if (L.ev_main) (void)hipEventDestroy(L.ev_main);
+    if (L.ev_filter) (void)hipEventDestroy(L.ev_filter);
+    if (L.ev_walk) (void)hipEventDestroy(L.ev_walk);
+    if (L.aux) { (void)hipStreamSynchronize(L.aux); (void)hipStreamDestroy(L.aux); }
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
+  if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
+  if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
+  if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+  buf_free(c->step_nn);
+  buf_free(c->walk_scratch);
+  if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
   sf_netvlad_free(c);
   sf_ingest_pool_destroy(c);
   if (c->ingest_pinned) (void)hipHostFree(c->ingest_pinned);
@@ -805,6 +817,7 @@ extern "C" void sf_destroy(sf_handle c) {
   for (auto& sb : c->step_blocks) {
     if (sb.pinned) (void)hipHostFree(sb.pinned);
     if (sb.done) (void)hipEventDestroy(sb.done);
+    buf_free(sb.dev);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -841,7 +854,11 @@ extern "C" int sf_set_stream(sf_handle c, void* hip_stream) {
 extern "C" int sf_synchronize(sf_handle c) {
   if (!c) return SF_EINVAL;
   SF_HIP(c, hipStreamSynchronize(c->stream));
-  if (c->lane1.stream) SF_HIP(c, hipStreamSynchronize(c->lane1.stream));
+  for (auto& L : c->lanes) {
+    if (L.stream) SF_HIP(c, hipStreamSynchronize(L.stream));
+    if (L.aux) SF_HIP(c, hipStreamSynchronize(L.aux));
+  }
+  if (c->aux) SF_HIP(c, hipStreamSynchronize(c->aux));
   return SF_OK;
 }
 
@@ -1184,7 +1201,7 @@ static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the wo
 // Which form the 3D-3D verification of n pairs takes: the fused kernel (one workgroup carries a pair through matching
 // and both motion-estimation chains) or the split form (k_match_split over all pairs + k_chain over the survivors).
 // On one stream the fused kernel wins (its chains overlap other pairs' matching inside the launch: 19.5 against 17.1 M
-// pairs/s at the bench shape); when sf_step_issue alternates the steps between two streams the neighbouring step fills a
+// pairs/s at the bench shape); when sf_step_issue deals the steps over several streams the neighbouring step fills a
 // launch's tail anyway and the split form is faster (21.9 against 20.7 M pairs/s; 18.3 against 16.8 M at 40 000
 // keyframes): its matching kernel keeps four "to" tiles per wavefront at three workgroups per CU.  Frames that put
 // the fused kernel into its WIDE form (K = 1000), 512-bit descriptors and queries of more than 65 536 candidates
@@ -1198,25 +1215,46 @@ static bool sf_use_split(const sf_context* c, const StoreView& v, int n) {
   return sf_fused_lds_bytes(c, v) * 4 <= 160 * 1024;       // (not the WIDE form: sf_launch_verify_fused)
 }
 
-// One launch sequence for m <= SF_CHUNK pairs on ctx's stream and workspace.
-// `split`: the form decided ONCE for the whole call (sf_use_split over all its pairs: the workspace was reserved for it).
+// ONE object decides the launch form of a verification call AND what its workspace must hold: it is made once per call
+// from the call's total pair count, the workspace is reserved from it and every chunk is launched from it.  (Round 3 made
+// the form decision per chunk and the reservation per call: the second chunk of a 140 000-candidate step took the split
+// form, which writes correspondence lists, on a workspace reserved for the fused form, which has none -- a device
+// out-of-bounds write; tests/test_gpu_step.py::test_step_queries_across_the_form_and_chunk_boundaries.)
+struct VerifyPlan {
+  enum Form { STAGES = 0, FUSED = 1, SPLIT = 2, SPLIT_PNP = 3, HALVES = 4 } form = STAGES;
+  bool lists = true;        // the correspondence lists live in HBM (every form but the plain fused kernel)
+  bool single = false;      // one launch sequence on one stream: a pair's index IS its position in the call
+  bool streams() const { return single && (form == FUSED || form == SPLIT || form == SPLIT_PNP); }   // chain kernels that can
+};                                                                                                // stream accepted results
+
+static VerifyPlan verify_plan(const sf_context* c, const StoreView& v, int n) {
+  VerifyPlan p;
+  if (c->overlap && n >= c->overlap_min_pairs) { p.form = VerifyPlan::HALVES; p.lists = true; p.single = false; return p; }
+  p.single = n <= SF_CHUNK;
+  if (c->chain_pnp && sf_split_pnp_applicable(c, v)) { p.form = VerifyPlan::SPLIT_PNP; p.lists = true; }
+  else if (sf_use_split(c, v, n)) { p.form = VerifyPlan::SPLIT; p.lists = true; }
+  else if (sf_fused_lds_bytes(c, v) != 0) { p.form = VerifyPlan::FUSED; p.lists = c->debug_corr; }
+  else { p.form = VerifyPlan::STAGES; p.lists = true; }
+  return p;
+}
+
+// One launch sequence for m <= SF_CHUNK pairs on ctx's stream and workspace, in the form the call's plan names.
 static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t* d_from, const int32_t* d_to, int m,
-                           sf_result* d_out, bool allow_fused, bool split = false) {
+                           sf_result* d_out, const VerifyPlan& plan) {
   int rc;
   ctx->dparams.dbg_corr = ctx->debug_corr ? 1 : 0;
-  if (allow_fused && ctx->chain_pnp && sf_split_pnp_applicable(ctx, view)) {
-    ctx->last_lists_valid = true;
-    if ((rc = sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out)) != SF_OK) return rc;
-    return SF_OK;
-  }
-  if (allow_fused && split) {
-    ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
-    return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
-  }
-  if (allow_fused && sf_fused_lds_bytes(ctx, view) != 0) {
-    // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
-    ctx->last_lists_valid = ctx->debug_corr;
-    return sf_launch_verify_fused(ctx, view, d_from, d_to, m, d_out);
+  switch (plan.form) {
+    case VerifyPlan::SPLIT_PNP:
+      ctx->last_lists_valid = true;
+      return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
+    case VerifyPlan::SPLIT:
+      ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
+      return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
+    case VerifyPlan::FUSED:
+      // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
+      ctx->last_lists_valid = ctx->debug_corr;
+      return sf_launch_verify_fused(ctx, view, d_from, d_to, m, d_out);
+    default: break;
   }
   ctx->last_lists_valid = true;
   SF_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));   // work-list counters of the stage kernels
@@ -1272,18 +1310,20 @@ static int ensure_twin(sf_context* c) {
 // The second stream starts after everything already queued on the handle's stream and the handle's stream
 // continues only after the second has finished, so the call keeps its single-stream semantics either way.
 static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, const int32_t* d_to, int n,
-                         sf_result* d_out) {
+                         sf_result* d_out, const VerifyPlan* given = nullptr) {
   if (n <= 0) return SF_OK;
   if (st.slots <= 0) return sf_fail(c, SF_EINVAL, "keyframe store is empty");
   const StoreView view = sf_store_view(st);
+  const VerifyPlan plan = given ? *given : verify_plan(c, view, n);
   int rc;
-  if (c->overlap && n >= c->overlap_min_pairs) {
+  if (plan.form == VerifyPlan::HALVES) {
     if ((rc = ensure_twin(c)) != SF_OK) return rc;
     sf_context* t = c->twin;
+    VerifyPlan stages;                                   // (two FUSED halves on two streams were measured too and gain nothing)
     const int span = std::min(n, 2 * SF_CHUNK);          // pairs per round: one chunk per stream
     const int half0 = (std::min(span, n) + 1) / 2;
-    if ((rc = ws_reserve(c, std::min(half0, SF_CHUNK), st.kcap, true)) != SF_OK) return rc;
-    if ((rc = ws_reserve(t, std::min(half0, SF_CHUNK), st.kcap, true)) != SF_OK) { c->err = t->err; return rc; }
+    if ((rc = ws_reserve(c, std::min(half0, SF_CHUNK), st.kcap, stages.lists)) != SF_OK) return rc;
+    if ((rc = ws_reserve(t, std::min(half0, SF_CHUNK), st.kcap, stages.lists)) != SF_OK) { c->err = t->err; return rc; }
     SF_HIP(c, hipEventRecord(c->ev_fork, c->stream));
     SF_HIP(c, hipStreamWaitEvent(t->stream, c->ev_fork, 0));
     c->ws_split = 0;
@@ -1291,9 +1331,8 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
       const int m = std::min(span, n - off);
       const int ma = (m + 1) / 2, mb = m - ma;
       if (off == 0) c->ws_split = ma;
-      // (stage kernels: two FUSED halves on two streams were measured too and gain nothing)
-      if ((rc = verify_sequence(c, view, d_from + off, d_to + off, ma, d_out + off, false)) != SF_OK) return rc;
-      if (mb > 0 && (rc = verify_sequence(t, view, d_from + off + ma, d_to + off + ma, mb, d_out + off + ma, false)) != SF_OK) {
+      if ((rc = verify_sequence(c, view, d_from + off, d_to + off, ma, d_out + off, stages)) != SF_OK) return rc;
+      if (mb > 0 && (rc = verify_sequence(t, view, d_from + off + ma, d_to + off + ma, mb, d_out + off + ma, stages)) != SF_OK) {
         c->err = t->err;
         return rc;
       }
@@ -1302,14 +1341,11 @@ static int verify_device(sf_context* c, const Store& st, const int32_t* d_from, 
     SF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return SF_OK;
   }
-  const bool split = sf_use_split(c, view, n);
-  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap,
-                       c->debug_corr || split || sf_fused_lds_bytes(c, view) == 0)) != SF_OK)
-    return rc;
+  if ((rc = ws_reserve(c, std::min(n, SF_CHUNK), st.kcap, plan.lists)) != SF_OK) return rc;
   c->ws_split = 0;
   for (int off = 0; off < n; off += SF_CHUNK) {
     const int m = std::min(SF_CHUNK, n - off);
-    if ((rc = verify_sequence(c, view, d_from + off, d_to + off, m, d_out + off, true, split)) != SF_OK) return rc;
+    if ((rc = verify_sequence(c, view, d_from + off, d_to + off, m, d_out + off, plan)) != SF_OK) return rc;
   }
   return SF_OK;
 }
@@ -1358,7 +1394,8 @@ extern "C" int sf_verify_matches_device(sf_handle c, const sf_match* matches, in
 // Called by the NN filter behind the refinement launch of a prefix level (k_nn.hip): candidate pair list on
 // the device, then the verification of every candidate slot, all on the handle's stream.
 // Hands the selected accepted-result block to the verification kernels of the launch that follows (fused kernel, chain
-// kernels): the counter is word 4 of the candidate list's header, zeroed with the candidate count before the filter ran.
+// kernels) -- by value, in their kernel arguments: the counter is word 4 of the candidate list's header, zeroed with the
+// candidate count before the filter ran (or the caller's own word).
 static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   c->accept_streamed = false;
   if (c->accept_sel < 0 || !c->accept_blocks[c->accept_sel].set) return SF_OK;
@@ -1367,60 +1404,44 @@ static int arm_accept_stream(sf_context* c, const unsigned* d_count) {
   // records (the kernel drops what does not fit and the slot counter is not the caller's to read), so such a block
   // is not armed -- sf_accept_stream_status then reports streamed = 0 and the caller takes the compaction.
   if ((unsigned)ab.s.cap < c->spec.grid) return SF_OK;
-  const unsigned* counter = ab.s.ext_counter ? ab.s.counter : d_count + 4;
-  // (the candidate list's counter blocks alternate: one device copy of the block per counter block)
-  const int ci = (d_count == (const unsigned*)c->nn_cand.p) ? 0 : 1;
-  const size_t off = 64 * (size_t)(2 * c->accept_sel + ci);
-  int rc0;
-  if ((rc0 = sf_buf_reserve(c, c->accept_dev, 4 * 64, true)) != SF_OK) return rc0;
-  if (ab.uploaded[ci] != counter) {
-    ab.s.counter = const_cast<unsigned*>(counter);
-    SF_HIP(c, hipMemcpyAsync((char*)c->accept_dev.p + off, &ab.s, sizeof(AcceptStream), hipMemcpyHostToDevice, c->stream));
-    SF_HIP(c, hipStreamSynchronize(c->stream));      // (rare: first use, or the candidate buffer moved)
-    ab.uploaded[ci] = counter;
-  }
-  c->dparams.accept = (const AcceptStream*)((char*)c->accept_dev.p + off);
+  c->dparams.accept = ab.s;
+  if (!ab.s.ext_counter) c->dparams.accept.counter = const_cast<unsigned*>(d_count) + 4;
+  c->dparams.accept_on = 1;
   c->accept_streamed = true;
   c->accept_armed = true;
   return SF_OK;
 }
 
+// The verification of `grid` pair slots taken from a (row, column) list on the device -- the NN filter's candidates
+// (speculative path) or the device walk's matches -- with the accepted-result stream armed where the launch form has it.
 int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
   const unsigned grid = c->spec.grid;
-  // one chunk on the fused kernel: it derives the pairs from the candidate list itself (one launch and its gap less
-  // between the NN filter and the verification)
-  const bool split_form = c->store.slots > 0 && sf_use_split(c, sf_store_view(c->store), (int)grid);
-  if (grid <= (unsigned)SF_CHUNK && !c->overlap && !split_form && c->store.slots > 0 &&
-      sf_fused_lds_bytes(c, sf_store_view(c->store)) != 0) {
+  if (c->store.slots <= 0) return sf_fail(c, SF_EINVAL, "keyframe store is empty");
+  const StoreView view = sf_store_view(c->store);
+  const VerifyPlan plan = verify_plan(c, view, (int)grid);
+  int rc = SF_OK;
+  if (plan.form == VerifyPlan::FUSED && plan.single) {
+    // one chunk on the fused kernel: it derives the pairs from the list itself (one launch and its gap less between
+    // the NN stage and the verification)
     c->pair_src.cand = (const uint2*)d_cand;
     c->pair_src.count = d_count;
     c->pair_src.n_l = c->nn_local.n; c->pair_src.n_r = c->nn_recv.n;
     c->pair_src.slot_other = c->spec.slot_other; c->pair_src.slot_local = c->spec.slot_local;
     c->pair_src.n_slots = c->store.slots;
-    int rc0 = arm_accept_stream(c, d_count);
-    if (rc0 != SF_OK) return rc0;
-    const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
-                                 (sf_result*)c->spec_results.p);
-    c->dparams.accept = nullptr;
-    c->pair_src = PairSource();
-    return rc;
+  } else {
+    hipLaunchKernelGGL(k_spec_pairs, dim3((grid + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_cand, d_count, grid,
+                       c->nn_local.n, c->nn_recv.n, c->spec.slot_other, c->spec.slot_local, c->store.slots,
+                       (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
+    SF_HIP(c, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_spec_pairs, dim3((grid + 255) / 256), dim3(256), 0, c->stream, (const uint2*)d_cand, d_count, grid,
-                     c->nn_local.n, c->nn_recv.n, c->spec.slot_other, c->spec.slot_local, c->store.slots,
-                     (int32_t*)c->spec_from.p, (int32_t*)c->spec_to.p);
-  SF_HIP(c, hipGetLastError());
-  // the PnP estimator's chain kernel streams too (one chunk, one stream: a pair's index is its candidate slot)
-  // ... and so does the 3D-3D chain kernel of the split form (SF_FUSED=2: k_match_split + k_chain)
-  const bool pnp_chain = c->dparams.estimation_type == 1 && c->fused && c->chain_pnp &&
-                         sf_split_pnp_applicable(c, sf_store_view(c->store));
-  const bool split_chain = split_form && !pnp_chain;
-  if (grid <= (unsigned)SF_CHUNK && !c->overlap && c->store.slots > 0 && (pnp_chain || split_chain)) {
-    int rc0 = arm_accept_stream(c, d_count);
-    if (rc0 != SF_OK) return rc0;
-  }
-  const int rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
-                               (sf_result*)c->spec_results.p);
-  c->dparams.accept = nullptr;
+  // (one chunk, one stream: a pair's index is its slot in the list -- the fused kernel, the 3D-3D chain kernel of the
+  //  split form and the PnP estimator's chain kernel stream their accepted results)
+  if (plan.streams()) rc = arm_accept_stream(c, d_count);
+  if (rc == SF_OK)
+    rc = verify_device(c, c->store, (const int32_t*)c->spec_from.p, (const int32_t*)c->spec_to.p, (int)grid,
+                       (sf_result*)c->spec_results.p, &plan);
+  c->dparams.accept_on = 0;
+  c->pair_src = PairSource();
   return rc;
 }
 
@@ -1528,11 +1549,15 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
 // k_compact_count + k_compact_move (kept for batches with more chunks than can be resident at once).
 constexpr int COMPACT_CHUNK = 256;        // records per workgroup of k_compact_chain
 constexpr int COMPACT_MAX_CHUNKS = 1024;  // all resident at once (256 CUs x 8 workgroups of 256 threads)
+// state[0 .. chunks): the chunks' {epoch, own count}; state[chunks]: the launch's arrival word {arrived:16, timed out:16,
+// sum:32}, zero between launches (the chunk that arrives last reads the total, publishes it and clears the word).
+// cap2: record slots behind acc2 (a mirror smaller than the batch: what does not fit is dropped THERE only and shows in
+// *total2, which still carries the full count -- the owner's overflow path)
 __global__ void __launch_bounds__(COMPACT_CHUNK)
 k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ index, int n, sf_result* __restrict__ acc,
                 uint8_t* __restrict__ flags, unsigned long long* __restrict__ state, unsigned epoch,
                 int32_t* __restrict__ total, sf_result* __restrict__ acc2, uint8_t* __restrict__ flags2,
-                int32_t* __restrict__ total2) {
+                int32_t* __restrict__ total2, int cap2) {
   __shared__ int wsum[COMPACT_CHUNK / 64];
   __shared__ int s_dst[COMPACT_CHUNK];
   __shared__ int s_src[COMPACT_CHUNK];
@@ -1580,12 +1605,17 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
     const bool any_timeout = __any(timed_out);
     if (lane == 0) {
       s_base = (int)sum;
-      if (any_timeout) {
-        *total = -1;
-        if (total2) *total2 = -1;
-      } else if (blockIdx.x == gridDim.x - 1) {
-        *total = (int)sum + own;
-        if (total2) *total2 = (int)sum + own;
+      // the total is published by whichever chunk ARRIVES last, and a time-out anywhere in the launch makes it -1: a
+      // chunk that gave up on a predecessor has moved its records to wrong places whatever the other chunks saw
+      const unsigned long long mine = (1ull << 48) | ((unsigned long long)(any_timeout ? 1u : 0u) << 32) |
+                                      (unsigned long long)(unsigned)own;
+      const unsigned long long old = atomicAdd(&state[gridDim.x], mine);
+      if ((unsigned)(old >> 48) + 1u == gridDim.x) {
+        const unsigned long long tot = old + mine;
+        const int t = ((tot >> 32) & 0xFFFFull) ? -1 : (int)(unsigned)(tot & 0xFFFFFFFFull);
+        *total = t;
+        if (total2) *total2 = t;
+        __hip_atomic_store(&state[gridDim.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -1599,27 +1629,28 @@ k_compact_chain(const sf_result* __restrict__ res, const int32_t* __restrict__ i
     if (dst >= 0) {
       const uint4 v = reinterpret_cast<const uint4*>(res + s_src[c])[piece];
       reinterpret_cast<uint4*>(acc + dst)[piece] = v;
-      if (acc2) reinterpret_cast<uint4*>(acc2 + dst)[piece] = v;
+      if (acc2 && dst < cap2) reinterpret_cast<uint4*>(acc2 + dst)[piece] = v;
     }
   }
 }
 
 static int compact_launch(sf_context* c, const sf_result* d_results, int n, sf_result* d_accepted, uint8_t* d_flags,
                           int32_t* d_count, const int32_t* index = nullptr, sf_result* d_accepted2 = nullptr,
-                          uint8_t* d_flags2 = nullptr, int32_t* d_count2 = nullptr) {
+                          uint8_t* d_flags2 = nullptr, int32_t* d_count2 = nullptr, int cap2 = 0x7FFFFFFF) {
   const int chunks = (n + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
   int rc;
   if ((rc = sf_buf_reserve(c, c->compact_scratch, (size_t)(chunks + 2) * 8)) != SF_OK) return rc;
   if (chunks <= COMPACT_MAX_CHUNKS) {
-    if (c->compact_state_chunks < chunks || c->compact_state_ptr != c->compact_scratch.p) {
-      // fresh (or regrown / reallocated) state: make every epoch tag invalid once
-      SF_HIP(c, hipMemsetAsync(c->compact_scratch.p, 0, (size_t)(chunks + 1) * 8, c->stream));
+    if (c->compact_state_chunks != chunks || c->compact_state_ptr != c->compact_scratch.p) {
+      // fresh (or regrown / reallocated) state, or another chunk count (the arrival word sits behind the chunks' words):
+      // make every epoch tag invalid and the arrival word zero once
+      SF_HIP(c, hipMemsetAsync(c->compact_scratch.p, 0, (size_t)(chunks + 2) * 8, c->stream));
       c->compact_state_chunks = chunks;
       c->compact_state_ptr = c->compact_scratch.p;
     }
     if (++c->compact_epoch == 0) c->compact_epoch = 1;
     hipLaunchKernelGGL(k_compact_chain, dim3(chunks), dim3(COMPACT_CHUNK), 0, c->stream, d_results, index, n, d_accepted, d_flags,
-                       (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count, d_accepted2, d_flags2, d_count2);
+                       (unsigned long long*)c->compact_scratch.p, c->compact_epoch, d_count, d_accepted2, d_flags2, d_count2, cap2);
     SF_HIP(c, hipGetLastError());
     if (index && index == (const int32_t*)c->spec_index_pinned)
       SF_HIP(c, hipEventRecord(c->spec_index_staged, c->stream));   // the pinned index block may be rewritten after this
@@ -1655,7 +1686,7 @@ extern "C" int sf_accept_stream_set(sf_handle c, int32_t which, sf_result* recor
   ab.s.records = records; ab.s.index = index; ab.s.flags = flags; ab.s.cap = cap;
   ab.s.records2 = d_records2;
   ab.s.counter = d_counter; ab.s.ext_counter = d_counter ? 1 : 0;
-  ab.set = true; ab.uploaded[0] = ab.uploaded[1] = nullptr;
+  ab.set = true;
   return SF_OK;
 }
 
@@ -1673,10 +1704,20 @@ extern "C" int sf_accept_stream_status(sf_handle c, int32_t* streamed, int32_t* 
 }
 
 // ---- the caller's loop body as a begin / retire pair (find_separators.py:59-133) -------------------------------------
-// sf_step_issue = s_find_matches_query + the estimate_transformation calls of every returned candidate, queued;
-// sf_step_retire = the per-candidate outcome the loop forwards (find_separators.py:97-133).  What bench.py's Python
-// choreography did in round 2 (stream selection, speculative verification, accepted-result stream, index -> match
-// filtering) lives here, so that a C++ host reaches the same rate with two calls per step.
+// sf_step_issue = s_find_matches_query + the estimate_transformation calls of every returned candidate, QUEUED;
+// sf_step_retire = the per-candidate outcome the loop forwards (find_separators.py:97-133).
+//
+// Round 4: the step is device-resident.  sf_step_issue queues, on ONE stream and with no host wait,
+//     NN filter (or fp32 ranking) -> exact re-evaluation -> per-row minima -> argsort + walk (k_walk_*: data_handler.py:
+//     191-205) -> verification of the walk's matches, taken from the device list -> accepted separators streaming
+//     into the step's host-pinned block,
+// and returns; up to `step_depth` steps are in flight, dealt over `step_lanes` streams, and sf_step_retire is the only
+// wait.  (Round 3 waited inside sf_step_issue for the row minima and walked them on the host, with the verification of
+// EVERY filter candidate running speculatively beside it: any host hiccup landed in the step time -- one 6.9 ms step of
+// 20 halved the driver's figure.)  What the device cannot decide -- a candidate set denser than the filter level the handle
+// last settled on allows, which takes the prefix ladder of nn_run_filter -- is reported through the pinned status word; the
+// retire then runs the query again on the synchronous path below (step_issue_sync: round 3's body), once, and the ladder
+// level it settles on serves the following steps.
 static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t cap) {
   if (!b.done) SF_HIP(c, hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   if (cap <= b.cap) return SF_OK;
@@ -1685,7 +1726,9 @@ static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t c
   const int32_t want = cap + cap / 4 + 64;
   const size_t rec_bytes = (size_t)want * sizeof(sf_result);
   const size_t idx_off = rec_bytes, flag_off = idx_off + (size_t)want * 4, cnt_off = (flag_off + (size_t)want + 63) & ~(size_t)63;
-  const size_t total = cnt_off + 64;
+  const size_t match_off = cnt_off + 64, slot_off = match_off + (size_t)want * sizeof(sf_match);
+  const size_t word_off = (slot_off + (size_t)want * 4 + 63) & ~(size_t)63;
+  const size_t total = word_off + 64;
   if (hipHostMalloc(&b.pinned, total, hipHostMallocDefault) != hipSuccess)
     return sf_fail(c, SF_ENOMEM, "hipHostMalloc(%zu) failed", total);
   b.pinned_bytes = total;
@@ -1693,12 +1736,22 @@ static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t c
   b.index = (int32_t*)((char*)b.pinned + idx_off);
   b.flags = (uint8_t*)b.pinned + flag_off;
   b.count = (int32_t*)((char*)b.pinned + cnt_off);
+  b.walk_matches = (sf_match*)((char*)b.pinned + match_off);
+  b.walk_slots = (int32_t*)((char*)b.pinned + slot_off);
+  b.walk_n = (int32_t*)((char*)b.pinned + word_off);
+  b.walk_status = b.walk_n + 1;
   b.cap = want;
   for (int32_t i = 0; i < want; ++i) b.index[i] = -1;
   memset(b.flags, 0, (size_t)want);
   *b.count = 0;
-  return SF_OK;
+  *b.walk_n = 0;
+  *b.walk_status = 0;
+  return sf_buf_reserve(c, b.dev, 64 + (size_t)want * 8);
 }
+
+static inline int step_ring(const sf_context* c) { return c->step_depth + 1; }
+
+static int step_settle_all(sf_context* c);
 
 extern "C" int sf_step_mirror_pair(sf_handle c, sf_result* d_records_even, uint32_t* d_counter_even,
                                    sf_result* d_records_odd, uint32_t* d_counter_odd, int32_t cap) {
@@ -1712,8 +1765,7 @@ extern "C" int sf_step_mirror_pair(sf_handle c, sf_result* d_records_even, uint3
   c->step_mirror_counter[1] = d_counter_odd;
   c->step_mirror_cap = d_records_even ? cap : 0;
   c->step_mirror_lanes = false;
-  c->step_head = 0;                                                     // the next step is an even one
-  for (auto& ab : c->accept_blocks) ab = sf_context::AcceptHost();      // (re-registered by the next sf_step_issue)
+  c->step_seq = 0;                                                      // the next step is an even one
   return SF_OK;
 }
 
@@ -1721,44 +1773,55 @@ extern "C" int sf_step_mirror(sf_handle c, sf_result* d_records2, uint32_t* d_co
   return sf_step_mirror_pair(c, d_records2, d_counter, d_records2, d_counter, cap);
 }
 
-// ---- SF_OPT_STEP_OVERLAP: the second lane of the step pipeline ------------------------------------------------------
-static void lane_swap(sf_context* c) {
-  sf_context::StepLane& L = c->lane1;
+// ---- SF_OPT_STEP_OVERLAP: the further lanes of the step pipeline ----------------------------------------------------
+static void lane_swap(sf_context* c, int k) {
+  sf_context::StepLane& L = c->lanes[k - 1];
   std::swap(c->stream, L.stream);
+  std::swap(c->aux, L.aux); std::swap(c->ev_filter, L.ev_filter); std::swap(c->ev_walk, L.ev_walk);
 #define SF_SWAP(m) std::swap(c->m, L.m)
   SF_SWAP(pair_from); SF_SWAP(pair_to); SF_SWAP(corr1); SF_SWAP(corr2); SF_SWAP(hdr1); SF_SWAP(hdr2); SF_SWAP(pass1);
   SF_SWAP(pass2); SF_SWAP(pass_back); SF_SWAP(dir_mask); SF_SWAP(list1); SF_SWAP(list3); SF_SWAP(counters);
   SF_SWAP(results); SF_SWAP(flags); SF_SWAP(nn_cand); SF_SWAP(spec_from); SF_SWAP(spec_to); SF_SWAP(spec_results);
-  SF_SWAP(spec_index); SF_SWAP(compact_scratch); SF_SWAP(ws_pairs); SF_SWAP(ws_kcap); SF_SWAP(nn_count_idx);
-  SF_SWAP(nn_count_primed); SF_SWAP(compact_epoch); SF_SWAP(compact_state_chunks); SF_SWAP(compact_state_ptr);
+  SF_SWAP(spec_index); SF_SWAP(compact_scratch); SF_SWAP(step_nn); SF_SWAP(walk_scratch); SF_SWAP(ws_pairs); SF_SWAP(ws_kcap);
+  SF_SWAP(nn_count_idx); SF_SWAP(nn_count_primed); SF_SWAP(compact_epoch); SF_SWAP(compact_state_chunks);
+  SF_SWAP(compact_state_ptr);
 #undef SF_SWAP
 }
 
+// A database (or a mask) is about to change: every step in flight is settled first -- waited for, and re-run on the
+// synchronous path if its device walk asked for that -- so that no queued kernel reads what the caller is about to
+// write and a fallback still sees the state its step was issued on.  `drain` also waits for the lanes' streams.
 int sf_lanes_touch(sf_context* c, bool drain) {
   c->db_epoch += 1;
-  if (drain && c->lane1.stream && c->step_blocks[1].issued) SF_HIP(c, hipStreamSynchronize(c->lane1.stream));
+  (void)step_settle_all(c);
+  if (drain)
+    for (auto& L : c->lanes)
+      if (L.stream) SF_HIP(c, hipStreamSynchronize(L.stream));
   return SF_OK;
 }
 
-static int lane1_create(sf_context* c) {
-  sf_context::StepLane& L = c->lane1;
+static int stream_with_own_queue(sf_context* c, hipStream_t* out, bool aux);
+
+static int lane_create(sf_context* c, int k) {
+  sf_context::StepLane& L = c->lanes[k - 1];
   if (L.stream) return SF_OK;
-  SF_HIP(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  int rc0 = stream_with_own_queue(c, &L.stream, false);
+  if (rc0 != SF_OK) return rc0;
   SF_HIP(c, hipEventCreateWithFlags(&L.ev_main, hipEventDisableTiming));
   return sf_buf_reserve(c, L.counters, 64);          // (the work-list counters of the stage kernels; the handle's own
 }                                                    //  are reserved at sf_create)
 
-static int lane1_enter(sf_context* c) {
-  sf_context::StepLane& L = c->lane1;
-  int rc0 = lane1_create(c);
+static int lane_enter(sf_context* c, int k) {
+  int rc0 = lane_create(c, k);
   if (rc0 != SF_OK) return rc0;
+  sf_context::StepLane& L = c->lanes[k - 1];
   if (L.seen_db_epoch != c->db_epoch) {
     // the databases were written through the handle's stream since this lane last looked: wait for that work once
     SF_HIP(c, hipEventRecord(L.ev_main, c->stream));
     SF_HIP(c, hipStreamWaitEvent(L.stream, L.ev_main, 0));
     L.seen_db_epoch = c->db_epoch;
   }
-  lane_swap(c);
+  lane_swap(c, k);
   return SF_OK;
 }
 
@@ -1769,62 +1832,38 @@ extern "C" int sf_step_mirror_streams(sf_handle c, void** stream_even, void** st
     return sf_fail(c, SF_EINVAL, "sf_step_mirror_streams: needs two distinct mirrors (sf_step_mirror_pair)");
   SF_HIP(c, hipSetDevice(c->device));
   *stream_even = *stream_odd = (void*)c->stream;
-  if (c->step_overlap && !c->overlap) {
-    int rc = lane1_create(c);
+  if (c->step_overlap && !c->overlap && c->step_lanes >= 2) {
+    int rc = lane_create(c, 1);
     if (rc != SF_OK) return rc;
-    *stream_odd = (void*)c->lane1.stream;
+    *stream_odd = (void*)c->lanes[0].stream;
     c->step_mirror_lanes = true;
   }
   return SF_OK;
 }
 
-static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_base_local);
-
-extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_base_local) {
-  if (!c) return SF_EINVAL;
-  if (c->step_inflight >= 2) return sf_fail(c, SF_EINVAL, "two steps are in flight: call sf_step_retire first");
-  if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
-    return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
-  SF_HIP(c, hipSetDevice(c->device));
-  const bool lanes = c->step_overlap && !c->overlap && (!c->step_mirror_records[0] || c->step_mirror_lanes);
-  const bool lane1 = lanes && c->step_head == 1;
-  c->in_overlapped_step = lanes;            // (sf_use_split: the form the verification takes)
-  int rc;
-  if (!lane1) {
-    rc = step_issue_body(c, slot_base_other, slot_base_local);
-  } else if ((rc = lane1_enter(c)) == SF_OK) {
-    rc = step_issue_body(c, slot_base_other, slot_base_local);
-    lane_swap(c);
-  }
-  c->in_overlapped_step = false;
-  return rc;
-}
-
-static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_base_local) {
-  const int which = c->step_head;
-  sf_context::StepBlock& b = c->step_blocks[which];
+// ---- the synchronous body (round 3's step): the NN stage is walked on the host inside the call -----------------------
+// Used when the device walk does not apply (SF_OPT_STEP_DEVICE_WALK off, the two-halves verification) and as the fallback
+// of a device step whose candidate set was too dense for the filter level.
+static int step_issue_sync(sf_context* c, sf_context::StepBlock& b, int32_t slot_base_other, int32_t slot_base_local) {
   const int n_l = c->nn_local.n;
-  // every slot of a speculative verification may be accepted: the block holds them all (see arm_accept_stream)
-  const int32_t need = n_l + n_l / 8 + 256;
   int rc;
-  if ((rc = step_block_reserve(c, b, need)) != SF_OK) return rc;
-  sf_result* const mirror_rec = c->step_mirror_records[which];
-  uint32_t* const mirror_cnt = c->step_mirror_counter[which];
+  sf_result* const mirror_rec = c->step_mirror_records[b.parity];
+  uint32_t* const mirror_cnt = c->step_mirror_counter[b.parity];
   const int32_t mirror_cap = mirror_rec ? c->step_mirror_cap : b.cap;
-  sf_context::AcceptHost& ab = c->accept_blocks[which];
-  if (!ab.set || ab.s.records != b.records || ab.s.cap != std::min(b.cap, mirror_cap) ||
-      ab.s.records2 != mirror_rec) {
-    if ((rc = sf_accept_stream_set(c, which, b.records, b.index, nullptr, std::min(b.cap, mirror_cap),
-                                   mirror_rec, mirror_cnt)) != SF_OK) return rc;
-  }
+  sf_context::AcceptHost& ab = c->accept_blocks[2];
+  ab.s.records = b.records; ab.s.index = b.index; ab.s.flags = nullptr; ab.s.cap = std::min(b.cap, mirror_cap);
+  ab.s.records2 = mirror_rec; ab.s.counter = mirror_cnt; ab.s.ext_counter = mirror_cnt ? 1 : 0;
+  ab.set = true;
   b.matches.resize((size_t)std::max(n_l, 1));
-  c->accept_sel = which;
+  const int sel_before = c->accept_sel;
+  c->accept_sel = 2;
   int32_t n = 0;
   rc = sf_find_matches_and_verify_device(c, slot_base_other, slot_base_local, b.matches.data(), n_l, &n, nullptr);
-  c->accept_sel = -1;
+  c->accept_sel = sel_before;
+  b.device_walk = false;
+  b.armed = c->accept_armed;                  // the block may hold streamed records (also of an abandoned speculation)
   if (rc != SF_OK) return rc;
   b.n = n;
-  b.armed = c->accept_armed;                  // the block may hold streamed records (also of an abandoned speculation)
   b.streamed = c->accept_streamed && n > 0;
   b.pairs = b.armed ? (int32_t)c->spec.grid : 0;
   if (b.streamed) {
@@ -1833,33 +1872,285 @@ static int step_issue_body(sf_context* c, int32_t slot_base_other, int32_t slot_
     for (int i = 0; i < n; ++i) b.slot_of_match[i] = ix ? ix[i] : i;
   } else if (n > 0) {
     // not streamed (no speculation for this query, or a launch shape the stream does not cover): the accepted results of
-    // the matches are compacted, in match order, straight into the block
+    // the matches are compacted, in match order, straight into the block (mirror writes beyond its capacity are dropped
+    // and show in the mirror's count: the exchange's overflow path)
     if (n > b.cap) return sf_fail(c, SF_ERANGE, "sf_step_issue: %d matches exceed the block's %d records", n, b.cap);
     if ((rc = compact_launch(c, c->last_results, n, b.records, b.flags, b.count, c->last_results_index,
-                             mirror_rec, nullptr, (int32_t*)mirror_cnt)) != SF_OK) return rc;
+                             mirror_rec, nullptr, (int32_t*)mirror_cnt, mirror_cap)) != SF_OK) return rc;
   }
   SF_HIP(c, hipEventRecord(b.done, c->stream));
+  return SF_OK;
+}
+
+// ---- the device-resident bodies --------------------------------------------------------------------------------------
+static int stream_with_own_queue(sf_context* c, hipStream_t* out, bool aux) {
+  // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a stream that lands
+  // on the queue of another runs BEHIND it, not beside it.  Streams of another priority level draw from queues of their
+  // own, so unless the process raised the queue budget the library's extra streams get the highest priority.
+  // The second stream of a speculative step (exact re-evaluation, row minima, walk: a chain of nine small dependent
+  // launches) ALWAYS gets it: beside a matching launch, which holds every register of every CU, a launch of default
+  // priority waits for hundreds of microseconds for its first workgroup slot (k_walk_tile_sort: 435 us instead of 32,
+  // profiles/r04d_timeline_*), and the step is not done before its walk is.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+  int prio = (hwq && atoi(hwq) >= 8 && !aux) ? 0 : prio_greatest;
+  if (const char* v = getenv(aux ? "SF_AUX_PRIO" : "SF_LANE_PRIO")) prio = atoi(v) > 0 ? prio_greatest : (atoi(v) < 0 ? prio_least : 0);
+  SF_HIP(c, hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio));
+  return SF_OK;
+}
+
+static void step_accept_block(sf_context* c, sf_context::StepBlock& b, sf_result** mirror_rec, uint32_t** mirror_cnt,
+                              int32_t* mirror_cap) {
+  *mirror_rec = c->step_mirror_records[b.parity];
+  *mirror_cnt = c->step_mirror_counter[b.parity];
+  *mirror_cap = *mirror_rec ? c->step_mirror_cap : b.cap;
+  sf_context::AcceptHost& ab = c->accept_blocks[2];
+  ab.s.records = b.records; ab.s.index = b.index; ab.s.flags = nullptr; ab.s.cap = std::min(b.cap, *mirror_cap);
+  ab.s.records2 = *mirror_rec; ab.s.counter = *mirror_cnt; ab.s.ext_counter = *mirror_cnt ? 1 : 0;
+  ab.set = true;
+}
+
+// Batch mode (the walk may return every local row) on the fp16 filter: the verification of EVERY filter candidate goes
+// onto the step's stream straight behind the filter, and the exact re-evaluation, the row minima and the walk run on a
+// second stream beside it -- off the chain of dependent launches that decides how soon the lane is free for its next
+// step.  The walk's matches then name their candidate's verification slot (walk_slots); round 3 did the same with the
+// host in the middle.  A step of the reference's cadence (20 matches of 10 000 rows) would verify 500 x too much this way
+// and takes step_issue_serial.
+static int step_issue_speculative(sf_context* c, sf_context::StepBlock& b, int32_t slot_base_other, int32_t slot_base_local,
+                                  int lim) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n;
+  int rc;
+  if (!c->aux) {
+    if ((rc = stream_with_own_queue(c, &c->aux, true)) != SF_OK) return rc;
+    SF_HIP(c, hipEventCreateWithFlags(&c->ev_filter, hipEventDisableTiming));
+    SF_HIP(c, hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming));
+  }
+  const size_t min_b = ((size_t)n_l * 8 + 63) & ~(size_t)63, i32_b = ((size_t)n_l * 4 + 63) & ~(size_t)63;
+  if ((rc = sf_buf_reserve(c, c->step_nn, 2 * min_b + 2 * i32_b + 64)) != SF_OK) return rc;
+  char* base = (char*)c->step_nn.p;
+  double* d_min = (double*)base;
+  int32_t* d_arg = (int32_t*)(base + min_b);
+  int32_t* d_cand = (int32_t*)(base + min_b + i32_b);
+  unsigned long long* d_arg64 = (unsigned long long*)(base + min_b + 2 * i32_b);
+  int32_t* d_status = (int32_t*)(base + 2 * min_b + 2 * i32_b);
+  NnFilterOut fo;
+  if ((rc = sf_nn_filter_dev(c, &fo)) != SF_OK) return rc;
+  SF_HIP(c, hipEventRecord(c->ev_filter, c->stream));
+  // the step's stream: every candidate slot verified (slots past the device-side count are void)
+  c->spec.grid = (unsigned)(n_l + n_l / 8 + 256);       // room for rows with more than one candidate
+  c->spec.slot_other = slot_base_other;
+  c->spec.slot_local = slot_base_local;
+  if ((rc = sf_buf_reserve(c, c->spec_from, (size_t)c->spec.grid * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->spec_to, (size_t)c->spec.grid * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->spec_results, (size_t)c->spec.grid * sizeof(sf_result))) != SF_OK) return rc;
+  sf_result* mirror_rec; uint32_t* mirror_cnt; int32_t mirror_cap;
+  step_accept_block(c, b, &mirror_rec, &mirror_cnt, &mirror_cap);
+  const int sel_before = c->accept_sel;
+  c->accept_sel = 2;
+  c->accept_armed = false;
+  c->accept_streamed = false;
+  rc = sf_spec_launch(c, fo.cand, fo.count);
+  c->accept_sel = sel_before;
+  b.armed = c->accept_armed;
+  b.streamed = c->accept_streamed;
+  b.pairs = (int32_t)c->spec.grid;
+  if (rc != SF_OK) return rc;
+  // the second stream: exact distances -> row minima (with each minimum's candidate index) -> argsort + walk
+  {
+    SF_HIP(c, hipStreamWaitEvent(c->aux, c->ev_filter, 0));
+    const hipStream_t lane_stream = c->stream;
+    c->stream = c->aux;                      // (the launchers queue on, and bracket for, the handle's current stream)
+    rc = sf_nn_minima_of_candidates_dev(c, fo, d_min, d_arg, d_status, d_cand, d_arg64, c->store.kcap >= 256);
+    if (rc == SF_OK)
+      rc = sf_nn_walk_dev(c, d_min, d_arg, d_status, n_l, n_r, c->params.netvlad_distance, c->params.netvlad_max_matches_nb,
+                          lim, nullptr, nullptr, b.walk_matches, b.walk_n, b.walk_status, d_cand, b.walk_slots, fo.count,
+                          c->spec.grid);
+    c->stream = lane_stream;
+    if (rc != SF_OK) { (void)hipStreamSynchronize(c->aux); return rc; }
+    SF_HIP(c, hipEventRecord(c->ev_walk, c->aux));
+  }
+  SF_HIP(c, hipStreamWaitEvent(c->stream, c->ev_walk, 0));      // the step is done when both streams are
+  if (!b.streamed)      // (step_issue_device picks this form only where the launch streams: a plan / arm mismatch)
+    return sf_fail(c, SF_EHIP, "speculative step: the verification launch did not arm the accepted-result stream");
+  SF_HIP(c, hipEventRecord(b.done, c->stream));
+  return SF_OK;
+}
+
+// Everything on one stream: NN kernels -> row minima -> argsort + walk -> verification of the walk's matches, taken from
+// the device list.  Any query shape (the reference's cadence of 20 matches per tick included), both NN precisions.
+static int step_issue_serial(sf_context* c, sf_context::StepBlock& b, int32_t slot_base_other, int32_t slot_base_local, int lim) {
+  const int n_l = c->nn_local.n, n_r = c->nn_recv.n;
+  int rc;
+  const size_t min_bytes = ((size_t)n_l * 8 + 63) & ~(size_t)63, arg_bytes = ((size_t)n_l * 4 + 63) & ~(size_t)63;
+  if ((rc = sf_buf_reserve(c, c->step_nn, min_bytes + arg_bytes + 64)) != SF_OK) return rc;
+  double* d_min = (double*)c->step_nn.p;
+  int32_t* d_arg = (int32_t*)((char*)c->step_nn.p + min_bytes);
+  int32_t* d_status = (int32_t*)((char*)c->step_nn.p + min_bytes + arg_bytes);
+  unsigned* d_count = (unsigned*)b.dev.p;                       // {matches, -, -, -, accept slot counter, ...}
+  void* d_match_rc = (char*)b.dev.p + 64;
+  if ((rc = sf_nn_row_minima_dev(c, d_min, d_arg, d_status)) != SF_OK) return rc;
+  if ((rc = sf_nn_walk_dev(c, d_min, d_arg, d_status, n_l, n_r, c->params.netvlad_distance, c->params.netvlad_max_matches_nb,
+                           lim, d_match_rc, d_count, b.walk_matches, b.walk_n, b.walk_status)) != SF_OK) return rc;
+  // verification of the walk's matches: `lim` pair slots, those past the device-side count are void
+  c->spec.grid = (unsigned)lim;
+  c->spec.slot_other = slot_base_other;
+  c->spec.slot_local = slot_base_local;
+  if ((rc = sf_buf_reserve(c, c->spec_from, (size_t)lim * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->spec_to, (size_t)lim * 4)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->spec_results, (size_t)lim * sizeof(sf_result))) != SF_OK) return rc;
+  sf_result* mirror_rec; uint32_t* mirror_cnt; int32_t mirror_cap;
+  step_accept_block(c, b, &mirror_rec, &mirror_cnt, &mirror_cap);
+  const int sel_before = c->accept_sel;
+  c->accept_sel = 2;
+  c->accept_armed = false;
+  c->accept_streamed = false;
+  rc = sf_spec_launch(c, d_match_rc, d_count);
+  c->accept_sel = sel_before;
+  b.armed = c->accept_armed;
+  b.streamed = c->accept_streamed;
+  b.pairs = lim;
+  if (rc != SF_OK) return rc;
+  if (!b.streamed) {
+    // a launch shape the stream does not cover (stage kernels, more than one chunk, a mirror smaller than the query):
+    // ordered compaction of the `lim` slots, match order -- the void slots past the match count carry success = 0
+    if (lim > b.cap) return sf_fail(c, SF_ERANGE, "sf_step_issue: %d pair slots exceed the block's %d records", lim, b.cap);
+    if ((rc = compact_launch(c, (const sf_result*)c->spec_results.p, lim, b.records, b.flags, b.count, nullptr, mirror_rec,
+                             nullptr, (int32_t*)mirror_cnt, mirror_cap)) != SF_OK) return rc;
+  }
+  SF_HIP(c, hipEventRecord(b.done, c->stream));
+  return SF_OK;
+}
+
+static int step_issue_device(sf_context* c, sf_context::StepBlock& b, int32_t slot_base_other, int32_t slot_base_local) {
+  const int n_l = c->nn_local.n;
+  const int lim = std::min(n_l, c->params.netvlad_max_matches_nb);     // the walk looks at `lim` rows: at most `lim` matches
+  b.device_walk = true;
+  b.speculative = false;
+  b.streamed = false; b.armed = false; b.n = 0; b.pairs = 0;
+  *b.walk_status = 0;
+  *b.walk_n = 0;
+  if (lim <= 0) {                                   // (netvlad_max_matches_nb = 0: the walk returns nothing)
+    SF_HIP(c, hipEventRecord(b.done, c->stream));
+    return SF_OK;
+  }
+  // the speculative form where round 3 speculated (the walk may return every local row, filter path) and where every
+  // verified slot can stream: one chunk, a chain-type launch, a block / mirror with a record slot for every candidate slot
+  if (c->step_speculate && c->params.nn_precision == 1 && lim >= n_l) {
+    const int grid = n_l + n_l / 8 + 256;
+    const VerifyPlan plan = verify_plan(c, sf_store_view(c->store), grid);
+    sf_result* const mirror_rec = c->step_mirror_records[b.parity];
+    const int32_t cap = std::min(b.cap, mirror_rec ? c->step_mirror_cap : b.cap);
+    if (plan.streams() && cap >= grid) {
+      b.speculative = true;
+      return step_issue_speculative(c, b, slot_base_other, slot_base_local, lim);
+    }
+  }
+  return step_issue_serial(c, b, slot_base_other, slot_base_local, lim);
+}
+
+extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_base_local) {
+  if (!c) return SF_EINVAL;
+  if (c->step_inflight >= c->step_depth)
+    return sf_fail(c, SF_EINVAL, "%d steps are in flight (SF_OPT_STEP_DEPTH): call sf_step_retire first", c->step_inflight);
+  if (c->nn_local.n <= 0 || c->nn_recv.n <= 0)
+    return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
+  SF_HIP(c, hipSetDevice(c->device));
+  const bool mirrored = c->step_mirror_records[0] != nullptr;
+  int lanes = (c->step_overlap && !c->overlap && (!mirrored || c->step_mirror_lanes)) ? c->step_lanes : 1;
+  if (mirrored) lanes = std::min(lanes, 2);          // (a mirror's buffer and its collective live on the stream of its parity)
+  if (c->params.nn_precision == 0) lanes = 1;        // (the fp32-ranking path keeps its partial minima in ONE workspace)
+  const int lane = (int)(c->step_seq % (uint64_t)lanes);
+  sf_context::StepBlock& b = c->step_blocks[c->step_seq % (uint64_t)step_ring(c)];
+  const int n_l = c->nn_local.n;
+  int rc;
+  // every slot of a speculative verification may be accepted: the block holds them all (see arm_accept_stream)
+  if ((rc = step_block_reserve(c, b, n_l + n_l / 8 + 256)) != SF_OK) return rc;
+  b.parity = (int)(c->step_seq & 1);
+  b.slot_other = slot_base_other; b.slot_local = slot_base_local;
+  b.settled = false; b.settle_rc = SF_OK;
+  c->in_overlapped_step = lanes > 1;            // (sf_use_split: the form the verification takes)
+  const bool device = c->step_device_walk && !c->overlap && c->store.slots > 0;
+  if (lane > 0 && (rc = lane_enter(c, lane)) != SF_OK) { c->in_overlapped_step = false; return rc; }
+  // state every lane reads (fp16 copies, coefficients, masks) prepared by another lane since this one last looked?
+  if (c->lane_seen_prep[lane] != c->prep_epoch && c->ev_prep) {
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_prep, 0);
+    if (e != hipSuccess) rc = sf_fail(c, SF_EHIP, "hipStreamWaitEvent -> %s", hipGetErrorString(e));
+  }
+  c->lane_seen_prep[lane] = c->prep_epoch;
+  const uint64_t prep_before = c->prep_count;
+  if (rc == SF_OK) rc = device ? step_issue_device(c, b, slot_base_other, slot_base_local)
+                               : step_issue_sync(c, b, slot_base_other, slot_base_local);
+  if (c->prep_count != prep_before) {
+    if (!c->ev_prep) (void)hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming);
+    if (c->ev_prep) (void)hipEventRecord(c->ev_prep, c->stream);
+    c->prep_epoch += 1;
+    c->lane_seen_prep[lane] = c->prep_epoch;
+  }
+  if (rc != SF_OK) {
+    // nothing of a failed issue may stay behind: whatever was queued is waited for and the block's streamed entries are
+    // reset, so the next step starts from a clean block
+    (void)hipStreamSynchronize(c->stream);
+    for (int32_t r = 0; r < b.cap && b.index[r] >= 0; ++r) b.index[r] = -1;
+  }
+  if (lane > 0) lane_swap(c, lane);
+  c->in_overlapped_step = false;
+  if (rc != SF_OK) return rc;
   b.issued = true;
-  c->step_head ^= 1;
+  c->step_seq += 1;
   c->step_inflight += 1;
   return SF_OK;
+}
+
+// Waits for a step and, if its device walk reported a candidate set too dense for the filter level, runs the query again
+// on the synchronous path (the handle is idle by then: every step in flight is waited for first, since the ladder rewrites
+// state all lanes read).  Idempotent.
+static int step_settle(sf_context* c, sf_context::StepBlock& b) {
+  if (b.settled) return b.settle_rc;
+  b.settled = true;
+  hipError_t e = hipEventSynchronize(b.done);
+  if (e != hipSuccess) return b.settle_rc = sf_fail(c, SF_EHIP, "hipEventSynchronize(step) -> %s", hipGetErrorString(e));
+  if (!b.device_walk || *b.walk_status == 0) return b.settle_rc = SF_OK;
+  for (auto& o : c->step_blocks)
+    if (o.issued && o.done) (void)hipEventSynchronize(o.done);
+  // (what the void verification may have streamed: nothing -- the walk emitted no match -- but the entries are the next
+  //  query's, so make sure)
+  for (int32_t r = 0; r < b.cap && b.index[r] >= 0; ++r) b.index[r] = -1;
+  const bool mirrored = c->step_mirror_records[b.parity] != nullptr;
+  c->in_overlapped_step = false;
+  int rc = step_issue_sync(c, b, b.slot_other, b.slot_local);        // (on the handle's own stream and buffers)
+  if (rc == SF_OK && (e = hipEventSynchronize(b.done)) != hipSuccess)
+    rc = sf_fail(c, SF_EHIP, "hipEventSynchronize(step fallback) -> %s", hipGetErrorString(e));
+  if (rc == SF_OK && mirrored)
+    rc = sf_fail(c, SF_ERANGE, "sf_step_retire: the NN candidate set outgrew the filter level while a mirror was set -- the "
+                               "mirror missed this step's records (the level is settled now: issue the step again)");
+  return b.settle_rc = rc;
+}
+
+static int step_settle_all(sf_context* c) {
+  int rc = SF_OK;
+  for (int k = c->step_inflight; k >= 1; --k) {          // oldest first
+    sf_context::StepBlock& b = c->step_blocks[(c->step_seq - (uint64_t)k) % (uint64_t)step_ring(c)];
+    const int r = step_settle(c, b);
+    if (rc == SF_OK) rc = r;
+  }
+  return rc;
 }
 
 extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
   if (!c || !out) return SF_EINVAL;
   memset(out, 0, sizeof(*out));
   if (c->step_inflight <= 0) return sf_fail(c, SF_EINVAL, "sf_step_retire: no step in flight");
-  const int which = c->step_inflight == 2 ? c->step_head : (c->step_head ^ 1);      // the OLDEST issued step
-  sf_context::StepBlock& b = c->step_blocks[which];
+  sf_context::StepBlock& b = c->step_blocks[(c->step_seq - (uint64_t)c->step_inflight) % (uint64_t)step_ring(c)];   // the OLDEST
   SF_HIP(c, hipSetDevice(c->device));
-  SF_HIP(c, hipEventSynchronize(b.done));        // its verification (and compaction) has left the device
-  const int n = b.n;
-  b.record_of_match.assign((size_t)std::max(n, 1), -1);
-  int32_t n_records = 0, n_accepted = 0;
+  int rc = step_settle(c, b);                    // its verification (and compaction) has left the device
+  // whatever happens below, the step leaves the pipeline and its block is clean for its next use
+  b.issued = false;
+  c->step_inflight -= 1;
   int32_t n_streamed = 0;
   if (b.armed) {
     // streamed records: completion order, one per ACCEPTED verified slot; the used entries of the index list are its
-    // prefix.  They are reset here for the step after next -- also when the query fell back and never read them.
+    // prefix.  They are reset here for the block's next step -- also when the query fell back and never read them.
     while (n_streamed < b.cap && b.index[n_streamed] >= 0) ++n_streamed;
     if (b.streamed) b.rec_of_slot.assign((size_t)std::max(b.pairs, 1), -1);
     for (int32_t r = 0; r < n_streamed; ++r) {
@@ -1868,10 +2159,21 @@ extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
       b.index[r] = -1;
     }
   }
+  if (rc != SF_OK) return rc;
+  const sf_match* matches = b.matches.data();
+  int n = b.n;
+  if (b.device_walk) {
+    n = *b.walk_n;
+    if (n < 0 || n > std::max(b.pairs, c->nn_local.n)) return sf_fail(c, SF_EHIP, "sf_step_retire: the device walk reports %d matches of %d slots", n, b.pairs);
+    matches = b.walk_matches;
+  }
+  b.record_of_match.assign((size_t)std::max(n, 1), -1);
+  int32_t n_records = 0, n_accepted = 0;
   if (b.streamed) {
     n_records = n_streamed;
     for (int i = 0; i < n; ++i) {
-      const int32_t slot = b.slot_of_match[i];
+      // (serial device step: pair slot i IS match i; speculative: the slot of the match's candidate)
+      const int32_t slot = b.device_walk ? (b.speculative ? b.walk_slots[i] : i) : b.slot_of_match[i];
       const int32_t r = (slot >= 0 && slot < b.pairs) ? b.rec_of_slot[slot] : -1;
       b.record_of_match[i] = r;
       n_accepted += r >= 0;
@@ -1884,15 +2186,13 @@ extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
     n_accepted = run;
     if (run != n_records) return sf_fail(c, SF_EHIP, "sf_step_retire: %d flags set, %d records compacted", run, n_records);
   }
-  out->matches = b.matches.data();
+  out->matches = matches;
   out->n_matches = n;
   out->record_of_match = b.record_of_match.data();
   out->records = b.records;
   out->n_records = n_records;
   out->n_accepted = n_accepted;
   out->streamed = b.streamed ? 1 : 0;
-  b.issued = false;
-  c->step_inflight -= 1;
   return SF_OK;
 }
 
@@ -2153,6 +2453,25 @@ extern "C" int sf_set_option(sf_handle c, int32_t option, int32_t value) {
       if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_OVERLAP cannot change while steps are in flight");
       c->step_overlap = value != 0;
       return SF_OK;
+    case SF_OPT_STEP_DEPTH:
+      if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_DEPTH cannot change while steps are in flight");
+      if (value < 1 || value > SF_STEP_MAX_DEPTH) return sf_fail(c, SF_ERANGE, "SF_OPT_STEP_DEPTH %d not in 1..%d", value, SF_STEP_MAX_DEPTH);
+      c->step_depth = value;
+      c->step_seq = 0;
+      return SF_OK;
+    case SF_OPT_STEP_LANES:
+      if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_LANES cannot change while steps are in flight");
+      if (value < 1 || value > SF_STEP_MAX_LANES) return sf_fail(c, SF_ERANGE, "SF_OPT_STEP_LANES %d not in 1..%d", value, SF_STEP_MAX_LANES);
+      c->step_lanes = value;
+      return SF_OK;
+    case SF_OPT_STEP_SPECULATE:
+      if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_SPECULATE cannot change while steps are in flight");
+      c->step_speculate = value != 0;
+      return SF_OK;
+    case SF_OPT_STEP_DEVICE_WALK:
+      if (c->step_inflight) return sf_fail(c, SF_EINVAL, "SF_OPT_STEP_DEVICE_WALK cannot change while steps are in flight");
+      c->step_device_walk = value != 0;
+      return SF_OK;
     default: return sf_fail(c, SF_EINVAL, "unknown option %d", option);
   }
 }
@@ -2192,6 +2511,7 @@ extern "C" int sf_nn_sizes(sf_handle c, int32_t* n_local, int32_t* n_received) {
 
 extern "C" int sf_nn_mark_local_used(sf_handle c, int32_t idx) {
   if (!c) return SF_EINVAL;
+  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (idx < 0 || idx >= c->nn_local.n) return sf_fail(c, SF_ERANGE, "local index %d outside [0,%d)", idx, c->nn_local.n);
   if ((int)c->mask_local.size() < c->nn_local.n) c->mask_local.resize(c->nn_local.n, 0);
   c->mask_local[idx] = 1;
@@ -2201,6 +2521,7 @@ extern "C" int sf_nn_mark_local_used(sf_handle c, int32_t idx) {
 
 extern "C" int sf_nn_mark_other_used(sf_handle c, int32_t idx) {
   if (!c) return SF_EINVAL;
+  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (idx < 0 || idx >= c->nn_recv.n) return sf_fail(c, SF_ERANGE, "other index %d outside [0,%d)", idx, c->nn_recv.n);
   if ((int)c->mask_other.size() < c->nn_recv.n) c->mask_other.resize(c->nn_recv.n, 0);
   c->mask_other[idx] = 1;
@@ -2210,6 +2531,7 @@ extern "C" int sf_nn_mark_other_used(sf_handle c, int32_t idx) {
 
 extern "C" int sf_nn_ignore_pair(sf_handle c, int32_t il, int32_t io) {
   if (!c) return SF_EINVAL;
+  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (il < 0 || il >= c->nn_local.n || io < 0 || io >= c->nn_recv.n)
     return sf_fail(c, SF_ERANGE, "pair (%d,%d) outside the %d x %d distance matrix", il, io, c->nn_local.n, c->nn_recv.n);
   c->ignored.push_back(il);
@@ -2259,6 +2581,15 @@ extern "C" int sf_nn_row_minima_device(sf_handle c, double* d_row_min, int32_t* 
   if (!c || !d_row_min || !d_row_arg || !d_status) return SF_EINVAL;
   SF_HIP(c, hipSetDevice(c->device));
   return sf_nn_row_minima_dev(c, d_row_min, d_row_arg, d_status);
+}
+
+extern "C" int sf_nn_walk_device(sf_handle c, const double* d_row_min, const int32_t* d_row_arg, const int32_t* d_status,
+                                 int32_t n_local, int32_t n_received, sf_match* d_matches, int32_t cap, int32_t* d_n_matches) {
+  if (!c || !d_row_min || !d_row_arg || !d_n_matches || cap < 0 || (cap > 0 && !d_matches)) return SF_EINVAL;
+  if (n_local <= 0 || n_received <= 0) return sf_fail(c, SF_EINVAL, "sf_nn_walk_device over %d x %d minima", n_local, n_received);
+  SF_HIP(c, hipSetDevice(c->device));
+  return sf_nn_walk_dev(c, d_row_min, d_row_arg, d_status, n_local, n_received, c->params.netvlad_distance,
+                        c->params.netvlad_max_matches_nb, cap, nullptr, nullptr, d_matches, d_n_matches, nullptr);
 }
 
 extern "C" int sf_nn_walk(sf_handle c, const double* row_min, const int32_t* row_arg, int32_t n_local, int32_t n_received,

@@ -11,6 +11,8 @@
 
 #define SF_BLOCK 256            // every verification kernel runs 256-thread workgroups (4 waves)
 #define SF_MAX_KCAP 4096        // per-keyframe feature capacity ceiling of the GPU kernels
+#define SF_STEP_MAX_DEPTH 16     // sf_step_issue: steps in flight at most (SF_OPT_STEP_DEPTH)
+#define SF_STEP_MAX_LANES 4      // ... dealt over at most this many streams (SF_OPT_STEP_LANES)
 
 // ---- device-resident keyframe store (one arena per field, fixed per-slot stride) ---------------
 // desc : [slots][kcap][W] uint32   W = 8 (<=256-bit descriptors) or 16 (<=512-bit), zero padded
@@ -87,7 +89,8 @@ struct DeviceParams {
   int32_t bidirectional;      // Vis/ForwardEstOnly = false (stage pipeline only)
   int32_t dbg_corr;           // fused kernel: also copy correspondence lists / headers / pass states to the global
                               // workspace (SF_OPT_DEBUG_CORR; sf_debug_correspondences)
-  const struct AcceptStream* accept;   // fused kernel: accepted results also stream to the host as they are produced (or null)
+  int32_t accept_on;          // chain kernels: accepted results also stream to the host as they are produced, into ...
+  AcceptStream accept;        // ... this block (by value in the kernel arguments: nothing to upload, nothing to keep in step)
   unsigned long long* dbg_trace;   // SF_CHAIN_TRACE builds only (tools/chain_trace.py): [pair][SF_TRACE_SLOTS] timestamps; else null
 };
 
@@ -230,7 +233,7 @@ struct sf_context {
   bool gf_select_attr = false; // k_gftt_select_lds: dynamic LDS attribute set
   bool nn_k128_attr = false;   // k_nn_filter_f16_k128: dynamic LDS attribute set
   bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
-  bool split_auto = true;   // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip)
+  bool split_auto = false;  // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip); off since round 4
   int split_auto_min = 2048;   // ... for queries of at least this many candidates (SF_STEP_SPLIT_MIN): below, one launch wins
   bool in_overlapped_step = false;   // set around sf_step_issue's body while the steps alternate between two streams
   bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
@@ -287,50 +290,77 @@ struct sf_context {
   } spec;
   // accepted-result streams (sf_accept_stream_set / _select): two registered blocks, the one selected for the next
   // speculative query is handed to the fused kernel; `streamed` says whether the last query used it
-  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; bool set = false; const unsigned* uploaded[2] = {nullptr, nullptr}; } accept_blocks[2];
-  Buf accept_dev;                    // AcceptStream blocks on the device: [registered block][counter block]
+  struct AcceptHost { AcceptStream s = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; bool set = false; } accept_blocks[3];   // [2]: the step pair's own
   int accept_sel = -1;
   bool accept_streamed = false;     // the last query's results are in the selected block (keyed by verified slot)
   bool accept_armed = false;        // the selected block was handed to a verification launch of the last query (it may
                                     // hold records even when the query then fell back: streamed = false)
   Buf spec_from, spec_to, spec_results, spec_index;
-  // sf_step_issue / sf_step_retire: the caller's loop body (find_separators.py:59-133) as a begin / retire pair.  Two
-  // blocks alternate, so that one step's separators stay untouched while the next step runs.
+  // sf_step_issue / sf_step_retire: the caller's loop body (find_separators.py:59-133) as a begin / retire pair.  A ring
+  // of `step_depth + 1` blocks: up to `step_depth` steps in flight, and the block of the step retired last stays
+  // untouched until the next retire.
   struct StepBlock {
-    void* pinned = nullptr;            // ONE host-pinned allocation: records | index | flags | count
+    void* pinned = nullptr;            // ONE host-pinned allocation: records | index | flags | count | matches | walk words
     size_t pinned_bytes = 0;
     sf_result* records = nullptr;      // [cap] accepted results (streamed: completion order; compacted: match order)
     int32_t* index = nullptr;          // [cap] streamed: verified slot of each record, -1 = unused entry
     uint8_t* flags = nullptr;          // [cap] compacted: success of every match
     int32_t* count = nullptr;          // compacted: number of accepted matches
+    sf_match* walk_matches = nullptr;  // [cap] device walk: the matches, written by k_walk_emit
+    int32_t* walk_slots = nullptr;     // [cap] speculative device step: the verification slot (= candidate index) of each match
+    int32_t* walk_n = nullptr;         // device walk: their number ...
+    int32_t* walk_status = nullptr;    // ... and the NN stage's status (0, or 1 = candidate set denser than the filter level allows)
     int32_t cap = 0;
-    std::vector<sf_match> matches;
+    Buf dev;                           // device: 64-byte counter block {matches, -, -, -, accept slot counter} + (row, column)[cap]
+    std::vector<sf_match> matches;     // host walk: the matches
     std::vector<int32_t> slot_of_match, record_of_match, rec_of_slot;
     int32_t n = 0, pairs = 0;
     bool streamed = false, armed = false, issued = false;
+    bool speculative = false;          // device walk, speculative form: record of match i = the record of slot walk_slots[i]
+    bool device_walk = false;          // the NN walk ran on the device: matches / n come from the pinned block at retire
+    bool settled = false;              // its `done` event has been waited for (and a fallback, if needed, has run)
+    int32_t slot_other = 0, slot_local = 0, parity = 0;   // (what a fallback needs to run the query again)
+    int settle_rc = 0;
     hipEvent_t done = nullptr;
-  } step_blocks[2];
-  int step_head = 0, step_inflight = 0;
-  // SF_OPT_STEP_OVERLAP: the two steps in flight run on two streams -- the odd steps on `lane1.stream` with their own copy
-  // of every device buffer a step writes (parked in `lane1` while an even step owns the handle's members of the same
-  // names, swapped in for the duration of sf_step_issue) -- so that the tail of one step's verification (its last
-  // motion-estimation chains on an emptying chip) and the NN filter of the next overlap.
+  } step_blocks[SF_STEP_MAX_DEPTH + 1];
+  int step_depth = 6;                      // SF_OPT_STEP_DEPTH: steps in flight
+  int step_lanes = 3;                      // SF_OPT_STEP_LANES: streams the steps in flight are dealt over (step k on lane k mod lanes)
+  bool step_device_walk = true;            // SF_OPT_STEP_DEVICE_WALK: no host wait inside sf_step_issue
+  uint64_t step_seq = 0;                   // steps issued so far (the next step's number)
+  int step_inflight = 0;
+  // SF_OPT_STEP_OVERLAP: the steps in flight run on `step_lanes` streams -- lane k > 0 with its own copy of every device
+  // buffer a step writes (parked in `lanes[k - 1]` while another lane's step owns the handle's members of the same names,
+  // swapped in for the duration of sf_step_issue) -- so that the tail of one step's verification (its last
+  // motion-estimation chains on an emptying chip) and the NN stage of the next overlap.
   struct StepLane {
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;             // speculative device step: exact re-evaluation + minima + walk beside the verification
+    hipEvent_t ev_filter = nullptr, ev_walk = nullptr;
     hipEvent_t ev_main = nullptr;          // "the handle's stream up to here": awaited when the databases changed
     Buf pair_from, pair_to, corr1, corr2, hdr1, hdr2, pass1, pass2, pass_back, dir_mask, list1, list3, counters, results,
-        flags, nn_cand, spec_from, spec_to, spec_results, spec_index, compact_scratch;
+        flags, nn_cand, spec_from, spec_to, spec_results, spec_index, compact_scratch, step_nn, walk_scratch;
     int ws_pairs = 0, ws_kcap = 0, nn_count_idx = 0;
     bool nn_count_primed = false;
     unsigned compact_epoch = 0;
     int compact_state_chunks = 0;
     void* compact_state_ptr = nullptr;
     uint64_t seen_db_epoch = ~0ull;
-  } lane1;
+  } lanes[SF_STEP_MAX_LANES - 1];
+  Buf step_nn;                             // device walk: row minima (f64) | row arg (i32) | row candidate (i32) | packed arg (u64) | status
+  hipStream_t aux = nullptr;               // (lane 0's; swapped with the lanes' like `stream`)
+  hipEvent_t ev_filter = nullptr, ev_walk = nullptr;
+  bool step_speculate = true;              // SF_OPT_STEP_SPECULATE: batch-mode steps verify every filter candidate beside the walk
+  Buf walk_scratch;                        // device walk: tile keys / rows, sorted rows, column claims (sf_nn_walk_dev)
+  // Work that prepares state ALL lanes read (fp16 copies of the databases, filter coefficients, masks) is queued by
+  // whichever lane first needs it; it bumps prep_count, the issuing step records ev_prep behind it and the other lanes
+  // wait for that event once (lane_seen_prep).
+  uint64_t prep_count = 0, prep_epoch = 0;
+  uint64_t lane_seen_prep[SF_STEP_MAX_LANES] = {0, 0, 0, 0};
+  hipEvent_t ev_prep = nullptr;
   bool step_overlap = true;                // the option (SF_STEP_OVERLAP=0 / sf_set_option turn it off)
   uint64_t db_epoch = 0;                   // bumped by every call that writes a database through the handle's stream
   sf_result* step_mirror_records[2] = {nullptr, nullptr};   // sf_step_mirror[_pair]: second (device) destination of every
-  uint32_t* step_mirror_counter[2] = {nullptr, nullptr};    // accepted record and the caller's slot counter, per step block
+  uint32_t* step_mirror_counter[2] = {nullptr, nullptr};    // accepted record and the caller's slot counter, per step parity
   int32_t step_mirror_cap = 0;
   bool step_mirror_lanes = false;             // sf_step_mirror_streams: the odd steps of a mirror pair run on lane 1
   void* spec_index_pinned = nullptr;
@@ -426,6 +456,20 @@ int sf_launch_ingest(sf_context* c, Store& st, int first_slot, int n, int rows, 
 // NN stage
 int sf_nn_run(sf_context* c, sf_match* out, int cap, int* n_out);
 int sf_nn_row_minima_dev(sf_context* c, double* d_row_min, int32_t* d_row_arg, int32_t* d_status);
+int sf_nn_walk_dev(sf_context* c, const double* d_row_min, const int32_t* d_row_arg, const int32_t* d_status, int n_l,
+                   int n_r, double thr, int max_matches_nb, int cap, void* d_match_rc, unsigned* d_count_block,
+                   sf_match* out_matches, int32_t* out_n, int32_t* out_status, const int32_t* d_row_cand = nullptr,
+                   int32_t* out_slot = nullptr, const unsigned* d_cand_count = nullptr, unsigned cand_grid = 0);
+// the filter path of sf_nn_row_minima_dev in its two halves (k_nn.hip)
+struct NnFilterOut {
+  const void* cand = nullptr;       // uint2 (row, column)[]
+  const unsigned* count = nullptr;  // its length (device), word 4 of the same 64-byte block: the accept stream's slot counter
+  double* cdist = nullptr;          // exact distances, filled by the second half
+  unsigned limit = 0, typical = 0;
+};
+int sf_nn_filter_dev(sf_context* c, NnFilterOut* out);
+int sf_nn_minima_of_candidates_dev(sf_context* c, const NnFilterOut& fo, double* d_row_min, int32_t* d_row_arg,
+                                   int32_t* d_status, int32_t* d_row_cand, unsigned long long* d_arg64, bool throttle);
 int sf_nn_walk_host(sf_context* c, const double* row_min, const int32_t* row_arg, int n_l, int n_r, double thr,
                     int max_matches_nb, sf_match* out, int cap, int* n_out);
 // Speculation hook (sf_api.hip), called by the NN filter right behind the refinement launch of a prefix level:

@@ -126,6 +126,7 @@ def load():
         "sf_allgather_separators_device": (C.c_int, [vp, vp, vp, i32]),
         "sf_allgather_bytes_device": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "sf_nn_row_minima_device": (C.c_int, [vp, vp, vp, vp]),
+        "sf_nn_walk_device": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, i32, vp]),
         "sf_get_features_and_descriptor_batch_device": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, C.c_size_t, vp, vp, vp,
                                                                    P(i32), vp, vp, vp, vp]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
@@ -159,7 +160,7 @@ EXPORTED = [
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_step_mirror_pair", "sf_step_mirror_streams", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
-    "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device",
+    "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_nn_walk_device",
     "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name",
 ]
@@ -280,6 +281,13 @@ class SeparatorFinder:
         self._check(self._L.sf_nn_walk(self._h, _ptr(d), _ptr(a), d.size, int(n_received), out.ctypes.data, cap,
                                        C.byref(n)))
         return out[: n.value]
+
+    def nn_walk_device(self, d_row_min, d_row_arg, d_status, n_local, n_received, d_matches, cap, d_n_matches):
+        """data_handler.py:191-205 on the device, on device-resident minima (raw pointers); asynchronous on the
+        handle's stream.  d_matches: MATCH_DTYPE[cap], d_n_matches: int32[1] (device or pinned host memory)."""
+        self._check(self._L.sf_nn_walk_device(self._h, C.c_void_p(d_row_min), C.c_void_p(d_row_arg),
+                                              C.c_void_p(d_status) if d_status else None, int(n_local), int(n_received),
+                                              C.c_void_p(d_matches), int(cap), C.c_void_p(d_n_matches)))
 
     def nn_row_minima_device(self, d_row_min, d_row_arg, d_status):
         """The NN kernels of this handle's local rows without the walk; results stay in device memory (raw pointers:
@@ -477,13 +485,13 @@ class SeparatorFinder:
 
     # -- the caller's loop body as a begin / retire pair (find_separators.py:59-133) ----------------------------------
     def step_issue(self, slot_base_other, slot_base_local):
-        """Queue one find-and-verify step (NN search, verification of every returned candidate); returns once the
-        candidate list is known.  At most two steps in flight."""
+        """Queue one find-and-verify step (NN search, walk, verification of every returned candidate, all on the
+        device); does not wait for any of it.  At most SF_OPT_STEP_DEPTH (default 4) steps in flight."""
         self._check(self._L.sf_step_issue(self._h, int(slot_base_other), int(slot_base_local)))
 
     def step_retire(self, copy=False):
         """The oldest step in flight: (matches, record_of_match, records, info).  The arrays are VIEWS of memory the
-        handle owns (valid until the second-next step_issue) unless copy=True; records[record_of_match[i]] is the
+        handle owns (valid until the next step_retire) unless copy=True; records[record_of_match[i]] is the
         accepted result of match i, record_of_match[i] = -1 means its estimation failed."""
         r = _abi.StepResult()
         self._check(self._L.sf_step_retire(self._h, C.byref(r)))

@@ -61,15 +61,20 @@ def _check_step(out, m_ref, res_ref, want_streamed):
     assert recs["success"].all()          # only accepted results are ever delivered
 
 
+@pytest.mark.parametrize("walk", [1, 2, 0])
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("est", [0, 1])
-def test_step_pair_equals_the_separate_calls(est, overlap):
-    """Batch mode (the walk may return every local row: speculative verification, separators streamed out of the kernel)
-    and the reference's cadence (netvlad_max_matches_nb = 20: no speculation, ordered compaction), both estimators, with
-    masked rows / columns and ignored pairs; steps overlapped two deep as a host would run them."""
+def test_step_pair_equals_the_separate_calls(est, overlap, walk):
+    """Batch mode (the walk may return every local row) and the reference's cadence (netvlad_max_matches_nb = 20), both
+    estimators, with masked rows / columns and ignored pairs; steps overlapped two deep as a host would run them.
+    walk = 1: the device-resident step (no host wait in sf_step_issue; batch mode verifies every filter candidate beside
+    the walk on a second stream -- SF_OPT_STEP_SPECULATE --, the reference's cadence takes the walk's matches from the
+    device list; the accepted separators stream in both modes); walk = 2: the same with SF_OPT_STEP_SPECULATE off (NN ->
+    walk -> verification on one stream in both modes); walk = 0: round 3's form (host walk inside
+    sf_step_issue; speculative verification in batch mode, ordered compaction at the reference's cadence)."""
     n_kf, k, dim = 96, 200, 512
     feats, nv_a, nv_b = _world(177 + est, n_kf, k, dim)
-    for max_nb, want_streamed in ((n_kf, True), (20, False)):
+    for max_nb, want_streamed in ((n_kf, True), (20, bool(walk))):
         p = synth.camera_params()
         p.iterations = 200
         p.estimation_type = est
@@ -79,6 +84,9 @@ def test_step_pair_equals_the_separate_calls(est, overlap):
         with lib.SeparatorFinder(p) as f:
             f.set_stream(torch.cuda.current_stream().cuda_stream)
             f.set_option(_abi.SF_OPT_STEP_OVERLAP, overlap)       # the two steps in flight on two streams / on one
+            f.set_option(_abi.SF_OPT_STEP_DEVICE_WALK, int(walk != 0))
+            f.set_option(_abi.SF_OPT_STEP_SPECULATE, int(walk != 2))
+            f.set_option(_abi.SF_OPT_STEP_DEPTH, 2)
             sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
             f.nn_mark_local_used(3); f.nn_mark_other_used(5); f.nn_ignore_pair(20, 20); f.nn_ignore_pair(21, 22)
             m_ref, res_ref = _two_calls(f, sa, sb, max_nb)
@@ -108,13 +116,14 @@ def test_step_pair_equals_the_separate_calls(est, overlap):
             _check_step(f.step_retire(copy=True), m2, res2, want_streamed)
 
 
-@pytest.mark.parametrize("form", ["forced_two_streams", "forced_one_stream", "auto", "auto_one_stream", "off"])
+@pytest.mark.parametrize("form", ["forced_lanes", "forced_one_stream", "opt_in", "opt_in_one_stream", "default"])
 def test_step_pair_in_the_split_form(form, monkeypatch):
     """The 3D-3D verification as one matching launch + one chain launch over the survivors (k_match_split + k_chain)
-    instead of the fused kernel: everywhere with SF_FUSED=2 (read at sf_create); by the library's own choice inside
-    overlapped steps (SF_OPT_STEP_SPLIT, default on) -- not when the steps share one stream, not with the option off.
-    The chain kernel streams the accepted separators like the fused one does, and a step's matches, flags and records
-    are the separate calls', byte for byte, in every form."""
+    instead of the fused kernel: everywhere with SF_FUSED=2 (read at sf_create); with SF_OPT_STEP_SPLIT on, by the
+    library's own choice inside steps that are dealt over several streams -- not when the steps share one stream, and not
+    by default (since round 4 the fused kernel is the faster form there).  The chain kernel streams the accepted
+    separators like the fused one does, and a step's matches, flags and records are the separate calls', byte for byte,
+    in every form."""
     n_kf, k, dim = 96, 200, 512
     feats, nv_a, nv_b = _world(577, n_kf, k, dim)
     p = synth.camera_params()
@@ -136,8 +145,8 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
     with lib.SeparatorFinder(p) as f:
         f.set_stream(torch.cuda.current_stream().cuda_stream)
         f.set_option(_abi.SF_OPT_STEP_OVERLAP, 0 if form.endswith("one_stream") else 1)
-        if form == "off":
-            f.set_option(_abi.SF_OPT_STEP_SPLIT, 0)
+        if form.startswith("opt_in"):
+            f.set_option(_abi.SF_OPT_STEP_SPLIT, 1)
         sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
         m2, res2 = _two_calls(f, sa, sb, n_kf)     # the separate calls in this handle's form: the same bytes
         assert m2.tobytes() == m_ref.tobytes() and res2.tobytes() == res_ref.tobytes()
@@ -154,7 +163,7 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
         prof = f.prof_get()
         f.prof_enable(False)
         split_ran = prof["k_match_global"][0] > 0          # (the matching launch's profiling slot)
-        assert split_ran == (form in ("forced_two_streams", "forced_one_stream", "auto")), (form, prof)
+        assert split_ran == (form in ("forced_lanes", "forced_one_stream", "opt_in")), (form, prof)
         assert prof["k_verify_fused"][0] == 6              # the fused kernel, or the chain launch in its slot
 
 
@@ -174,8 +183,14 @@ def test_step_with_a_mirror_for_the_exchange():
         sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
         m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
         n_acc = int(res_ref["success"].sum())
-        for cap, want_streamed in ((n_kf + n_kf // 8 + 256, True), (n_kf, False)):
-            send = torch.zeros((cap + 1, RB), dtype=torch.uint8, device=DEV)       # slot 0 = header (count)
+        assert n_acc > 8
+        # a mirror with a slot for every pair slot of the query: streamed; smaller than the query (also smaller than the
+        # accepted separators: 8 slots): the compaction, whose mirror writes stop at the mirror's capacity -- the host
+        # block still receives every record and the mirror's count word carries the full count (the exchange's overflow
+        # signal); round 3 wrote past the mirror here
+        for cap, want_streamed in ((n_kf + n_kf // 8 + 256, True), (n_kf, True), (8, False)):
+            send = torch.zeros((cap + 1 + 64, RB), dtype=torch.uint8, device=DEV)       # slot 0 = header (count)
+            send[1 + cap:].fill_(0xEE)                                             # guard rows behind the mirror
             f.step_mirror(send[1:].data_ptr(), send.data_ptr(), cap)
             for rep in range(3):
                 send[0].zero_()
@@ -185,9 +200,26 @@ def test_step_with_a_mirror_for_the_exchange():
                 torch.cuda.synchronize()
                 cnt = int(send[0, :4].view(torch.int32).item())
                 assert cnt == out[3]["n_records"] >= n_acc
-                mirror = np.frombuffer(send[1: 1 + cnt].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
-                assert mirror.tobytes() == out[2][:cnt].tobytes()
+                held = min(cnt, cap)
+                mirror = np.frombuffer(send[1: 1 + held].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+                assert mirror.tobytes() == out[2][:held].tobytes()
+                assert bool((send[1 + cap:] == 0xEE).all()), "a write past the mirror's capacity"
             f.step_mirror(None, None, 0)
+        # round 3's form of the step (host walk, speculative verification of n_kf * 9 / 8 + 256 slots): a mirror of n_kf
+        # slots is smaller than that query -> the compaction
+        f.set_option(_abi.SF_OPT_STEP_DEVICE_WALK, 0)
+        send = torch.zeros((n_kf + 1, RB), dtype=torch.uint8, device=DEV)
+        f.step_mirror(send[1:].data_ptr(), send.data_ptr(), n_kf)
+        send[0].zero_()
+        f.step_issue(sa, sb)
+        out = f.step_retire(copy=True)
+        _check_step(out, m_ref, res_ref, False)
+        torch.cuda.synchronize()
+        cnt = int(send[0, :4].view(torch.int32).item())
+        assert cnt == out[3]["n_records"] == n_acc
+        assert np.frombuffer(send[1: 1 + cnt].cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE).tobytes() == out[2][:cnt].tobytes()
+        f.step_mirror(None, None, 0)
+        f.set_option(_abi.SF_OPT_STEP_DEVICE_WALK, 1)
         f.step_issue(sa, sb)
         with pytest.raises(lib.SepfinderError):
             f.step_mirror(None, None, 0)            # not while a step is in flight
@@ -328,3 +360,144 @@ def test_overlapped_steps_and_a_growing_store():
         f.step_issue(sa, sb)                          # lane 1
         _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
         _check_step(f.step_retire(copy=True), m2, res2, True)
+
+
+@pytest.mark.parametrize("speculate", [1, 0])
+@pytest.mark.parametrize("depth,lanes", [(1, 1), (4, 2), (4, 3), (8, 4), (16, 2)])
+def test_step_ring_depth_and_lanes(depth, lanes, speculate):
+    """SF_OPT_STEP_DEPTH steps in flight dealt over SF_OPT_STEP_LANES streams: the (depth + 1)-th issue is refused, steps
+    retire oldest first with the separate calls' bytes, and what sf_step_retire hands out stays valid -- without a copy --
+    through further issues until the next retire."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(677, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.set_option(_abi.SF_OPT_STEP_DEPTH, depth)
+        f.set_option(_abi.SF_OPT_STEP_LANES, lanes)
+        f.set_option(_abi.SF_OPT_STEP_SPECULATE, speculate)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+        for _ in range(depth):
+            f.step_issue(sa, sb)
+        with pytest.raises(lib.SepfinderError):
+            f.step_issue(sa, sb)
+        with pytest.raises(lib.SepfinderError):
+            f.set_option(_abi.SF_OPT_STEP_DEPTH, 2)          # not while steps are in flight
+        for _ in range(3 * depth + 2):
+            view = f.step_retire(copy=False)
+            f.step_issue(sa, sb)                            # (the ring has depth + 1 blocks: the view is still the step's)
+            _check_step(view, m_ref, res_ref, True)
+        for _ in range(depth):
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        with pytest.raises(lib.SepfinderError):
+            f.step_retire()
+
+
+@pytest.mark.parametrize("max_nb", [200, 400])       # 200 < local rows: the serial device form; 400: the speculative one
+def test_step_falls_back_when_the_filter_level_is_too_dense(oracle, max_nb):
+    """Every vector shares its first 512 dimensions: at the 128-dimension prefix level the handle starts on every pair is
+    a candidate, which only the DEVICE notices now (status word of the walk).  sf_step_retire then runs that query through
+    the prefix ladder itself; the ladder settles on the full length and the following steps stay on the device."""
+    rng = np.random.default_rng(21)
+    dim, n_l, n_r, k = 4096, 260, 300, 128
+    shared = rng.normal(size=512).astype(np.float32) * 0.03
+    a = rng.normal(size=(n_l, dim)).astype(np.float32) / np.sqrt(dim)
+    b = rng.normal(size=(n_r, dim)).astype(np.float32) / np.sqrt(dim)
+    a[:, :512] = shared
+    b[:, :512] = shared
+    b[:80] = a[100:180] + rng.normal(size=(80, dim)).astype(np.float32) * (0.03 / np.sqrt(dim))
+    b[:80, :512] = shared
+    feats = synth.make_store_batch(5, n_r, k=k, cols=32, true_frac=0.5)
+    p = synth.camera_params()
+    p.iterations = 100
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = max_nb
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        T = {key: _up(feats[key]) for key in ("desc_a", "xyz_a", "kp_a", "desc_b", "xyz_b", "kp_b")}
+        sa = f.store_add_keyframes_device(n_r, k, 32, T["desc_a"].data_ptr(), T["xyz_a"].data_ptr(), T["kp_a"].data_ptr())
+        sb = f.store_add_keyframes_device(n_r, k, 32, T["desc_b"].data_ptr(), T["xyz_b"].data_ptr(), T["kp_b"].data_ptr())
+        torch.cuda.synchronize()
+        f.nn_append_local(a)
+        f.nn_append_received(b)
+        # three steps queued before anybody knows the level is too dense: all three fall back, in order
+        for _ in range(3):
+            f.step_issue(sa, sb)
+        outs = [f.step_retire(copy=True) for _ in range(3)]
+        assert f.nn_last_filter_dims() == dim                # the ladder went to the full length
+        mo, _, _ = oracle.find_matches(a.astype(np.float64), b.astype(np.float64), netvlad_distance=p.netvlad_distance,
+                                       max_matches_nb=max_nb)
+        assert len(mo) == 80
+        m_ref, res_ref = _two_calls(f, sa, sb, max_nb)
+        assert np.array_equal(m_ref["idx_local"], mo["idx_local"]) and np.array_equal(m_ref["idx_other"], mo["idx_other"])
+        for out in outs:
+            m, rom, recs, info = out
+            assert m.tobytes() == m_ref.tobytes()
+            assert np.array_equal(rom >= 0, res_ref["success"].astype(bool))
+            for i in np.nonzero(rom >= 0)[0]:
+                assert recs[rom[i]].tobytes() == res_ref[i].tobytes()
+        # the level is settled: these stay on the device (streamed, no fallback) and give the same bytes
+        for _ in range(3):
+            f.step_issue(sa, sb)
+        for _ in range(3):
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+
+
+@pytest.mark.parametrize("n", [65537, 131073, 140000])
+def test_step_queries_across_the_form_and_chunk_boundaries(n):
+    """Overlapped steps (two streams) whose query has more candidates than the split form takes (65 536) and than one
+    launch sequence holds (131 072): every chunk must run in the form the workspace was reserved for.  Round 3 decided
+    the form per chunk: at 140 000 candidates the second chunk (8 928 pairs) took the split form -- which writes
+    correspondence lists -- on a workspace reserved for the fused form, which has none: a device out-of-bounds write
+    (commit 4822be5 fixed the decision, this is its regression test).  Results against sf_verify_pairs_device of the
+    same pairs."""
+    k, dim, base = 64, 128, 500
+    feats = synth.make_store_batch(91, base, k=k, cols=32, true_frac=0.5)
+    rng = np.random.default_rng(92)
+    nv_a = rng.normal(size=(n, dim)).astype(np.float32); nv_a /= np.linalg.norm(nv_a, axis=1, keepdims=True)
+    nv_b = nv_a + (0.002 * rng.normal(size=(n, dim))).astype(np.float32); nv_b /= np.linalg.norm(nv_b, axis=1, keepdims=True)
+    p = synth.camera_params()
+    p.iterations = 50
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n
+    p.max_features = k
+    p.store_capacity = 2 * n
+    reps = (n + base - 1) // base
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        slots = []
+        for which in ("a", "b"):        # keyframe i of a robot = base keyframe i mod 500 (tiled on the device)
+            d = _up(feats["desc_" + which]).repeat(reps, 1, 1)[:n].contiguous()
+            x = _up(feats["xyz_" + which]).repeat(reps, 1, 1)[:n].contiguous()
+            kp = _up(feats["kp_" + which]).view(base, -1).repeat(reps, 1)[:n].contiguous()
+            slots.append(f.store_add_keyframes_device(n, k, 32, d.data_ptr(), x.data_ptr(), kp.data_ptr()))
+            torch.cuda.synchronize()
+            del d, x, kp
+        sa, sb = slots
+        ta, tb = torch.from_numpy(nv_a).to(DEV), torch.from_numpy(nv_b).to(DEV)
+        f.nn_append_received_device(ta.data_ptr(), n, dim)
+        f.nn_append_local_device(tb.data_ptr(), n, dim)
+        torch.cuda.synchronize()
+        f.step_issue(sa, sb)
+        f.step_issue(sa, sb)                         # two steps in flight on two streams: the overlapped form
+        outs = [f.step_retire(copy=True), f.step_retire(copy=True)]
+        m = outs[0][0]
+        assert len(m) == n and np.array_equal(np.sort(m["idx_local"]), np.arange(n)) and np.array_equal(m["idx_local"], m["idx_other"])
+        d_from = torch.from_numpy((sa + m["idx_other"]).astype(np.int32)).to(DEV)
+        d_to = torch.from_numpy((sb + m["idx_local"]).astype(np.int32)).to(DEV)
+        d_res = torch.zeros((n, RB), dtype=torch.uint8, device=DEV)
+        f.verify_pairs_device(d_from.data_ptr(), d_to.data_ptr(), n, d_res.data_ptr())
+        torch.cuda.synchronize()
+        ref = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=_abi.RESULT_DTYPE)
+        ok = ref["success"].astype(bool)
+        assert 0.2 * n < ok.sum() < 0.8 * n
+        for mm, rom, recs, info in outs:
+            assert mm.tobytes() == m.tobytes()
+            assert np.array_equal(rom >= 0, ok) and info["n_accepted"] == int(ok.sum())
+            assert recs[rom[ok]].tobytes() == ref[ok].tobytes()
