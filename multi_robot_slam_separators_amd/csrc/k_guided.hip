@@ -103,18 +103,22 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     // points of lanes 48-63 of one wavefront with different X coefficients (the LOW halves of the packed results; Y and
     // Z, the high halves and the scalar ones, were right) when this block was SLP-vectorised -- DESIGN.md section 3.
     // Kept scalar here AND the translation unit is built with -fno-slp-vectorize; either alone removed the symptom.
+#ifndef SF_NO_PK_BARRIERS      // (tools/pk_isa_scan.py builds the block WITHOUT them, SLP on, to show the instructions of the symptom)
 #pragma unroll
     for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(GR[i]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(Gt[i]));
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) Rc[3 * i + j] = GR[3 * j + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) tc[i] = -((Rc[3 * i] * Gt[0] + Rc[3 * i + 1] * Gt[1]) + Rc[3 * i + 2] * Gt[2]);
+#ifndef SF_NO_PK_BARRIERS
 #pragma unroll
     for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(tc[i]));
+#endif
   }
   __syncthreads();
 

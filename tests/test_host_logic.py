@@ -253,3 +253,19 @@ def test_option_constants_equal_the_header_enums():
     assert len(found) >= 8 and len(set(found.values())) == len(found)
     for name, value in found.items():
         assert getattr(_abi, name) == value, name
+
+
+def test_no_packed_f32_reads_of_rewritten_sgprs():
+    """Build gate for the position-dependent pose of round 3: under the product's flags the ISA of
+    the verification kernels holds no packed-f32 instruction whose SGPR operand is rewritten by the scalar unit (or was
+    lane-read) within four instructions -- the shape hipcc's SLP vectoriser produces hundreds of times in this
+    translation unit (tools/pk_isa_scan.py --slp) and that gave one survivor chain in a thousand another pose.  A
+    compiler bump or a dropped flag fails here, without a GPU."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pk_isa_scan.py"), "--tu", "k_verify.hip", "--fail"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "total: 0 packed-f32 reads" in r.stdout
+    mk = open(os.path.join(ROOT, "multi_robot_slam_separators_amd", "csrc", "Makefile")).read()
+    assert "-fno-slp-vectorize" in mk.split("COMMON =")[1].split("\n")[0]        # every translation unit is built with it

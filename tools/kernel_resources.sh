@@ -4,7 +4,7 @@
 # usage: tools/kernel_resources.sh k_verify.hip [filter-regex]
 cd "$(dirname "$0")/../multi_robot_slam_separators_amd/csrc" || exit 1
 f=${1:-k_verify.hip}; pat=${2:-.}
-canon=""; [ "$f" = k_verify.hip ] && canon="-ffp-contract=off -fno-slp-vectorize"
+canon="-fno-slp-vectorize"; case "$f" in k_verify.hip|k_extract.hip|k_gftt.hip|k_lk.hip) canon="$canon -ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed $canon \
   -c "$f" -o /tmp/kres_$$.o -Rpass-analysis=kernel-resource-usage 2>&1 |
   python3 -c '
