@@ -185,10 +185,20 @@ class RecordExchange:
         else:
             self._h_counts.copy_(self._hdr_all, non_blocking=True)
 
-    def counts(self):
-        """Per-rank record counts; valid once the stream the exchange ran on has been synchronised."""
+    def counts(self, limit=None):
+        """Per-rank record counts; valid once the stream the exchange ran on has been synchronised.  The header row
+        carries the count in its first FOUR bytes as an int32 when the producer stamped it on the device
+        (sf_compact_accepted_device_async; -1 = the compaction's look-back timed out) and as an int64 when exchange(n)
+        did: the low word is read as int32 either way, a negative count -- or one above `limit`, the number of records a
+        rank can hold at all -- raises on every rank alike (they all read the same gathered headers)."""
+        import torch
         h = self._h_counts if self.h_recv is None else self.h_recv[:, 0, :8].contiguous()
-        return [int(c) for c in h.view(torch_int64()).reshape(-1).tolist()]
+        out = [int(c) for c in h.view(torch.int32).reshape(-1, 2)[:, 0].tolist()]
+        for r, c in enumerate(out):
+            if c < 0 or (limit is not None and c > limit):
+                raise RuntimeError("record exchange: rank %d reports %d records (limit %s): the producer's count is invalid"
+                                   % (r, c, limit))
+        return out
 
     def gathered(self, r, counts=None):
         c = (counts or self.counts())[r]

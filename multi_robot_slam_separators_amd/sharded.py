@@ -11,17 +11,21 @@ writes it (the reference runs this step on one CPU core: find_separators.py:59-1
                  separator records (`dist.RecordExchange`); `interleave` puts the accepted records back into the
                  candidate order of the walk, so the node's output is byte-identical to a single GPU's.
 
-The step keeps its data on the device between the stages, like the single-GPU step (sf_step_issue / sf_step_retire):
+The step keeps its data on the device between the stages, like the single-GPU step (sf_step_issue / sf_step_retire),
+and since round 4 a rank's step has ONE host wait, at its end:
 
   * the rank's minima are written by the NN kernels straight into the all-gather's send block (GPU backend:
-    sf_nn_row_minima_device -- no walk that is thrown away, no candidate list on the host); the gathered block comes
-    back through pinned memory behind ONE event wait, because the walk is sequential host work
-    (data_handler.py:191-205), exactly as inside sf_step_issue;
+    sf_nn_row_minima_device -- no walk that is thrown away, no candidate list on the host);
+  * the gathered blocks are unpacked on the device and the walk runs THERE (sf_nn_walk_device, data_handler.py:191-205:
+    every rank the identical walk on identical minima); the rank's candidates p = rank, rank + G, ... are taken from the
+    device match list, slots past the device-side match count are void pairs;
   * the verification's accepted records are compacted straight into the record exchange's payload, their count is
     stamped into its header on the device, and the per-candidate success flags ride in the same block (the `extra`
-    region of dist.RecordExchange): ONE collective, mirrored into pinned host memory;
-  * the second and last wait of the step is the caller's synchronisation behind `finish`; the interleave is then host
-    arithmetic on the pinned mirror.
+    region of dist.RecordExchange): ONE collective, mirrored into pinned host memory together with the match list;
+  * the wait is the caller's synchronisation behind `finish`; the interleave is then host arithmetic on the pinned
+    mirror.  What the device cannot decide -- a rank's candidate set too dense for the filter level (status word) --
+    shows in the mirrored status after that wait; the step is then run again in round 3's form (`find_matches` +
+    `verify`: the ranks concerned recompute synchronously, the minima are gathered once more, host walk).
 
 The compute is behind a small backend interface so that the SAME orchestration runs on the GPUs (bench.py, the
 library) and, in the CPU tests, on the oracle with gloo ranks.  All tensors are on the collective device:
@@ -29,10 +33,15 @@ library) and, in the CPU tests, on the oracle with gloo ranks.  All tensors are 
   backend.row_minima_into(row_min f64[n], row_arg i32[n], status i32[1])   this rank's block, asynchronous;
                                            status 1 = "too dense for the device path" (every rank then sees it)
   backend.row_minima_sync() -> (float64[n], int32[n])   the synchronous form that cannot fail (taken on status 1)
-  backend.walk(row_min, row_arg) -> structured MATCH_DTYPE array  the replicated walk
+  backend.walk(row_min, row_arg) -> structured MATCH_DTYPE array  the replicated walk (host; the fallback path)
   backend.verify_into(matches, payload u8[rows, RESULT bytes], count i32[1] view, flags u8[len])
                                            results of these candidates: accepted records compacted into `payload` in
                                            candidate order, their number into `count`, success flags into `flags`
+  backend.walk_into(row_min f64[n_local], row_arg i32[n_local], status i32[1], matches u8[n_local, 16], n i32[2])
+                                           the replicated walk on tensors of the collective device, asynchronous:
+                                           MATCH_DTYPE rows + n[0] = their number, n[1] = status (non-zero voids it)
+  backend.verify_mine_into(matches u8[n_local, 16], n i32[2], rank, world, max_mine, payload, count, flags u8[max_mine])
+                                           the same for the candidates p = rank, rank + world, ... of the DEVICE list
   backend.sync()                           wait for the work queued so far (the step's final synchronisation)
 
 N robot pairs (BASELINE configs[4]: 5 robots = 10 robot pairs) are flattened into one candidate list by
@@ -164,7 +173,12 @@ class ShardedStep:
         self.exch.exchange(None, finish=True)
         self.b.sync()                                   # the step's final wait
         self.waits += 1
-        counts = self.exch.counts()
+        return self._collect(n)
+
+    def _collect(self, n):
+        """Behind the step's synchronisation: flags + accepted records of every rank from the pinned mirror, interleaved
+        into the candidate order."""
+        counts = self.exch.counts(limit=self.max_mine)
         if max(counts) > self.exch.cap:                 # (rare) some rank accepted more than the block holds
             allrec, counts = self.exch.all_gathered()
             allrec = allrec.cpu().numpy()
@@ -178,11 +192,62 @@ class ShardedStep:
                          for r in range(self.world)]
         return interleave(flags_by_rank, recs, self.world)
 
-    def step(self):
-        m = self.find_matches()
-        flags, acc = self.verify(m)
-        return m, flags, acc
+    def _unpack_minima(self):
+        """The gathered per-rank blocks -> contiguous minima of all local rows + the worst status, on the device."""
+        import torch
+        mb = self.max_block
+        g = self.min_recv.view(self.world, self.min_bytes)
+        if self.world == 1:
+            lo, hi = self.blocks[0]
+            return g[0, : mb * 8].view(torch.float64)[: hi - lo], g[0, mb * 8: mb * 12].view(torch.int32)[: hi - lo], \
+                g[0, mb * 12: mb * 12 + 4].view(torch.int32)
+        d = torch.cat([g[r, : mb * 8].view(torch.float64)[: hi - lo] for r, (lo, hi) in enumerate(self.blocks)])
+        a = torch.cat([g[r, mb * 8: mb * 12].view(torch.int32)[: hi - lo] for r, (lo, hi) in enumerate(self.blocks)])
+        st = g[:, mb * 12: mb * 12 + 4].contiguous().view(torch.int32).max().reshape(1)
+        return d, a, st
 
+    def step(self):
+        """One step with ONE host wait (see the module docstring); falls back to find_matches() + verify() when some
+        rank's candidate set was too dense for its device path."""
+        import torch
+        if not hasattr(self.b, "walk_into"):            # (a backend without the device walk: round 3's form)
+            m = self.find_matches()
+            flags, acc = self.verify(m)
+            return m, flags, acc
+        lo, hi = self.blocks[self.rank]
+        n = hi - lo
+        self.waits = 0
+        if n:
+            self.b.row_minima_into(self.v_min[:n], self.v_arg[:n], self.v_status)
+        else:
+            self.v_status.zero_()
+        self.td.all_gather_into_tensor(self.min_recv, self.min_send, group=self.group)
+        d, a, st = self._unpack_minima()
+        if not hasattr(self, "d_matches"):
+            self.d_matches = torch.zeros((max(self.n_local, 1), _abi.MATCH_DTYPE.itemsize), dtype=torch.uint8, device=self.dev)
+            self.d_n = torch.zeros(2, dtype=torch.int32, device=self.dev)
+            self.h_matches = torch.zeros_like(self.d_matches, device="cpu")
+            self.h_n = torch.zeros(2, dtype=torch.int32)
+            if self.dev.type == "cuda":
+                self.h_matches, self.h_n = self.h_matches.pin_memory(), self.h_n.pin_memory()
+        self.b.walk_into(d, a, st, self.d_matches, self.d_n)
+        self.b.verify_mine_into(self.d_matches, self.d_n, self.rank, self.world, self.max_mine, self.exch.payload,
+                                self.v_count, self.exch.extra[: self.max_mine])
+        self.exch.exchange(None, finish=True)
+        self.h_matches.copy_(self.d_matches, non_blocking=True)
+        self.h_n.copy_(self.d_n, non_blocking=True)
+        self.b.sync()                                   # the step's ONE wait
+        self.waits += 1
+        if int(self.h_n[1]) != 0:
+            w = self.waits
+            m = self.find_matches()                     # (resets and counts its own waits)
+            flags, acc = self.verify(m)
+            self.waits += w
+            return m, flags, acc
+        n_m = int(self.h_n[0])
+        m = np.frombuffer(self.h_matches.numpy()[:n_m].tobytes(), dtype=_abi.MATCH_DTYPE).copy()
+        flags, acc = self._collect(n_m)
+        return m, flags, acc
 
 class GpuShardBackend:
     """multi_robot_slam_separators_amd.sharded backend on one GPU: the handle holds THIS rank's block of local
@@ -215,6 +280,31 @@ class GpuShardBackend:
             return
         self.f.verify_matches_device(np.ascontiguousarray(matches), self.slot_a, self.slot_b, self.d_res.data_ptr())
         self.f.compact_accepted_device_async(self.d_res.data_ptr(), n, payload.data_ptr(), flags.data_ptr(), count.data_ptr())
+
+    def walk_into(self, row_min, row_arg, status, matches, n):
+        self.f.nn_walk_device(row_min.data_ptr(), row_arg.data_ptr(), status.data_ptr(), int(row_min.numel()), self.n_r,
+                              matches.data_ptr(), int(matches.shape[0]), n.data_ptr())
+        n[1:2].copy_(status)                             # (the walk is void when it is non-zero: the caller looks here)
+
+    def verify_mine_into(self, matches, n, rank, world, max_mine, payload, count, flags):
+        import torch
+        if max_mine <= 0:
+            count.zero_()
+            return
+        rc = matches.view(torch.int32).view(-1, 4)[rank::world][:max_mine]       # (idx_local, idx_other, distance lo, hi)
+        k = int(rc.shape[0])
+        if not hasattr(self, "d_from") or self.d_from.numel() < max_mine:
+            self.d_from = torch.empty(max_mine, dtype=torch.int32, device=self.dev)
+            self.d_to = torch.empty(max_mine, dtype=torch.int32, device=self.dev)
+            self.p_idx = torch.arange(max_mine, dtype=torch.int32, device=self.dev) * world + rank
+        valid = self.p_idx[:k] < n[0]                    # candidate p exists: p < the device-side match count
+        self.d_from.fill_(-1)
+        self.d_to.fill_(-1)
+        self.d_from[:k] = torch.where(valid, rc[:, 1] + self.slot_a, -1)     # "from" = the querying robot's frame
+        self.d_to[:k] = torch.where(valid, rc[:, 0] + self.slot_b, -1)       # "to"   = the computing robot's frame
+        self.f.verify_pairs_device(self.d_from.data_ptr(), self.d_to.data_ptr(), max_mine, self.d_res.data_ptr())
+        self.f.compact_accepted_device_async(self.d_res.data_ptr(), max_mine, payload.data_ptr(), flags.data_ptr(),
+                                             count.data_ptr())
 
     def sync(self):
         import torch

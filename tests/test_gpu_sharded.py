@@ -96,7 +96,7 @@ def _store(f, feats, n_kf, k):
 
 def test_sharded_step_on_one_gpu_equals_the_separate_calls():
     """One rank, no process group (the collectives are copies): candidate list, flags and accepted records of
-    ShardedStep equal sf_nn_find_matches + sf_verify_matches_device; the step waits twice."""
+    ShardedStep equal sf_nn_find_matches + sf_verify_matches_device; the step waits ONCE (device walk)."""
     n_kf, k, dim = 96, 200, 512
     feats = synth.make_store_batch(31, n_kf, k=k, cols=32, true_frac=0.5)
     a, b = _descriptors(32, n_kf, dim)
@@ -121,7 +121,7 @@ def test_sharded_step_on_one_gpu_equals_the_separate_calls():
         st = sharded.ShardedStep(be, 0, 1, n_kf, DEV, accept_cap=4)     # small block: the overflow path runs as well
         for _ in range(2):
             m, flags, acc = st.step()
-            assert st.waits == 2
+            assert st.waits == 1
             assert m.tobytes() == m_ref.tobytes()
             assert np.array_equal(flags, ok)
             assert acc.tobytes() == res[ok].tobytes()
@@ -132,7 +132,7 @@ def test_sharded_step_on_one_gpu_equals_the_separate_calls():
 
 def test_partition_8e_bench_line_over_rccl_world_1():
     """`bench.py --partition 8e` with a world-1 RCCL process group (BENCH_FORCE_DIST=1): the minima block and the
-    record block go through ncclAllGather; every decision matches the ground truth and a step waits twice."""
+    record block go through ncclAllGather; every decision matches the ground truth and a step waits once."""
     env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -143,7 +143,7 @@ def test_partition_8e_bench_line_over_rccl_world_1():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["scaling"] == "strong"
     assert j["check"]["decisions_matching_ground_truth"] == j["check"]["of"] > 1000
-    assert j["check"]["host_waits_per_robot_pair_step"] == 2
+    assert j["check"]["host_waits_per_robot_pair_step"] == 1
 
 
 @pytest.mark.parametrize("form", ["two_buffers_two_streams", "two_buffers_one_stream", "one_buffer"])

@@ -53,8 +53,8 @@ def test_sharded_step_equals_single_rank(tmp_path, oracle, world):
 
 def test_sharded_step_dense_fallback(tmp_path, oracle):
     """One rank reports "candidate set too dense for the device path": every rank sees it in the gathered block, that
-    rank recomputes synchronously, the minima are gathered once more (three waits instead of two, asserted in the
-    worker) and the result is the same."""
+    rank recomputes synchronously, the minima are gathered once more (the step's one wait + the three of the fallback,
+    asserted in the worker) and the result is the same."""
     ref = str(tmp_path / "ref")
     _run(1, ref)
     out = str(tmp_path / "dense")
