@@ -523,6 +523,186 @@ def run_cfg4(args, rank, world, dev, dev_index, coll_dev, dist_on):
     f.close()
 
 
+def run_cfg3(args, rank, world, dev, dev_index, coll_dev, dist_on):
+    """BASELINE configs[2]: 3 robots = 3 robot pairs, 100 000 keyframes per robot, 4096-D NetVLAD, 1000 x 256-bit ORB per
+    keyframe, <= 2000 RANSAC hypotheses per pass.  One step = one find-and-verify pass (sf_step_issue / sf_step_retire)
+    of EVERY robot pair: 100 000 x 100 000 x 4096 NN + 100 000 candidate verifications each (every local row has a
+    perceptual alias under netvlad_distance, a fifth of them are true revisits).  Each robot pair lives in its own handle
+    (its two NetVLAD databases: 3.3 GB fp32, its replicated keyframe store: 12 GB).  N > 1: one such topology per rank
+    (weak scaling, no data-path collective).  The keyframes of a robot are `--cfg3-base` generated frames tiled on the
+    device (every slot its own HBM bytes; generating 300 000 x 1000 features on the host would take minutes)."""
+    import torch
+    import torch.distributed as td
+    from multi_robot_slam_separators_amd import _abi, lib, synth
+    n_kf, k, cols, dim, base = args.keyframes, args.features, args.desc_bytes, args.dim, args.cfg3_base
+    n_rp = args.robots * (args.robots - 1) // 2
+    p = synth.camera_params()
+    p.iterations = args.iterations
+    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.nn_precision = args.nn_precision
+    p.max_features = k
+    p.desc_bytes = cols
+    p.store_capacity = 2 * n_kf
+    t_gen0 = time.time()
+    reps = (n_kf + base - 1) // base
+
+    def up(x):
+        x = np.ascontiguousarray(x)
+        return torch.from_numpy(x.view(np.uint8) if x.dtype.fields else x).to(dev)
+
+    handles, truths, feats0, nv0 = [], [], None, None
+    for rp in range(n_rp):
+        feats = synth.make_store_batch(12345 + 97 * rank + rp, base, k=k, cols=cols, true_frac=args.true_frac)
+        f = lib.SeparatorFinder(p, device=dev_index)
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.set_option(_abi.SF_OPT_STEP_DEPTH, 2)          # (a step is tens of milliseconds: two in flight per robot pair)
+        slots = []
+        for which in ("a", "b"):
+            d0, x0, k0 = up(feats["desc_" + which]), up(feats["xyz_" + which]), up(feats["kp_" + which]).view(base, -1)
+            CH = 8 * base
+            first = None
+            for s0 in range(0, n_kf, CH):                # tile the base frames over the robot's keyframes, CH slots at a time
+                m = min(CH, n_kf - s0)
+                r_ = (m + base - 1) // base
+                dd = d0.repeat(r_, 1, 1)[:m].contiguous(); xx = x0.repeat(r_, 1, 1)[:m].contiguous(); kk = k0.repeat(r_, 1)[:m].contiguous()
+                fs = f.store_add_keyframes_device(m, k, cols, dd.data_ptr(), xx.data_ptr(), kk.data_ptr())
+                torch.cuda.synchronize()
+                first = fs if first is None else first
+                del dd, xx, kk
+            slots.append(first)
+        g = torch.Generator(device=dev)
+        g.manual_seed(777 + 31 * rank + rp)
+        a = torch.randn((n_kf, dim), generator=g, device=dev, dtype=torch.float32)
+        a /= a.norm(dim=1, keepdim=True)
+        b = a + torch.randn((n_kf, dim), generator=g, device=dev, dtype=torch.float32) * (0.05 / np.sqrt(dim))
+        b /= b.norm(dim=1, keepdim=True)
+        f.nn_append_received_device(a.data_ptr(), n_kf, dim)     # robot A's descriptors, as received by B
+        f.nn_append_local_device(b.data_ptr(), n_kf, dim)        # robot B's own
+        torch.cuda.synchronize()
+        if rp == 0:
+            feats0 = feats
+            nv0 = (a[:, :].cpu().numpy(), b[: args.cpu_sample_rows].cpu().numpy())
+        del a, b
+        handles.append((f, slots[0], slots[1]))
+        truths.append(np.tile(feats["is_true"], reps)[:n_kf])
+    t_gen = time.time() - t_gen0
+    inflight = [0] * n_rp
+    state = {"pairs": 0, "last": [None] * n_rp}
+
+    def retire(rp, copy=False):
+        m, rom, recs, info = handles[rp][0].step_retire(copy=copy)
+        inflight[rp] -= 1
+        state["pairs"] += info["n_matches"]
+        state["last"][rp] = (m, rom, info)
+
+    def step():
+        for rp, (f, sa, sb) in enumerate(handles):
+            if inflight[rp] >= 2:
+                retire(rp)
+            f.step_issue(sa, sb)
+            inflight[rp] += 1
+
+    def drain(copy=False):
+        for rp in range(n_rp):
+            while inflight[rp]:
+                retire(rp, copy)
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    f0 = handles[0][0]
+    f0.prof_reset(); f0.prof_select(("k_verify_fused", "k_match_global", "k_nn_filter_f16")); f0.prof_enable(True)
+    state["pairs"] = 0
+    if dist_on:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain(copy=True)
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = f0.prof_get()
+    f0.prof_enable(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    npairs = torch.tensor([state["pairs"]], dtype=torch.float64, device=coll_dev)
+    if dist_on:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        td.all_reduce(npairs, op=td.ReduceOp.SUM)
+    elapsed, total_pairs = float(t.item()), float(npairs.item())
+    correct = total = accepted = 0
+    for rp in range(n_rp):
+        m, rom, info = state["last"][rp]
+        want = truths[rp][m["idx_local"]] & (m["idx_local"] == m["idx_other"])
+        correct += int(((rom >= 0) == want).sum())
+        total += len(m)
+        accepted += info["n_accepted"]
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle on a bounded sample: verification of the first pairs of robot pair 0 + the NN rows of a few queries
+        from oracle import pyoracle
+        threads = pyoracle.num_threads()
+        S = min(args.cpu_sample_pairs, base, 1500)
+        A = [_abi.FeatureArrays(feats0["desc_a"][i], feats0["xyz_a"][i], feats0["kp_a"][i]) for i in range(S)]
+        B = [_abi.FeatureArrays(feats0["desc_b"][i], feats0["xyz_b"][i], feats0["kp_b"][i]) for i in range(S)]
+        pyoracle.estimate_transform_batch(p, A[:8], B[:8], threads)
+        tv = time.time(); res = pyoracle.estimate_transform_batch(p, A, B, threads); tv = time.time() - tv
+        R = min(args.cpu_sample_rows, 128)
+        tn = time.time()
+        pyoracle.find_matches(nv0[1][:R].astype(np.float64), nv0[0].astype(np.float64), netvlad_distance=p.netvlad_distance,
+                              max_matches_nb=R)
+        tn = time.time() - tn
+        t_full = tv * (n_kf / S) + tn * (n_kf / R)
+        cpu = {"value": n_kf / t_full, "unit": "pairs/s", "cores": threads, "kind": "port",
+               "sample": "%d of %d candidate pairs of one robot pair verified in %.2f s + NN rows %d of %d x %d x %d in %.2f s, both "
+                         "scaled to that robot pair's step; OpenMP over pairs / rows" % (S, n_kf, tv, R, n_kf, n_kf, dim, tn),
+               "verify_pairs_per_s": S / tv, "accepted_in_sample": int(res["success"].sum())}
+    if rank == 0:
+        nm, tm = prof.get("k_verify_fused", (0, 0.0))
+        nf, tf_ = prof.get("k_nn_filter_f16", (0, 0.0))
+        bpp = bytes_per_pair(k, cols)
+        launch_ms = tm / max(nm, 1)
+        ach = n_kf * bpp / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        flop4 = 2.0 * k * k * cols * 8 * n_kf
+        filt_ms = tf_ / max(nf, 1)
+        kd = f0.nn_last_filter_dims()
+        print(json.dumps({
+            "metric": METRIC, "value": total_pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8+f16+f32+f64" if args.nn_precision == 1 else "u8+f32+f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 1xMI355X per rank, %d robots = %d robot pairs x %d keyframes per robot, "
+                                   "%d-D fp32 NetVLAD, %d x %d-bit ORB per keyframe, <= %d RANSAC hypotheses per pass with PCL's "
+                                   "adaptive stop (%s), both registration passes, %.0f %% true revisits, every local row has an "
+                                   "alias under netvlad_distance (all rows become candidates); keyframes = %d generated frames "
+                                   "per robot tiled on the device; NN filter contracted %d of %d dimensions"
+                                   % (args.robots, n_rp, n_kf, dim, k, cols * 8, args.iterations, args.estimator,
+                                      100 * args.true_frac, base, kd, dim),
+                       "pairs_per_step_per_gpu": total_pairs / args.steps / world, "parallelism": "single GPU" if world == 1 else
+                       "one topology per rank"},
+            "roofline": {"kernel": "k_verify_fused (WIDE form: K = 1000)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_pair": bpp,
+                         "pairs_per_launch": float(n_kf), "avg_launch_ms": launch_ms,
+                         "compute": {"matrix_core": {"achieved": flop4 / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0,
+                                                      "peak": MFMA_FP4_PEAK_TF, "unit": "TFLOP/s",
+                                                      "frac": flop4 / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TF if launch_ms > 0 else 0.0},
+                                     "note": "K x K Hamming table on the fp4 matrix cores (2*K*K*bits flop per pair) + the "
+                                             "motion-estimation chains of the surviving fifth inside the same launch"}},
+            "roofline_nn": {"kernel": "k_nn_filter_f16", "bound": "mfma", "avg_launch_ms": filt_ms, "contracted_dims": kd,
+                            "achieved": 2.0 * n_kf * n_kf * kd / (filt_ms * 1e-3) / 1e12 if filt_ms > 0 else 0.0,
+                            "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": 2.0 * n_kf * n_kf * kd / (filt_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF if filt_ms > 0 else 0.0},
+            "cpu_baseline": cpu,
+            "check": {"decisions_matching_ground_truth": correct, "of": total, "accepted_last_step": accepted},
+            "input_generation_s": t_gen,
+        }))
+    for f, _, _ in handles:
+        f.close()
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no launcher: one child process per GPU with the torchrun environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rank 0's stdout (the JSON line) passed through.  The parent has not
@@ -556,11 +736,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--keyframes", type=int, default=10000, help="keyframes per robot (configs[1]: 10k)")
-    ap.add_argument("--features", type=int, default=500)
+    ap.add_argument("--keyframes", type=int, default=None, help="keyframes per robot (configs[1]: 10k; --workload cfg3: 100k)")
+    ap.add_argument("--features", type=int, default=None, help="features per keyframe (500; --workload cfg3: 1000)")
     ap.add_argument("--desc-bytes", type=int, default=32)
     ap.add_argument("--dim", type=int, default=4096)
-    ap.add_argument("--iterations", type=int, default=500)
+    ap.add_argument("--iterations", type=int, default=None, help="RANSAC hypotheses per pass at most (500; --workload cfg3: 2000)")
+    ap.add_argument("--cfg3-base", type=int, default=4000, help="--workload cfg3: generated keyframes per robot (tiled on the device)")
     ap.add_argument("--true-frac", type=float, default=0.2)
     ap.add_argument("--nn-precision", type=int, default=1,
                     help="1 = fp16 MFMA filter with rigorous error band + exact f64 refinement (identical "
@@ -581,14 +762,20 @@ def main():
     ap.add_argument("--partition", choices=("robot-pairs", "8e"), default="robot-pairs",
                     help="N > 1: robot-pairs = one independent robot pair per rank (weak scaling); 8e = one robot "
                          "pair's step cut over the ranks as SURVEY.md section 8(e) writes it (strong scaling)")
-    ap.add_argument("--robots", type=int, default=2,
+    ap.add_argument("--robots", type=int, default=None,
                     help="--partition 8e: robots in the topology; their R(R-1)/2 robot pairs are flattened into one "
                          "candidate list before the round-robin (BASELINE configs[4]: 5)")
-    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2",
-                    help="cfg2 = NN + verification step (configs[1], the metric's configuration); cfg4 = "
-                         "configs[3]: --pairs candidate pairs round-robin over the ranks, verification only")
+    ap.add_argument("--workload", choices=("cfg2", "cfg3", "cfg4"), default="cfg2",
+                    help="cfg2 = NN + verification step (configs[1], the metric's configuration); cfg3 = configs[2]: 3 robot "
+                         "pairs x 100k keyframes, K = 1000, 2000 iterations; cfg4 = configs[3]: --pairs candidate pairs "
+                         "round-robin over the ranks, verification only")
     ap.add_argument("--pairs", type=int, default=1000000, help="--workload cfg4: candidate pairs per step (all ranks)")
     args = ap.parse_args()
+    big = args.workload == "cfg3"
+    args.keyframes = args.keyframes if args.keyframes is not None else (100000 if big else 10000)
+    args.features = args.features if args.features is not None else (1000 if big else 500)
+    args.iterations = args.iterations if args.iterations is not None else (2000 if big else 500)
+    args.robots = args.robots if args.robots is not None else (3 if big else 2)
 
     # ---- N > 1 without a launcher: start the N ranks here, BEFORE anything touches the GPU (a process that has
     # initialised HIP must never exec or fork GPU work; this parent only waits for its children) ----------------
@@ -637,8 +824,9 @@ def main():
 
     from multi_robot_slam_separators_amd import _abi, dist, lib, synth
 
-    if args.workload == "cfg4" or args.partition == "8e":
-        (run_cfg4 if args.workload == "cfg4" else run_partition_8e)(args, rank, world, dev, dev_index, coll_dev, dist_on)
+    if args.workload in ("cfg3", "cfg4") or args.partition == "8e":
+        (run_cfg3 if args.workload == "cfg3" else run_cfg4 if args.workload == "cfg4" else run_partition_8e)(
+            args, rank, world, dev, dev_index, coll_dev, dist_on)
         if dist_on:
             td.destroy_process_group()
         return
@@ -1055,30 +1243,45 @@ def main():
         state["pairs"] = pairs_timed
         state["last"] = last_timed
 
-    # ---- the same step with the prefix ladder of the NN filter forced to the FULL descriptor length (the cost on a
+    def pipe_rate(ff, sa_, sb_, n_steps):
+        """Pairs per second of `n_steps` steps of the timed region's form (sf_step_issue / sf_step_retire, `depth` in
+        flight) on handle ff, behind three warm-up steps; returns (rate, accepted separators of the last step)."""
+        infl, n_pairs, last_acc = 0, 0, 0
+        for _ in range(3):
+            ff.step_issue(sa_, sb_)
+            ff.step_retire()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_steps):
+            if infl >= depth:
+                info = ff.step_retire()[3]
+                n_pairs += info["n_matches"]; last_acc = info["n_accepted"]; infl -= 1
+            ff.step_issue(sa_, sb_)
+            infl += 1
+        while infl:
+            info = ff.step_retire()[3]
+            n_pairs += info["n_matches"]; last_acc = info["n_accepted"]; infl -= 1
+        torch.cuda.synchronize()
+        return n_pairs / (time.perf_counter() - t1) * world, last_acc
+
+    # ---- the same steps with the prefix ladder of the NN filter forced to the FULL descriptor length (the cost on a
     # data set whose prefixes are uninformative; the timed steps contract `filter_dims` dimensions), untimed ----
     alt_full = None
-    if args.nn_precision == 1 and not args.no_extras:
+    if args.nn_precision == 1 and not args.no_extras and pipelined and not dist_on:
         try:
             f.set_option(_abi.SF_OPT_NN_FULL_FILTER, 1)
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_alt = 0
-            for _ in range(20):
-                n_alt += step()
-            torch.cuda.synchronize()
-            alt_full = {"value": n_alt / (time.perf_counter() - t1) * world, "contracted_dims": f.nn_last_filter_dims(),
-                        "steps": 20, "one_synchronisation_per_step": True}
+            rate, _ = pipe_rate(f, slot_a, slot_b, 20)
+            alt_full = {"value": rate, "contracted_dims": f.nn_last_filter_dims(), "steps": 20}
         except Exception as e:
             print("bench: full-length filter comparison run failed: %r" % (e,), file=sys.stderr)
         f.set_option(_abi.SF_OPT_NN_FULL_FILTER, 0)
         step()
 
-    # ---- the same step with EXACTLY iterations + 1 hypotheses per pass (ransac_adaptive_stop = 0), untimed: a second
-    # handle with the same stores and databases (parameters are fixed at sf_create) ----
-    alt_fixed = None
-    if not args.no_extras:
+    # ---- the same steps with EXACTLY iterations + 1 hypotheses per pass (ransac_adaptive_stop = 0), untimed: a second
+    # handle with the same stores and databases (parameters are fixed at sf_create); and the STRICT reading of the
+    # configuration: fixed hypotheses AND the full-length filter together ----
+    alt_fixed = alt_strict = None
+    if not args.no_extras and pipelined and not dist_on:
         try:
             q = _abi.copy_params(p)
             q.ransac_adaptive_stop = 0
@@ -1088,23 +1291,18 @@ def main():
             getattr(f2, nn_append_received)(ta.data_ptr(), n_kf, dim)
             getattr(f2, nn_append_local)(tb.data_ptr(), n_kf, dim)
             torch.cuda.synchronize()
-
-            def step_fixed():
-                m2 = f2.find_matches_and_verify_device(sa2, sb2, d_res.data_ptr(), cap=n_kf)
-                n_acc2 = f2.compact_accepted_device(d_res.data_ptr(), len(m2), d_acc.data_ptr(), d_flags.data_ptr())
-                return len(m2), n_acc2
-            step_fixed()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_alt = 0
-            for _ in range(20):
-                n_alt += step_fixed()[0]
-            torch.cuda.synchronize()
-            alt_fixed = {"value": n_alt / (time.perf_counter() - t1) * world, "accepted_last_step": step_fixed()[1],
-                         "hypotheses_per_pass": args.iterations + 1, "steps": 20}
+            rate, acc2 = pipe_rate(f2, sa2, sb2, 20)
+            alt_fixed = {"value": rate, "accepted_last_step": acc2, "hypotheses_per_pass": args.iterations + 1, "steps": 20}
+            if args.nn_precision == 1:
+                f2.set_option(_abi.SF_OPT_NN_FULL_FILTER, 1)
+                rate, acc2 = pipe_rate(f2, sa2, sb2, 30)
+                alt_strict = {"value": rate, "accepted_last_step": acc2, "hypotheses_per_pass": args.iterations + 1,
+                              "contracted_dims": f2.nn_last_filter_dims(), "steps": 30,
+                              "what": "every pass evaluates all %d hypotheses (no adaptive stop) AND the NN filter contracts "
+                                      "the full descriptor length -- the configuration read to the letter" % (args.iterations + 1)}
             f2.close()
         except Exception as e:
-            print("bench: fixed-iteration comparison run failed: %r" % (e,), file=sys.stderr)
+            print("bench: fixed-iteration / strict comparison runs failed: %r" % (e,), file=sys.stderr)
 
     # ---- the same step with the VALU matcher (xor + popcount; north_star's literal kernel mix), untimed ----
     alt_valu = None
@@ -1408,6 +1606,9 @@ def main():
         if alt_full is not None:
             out["value_full_length_filter"] = alt_full["value"]
             out["full_length_filter"] = alt_full
+        if alt_strict is not None:
+            out["value_strict"] = alt_strict["value"]
+            out["strict"] = alt_strict
         if nn_only is not None:
             out["nn_only_survey_8d_generator"] = nn_only
         if next_rows:

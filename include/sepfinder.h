@@ -54,7 +54,7 @@ extern "C" {
       sf_netvlad_infer_batch_device, sf_get_features_and_descriptor_batch_device added.                                                                          */
 /* 4: sf_step_mirror_pair, sf_step_mirror_streams, SF_OPT_STEP_SPLIT added (nothing existing changed).                */
 /* 5: sf_step_issue no longer waits for the device (SF_OPT_STEP_DEVICE_WALK, _DEPTH, _LANES), sf_nn_walk_device added; 
-      sf_step_result pointers stay valid until the next sf_step_retire.                                             */
+      sf_step_result pointers stay valid until the next sf_step_retire; sf_params grew desc_type (appended).         */
 #define SF_ABI_VERSION 5
 
 /* ---- status codes ---------------------------------------------------------------------- */
@@ -71,6 +71,7 @@ enum {
 /* ---- limits inherited from the reference IDL --------------------------------------------- */
 #define SF_MAX_FEATURES   32767  /* KeyPoint3DVec.msg:1 / KeyPointVec.msg:1  `int16 size`   */
 #define SF_MAX_DESC_BYTES 64     /* 512-bit binary descriptors (BASELINE.json configs[4])   */
+#define SF_MAX_DESC_BYTES_F32 512 /* float32 descriptors (desc_type 1): 64 or 128 dimensions  */
 
 /* ---- parameters -------------------------------------------------------------------------- */
 typedef struct sf_params {
@@ -133,6 +134,14 @@ typedef struct sf_params {
      backward one, its covariance their mean, inliers / matches the union of both directions' ids.  Implemented for
      estimation_type 0 without bundle adjustment (sf_create -> SF_EINVAL otherwise).                             */
   int32_t forward_est_only;        /* 1 */
+  /* Descriptor type of every keyframe of this handle (rtabmap Vis/FeatureType is fixed per run).  0 = binary rows
+     (CV_8U: BRIEF / ORB, Hamming distance -- the only kind the reference's own wire carries, MsgConversion.cpp:113-129);
+     1 = float32 rows (SURF / SIFT: `desc` points at rows x dims float32, `cols` = 4 * dims with dims = 64 or 128):
+     brute-force kNN-2 on the L2 distance with the same NNDR / uniqueness / window rules -- squared distances in the
+     global matching (myRegistrationVis.cpp:839-854 -> VWDictionary::addNewWords [upstream]), cv::BFMatcher(NORM_L2)
+     distances in the guided matching (:739-749).  north_star's "ORB/SURF ... Hamming/L2 matching".               */
+  int32_t desc_type;               /* 0 */
+  int32_t reserved0;               /* 0 (keeps the struct a multiple of 8 bytes)                               */
 } sf_params;
 
 /* ---- wire layouts ------------------------------------------------------------------------ */

@@ -11,6 +11,7 @@ import numpy as np
 SF_OK, SF_EINVAL, SF_EHIP, SF_ENOMEM, SF_ERANGE, SF_ENODEV, SF_ERCCL = range(7)
 SF_MAX_FEATURES = 32767
 SF_MAX_DESC_BYTES = 64
+SF_MAX_DESC_BYTES_F32 = 512
 
 (SF_K_MATCH, SF_K_RANSAC1, SF_K_GUIDED, SF_K_RANSAC2, SF_K_NN, SF_K_NN_SELECT, SF_K_NN_FILTER,
  SF_K_NN_REFINE, SF_K_FUSED, SF_K_NN_WALK, SF_K_COUNT) = range(11)
@@ -58,6 +59,8 @@ class Params(C.Structure):
         ("stereo_baseline", C.c_float),
         ("force_3dof", C.c_int32),
         ("forward_est_only", C.c_int32),
+        ("desc_type", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -260,6 +263,8 @@ def default_params() -> Params:
     p.stereo_baseline = 0.0
     p.force_3dof = 0
     p.forward_est_only = 1
+    p.desc_type = 0
+    p.reserved0 = 0
     return p
 
 
@@ -274,9 +279,12 @@ class FeatureArrays:
     borrows them (zero copy, like descriptorsFromROS at MsgConversion.cpp:113-116)."""
 
     def __init__(self, desc, xyz, kpts):
+        desc = np.asarray(desc)
+        if desc.dtype == np.float32:       # float32 descriptor rows (sf_params.desc_type 1): handed over as their bytes
+            desc = np.ascontiguousarray(desc).view(np.uint8).reshape(desc.shape[0], 4 * desc.shape[1])
         self.desc = np.ascontiguousarray(desc, dtype=np.uint8)
         if self.desc.ndim != 2:
-            raise ValueError("desc must be rows x cols uint8")
+            raise ValueError("desc must be rows x cols uint8 (or rows x dims float32)")
         self.xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         kpts = np.asarray(kpts)
         if kpts.dtype != KEYPOINT_DTYPE:

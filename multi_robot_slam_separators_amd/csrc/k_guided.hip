@@ -29,7 +29,11 @@ namespace {
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
 // `out` / hdr_out / pass2_out / guided_flag_out: the pair's pass-2 correspondence list, header, state and flag
 // (global arrays in the stage kernel, LDS in the fused kernel).
-template <int W>
+// L2: float32 descriptor rows of W dimensions (desc_type 1): the combinations that pass the window and octave tests are
+// compared by their L2 distance -- sqrtf of the float32 sum of squared differences in dimension order, as
+// cv::BFMatcher(NORM_L2) reports it (:739-749) -- in the per-lane search loop (same tests, same decisions; the
+// candidate-parallel pass with its packed 32-bit keys is the binary descriptors').
+template <int W, bool L2 = false>
 __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int sF, int sT, const PassState& pass1,
                                             PassState& pass2_out, uint8_t& guided_flag_out, uint32_t* out,
                                             CorrHeader& hdr_out, int32_t* __restrict__ list,
@@ -393,7 +397,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
 #ifdef SF_CHAIN_TRACE
   if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * SF_TRACE_SLOTS + 27] = (unsigned long long)n_cand;
 #endif
-  if (n_cand <= cand_cap) {
+  if (!L2 && n_cand <= cand_cap) {
     // pass B: one combination per lane (<= GUIDED_CPT per thread, kept in registers between the two atomic passes)
     uint32_t ck[GUIDED_CPT], ci[GUIDED_CPT];
 #pragma unroll
@@ -457,6 +461,8 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
       }
       int oi = 0, last = -1;
       uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;  // (dist << 16 | to_idx) keys
+      float f0 = __int_as_float(0x7F800000), f1 = __int_as_float(0x7F800000);   // L2: best / second-best distance ...
+      int t0 = -1;                                                               // ... and the best's "to" row
       const int cx0 = min(max((int)floorf((u - reach) * inv_cell), 0), gxm);
       const int cx1 = min(max((int)floorf((u + reach) * inv_cell), 0), gxm);
       const int cy0 = min(max((int)floorf((v - reach) * inv_cell), 0), gym);
@@ -470,12 +476,26 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
           if (d2 < r2lim && __float_as_int(it.z) == octf) {
             const int t = __float_as_int(it.w);
             const uint32_t* r = dT + (size_t)t * W;
-            uint32_t d = 0;
+            if constexpr (L2) {
+              float sq = 0.f;
 #pragma unroll
-            for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
-            const uint32_t key = (d << 16) | (uint32_t)t;
-            b1 = min(max(key, b0), b1);
-            b0 = min(b0, key);
+              for (int c = 0; c < W; ++c) {
+                const float dd = __uint_as_float(q[c]) - __uint_as_float(r[c]);
+                sq = sq + dd * dd;
+              }
+              const float d = sqrtf(sq);
+              // (candidates arrive in grid order, not in "to" order: the better of two equal distances is the lower row,
+              //  as a scan in "to" order with strict comparisons leaves it)
+              if (d < f0 || (d == f0 && t < t0)) { f1 = f0; f0 = d; t0 = t; }
+              else if (d < f1) { f1 = d; }
+            } else {
+              uint32_t d = 0;
+#pragma unroll
+              for (int c = 0; c < W; ++c) d += __popc(r[c] ^ q[c]);
+              const uint32_t key = (d << 16) | (uint32_t)t;
+              b1 = min(max(key, b0), b1);
+              b0 = min(b0, key);
+            }
             ++oi;
             if (last < 0 || t > last) last = t;
           }
@@ -483,7 +503,8 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
       }
       int m = -1;
       if (oi >= 2) {
-        if ((float)(b0 >> 16) < P.nndr * (float)(b1 >> 16)) m = (int)(b0 & 0xFFFFu);  // :744
+        if constexpr (L2) { if (t0 >= 0 && f0 < P.nndr * f1) m = t0; }
+        else if ((float)(b0 >> 16) < P.nndr * (float)(b1 >> 16)) m = (int)(b0 & 0xFFFFu);  // :744
       } else if (oi == 1) {
         m = last;                                                                    // :751-764
       }
@@ -576,7 +597,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   return survivor;
 }
 
-template <int W>
+template <int W, bool L2 = false>
 __global__ void __launch_bounds__(SF_BLOCK)
 k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
          const PassState* __restrict__ pass1, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
@@ -584,8 +605,8 @@ k_guided(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
          int32_t* __restrict__ counter, DeviceParams P) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   const int pair = (int)blockIdx.x;
-  guided_body<W>(st, pair, pair_from[pair], pair_to[pair], pass1[pair], pass2[pair], guided_flag[pair],
-                 corr + (size_t)pair * st.kcap, hdr[pair], list, counter, P, smem);
+  guided_body<W, L2>(st, pair, pair_from[pair], pair_to[pair], pass1[pair], pass2[pair], guided_flag[pair],
+                     corr + (size_t)pair * st.kcap, hdr[pair], list, counter, P, smem);
 }
 
 // ---- result assembly: myRegistration.cpp:279-295 covariance clamp + MsgConversion.cpp:61-81 ------
@@ -684,7 +705,16 @@ int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const i
   const size_t lds = sf_guided_lds_bytes(st.kcap, nc);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_GUIDED);
-  if (st.w == 8) {
+  if (c->params.desc_type == 1) {
+    if (st.w == 64)
+      hipLaunchKernelGGL((k_guided<64, true>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                         (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                         (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2, c->dparams);
+    else
+      hipLaunchKernelGGL((k_guided<128, true>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                         (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                         (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2, c->dparams);
+  } else if (st.w == 8) {
     hipLaunchKernelGGL(k_guided<8>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                        (const PassState*)c->pass1.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                        (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (int32_t*)c->list3.p, counters + 2,

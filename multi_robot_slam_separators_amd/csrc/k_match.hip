@@ -55,6 +55,27 @@ __device__ __forceinline__ void knn2_scan(const uint32_t* __restrict__ dF, int K
   }
 }
 
+// Float32 descriptor rows (desc_type 1: SURF / SIFT, W = dimensions): squared L2 distance of every "from" row to the ONE
+// "to" row this lane keeps in VGPRs, accumulated in float32 in dimension order, multiply and add unfused (the
+// translation unit is built with -ffp-contract=off) -- the oracle's loop, bit for bit.  Strict comparisons: ties keep
+// the lower "from" index (BFMatcher order); a NaN distance is never taken.
+template <int W>
+__device__ __forceinline__ void knn2_scan_l2(const uint32_t* __restrict__ dF, int Kf, const uint32_t (&q)[W], float& d1,
+                                             float& d2, int& i1) {
+#pragma unroll 1
+  for (int f = 0; f < Kf; ++f) {
+    const uint32_t* r = dF + (size_t)f * W;         // wave-uniform: scalar loads
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const float d = __uint_as_float(q[c]) - __uint_as_float(r[c]);
+      s = s + d * d;
+    }
+    if (s < d1) { d2 = d1; d1 = s; i1 = f; }
+    else if (s < d2) { d2 = s; }
+  }
+}
+
 template <int W>
 __device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int row, bool valid, uint32_t (&q)[W]) {
   const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)(valid ? row : 0) * W);
@@ -68,7 +89,8 @@ __device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int
 // W  : dwords per descriptor (8 / 16)
 // NQ : "to" descriptors resident per lane
 // NT : threads per workgroup (one workgroup per candidate pair)
-template <int W, int NQ, int NT>
+// L2 : float32 descriptor rows of W dimensions (squared L2, NQ = 1) instead of binary rows of W dwords (Hamming)
+template <int W, int NQ, int NT, bool L2 = false>
 __global__ void __launch_bounds__(NT)
 k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                float nndr, int min_inliers, int est, uint32_t* __restrict__ corr, CorrHeader* __restrict__ hdr,
@@ -107,6 +129,29 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   __syncthreads();
 
   int rejected = 0;
+  if constexpr (L2) {
+    static_assert(!L2 || NQ == 1, "one resident float row per lane");
+    if (Kf > 0) {
+      for (int base = 0; base < Kt; base += NT) {
+        const int t = base + tid;
+        uint32_t q[W];
+        load_desc<W>(dT, t, t < Kt, q);
+        float d1 = __int_as_float(0x7F800000), d2 = __int_as_float(0x7F800000);
+        int i1 = -1;
+        if (Kt - base - (tid & ~63) > 0)          // (wave-uniform: this wavefront holds at least one valid row)
+          knn2_scan_l2<W>(dF, Kf, q, d1, d2, i1);
+        if (t < Kt) {
+          const bool acc = (Kf >= 2) && i1 >= 0 && !(d1 > nndr * d2);
+          if (acc) {
+            atomicAdd(&cnt[i1], 1);
+            owner[i1] = t;
+          } else {
+            ++rejected;
+          }
+        }
+      }
+    }
+  } else
   if (Kf > 0) {
     for (int base = 0; base < Kt; base += NQ * NT) {
       uint32_t q[NQ][W], k1[NQ], k2[NQ];
@@ -777,10 +822,27 @@ void launch_match(sf_context* c, StoreView st, const int32_t* d_from, const int3
                      (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
 }
 
+template <int W>
+void launch_match_l2(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
+  const size_t lds = (size_t)(2 * st.kcap + 16) * sizeof(int);
+  int32_t* counters = (int32_t*)c->counters.p;
+  hipLaunchKernelGGL((k_match_global<W, 1, 256, true>), dim3(n), dim3(256), lds, c->stream, st, d_from, d_to,
+                     c->dparams.nndr, c->dparams.min_inliers, sf_est_mode(c), (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p,
+                     (PassState*)c->pass1.p, (int32_t*)c->list1.p, counters + 0);
+}
+
 }  // namespace
 
 int sf_launch_match_global(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {
   if (n <= 0) return SF_OK;
+  if (c->params.desc_type == 1) {       // float32 rows: exact L2 on the VALU (north_star: MFMA only for the NetVLAD matrix)
+    sf_prof_begin(c, SF_K_MATCH);
+    if (st.w == 64) launch_match_l2<64>(c, st, d_from, d_to, n);
+    else launch_match_l2<128>(c, st, d_from, d_to, n);
+    sf_prof_end(c, SF_K_MATCH);
+    SF_HIP(c, hipGetLastError());
+    return SF_OK;
+  }
   // geometry: variant = NQ * 1000 + NT (tunable through SF_MATCH_VARIANT for A/B runs)
   int variant = c->match_variant;
   if (variant == 0) {

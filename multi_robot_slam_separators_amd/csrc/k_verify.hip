@@ -230,6 +230,7 @@ size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_mat
 // apply (PnP estimator, SF_FUSED=0, or a stage that needs more than the 160 KB of a CU).
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
   if (!c->fused || c->dparams.estimation_type != 0 || c->dparams.bidirectional) return 0;   // (both directions: stage kernels)
+  if (c->params.desc_type != 0) return 0;     // float32 descriptors: the stage kernels (exact L2 on the VALU)
   const size_t match = sf_match_lds_bytes(st.kcap, st.w);
   // same rule as sf_launch_match_global: the LDS-staged matching body only while the staged "from"
   // block leaves room for >= 2 workgroups per CU; beyond that the stage kernels (scalar-load matcher)
@@ -342,7 +343,7 @@ bool sf_split_applicable(const sf_context* c, const StoreView& st) {
 
 // the PnP form: k_match_split + k_chain_pnp
 bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st) {
-  if (c->dparams.estimation_type != 1 || !c->fused || c->match_variant != 0) return false;
+  if (c->dparams.estimation_type != 1 || !c->fused || c->match_variant != 0 || c->params.desc_type != 0) return false;
   if (!(c->match_mfma && st.kcap <= MF_MAX_ROWS)) return false;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t lds = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +

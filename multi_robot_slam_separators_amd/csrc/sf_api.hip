@@ -313,10 +313,21 @@ k_compact_move(const sf_result* __restrict__ res, int n, sf_result* __restrict__
 
 }  // namespace
 
+// dwords per stored descriptor row: binary rows 8 (<= 256 bits) or 16; float32 rows (desc_type 1) one per dimension
+static int desc_dwords(const sf_context* c, int cols) {
+  if (c->params.desc_type == 1) return cols / 4;
+  return cols <= 32 ? 8 : 16;
+}
+
 static int store_reserve(sf_context* c, Store& s, int slots_needed, int rows, int cols) {
-  if (cols < 1 || cols > SF_MAX_DESC_BYTES) return sf_fail(c, SF_ERANGE, "descriptor bytes %d not in 1..%d", cols, SF_MAX_DESC_BYTES);
+  if (c->params.desc_type == 1) {
+    if (cols != 256 && cols != 512)
+      return sf_fail(c, SF_ERANGE, "float32 descriptors: %d bytes per row (64 or 128 dimensions = 256 or 512 bytes)", cols);
+  } else if (cols < 1 || cols > SF_MAX_DESC_BYTES) {
+    return sf_fail(c, SF_ERANGE, "descriptor bytes %d not in 1..%d", cols, SF_MAX_DESC_BYTES);
+  }
   if (rows > SF_MAX_FEATURES) return sf_fail(c, SF_ERANGE, "rows %d > int16 limit of KeyPointVec.size", rows);
-  const int w = cols <= 32 ? 8 : 16;
+  const int w = desc_dwords(c, cols);
   int kcap = s.kcap ? s.kcap : std::max(64, (c->params.max_features + 63) & ~63);
   while (kcap < rows) kcap *= 2;
   if (kcap > SF_MAX_KCAP) return sf_fail(c, SF_ERANGE, "%d features per keyframe exceed the kernel capacity %d", rows, SF_MAX_KCAP);
@@ -383,11 +394,11 @@ static int store_add_host(sf_context* c, Store& st, const sf_features* f, int* o
   if (rc != SF_OK) return rc;
   const int rows = f->rows;
   int cols = f->cols;
-  if (rows == 0 && cols == 0) cols = st.slots > 0 ? (st.w == 8 ? 32 : 64) : std::max(1, c->params.desc_bytes);
+  if (rows == 0 && cols == 0) cols = st.slots > 0 ? st.w * 4 : std::max(1, c->params.desc_bytes);
   if ((rc = store_reserve(c, st, st.slots + 1, rows, cols)) != SF_OK) return rc;
   if (st.slots > 0 || rows > 0) {
     // all keyframes of one store share the descriptor width class
-    if (st.w != (cols <= 32 ? 8 : 16)) return sf_fail(c, SF_EINVAL, "descriptor width mismatch");
+    if (st.w != desc_dwords(c, cols)) return sf_fail(c, SF_EINVAL, "descriptor width mismatch");
   }
   Staging sg = staging(c);
   const uint8_t* dd = nullptr; const float* dx = nullptr; const sf_keypoint* dk = nullptr;
@@ -512,11 +523,12 @@ static int store_add_host_batch(sf_context* c, Store& st, const sf_features* con
     max_rows = std::max<int>(max_rows, feats[i]->rows);
     if (feats[i]->rows > 0) {
       if (cols == 0) cols = feats[i]->cols;
-      if ((feats[i]->cols <= 32) != (cols <= 32)) return sf_fail(c, SF_EINVAL, "descriptor width classes differ inside one batch");
-      if (feats[i]->cols > SF_MAX_DESC_BYTES) return sf_fail(c, SF_ERANGE, "descriptor bytes %d > %d", (int)feats[i]->cols, SF_MAX_DESC_BYTES);
+      if (desc_dwords(c, feats[i]->cols) != desc_dwords(c, cols)) return sf_fail(c, SF_EINVAL, "descriptor width classes differ inside one batch");
+      if (feats[i]->cols > (c->params.desc_type == 1 ? SF_MAX_DESC_BYTES_F32 : SF_MAX_DESC_BYTES))
+        return sf_fail(c, SF_ERANGE, "descriptor bytes %d > %d", (int)feats[i]->cols, c->params.desc_type == 1 ? SF_MAX_DESC_BYTES_F32 : SF_MAX_DESC_BYTES);
     }
   }
-  if (cols == 0) cols = st.slots > 0 ? (st.w == 8 ? 32 : 64) : std::max(1, c->params.desc_bytes);
+  if (cols == 0) cols = st.slots > 0 ? st.w * 4 : std::max(1, c->params.desc_bytes);
   if ((rc = store_reserve(c, st, st.slots + n, max_rows, cols)) != SF_OK) return rc;
 
   // layout: [table][keyframe 0: desc | xyz | kp][keyframe 1 ...], chunk boundaries every ~4 MB
@@ -633,6 +645,7 @@ extern "C" void sf_default_params(sf_params* p) {
   p->stereo_baseline = 0.f;
   p->force_3dof = 0;                 // Reg/Force3DoF
   p->forward_est_only = 1;           // Vis/ForwardEstOnly
+  p->desc_type = 0;                  // binary descriptors (the reference's wire carries nothing else)
 }
 
 static int fill_device_params(sf_context* c) {
@@ -657,6 +670,9 @@ static int fill_device_params(sf_context* c) {
     if (p.ba_iterations < 0 || !(p.ba_pixel_variance > 0.f) || !(p.ba_robust_kernel_delta > 0.f) || !(p.stereo_baseline >= 0.f))
       return sf_fail(c, SF_EINVAL, "bundle adjustment: ba_iterations >= 0, ba_pixel_variance > 0, ba_robust_kernel_delta > 0, stereo_baseline >= 0");
   }
+  if (p.desc_type != 0 && p.desc_type != 1) return sf_fail(c, SF_EINVAL, "desc_type %d unknown (0 = binary rows, 1 = float32 rows)", p.desc_type);
+  if (p.desc_type == 1 && p.desc_bytes != 256 && p.desc_bytes != 512 && p.desc_bytes != 32)
+    return sf_fail(c, SF_EINVAL, "desc_type 1: desc_bytes %d (float32 rows of 64 or 128 dimensions: 256 or 512)", p.desc_bytes);
   if (p.forward_est_only == 0 && (p.estimation_type != 0 || p.bundle_adjustment != 0))
     return sf_fail(c, SF_EINVAL, "forward_est_only = 0 is implemented for estimation_type 0 without bundle adjustment");
   DeviceParams& d = c->dparams;
@@ -905,6 +921,8 @@ extern "C" int sf_brief_set_pattern(sf_handle c, const int8_t* tests, int32_t by
 }
 
 static int brief_ensure(sf_context* c) {
+  if (c->params.desc_type != 0)
+    return sf_fail(c, SF_EINVAL, "the feature extraction writes BRIEF (binary) descriptors: a handle with desc_type %d cannot store them", c->params.desc_type);
   if (c->brief_bytes) return SF_OK;
   const int want = c->params.desc_bytes;
   c->brief_bytes = (want == 16 || want == 64) ? want : 32;

@@ -116,6 +116,16 @@ def make_true_partner(rng, fa, T_gt, overlap=0.4, noise=0.02, flip=0.05):
     return _abi.FeatureArrays(desc, xyz, _keypoints(u, v)), gt
 
 
+def float_descriptors(fa, dims, rng=None, jitter=0.0):
+    """The float32-descriptor twin of a keyframe with binary descriptors (sf_params.desc_type 1): dimension d of a row is
+    +-1 by bit d of the binary descriptor (+ Gaussian jitter), so a true partner's rows stay close to their originals
+    (4 per flipped bit) and unrelated rows are ~4 * dims / 2 apart -- and, without jitter, distances tie often."""
+    bits = np.unpackbits(fa.desc, axis=1)[:, :dims].astype(np.float32) * 2.0 - 1.0
+    if jitter > 0:
+        bits = bits + rng.normal(scale=jitter, size=bits.shape).astype(np.float32)
+    return _abi.FeatureArrays(np.ascontiguousarray(bits, dtype=np.float32), fa.xyz, fa.kpts)
+
+
 def make_pairs(seed, n, k=500, cols=32, true_frac=0.2, overlap=0.4, noise=0.02, flip=0.05):
     """n candidate pairs (from=A, to=B).  Returns (list A, list B, is_true[n], T_gt list)."""
     rng = np.random.default_rng(seed)

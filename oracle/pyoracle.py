@@ -48,7 +48,7 @@ def lib():
         L.sfo_match_global.restype = C.c_int
         L.sfo_match_global.argtypes = [
             C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
-            C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+            C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), C.c_int]
         L.sfo_match_guided.restype = C.c_int
         L.sfo_match_guided.argtypes = [
             P(_abi.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -149,7 +149,11 @@ def find_matches(local, received, local_used=(), other_used=(), ignored_pairs=()
     return out[: n.value], row_min, row_arg
 
 
-def match_global(desc_from, desc_to, nndr=0.6, has3d_from=True, has3d_to=True):
+def match_global(desc_from, desc_to, nndr=0.6, has3d_from=True, has3d_to=True, desc_type=0):
+    """desc_type 1: rows of float32 handed over as their bytes (rows x 4 * dims uint8) or as a float32 array."""
+    if desc_type == 1:
+        desc_from = np.ascontiguousarray(desc_from, dtype=np.float32).view(np.uint8) if np.asarray(desc_from).dtype != np.uint8 else desc_from
+        desc_to = np.ascontiguousarray(desc_to, dtype=np.float32).view(np.uint8) if np.asarray(desc_to).dtype != np.uint8 else desc_to
     df = np.ascontiguousarray(desc_from, dtype=np.uint8)
     dt = np.ascontiguousarray(desc_to, dtype=np.uint8)
     cap = max(1, df.shape[0], dt.shape[0])
@@ -159,7 +163,7 @@ def match_global(desc_from, desc_to, nndr=0.6, has3d_from=True, has3d_to=True):
     cols = df.shape[1] if df.ndim == 2 and df.shape[0] else (dt.shape[1] if dt.ndim == 2 else 0)
     rc = lib().sfo_match_global(_ptr(df), df.shape[0], _ptr(dt), dt.shape[0], cols,
                                 C.c_float(nndr), int(has3d_from), int(has3d_to), cf.ctypes.data,
-                                ct.ctypes.data, C.byref(n), C.byref(wf), C.byref(wt), C.byref(wt2))
+                                ct.ctypes.data, C.byref(n), C.byref(wf), C.byref(wt), C.byref(wt2), int(desc_type))
     if rc != 0:
         raise RuntimeError("sfo_match_global -> %d" % rc)
     return cf[: n.value].copy(), ct[: n.value].copy(), wf.value, wt.value, wt2.value

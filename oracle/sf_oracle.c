@@ -408,10 +408,22 @@ static int sfo_popcount_row(const uint8_t* a, const uint8_t* b, int cols) {
 /* ========================================================================================= */
 /* Global matching: PKG/src/myRegistrationVis.cpp:826-895                                      */
 /* ========================================================================================= */
+/* desc_type 1 (float32 rows, `cols` = 4 * dimensions): squared L2 distance accumulated in float32 in dimension order,
+ * multiply and add unfused (-ffp-contract=off) -- the canonical order the device kernels follow (csrc/k_match.hip
+ * knn2_scan_l2).  [upstream] VWDictionary::addNewWords compares squared L2 distances of float descriptors;
+ * cv::BFMatcher(NORM_L2) in the guided branch reports their square root. */
+static float sfo_l2sq_row(const uint8_t* a, const uint8_t* b, int cols) {
+  const float* x = (const float*)a;
+  const float* y = (const float*)b;
+  float s = 0.0f;
+  for (int k = 0; k < cols / 4; ++k) { const float d = x[k] - y[k]; s = s + d * d; }
+  return s;
+}
+
 int sfo_match_global(const uint8_t* desc_from, int k_from, const uint8_t* desc_to, int k_to,
                      int cols, float nndr, int has3d_from, int has3d_to,
                      uint16_t* corr_from, uint16_t* corr_to, int* n_corr,
-                     int* n_words_from, int* n_words_to, int* n_words_to_2d) {
+                     int* n_words_from, int* n_words_to, int* n_words_to_2d, int desc_type) {
   *n_corr = 0; *n_words_from = 0; *n_words_to = 0; *n_words_to_2d = 0;
   if (k_from <= 0 || k_to <= 0) {
     /* :897-910 only fake "from" words; wordsTo stays empty */
@@ -428,12 +440,23 @@ int sfo_match_global(const uint8_t* desc_from, int k_from, const uint8_t* desc_t
   for (int t = 0; t < k_to; ++t) {
     const uint8_t* q = desc_to + (size_t)t * cols;
     int d1 = 1 << 30, d2 = 1 << 30, i1 = -1;
-    for (int f = 0; f < k_from; ++f) {
+    for (int f = 0; f < k_from && desc_type != 1; ++f) {
       int d = sfo_popcount_row(q, desc_from + (size_t)f * cols, cols);
       if (d < d1) { d2 = d1; d1 = d; i1 = f; }
       else if (d < d2) { d2 = d; }
     }
     int accept = 0;
+    if (desc_type == 1) {
+      /* float32 rows: the same scan on squared L2 distances (strict comparisons: ties keep the lower id) */
+      float f1 = INFINITY, f2 = INFINITY;
+      i1 = -1;
+      for (int f = 0; f < k_from; ++f) {
+        const float d = sfo_l2sq_row(q, desc_from + (size_t)f * cols, cols);
+        if (d < f1) { f2 = f1; f1 = d; i1 = f; }
+        else if (d < f2) { f2 = d; }
+      }
+      if (k_from >= 2 && i1 >= 0) accept = !(f1 > nndr * f2);
+    } else
     if (k_from >= 2) accept = !((float)d1 > nndr * (float)d2);
     match[t] = accept ? i1 : -1;
     if (accept) { cnt[i1]++; owner[i1] = t; }
@@ -522,17 +545,26 @@ int sfo_match_guided(const sf_params* p, const float* guess,
     int octf = sfo_octave(kp_from[i].octave);
     const uint8_t* q = desc_from + (size_t)i * cols;
     int oi = 0, d0 = 1 << 30, d1 = 1 << 30, i0 = -1, last = -1;
+    float f0 = INFINITY, f1 = INFINITY;     /* desc_type 1: cv::BFMatcher(NORM_L2) distances */
     for (int t = 0; t < k_to; ++t) {
       float dx = pu[i] - kp_to[t].x, dy = pv[i] - kp_to[t].y;
       float d2 = dx * dx + dy * dy;
       if (!(d2 < r2)) continue;
       if (sfo_octave(kp_to[t].octave) != octf) continue;
       ++oi; last = t;
+      if (p->desc_type == 1) {
+        const float d = sqrtf(sfo_l2sq_row(q, desc_to + (size_t)t * cols, cols));
+        if (d < f0) { f1 = f0; f0 = d; i0 = t; }
+        else if (d < f1) { f1 = d; }
+        continue;
+      }
       int d = sfo_popcount_row(q, desc_to + (size_t)t * cols, cols);
       if (d < d0) { d1 = d0; d0 = d; i0 = t; }
       else if (d < d1) { d1 = d; }
     }
     int matched = -1;
+    if (oi >= 2 && p->desc_type == 1) { if (i0 >= 0 && f0 < p->nndr * f1) matched = i0; }
+    else
     if (oi >= 2) { if ((float)d0 < p->nndr * (float)d1) matched = i0; }   /* :744 */
     else if (oi == 1) matched = last;                                     /* :751-754, :756-764 */
     if (matched >= 0 && claim[matched] < 0) claim[matched] = i;           /* :776-787 */
@@ -946,7 +978,7 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
                             &n_words_to_2d, &all_outside);
     } else {
       rc = sfo_match_global(from->desc, kf, to->desc, kt, from->cols, p->nndr, from->n3d > 0,
-                            to->n3d > 0, cf, ct, nc, &n_words_from, &n_words_to, &n_words_to_2d);
+                            to->n3d > 0, cf, ct, nc, &n_words_from, &n_words_to, &n_words_to_2d, p->desc_type);
     }
     if (rc != SF_OK) return rc;
   } else if (kf > 0) {
@@ -1061,6 +1093,8 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if ((rc = sfo_validate(from)) != SF_OK) return rc;
   if ((rc = sfo_validate(to)) != SF_OK) return rc;
   if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
+  if (p->desc_type != 0 && p->desc_type != 1) return SF_EINVAL;
+  if (p->desc_type == 1 && ((from->rows > 0 && from->cols % 4) || (to->rows > 0 && to->cols % 4))) return SF_EINVAL;
   if (!p->forward_est_only && (p->estimation_type != 0 || p->bundle_adjustment != 0)) return SF_EINVAL;
   if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations < 0)) return SF_EINVAL;
   if (p->bundle_adjustment != 0 &&

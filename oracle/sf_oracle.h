@@ -46,7 +46,7 @@ int sfo_find_matches(const double* local, int n_l, const double* received, int n
 int sfo_match_global(const uint8_t* desc_from, int k_from, const uint8_t* desc_to, int k_to,
                      int cols, float nndr, int has3d_from, int has3d_to,
                      uint16_t* corr_from, uint16_t* corr_to, int* n_corr,
-                     int* n_words_from, int* n_words_to, int* n_words_to_2d);
+                     int* n_words_from, int* n_words_to, int* n_words_to_2d, int desc_type /* 0 = binary rows (Hamming), 1 = float32 rows (squared L2) */);
 
 /* Guess-guided matching branch -- PKG/src/myRegistrationVis.cpp:476-825 (default sub-branch
  * :667-818, _guessMatchToProjection=false), exact radius search instead of FLANN's
