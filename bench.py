@@ -900,26 +900,23 @@ def main():
     OFF_SUCCESS = _abi.RESULT_DTYPE.fields["success"][1]
     state = {"pairs": 0, "accepted": 0, "last": None}
 
-    # single GPU: the one-synchronisation form of a step (`step()` below: comparison runs, BENCH_NO_PIPELINE=1) lets the
-    # compaction kernel write count, flags and accepted records STRAIGHT into a pinned host block (BENCH_HOST_COPY=1: a
-    # copy behind it, as up to round r02c)
-    zero_copy = exch is None and os.environ.get("BENCH_HOST_COPY") is None
+    # single GPU: the one-synchronisation form of a step (`step()` below: warm-up and comparison runs) lets the compaction
+    # kernel write count, flags and accepted records STRAIGHT into a pinned host block
+    zero_copy = exch is None
     hp = h_pack.data_ptr()
     h_cnt_np = h_cnt.numpy()                                  # (a view of the pinned word: no tensor indexing per step)
-    trace = os.environ.get("BENCH_STEP_TRACE") is not None    # per-phase wall times of a step on stderr
-    two_calls = os.environ.get("BENCH_TWO_CALLS") is not None
     # THE TIMED STEP is the library's begin / retire pair (include/sepfinder.h: sf_step_issue / sf_step_retire, the loop
-    # body of find_separators.py:59-133): step k is issued -- NN filter, speculative verification of every candidate,
-    # accepted separators streaming from inside the verification kernel into a pinned block of the handle -- before
-    # step k - 1 is retired, so the device never waits for the host; two blocks alternate inside the library.  All K
-    # steps are issued and retired inside the timed region.  examples/bench_cli.cpp runs the same loop from C++ (no
-    # torch).  BENCH_NO_PIPELINE=1: `step()`, one synchronisation per step, through the building blocks in
-    # include/sf_experimental.h (what value_one_synchronisation_per_step reports).
+    # body of find_separators.py:59-133): sf_step_issue queues the NN filter, the exact re-evaluation, the row minima,
+    # the argsort + walk of find_matches (on the device) and the verification, with the accepted separators streaming
+    # from inside the verification kernel into a pinned block of the handle, and returns without waiting;
+    # sf_step_retire hands out the oldest step.  `depth` steps are kept in flight; all K steps are issued and retired
+    # inside the timed region.  examples/bench_cli.cpp runs the same loop from C++ (no torch).
     # N > 1 (RCCL): sf_step_mirror makes every accepted record land in the exchange's send buffer too, the slot counter
     # IS that buffer's count header (zeroed by a fill queued behind the previous all-gather), and the all-gather starts
-    # right behind the verification; it is retired with the step.
+    # right behind the verification; it is retired with the step.  With gloo (CPU collectives: the rehearsal of the
+    # N > 1 path on one GPU) the steps are not pipelined: `step()`, one synchronisation per step.
     dist_cuda = exch is not None and coll_dev.type == "cuda"
-    pipelined = (exch is None or dist_cuda) and not trace and not two_calls and os.environ.get("BENCH_NO_PIPELINE") is None
+    pipelined = exch is None or dist_cuda
     # Two exchanges (send + receive buffers) alternate with the steps (sf_step_mirror_pair): the all-gather of step k,
     # on RCCL's stream, runs beside the verification of step k + 1; only the REUSE of a buffer -- the zeroing of its
     # count header for step k + 2 -- is ordered behind the collective that read it.  BENCH_ONE_EXCHANGE_BUFFER=1: one
@@ -998,72 +995,47 @@ def main():
         state["last"] = (m.copy(), torch.from_numpy(ordered.view(np.uint8).reshape(-1, RB).copy()), len(m))
 
     def step():
-        t_0 = time.perf_counter()
-        # NN kernels, then -- in ONE library call -- the verification of the candidates: the NN filter's
-        # candidates are verified speculatively on the device while the host reduces them to row minima, sorts
-        # and walks them (data_handler.py:187-205); the walk's matches then pick their results (sf_api.hip).
-        # BENCH_TWO_CALLS=1: the two separate calls (sf_nn_find_matches, then sf_verify_matches_device).
-        if two_calls:
-            m = f.nn_find_matches(cap=n_kf)                   # NN kernels + row minima to host + walk
-            t_1 = time.perf_counter()
-            f.verify_matches_device(m, slot_a, slot_b, d_res.data_ptr())
-        elif zero_copy and not trace:
-            # only the ACCEPTED separators leave the device: no gathered copy of all results (d_out = NULL), the
-            # compaction below reads them through the index list the call left behind
-            m = f.find_matches_and_verify_device(slot_a, slot_b, None, cap=n_kf)
-            t_1 = time.perf_counter()
-        else:
-            m = f.find_matches_and_verify_device(slot_a, slot_b, d_res.data_ptr(), cap=n_kf)
-            t_1 = time.perf_counter()
+        """One step with ONE synchronisation at its end, through the building blocks of include/sf_experimental.h (what
+        value_one_synchronisation_per_step reports; also the warm-up, the comparison runs and the gloo rehearsal)."""
+        # NN kernels, then -- in ONE library call -- the verification of the candidates: the NN filter's candidates are
+        # verified speculatively on the device while the host reduces them to row minima, sorts and walks them
+        # (data_handler.py:187-205); the walk's matches then pick their results (sf_api.hip).  Single GPU: only the
+        # ACCEPTED separators leave the device (d_out = NULL), the compaction reads them through the index list the call
+        # left behind.
+        m = f.find_matches_and_verify_device(slot_a, slot_b, None if zero_copy else d_res.data_ptr(), cap=n_kf)
         n = len(m)
-        # pair (from = querying robot A's keyframe idx_other, to = computing robot B's idx_local),
-        # find_separators.py:85-91
-        if trace:
-            t_1b = t_2 = time.perf_counter()
-            torch.cuda.synchronize()
-            t_3 = time.perf_counter()
-        # every candidate's success flag goes back to the two robots involved (failures feed the ignore
-        # list, data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to
-        # the back-end (data_handler.py:352-368).
-        # The compaction leaves its count on the device; count, flags and a speculative prefix of the accepted
-        # records (capacity for a 25 % acceptance rate) go to the host behind the step's ONE synchronisation.
+        # every candidate's success flag goes back to the two robots involved (failures feed the ignore list,
+        # data_handler.py:406-408); only ACCEPTED separators are exchanged between GPUs / handed to the back-end
+        # (data_handler.py:352-368).  The compaction leaves its count on the device.
         if exch is not None and coll_dev.type != "cuda":      # gloo rehearsal: the collective runs on CPU tensors
             n_acc = f.compact_accepted_device(d_res.data_ptr(), n, d_acc.data_ptr(), d_flags.data_ptr())
             acc = d_acc
             exch.payload[:n_acc].copy_(acc[:n_acc])
             exch.exchange(n_acc)
             d_cnt.fill_(n_acc)                                # (the packed copy below carries it to the host)
+        elif exch is not None:
+            # compaction writes records AND count straight into the exchange's send buffer
+            acc, d_cnt_view = exch.payload, exch.send[0, :4].view(torch.int32)
+            f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), exch.count_ptr)
+            exch.exchange(None, finish=False)                 # ONE all-gather, in flight beside the copies below
         else:
-            if exch is not None:
-                # compaction writes records AND count straight into the exchange's send buffer
-                acc, cnt_ptr, d_cnt_view = exch.payload, exch.count_ptr, exch.send[0, :4].view(torch.int32)
-            else:
-                acc, cnt_ptr, d_cnt_view = d_acc, d_cnt.data_ptr(), d_cnt
-            if zero_copy and not trace and not two_calls:
-                r_ptr, r_idx, r_n = f.last_match_results()
-                f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, hp + acc_off, hp + flags_off, hp)
-            elif zero_copy:
-                f.compact_accepted_device_async(d_res.data_ptr(), n, hp + acc_off, hp + flags_off, hp)
-            else:
-                f.compact_accepted_device_async(d_res.data_ptr(), n, acc.data_ptr(), d_flags.data_ptr(), cnt_ptr)
-            if exch is not None:
-                exch.exchange(None, finish=False)             # ONE all-gather, in flight beside the copies below
-        k_spec = min(n, spec_cap)
-        if zero_copy:
-            k_spec = n                                        # (everything is already in the pinned block)
-        elif acc is d_acc:
-            # count + flags + the speculative prefix of the accepted separators: one copy to the pinned mirror
+            acc = d_acc
+            r_ptr, r_idx, r_n = f.last_match_results()
+            f.compact_accepted_indexed_device_async(r_ptr, r_idx, n, hp + acc_off, hp + flags_off, hp)
+        k_spec = n if zero_copy else min(n, spec_cap)
+        if not zero_copy and acc is d_acc:
+            # count + flags + a speculative prefix of the accepted separators (capacity for a 25 % acceptance rate): one
+            # copy to the pinned mirror
             nb = acc_off + k_spec * RB
             h_pack[:nb].copy_(d_pack[:nb], non_blocking=True)
-        else:
-            if exch is not None and coll_dev.type == "cuda":
-                h_cnt.copy_(d_cnt_view, non_blocking=True)
+        elif not zero_copy:
+            h_cnt.copy_(d_cnt_view, non_blocking=True)
             h_flags[:n].copy_(d_flags[:n], non_blocking=True)
             h_res[:k_spec].copy_(acc[:k_spec], non_blocking=True)   # accepted separators delivered to the host (pinned)
         if exch is not None:
             exch.finish()                                     # the copies above ran beside the collective
         if zero_copy:
-            f.synchronize()                                   # (everything of the step is on the handle's stream)
+            f.synchronize()                                   # (everything of the step is on the handle's streams)
             n_acc = int(h_cnt_np[0])
         else:
             torch.cuda.synchronize()
@@ -1072,15 +1044,6 @@ def main():
             h_res[k_spec:n_acc].copy_(acc[k_spec:n_acc], non_blocking=True)
             torch.cuda.synchronize()
         host = h_res[:n_acc]
-        if trace:
-            t_4 = time.perf_counter()
-            pr = f.prof_get()
-            kv = sum(v[1] for kname, v in pr.items() if kname.startswith("k_verify") or kname.startswith("k_match")
-                     or kname.startswith("k_ransac") or kname.startswith("k_guided"))
-            print("[bench step] nn (+ verify launch) %.3f ms, - %.3f, - %.3f, verify wait %.3f, accepted-only "
-                  "gather + copies %.3f; verification kernels so far %.3f ms (hipEvents)"
-                  % ((t_1 - t_0) * 1e3, (t_1b - t_1) * 1e3, (t_2 - t_1b) * 1e3, (t_3 - t_2) * 1e3, (t_4 - t_3) * 1e3, kv),
-                  file=sys.stderr)
         state["pairs"] += n
         state["last"] = (m, host, n)
         state["gathered"] = sum(exch.counts()) if exch is not None else n_acc
@@ -1128,11 +1091,11 @@ def main():
     f.prof_enable(False)
     # HIP events over the timed region bracket ONLY the kernel the roofline prices (two timing events per launch
     # cost host time and a marker on the queue: with every kernel bracketed a step took 0.594 ms instead of 0.568);
-    # the other kernels are surveyed in a short pass after the timed region (BENCH_PROF_ALL=1: all, as up to r02d)
+    # the other kernels are surveyed in a short pass after the timed region
     dominant = ("k_verify_fused", "k_match_global")
     f.prof_reset()
-    f.prof_select(None if os.environ.get("BENCH_PROF_ALL") else dominant)
-    f.prof_enable(os.environ.get("BENCH_NO_PROF") is None)
+    f.prof_select(dominant)
+    f.prof_enable(True)
     state["pairs"] = 0
     del t_issue[:], t_retire[:]
     # The contract's bracket: barrier + synchronize, then EXACTLY K steps issued and retired, then synchronize + barrier.
@@ -1192,6 +1155,23 @@ def main():
     torch.cuda.synchronize()
     prof_all = f.prof_get()
     f.prof_enable(False)
+    # ... and the dominant kernel ALONE on the chip (one step at a time, one stream): inside the timed region up to
+    # SF_OPT_STEP_LANES launches of it run beside each other and share the CUs, so a launch's wall time there is a multiple
+    # of what it needs by itself
+    prof_alone = None
+    if pipelined and not dist_on:
+        try:
+            f.set_option(_abi.SF_OPT_STEP_LANES, 1)
+            f.prof_reset(); f.prof_select(dominant); f.prof_enable(True)
+            for _ in range(8):
+                f.step_issue(slot_a, slot_b)
+                f.step_retire()
+            torch.cuda.synchronize()
+            prof_alone = f.prof_get()
+            f.prof_enable(False)
+            f.set_option(_abi.SF_OPT_STEP_LANES, int(os.environ.get("SF_STEP_LANES", "3")))
+        except Exception as e:
+            print("bench: exclusive-launch pass failed: %r" % (e,), file=sys.stderr)
     state["pairs"] = pairs_timed
     state["last"] = last_timed
     filter_dims = f.nn_last_filter_dims()      # prefix length the fp16 filter contracted (0: exact path)
@@ -1416,7 +1396,7 @@ def main():
             torch.cuda.synchronize()
             for _ in range(3):
                 mm = f.nn_find_matches(cap=n_kf)
-            f.prof_reset(); f.prof_enable(True)
+            f.prof_reset(); f.prof_select(None); f.prof_enable(True)
             t1 = time.perf_counter()
             reps = 20
             for _ in range(reps):
@@ -1492,6 +1472,13 @@ def main():
         bpp_dom = (2 * k * cols + 352) if split_form else bpp
         pmc = pmc_traffic(dom_name, pairs_per_launch)
         ach = pairs_per_launch * bpp_dom / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
+        lanes_in_use = (1 if not pipelined else 2 if dist_cuda else int(os.environ.get("SF_STEP_LANES", "3")))
+        alone_roof = None
+        if prof_alone is not None and prof_alone.get(dom, (0, 0.0))[0] > 0:
+            a_ms = prof_alone[dom][1] / prof_alone[dom][0]
+            a_ach = pairs_per_launch * bpp_dom / (a_ms * 1e-3) / 1e9
+            alone_roof = {"avg_launch_ms": a_ms, "launches": prof_alone[dom][0], "achieved": a_ach, "unit": "GB/s",
+                          "frac": a_ach / HBM_PEAK_GBS}
         nn_kernel, nn_peak = (("k_nn_filter_f16", MFMA_F16_PEAK_TF) if args.nn_precision == 1
                               else ("k_nn_argmin", MFMA_F32_PEAK_TF))
         nn_n, nn_t = prof_all[nn_kernel]
@@ -1543,6 +1530,14 @@ def main():
                 "compute": compute_note(dom_name, k, cols, pairs_per_launch, match_ms),
                 "bytes_per_pair": bpp_dom, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": match_ms,
                 "launches_per_step": nm / args.steps,
+                # `achieved` / `frac` above: algorithmic bytes of a launch over its average duration INSIDE the timed
+                # region (HIP events), where the launches of the steps in flight share the chip; the same kernel alone
+                # on the chip and the step as a whole:
+                "launches_sharing_the_chip": lanes_in_use,
+                "alone": alone_roof,
+                "whole_step": {"bytes_per_step": pairs_per_step * bpp, "ms_per_step": ms_per_step,
+                               "achieved": pairs_per_step * bpp / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                               "frac": pairs_per_step * bpp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             },
             "verification_form": ("split: k_match_split over every candidate + k_chain over the survivors" if split_form
                                   else "split (PnP): k_match_split + k_chain_pnp (the library's k_verify_fused profiling slot)"

@@ -5,9 +5,8 @@
 // descriptors (find_matches) and one estimate_transformation per returned candidate, as the library's begin / retire
 // pair -- step k is issued before step k - 1 is retired, so the device never waits for the host:
 //
-//     sf_step_issue(h, slot_a, slot_b);                    // s_find_matches_query + every s_ans_est_transform, queued
-//     for (k = 1; k < K; ++k) { sf_step_issue(...); sf_step_retire(h, &r); consume(r); }
-//     sf_step_retire(h, &r);
+//     for (k = 0; k < K; ++k) { if (in_flight == 6) { sf_step_retire(h, &r); consume(r); }  sf_step_issue(h, slot_a, slot_b); }
+//     while (in_flight) { sf_step_retire(h, &r); consume(r); }      // sf_step_issue never waits for the device
 //
 // The synthetic workload follows SURVEY.md section 8(d) / multi_robot_slam_separators_amd/synth.py (same recipe, its
 // own random stream): K features per keyframe inside a 640 x 480 pin-hole image, 20 % of B's keyframes are revisits of
@@ -231,10 +230,12 @@ int main(int argc, char** argv) {
   sf_step_result r;
   long long pairs = 0;
   int inflight = 0;
+  const int depth = 6;        // steps kept in flight (the library's default SF_OPT_STEP_DEPTH)
   auto issue = [&]() -> int {
-    int rc = sf_step_issue(h, slot_a, slot_b);
+    int rc;
+    if (inflight >= depth) { rc = sf_step_retire(h, &r); if (rc != SF_OK) return rc; pairs += r.n_matches; --inflight; }
+    rc = sf_step_issue(h, slot_a, slot_b);      // queues the whole step on the device; does not wait
     if (rc != SF_OK) return rc;
-    if (inflight) { rc = sf_step_retire(h, &r); if (rc != SF_OK) return rc; pairs += r.n_matches; --inflight; }
     ++inflight;
     return SF_OK;
   };
@@ -256,9 +257,7 @@ int main(int argc, char** argv) {
   pairs = 0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int s = 0; s < steps; ++s) CHECK_SF(issue());
-  CHECK_SF(sf_step_retire(h, &r));
-  pairs += r.n_matches;
-  --inflight;
+  while (inflight) { CHECK_SF(sf_step_retire(h, &r)); pairs += r.n_matches; --inflight; }
   CHECK_SF(sf_synchronize(h));
   const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 

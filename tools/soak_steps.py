@@ -1,9 +1,10 @@
 """Soak of the step pair (sf_step_issue / sf_step_retire) in the forms it takes: random database sizes, feature counts,
-thresholds and duplicate rows; per round the reference is the two separate calls on a handle whose steps share one stream
-and keep the fused kernel, and the steps of three more handles -- two streams + the split form (k_match_split + k_chain,
-forced down to these sizes with SF_STEP_SPLIT_MIN=1), two streams + fused (SF_OPT_STEP_SPLIT = 0), a device mirror pair
-on two streams -- must deliver the same matches, the same accepted / rejected decision per match and, for every accepted
-match, the same 368 bytes.  3D-3D and PnP.  usage: python tools/soak_steps.py [rounds=40]"""
+thresholds, duplicate rows and max_matches (every row / the reference's 20); per round the reference is the two separate
+calls, and the steps of five more handles -- the device-resident step in its speculative and its serial form, the split
+form (k_match_split + k_chain, forced down to these sizes with SF_STEP_SPLIT_MIN=1), round 3's host walk, a device mirror
+pair -- each with a random ring depth (1 .. 9) and lane count (1 .. 4), nine steps kept `depth` in flight, must deliver the
+same matches, the same accepted / rejected decision per match and, for every accepted match, the same 368 bytes.
+3D-3D and PnP.  usage: python tools/soak_steps.py [rounds=40]"""
 import os
 import sys
 
@@ -37,7 +38,7 @@ def main():
         p.estimation_type = est
         p.iterations = int(rng.choice([50, 200]))
         p.netvlad_dimensions = dim
-        p.netvlad_max_matches_nb = n_kf
+        p.netvlad_max_matches_nb = n_kf if rng.random() < 0.7 else 20
         p.netvlad_distance = 0.13
         p.max_features = k
 
@@ -56,7 +57,7 @@ def main():
         with lib.SeparatorFinder(p) as f:
             f.set_option(_abi.SF_OPT_STEP_OVERLAP, 0)
             sa, sb = fill(f)
-            m_ref = f.nn_find_matches(cap=n_kf)
+            m_ref = f.nn_find_matches(cap=n_kf)       # (at most netvlad_max_matches_nb rows are walked)
             d = torch.zeros((max(len(m_ref), 1), RB), dtype=torch.uint8, device=dev)
             f.verify_matches_device(m_ref, sa, sb, d.data_ptr())
             torch.cuda.synchronize()
@@ -74,11 +75,19 @@ def main():
                 print("round %d %s: MISMATCH (n_kf %d, k %d, dim %d, est %d)" % (rd, what, n_kf, k, dim, est), flush=True)
             return good
 
-        for form in ("split", "fused", "mirror"):
+        for form in ("speculative", "serial", "split", "hostwalk", "mirror"):
             with lib.SeparatorFinder(p) as f:
                 sa, sb = fill(f)
-                if form == "fused":
-                    f.set_option(_abi.SF_OPT_STEP_SPLIT, 0)
+                depth = int(rng.choice([1, 2, 4, 6, 9]))
+                n_lanes = int(rng.choice([1, 2, 3, 4]))
+                f.set_option(_abi.SF_OPT_STEP_DEPTH, depth)
+                f.set_option(_abi.SF_OPT_STEP_LANES, n_lanes)
+                if form == "serial":
+                    f.set_option(_abi.SF_OPT_STEP_SPECULATE, 0)
+                if form == "split":
+                    f.set_option(_abi.SF_OPT_STEP_SPLIT, 1)
+                if form == "hostwalk":
+                    f.set_option(_abi.SF_OPT_STEP_DEVICE_WALK, 0)
                 lanes = [torch.cuda.current_stream()] * 2
                 send = None
                 if form == "mirror":
@@ -87,21 +96,26 @@ def main():
                     f.step_mirror_pair((send[0][1:].data_ptr(), send[0].data_ptr()), (send[1][1:].data_ptr(), send[1].data_ptr()), cap)
                     s_even, s_odd = f.step_mirror_streams()
                     lanes = [torch.cuda.current_stream(), torch.cuda.ExternalStream(s_odd)]
-                outs = []
-                for s_i in range(5):
+                    depth = min(depth, 2)                     # (a mirror's buffer is rewritten two steps later)
+                outs, infl, n_steps = [], 0, 9
+                for s_i in range(n_steps):
+                    if infl >= depth:
+                        outs.append(f.step_retire(copy=True))
+                        infl -= 1
                     with torch.cuda.stream(lanes[s_i & 1]):
                         if send is not None:
                             send[s_i & 1].zero_()
                         f.step_issue(sa, sb)
-                    if s_i:
-                        outs.append(f.step_retire(copy=True))
-                outs.append(f.step_retire(copy=True))
+                    infl += 1
+                while infl:
+                    outs.append(f.step_retire(copy=True))
+                    infl -= 1
                 torch.cuda.synchronize()
                 for o in outs:
                     steps += 1
-                    bad += 0 if check(o, form) else 1
+                    bad += 0 if check(o, "%s depth %d lanes %d" % (form, depth, n_lanes)) else 1
                 if send is not None:
-                    for b, o in ((0, outs[-1]), (1, outs[-2])):       # steps 4 (even) and 3 (odd) wrote last
+                    for b, o in ((0, outs[-1]), (1, outs[-2])):       # steps 8 (even) and 7 (odd) wrote last
                         cnt = int(send[b][0, :4].view(torch.int32).item())
                         got = send[b][1: 1 + cnt].cpu().numpy().tobytes()
                         if cnt != o[3]["n_records"] or got != o[2][:cnt].tobytes():
@@ -110,7 +124,7 @@ def main():
                     f.step_mirror(None, None, 0)
         if rd % 10 == 9:
             print("round %d: %d steps checked, %d accepted separators per reference pass so far, %d bad" % (rd, steps, accepted, bad), flush=True)
-    print("STEP SOAK DONE: %d rounds, %d steps in three forms, %d mismatching" % (rounds, steps, bad))
+    print("STEP SOAK DONE: %d rounds, %d steps in five forms, %d mismatching" % (rounds, steps, bad))
     return 1 if bad else 0
 
 
