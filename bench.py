@@ -814,6 +814,7 @@ def main():
     # the launcher gave, including 1 -- the rehearsal of the RCCL path on a one-GPU box
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") is not None
     if dist_on:
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")      # (RCCL's stream: see `xstream` below)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
@@ -845,7 +846,6 @@ def main():
 
     f = lib.SeparatorFinder(p, device=dev_index)
     f.set_stream(torch.cuda.current_stream().cuda_stream)
-
     # ---- make everything resident in HBM (untimed) -------------------------------------------------
     def up(x):
         x = np.ascontiguousarray(x)
@@ -911,39 +911,29 @@ def main():
     # from inside the verification kernel into a pinned block of the handle, and returns without waiting;
     # sf_step_retire hands out the oldest step.  `depth` steps are kept in flight; all K steps are issued and retired
     # inside the timed region.  examples/bench_cli.cpp runs the same loop from C++ (no torch).
-    # N > 1 (RCCL): sf_step_mirror makes every accepted record land in the exchange's send buffer too, the slot counter
-    # IS that buffer's count header (zeroed by a fill queued behind the previous all-gather), and the all-gather starts
-    # right behind the verification; it is retired with the step.  With gloo (CPU collectives: the rehearsal of the
-    # N > 1 path on one GPU) the steps are not pipelined: `step()`, one synchronisation per step.
+    # N > 1 (RCCL): a step's accepted separators are all-gathered when the step is RETIRED -- every accepted record also
+    # lands in a device buffer of the step's own block (sf_step_result.d_records), from which `retire` copies them into the
+    # send buffer of one of two alternating exchanges (device-to-device, on a stream of the exchanges' own) and starts
+    # the collective, which runs on RCCL's stream beside the steps in flight; only the REUSE of an exchange's buffers, two
+    # retires later, waits for it.  The steps themselves run exactly as at N = 1 (same ring, same streams): no buffer of a
+    # collective is tied to a step in flight.  (Rounds 2-3 mirrored the records into the send buffer from inside the
+    # verification kernel -- sf_step_mirror_pair, still in the library and its tests -- which chained step k + 2 behind
+    # the collective of step k.)  With gloo (CPU collectives: the rehearsal of the N > 1 path on one GPU) the steps are
+    # not pipelined: `step()`, one synchronisation per step.
     dist_cuda = exch is not None and coll_dev.type == "cuda"
     pipelined = exch is None or dist_cuda
-    # Two exchanges (send + receive buffers) alternate with the steps (sf_step_mirror_pair): the all-gather of step k,
-    # on RCCL's stream, runs beside the verification of step k + 1; only the REUSE of a buffer -- the zeroing of its
-    # count header for step k + 2 -- is ordered behind the collective that read it.  BENCH_ONE_EXCHANGE_BUFFER=1: one
-    # buffer, every step's kernels behind the previous step's collective (up to round r03k).  With two buffers the odd
-    # steps also move to the handle's second stream as they do at N = 1 (sf_step_mirror_streams): everything that
-    # touches a buffer -- the fill, the step, the collective's hand-over -- is then queued on that buffer's stream
-    # (BENCH_EXCHANGE_ONE_STREAM=1: both on the handle's stream).
     exchs = [exch]
-    lane_streams = [None]
-    issued = [0]
-    if pipelined and dist_cuda:
-        if os.environ.get("BENCH_ONE_EXCHANGE_BUFFER") is None:
-            exchs.append(dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf + n_kf // 8 + 256, n_kf // 4 + 256, coll_dev))
-            f.step_mirror_pair((exchs[0].payload.data_ptr(), exchs[0].count_ptr),
-                               (exchs[1].payload.data_ptr(), exchs[1].count_ptr), int(exch.payload.shape[0]))
-            lane_streams = [torch.cuda.current_stream()] * 2
-            if os.environ.get("BENCH_EXCHANGE_ONE_STREAM") is None:
-                s_even, s_odd = f.step_mirror_streams()
-                if s_odd != s_even:
-                    lane_streams[1] = torch.cuda.ExternalStream(s_odd)
-        else:
-            f.step_mirror(exch.payload.data_ptr(), exch.count_ptr, int(exch.payload.shape[0]))
+    retired = [0]
+    # the exchanges' own stream, at the highest priority like RCCL's (TORCH_NCCL_HIGH_PRIORITY, set in main()): their
+    # launches are a handful of small copies per step that must not wait behind a verification's dispatch (with both at
+    # the default priority a step took 0.488 ms at world size 1, with both raised 0.462 -- profiles/r05p; N = 1: 0.446)
+    xstream = torch.cuda.Stream(priority=-1) if dist_on and coll_dev.type == "cuda" else None
+    if pipelined and dist_cuda and os.environ.get("BENCH_ONE_EXCHANGE_BUFFER") is None:
+        exchs.append(dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf + n_kf // 8 + 256, n_kf // 4 + 256, coll_dev))
     inflight = [0]
 
-    # steps kept in flight: the library's ring (SF_OPT_STEP_DEPTH, default 6); with the RCCL exchange a step's buffer is
-    # reused two steps later, so two
-    depth = 2 if dist_cuda else int(os.environ.get("SF_STEP_DEPTH", "6"))
+    # steps kept in flight: the library's ring (SF_OPT_STEP_DEPTH, default 6)
+    depth = int(os.environ.get("SF_STEP_DEPTH", "6"))
     t_issue, t_retire = [], []
 
     def retire(copy=False):
@@ -955,6 +945,21 @@ def main():
         state["last"] = (m, rom, recs, info)
         if exch is None:
             state["gathered"] = info["n_accepted"]
+        if dist_cuda:
+            # the retired step's separators -> the node: copy into the send buffer of this retire's exchange, stamp the
+            # count, ONE all-gather (async: it runs beside the steps in flight)
+            # (all of it on a stream of its own: on the handle's stream -- which is also the first of the streams the steps
+            #  are dealt over -- the copy, the header fill and the wait for the previous collective would queue behind and
+            #  in front of every third step)
+            ex = exchs[retired[0] % len(exchs)]
+            retired[0] += 1
+            with torch.cuda.stream(xstream):
+                ex.finish()                   # the collective that last used these buffers (two retires ago)
+                nrec = min(info["n_records"], int(ex.payload.shape[0]))
+                if nrec:
+                    f.memcpy_device_async(ex.payload.data_ptr(), info["d_records"], nrec * RB, xstream.cuda_stream)
+                ex.exchange(nrec, finish=False)
+            state["exch_last"] = ex
 
     def issue(k):
         """Step k enters the pipeline; the oldest step is retired first when the ring is full (its outputs were queued
@@ -962,26 +967,15 @@ def main():
         if inflight[0] >= depth:
             retire()
         ts = time.perf_counter()
-        if dist_cuda:
-            b = issued[0] % len(exchs)           # (the library alternates its mirrors with the steps the same way)
-            ex, lane = exchs[b], lane_streams[b]
-            with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
-                ex.finish()                   # the collective that last read this buffer (step k - 2, or k - 1 with one buffer)
-                ex.send[0, :8].zero_()        # this rank's count header = the stream's slot counter
-                f.step_issue(slot_a, slot_b)
-                ex.exchange(None, finish=False)   # (behind the verification in stream order, on the collective's own stream)
-            state["exch_last"] = ex
-            issued[0] += 1
-        else:
-            f.step_issue(slot_a, slot_b)
+        f.step_issue(slot_a, slot_b)
         t_issue.append((time.perf_counter() - ts) * 1e3)
         inflight[0] += 1
 
     def drain_exchanges():
         """Every collective in flight finished, its header rows on the host; `gathered` = the last step's node-wide count."""
         if dist_cuda:
-            for ex, lane in zip(exchs, lane_streams):
-                with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+            with torch.cuda.stream(xstream):
+                for ex in exchs:
                     ex.finish()
             torch.cuda.synchronize()
             state["gathered"] = sum(state["exch_last"].counts())
@@ -1128,7 +1122,6 @@ def main():
     if pipelined:
         materialize_last()                # (check infrastructure: the last step's separators in match order)
         if dist_cuda:
-            f.step_mirror(None, None, 0)
             exch = state["exch_last"]     # (the checks below read the LAST step's exchange)
     timed_issue_ms, timed_retire_ms = list(t_issue), list(t_retire)
     prof = f.prof_get()
@@ -1472,7 +1465,7 @@ def main():
         bpp_dom = (2 * k * cols + 352) if split_form else bpp
         pmc = pmc_traffic(dom_name, pairs_per_launch)
         ach = pairs_per_launch * bpp_dom / (match_ms * 1e-3) / 1e9 if match_ms > 0 else 0.0
-        lanes_in_use = (1 if not pipelined else 2 if dist_cuda else int(os.environ.get("SF_STEP_LANES", "3")))
+        lanes_in_use = 1 if not pipelined else int(os.environ.get("SF_STEP_LANES", "3"))
         alone_roof = None
         if prof_alone is not None and prof_alone.get(dom, (0, 0.0))[0] > 0:
             a_ms = prof_alone[dom][1] / prof_alone[dom][0]
@@ -1588,8 +1581,8 @@ def main():
         # SF_OPT_STEP_OVERLAP (the library's default, SF_STEP_OVERLAP=0 turns it off): the two steps in flight on two
         # streams -- unless the separators are mirrored into an exchange buffer (N > 1), where one stream orders the
         # collective behind the step
-        out["steps_on_two_streams"] = bool(pipelined and os.environ.get("SF_STEP_OVERLAP", "1") != "0" and
-                                           (not dist_cuda or lane_streams[0] is not lane_streams[-1]))
+        out["steps_on_several_streams"] = bool(pipelined and os.environ.get("SF_STEP_OVERLAP", "1") != "0")
+        out["stream_placement"] = f.stream_placement()
         if dist_cuda:
             out["exchange_buffers"] = len(exchs)
         out["accepted_separators_streamed_from_the_kernel"] = bool(state.get("streamed_last", False))
@@ -1638,7 +1631,6 @@ def main():
     # were handed over on it); they go first, while that stream still exists
     exch = None
     exchs.clear()
-    lane_streams.clear()
     state.clear()
     gc.collect()
     torch.cuda.synchronize()

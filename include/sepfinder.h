@@ -526,9 +526,17 @@ typedef struct sf_step_result {
                                         the threshold had both verified, the walk kept one)                          */
   int32_t          n_accepted;       /* matches whose estimation succeeded                                           */
   int32_t          streamed;         /* 1: the records streamed out of the kernel, 0: compacted behind it            */
+  const sf_result* d_records;        /* the same n_records records, same order, in DEVICE memory (NULL while a mirror is
+                                        set): what a multi-GPU host hands to its all-gather after the retire -- by a
+                                        device-to-device copy into its send buffer (sf_memcpy_device_async) or directly;
+                                        valid until the next sf_step_retire like the other pointers                     */
 } sf_step_result;
 int  sf_step_issue(sf_handle h, int32_t slot_base_other, int32_t slot_base_local);
 int  sf_step_retire(sf_handle h, sf_step_result* out);      /* the OLDEST step in flight; waits for its verification */
+/* bytes from device memory to device memory, asynchronous on `hip_stream` (NULL: the handle's stream) -- e.g. a retired
+   step's sf_step_result.d_records -> the send buffer of the caller's collective, on the stream the caller runs its
+   collectives from (a stream of its own keeps that traffic out of the way of the steps in flight) */
+int  sf_memcpy_device_async(sf_handle h, void* d_dst, const void* d_src, size_t bytes, void* hip_stream);
 /* Optional second destination of every accepted record, on the device -- e.g. the send buffer of the all-gather that
    follows (sf_allgather_separators_device: slot 0 = header, records from slot 1): d_records2[slot] receives the record
    the host block receives at the same slot and *d_counter (a device word the CALLER zeroes before each sf_step_issue,

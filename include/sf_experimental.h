@@ -57,6 +57,10 @@ int  sf_accept_stream_status(sf_handle h, int32_t* streamed, int32_t* pairs);
    host time and a marker on the queue -- about 4 us per bracketed launch in a 0.6 ms step -- so a throughput
    measurement brackets only the kernel it prices (bench.py: the dominant one) and surveys the rest separately.  */
 int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
+/* One line on where the step pipeline's streams were placed on the hardware's dispatch pipes (measured once per handle at
+   the first step that needs a second stream: sf_api.hip place_streams; SF_STREAM_PLACEMENT=0 in the environment turns the
+   measurement off, =2 also prints the line to stderr). */
+int  sf_stream_placement(sf_handle h, char* buf, size_t n);
 
 /* Pass state of pair `pair` of the last verification (diagnostics, tools/diag_pair_index.py): pose of the pass (row-major
    3 x 4, p_from = T p_to; all zero when null), is_null / inliers / matches.  Needs SF_OPT_DEBUG_CORR like

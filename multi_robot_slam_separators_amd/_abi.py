@@ -219,7 +219,8 @@ assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 class StepResult(C.Structure):
     """sf_step_result (include/sepfinder.h): what sf_step_retire hands back; the pointers belong to the handle."""
     _fields_ = [("matches", C.c_void_p), ("record_of_match", C.c_void_p), ("records", C.c_void_p),
-                ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32)]
+                ("n_matches", C.c_int32), ("n_records", C.c_int32), ("n_accepted", C.c_int32), ("streamed", C.c_int32),
+                ("d_records", C.c_void_p)]
 
 
 SF_ABI_VERSION = 5      # include/sepfinder.h

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -808,6 +809,11 @@ extern "C" void sf_destroy(sf_handle c) {
   if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
   if (c->ev_walk) (void)hipEventDestroy(c->ev_walk);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+  for (int k = 0; k < SF_STEP_MAX_LANES; ++k) {                 // (placed streams nobody asked for)
+    if (c->placement.main[k]) (void)hipStreamDestroy(c->placement.main[k]);
+    if (c->placement.aux[k]) (void)hipStreamDestroy(c->placement.aux[k]);
+  }
+  if (c->placement.copy) (void)hipStreamDestroy(c->placement.copy);
   buf_free(c->step_nn);
   buf_free(c->walk_scratch);
   if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
@@ -834,6 +840,7 @@ extern "C" void sf_destroy(sf_handle c) {
     if (sb.pinned) (void)hipHostFree(sb.pinned);
     if (sb.done) (void)hipEventDestroy(sb.done);
     buf_free(sb.dev);
+    buf_free(sb.dev_records);
   }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1463,6 +1470,8 @@ int sf_spec_launch(sf_context* c, const void* d_cand, const unsigned* d_count) {
   return rc;
 }
 
+static int place_streams(sf_context* c);
+
 extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_other, int32_t slot_base_local,
                                                  sf_match* out, int32_t cap, int32_t* n_out, sf_result* d_out) {
   if (!c || !n_out || cap < 0 || (cap > 0 && !out)) return SF_EINVAL;
@@ -1487,11 +1496,14 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
       // Streams of another priority level get queues of their own, so unless the process raised the queue budget
       // (bench.py sets GPU_MAX_HW_QUEUES=8, measured slightly better than the priority) this stream is created
       // with the highest priority; its work (exact NN re-evaluation, small copies) is what the host waits for.
+      // (round 5: the stream's place is measured -- place_streams, further down -- and only if that fails created blind)
       int prio_least = 0, prio_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
       const char* hwq = getenv("GPU_MAX_HW_QUEUES");
       const int prio = (hwq && atoi(hwq) >= 8) ? 0 : prio_greatest;
-      SF_HIP(c, hipStreamCreateWithPriority(&c->spec.copy_stream, hipStreamNonBlocking, prio));
+      if (!c->placement.tried) (void)place_streams(c);
+      if (c->placement.copy) { c->spec.copy_stream = c->placement.copy; c->placement.copy = nullptr; }
+      else SF_HIP(c, hipStreamCreateWithPriority(&c->spec.copy_stream, hipStreamNonBlocking, prio));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_refined, hipEventDisableTiming));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec.ev_copied, hipEventDisableTiming));
       SF_HIP(c, hipEventCreateWithFlags(&c->spec_index_staged, hipEventDisableTiming));
@@ -1764,7 +1776,9 @@ static int step_block_reserve(sf_context* c, sf_context::StepBlock& b, int32_t c
   *b.count = 0;
   *b.walk_n = 0;
   *b.walk_status = 0;
-  return sf_buf_reserve(c, b.dev, 64 + (size_t)want * 8);
+  int rc = sf_buf_reserve(c, b.dev, 64 + (size_t)want * 8);
+  if (rc != SF_OK) return rc;
+  return sf_buf_reserve(c, b.dev_records, (size_t)want * sizeof(sf_result));
 }
 
 static inline int step_ring(const sf_context* c) { return c->step_depth + 1; }
@@ -1851,7 +1865,9 @@ extern "C" int sf_step_mirror_streams(sf_handle c, void** stream_even, void** st
   SF_HIP(c, hipSetDevice(c->device));
   *stream_even = *stream_odd = (void*)c->stream;
   if (c->step_overlap && !c->overlap && c->step_lanes >= 2) {
+    c->cur_lane = 1;
     int rc = lane_create(c, 1);
+    c->cur_lane = 0;
     if (rc != SF_OK) return rc;
     *stream_odd = (void*)c->lanes[0].stream;
     c->step_mirror_lanes = true;
@@ -1859,19 +1875,17 @@ extern "C" int sf_step_mirror_streams(sf_handle c, void** stream_even, void** st
   return SF_OK;
 }
 
+static void step_accept_block(sf_context* c, sf_context::StepBlock& b, sf_result** mirror_rec, uint32_t** mirror_cnt,
+                              int32_t* mirror_cap);
+
 // ---- the synchronous body (round 3's step): the NN stage is walked on the host inside the call -----------------------
 // Used when the device walk does not apply (SF_OPT_STEP_DEVICE_WALK off, the two-halves verification) and as the fallback
 // of a device step whose candidate set was too dense for the filter level.
 static int step_issue_sync(sf_context* c, sf_context::StepBlock& b, int32_t slot_base_other, int32_t slot_base_local) {
   const int n_l = c->nn_local.n;
   int rc;
-  sf_result* const mirror_rec = c->step_mirror_records[b.parity];
-  uint32_t* const mirror_cnt = c->step_mirror_counter[b.parity];
-  const int32_t mirror_cap = mirror_rec ? c->step_mirror_cap : b.cap;
-  sf_context::AcceptHost& ab = c->accept_blocks[2];
-  ab.s.records = b.records; ab.s.index = b.index; ab.s.flags = nullptr; ab.s.cap = std::min(b.cap, mirror_cap);
-  ab.s.records2 = mirror_rec; ab.s.counter = mirror_cnt; ab.s.ext_counter = mirror_cnt ? 1 : 0;
-  ab.set = true;
+  sf_result* mirror_rec; uint32_t* mirror_cnt; int32_t mirror_cap;
+  step_accept_block(c, b, &mirror_rec, &mirror_cnt, &mirror_cap);
   b.matches.resize((size_t)std::max(n_l, 1));
   const int sel_before = c->accept_sel;
   c->accept_sel = 2;
@@ -1901,7 +1915,194 @@ static int step_issue_sync(sf_context* c, sf_context::StepBlock& b, int32_t slot
 }
 
 // ---- the device-resident bodies --------------------------------------------------------------------------------------
+// ---- where the step pipeline's streams sit on the hardware ----------------------------------------------------------
+// The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 per priority level by default) and
+// the queues onto the FOUR dispatch pipes of the command processor.  A launch whose workgroups do not all fit on the
+// chip (every verification launch of a batch step) keeps its pipe's dispatcher busy until the last workgroup is placed:
+// a launch on another queue of the SAME pipe waits for that, one on another pipe starts at once
+// (tools/ubench/pipe_probe.hip, profiles/r05m_pipe_probe_*.txt: 0.93-1.01 of the blocking launch's duration against
+// 0.07).  Which pipe a new stream lands on depends on every stream the process created before -- torch's, RCCL's, the
+// caller's -- so the same library ran a step in 0.44 ms or 0.50-0.56 ms depending on whether ONE other stream had been
+// used first (profiles/r05k).  Hence: measure.  Twelve candidate streams (six per priority level) are sorted into
+// classes by "a long launch on X delays a one-wavefront launch on Y"; the lanes' main streams are taken from classes
+// other than the handle's own stream's (and each other's), the second streams -- the nine small dependent launches of
+// the device walk, which must never sit behind a verification's dispatch -- from a class no main stream uses,
+// highest priority first and on different queues where the class has several.  ~10-20 ms, once per handle.
+__global__ void __launch_bounds__(512) k_place_hog(int* sink, int spins) {
+  __shared__ int pad[16384];                           // 64 KB: two workgroups per CU, far fewer than the grid holds
+  pad[threadIdx.x] = (int)threadIdx.x;
+  for (int i = 0; i < spins; ++i) __builtin_amdgcn_s_sleep(127);
+  __syncthreads();
+  if (pad[(threadIdx.x + 1) & 511] == -1) sink[0] = 1;
+}
+__global__ void k_place_probe(int* sink) {
+  if (threadIdx.x == 999) sink[1] = 1;
+}
+
+namespace {
+struct PlaceProbe {
+  int* d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  int tests = 0;
+  // (end of a one-wavefront launch on y - start of a chip-filling launch on x) / duration of the latter; < 0: failed
+  float ratio(hipStream_t x, hipStream_t y) {
+    ++tests;
+    if (hipEventRecord(e0, x) != hipSuccess) return -1.f;
+    hipLaunchKernelGGL(k_place_hog, dim3(4096), dim3(512), 0, x, d, 5);
+    if (hipEventRecord(e1, x) != hipSuccess) return -1.f;
+    hipLaunchKernelGGL(k_place_probe, dim3(1), dim3(64), 0, y, d);
+    if (hipEventRecord(e2, y) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventSynchronize(e2) != hipSuccess) return -1.f;
+    float t_h = 0.f, t_y = 0.f;
+    if (hipEventElapsedTime(&t_h, e0, e1) != hipSuccess || t_h <= 0.f) return -1.f;
+    if (hipEventElapsedTime(&t_y, e0, e2) != hipSuccess) return 0.f;      // (the probe ran before the other queue started)
+    return std::max(0.f, t_y / t_h);
+  }
+};
+}  // namespace
+
+static int place_streams(sf_context* c) {
+  sf_context::StreamPlacement& P = c->placement;
+  if (P.tried) return SF_OK;
+  P.tried = true;
+  if (const char* v = getenv("SF_STREAM_PLACEMENT")) if (atoi(v) == 0) return SF_OK;
+  const auto t_begin = std::chrono::steady_clock::now();
+  constexpr int NC = 12, MAXCLS = 8;
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  hipStream_t S[NC + 1] = {};
+  bool high[NC + 1] = {};
+  int cls[NC + 1], queue_of[NC + 1];
+  PlaceProbe pr;
+  auto cleanup = [&](int rc) {
+    for (int i = 1; i <= NC; ++i) if (S[i]) { (void)hipStreamSynchronize(S[i]); (void)hipStreamDestroy(S[i]); }
+    if (pr.e0) (void)hipEventDestroy(pr.e0);
+    if (pr.e1) (void)hipEventDestroy(pr.e1);
+    if (pr.e2) (void)hipEventDestroy(pr.e2);
+    if (pr.d) (void)hipFree(pr.d);
+    return rc;
+  };
+  S[0] = c->stream;
+  for (int i = 1; i <= NC; ++i) {
+    high[i] = (i & 1) == 0;
+    if (hipStreamCreateWithPriority(&S[i], hipStreamNonBlocking, high[i] ? prio_greatest : 0) != hipSuccess) { S[i] = nullptr; return cleanup(SF_OK); }
+  }
+  if (hipMalloc((void**)&pr.d, 64) != hipSuccess || hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess ||
+      hipEventCreate(&pr.e2) != hipSuccess) return cleanup(SF_OK);
+  // every stream's hardware queue exists before anything is measured (the runtime creates it at the stream's first use)
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 1; i <= NC; ++i) {
+    hipLaunchKernelGGL(k_place_probe, dim3(1), dim3(64), 0, S[i], pr.d);
+    (void)hipStreamSynchronize(S[i]);
+  }
+  if (const char* v = getenv("SF_STREAM_PLACEMENT")) if (atoi(v) >= 3) {
+    fprintf(stderr, "sepfinder: placement matrix (row: chip-filling launch on X; column: small launch on Y; 0 = the handle's stream, even = highest priority)\n      ");
+    for (int y = 0; y <= NC; ++y) fprintf(stderr, " %c%-4d", high[y] ? 'H' : 'n', y);
+    fprintf(stderr, "\n");
+    for (int x = 0; x <= NC; ++x) {
+      fprintf(stderr, "%c%-4d ", high[x] ? 'H' : 'n', x);
+      for (int y = 0; y <= NC; ++y) { if (x == y) fprintf(stderr, "    - "); else fprintf(stderr, " %5.2f", pr.ratio(S[x], S[y])); }
+      fprintf(stderr, "\n");
+    }
+  }
+  // classes: streams a chip-filling launch on one of which delays the others (same pipe, or same queue)
+  int rep[MAXCLS], n_cls = 0;
+  bool failed = false;
+  for (int i = 0; i <= NC && !failed; ++i) {
+    cls[i] = -1;
+    for (int k = 0; k < n_cls && cls[i] < 0; ++k) {
+      float r = pr.ratio(S[rep[k]], S[i]);
+      if (r > 0.3f && r < 0.6f) r = pr.ratio(S[rep[k]], S[i]);      // (something else ran in between: once more)
+      if (r < 0.f) { failed = true; break; }
+      if (r >= 0.5f) cls[i] = k;
+    }
+    if (cls[i] < 0 && !failed) {
+      if (n_cls == MAXCLS) { failed = true; break; }
+      rep[n_cls] = i; cls[i] = n_cls++;
+    }
+  }
+  if (failed || n_cls < 2) {
+    snprintf(P.report, sizeof(P.report), "placement: measurement %s (%d classes): streams as created", failed ? "failed" : "found one class", n_cls);
+    return cleanup(SF_OK);
+  }
+  const int lanes = std::min(std::max(c->step_lanes, 1), SF_STEP_MAX_LANES);
+  bool cls_main[MAXCLS] = {};
+  cls_main[cls[0]] = true;
+  bool taken[NC + 1] = {};
+  auto take = [&](int i) { hipStream_t s = S[i]; S[i] = nullptr; taken[i] = true; return s; };
+  // main streams of lanes 1..: a class no earlier main stream uses, default priority where the class offers it
+  int main_cls[SF_STEP_MAX_LANES] = {}; main_cls[0] = cls[0];
+  for (int k = 1; k < lanes; ++k) {
+    int best = -1;
+    for (int pass = 0; pass < 2 && best < 0; ++pass)
+      for (int i = 1; i <= NC && best < 0; ++i)
+        if (!taken[i] && !cls_main[cls[i]] && (pass == 1 || !high[i])) best = i;
+    if (best < 0) break;                       // (fewer classes than lanes: the remaining lanes get streams as before)
+    main_cls[k] = cls[best];
+    cls_main[cls[best]] = true;
+    P.main[k] = take(best);
+  }
+  // second streams: a class without a main stream -- the one with most candidates -- else the least bad: the fullest class
+  int cnt[MAXCLS] = {}, aux_cls = -1;
+  for (int i = 1; i <= NC; ++i) if (!taken[i]) cnt[cls[i]] += 1;
+  for (int k = 0; k < n_cls; ++k) if (!cls_main[k] && cnt[k] > 0 && (aux_cls < 0 || cnt[k] > cnt[aux_cls])) aux_cls = k;
+  const bool aux_free_pipe = aux_cls >= 0;
+  if (aux_cls < 0) for (int k = 0; k < n_cls; ++k) if (cnt[k] > 0 && (aux_cls < 0 || cnt[k] > cnt[aux_cls])) aux_cls = k;
+  int n_queues = 0;
+  if (aux_cls >= 0) {
+    // queues inside the class: a launch on the SAME queue ends behind the blocking one (ratio >= 1), one on another queue
+    // of the pipe starts when the last workgroup has been placed (ratio ~ 1 - 1 / generations)
+    int members[NC], n_m = 0, qrep[NC];
+    for (int pass = 0; pass < 2; ++pass)       // highest priority first
+      for (int i = 1; i <= NC; ++i) if (!taken[i] && cls[i] == aux_cls && high[i] == (pass == 0)) members[n_m++] = i;
+    for (int m = 0; m < n_m; ++m) {
+      const int i = members[m];
+      queue_of[i] = -1;
+      for (int q = 0; q < n_queues && queue_of[i] < 0; ++q) {
+        const float r = pr.ratio(S[qrep[q]], S[i]);
+        if (r >= 0.985f) queue_of[i] = q;
+      }
+      if (queue_of[i] < 0) { qrep[n_queues] = i; queue_of[i] = n_queues++; }
+    }
+    // deal them out queue by queue: lanes' second streams first, then the synchronous call's
+    hipStream_t* want[SF_STEP_MAX_LANES + 1];
+    int n_w = 0;
+    for (int k = 0; k < lanes; ++k) want[n_w++] = &P.aux[k];
+    want[n_w++] = &P.copy;
+    int w = 0;
+    for (int round = 0; round < n_m && w < n_w; ++round)
+      for (int q = 0; q < n_queues && w < n_w; ++q)
+        for (int m = 0; m < n_m; ++m)
+          if (queue_of[members[m]] == q && !taken[members[m]]) { *want[w++] = take(members[m]); break; }
+  }
+  P.done = true;
+  const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  int off = snprintf(P.report, sizeof(P.report), "placement: %d classes, %d tests, %.1f ms; main classes", n_cls, pr.tests, ms);
+  for (int k = 0; k < lanes && off < (int)sizeof(P.report) - 8; ++k)
+    off += snprintf(P.report + off, sizeof(P.report) - off, " %d%s", main_cls[k], (k == 0 || P.main[k]) ? "" : "?");
+  int n_aux = 0;
+  for (int k = 0; k < SF_STEP_MAX_LANES; ++k) n_aux += P.aux[k] != nullptr;
+  if (off < (int)sizeof(P.report) - 8)
+    snprintf(P.report + off, sizeof(P.report) - off, "; second streams: class %d (%s), %d stream(s) on %d queue(s)%s", aux_cls,
+             aux_free_pipe ? "no main stream on it" : "SHARED with a main stream", n_aux, n_queues, P.copy ? " + 1 for the synchronous call" : "");
+  if (const char* v = getenv("SF_STREAM_PLACEMENT")) if (atoi(v) >= 2) fprintf(stderr, "sepfinder: %s\n", P.report);
+  return cleanup(SF_OK);
+}
+
+extern "C" int sf_stream_placement(sf_handle c, char* buf, size_t n) {
+  if (!c || !buf || n == 0) return SF_EINVAL;
+  snprintf(buf, n, "%s", c->placement.tried ? (c->placement.report[0] ? c->placement.report : "placement: off") : "placement: not measured yet");
+  return SF_OK;
+}
+
 static int stream_with_own_queue(sf_context* c, hipStream_t* out, bool aux) {
+  // a measured place first (place_streams)
+  if (!c->placement.tried) (void)place_streams(c);
+  if (c->placement.done) {
+    hipStream_t& slot = aux ? c->placement.aux[c->cur_lane] : c->placement.main[c->cur_lane];
+    if (slot) { *out = slot; slot = nullptr; return SF_OK; }
+  }
+
   // The runtime multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and a stream that lands
   // on the queue of another runs BEHIND it, not beside it.  Streams of another priority level draw from queues of their
   // own, so unless the process raised the queue budget the library's extra streams get the highest priority.
@@ -1923,6 +2124,9 @@ static void step_accept_block(sf_context* c, sf_context::StepBlock& b, sf_result
   *mirror_rec = c->step_mirror_records[b.parity];
   *mirror_cnt = c->step_mirror_counter[b.parity];
   *mirror_cap = *mirror_rec ? c->step_mirror_cap : b.cap;
+  // no caller mirror: every accepted record also lands in the block's own device buffer (sf_step_result.d_records), so
+  // that a multi-GPU host can hand a RETIRED step's separators to its collective without tying buffers to steps in flight
+  if (!*mirror_rec) *mirror_rec = (sf_result*)b.dev_records.p;
   sf_context::AcceptHost& ab = c->accept_blocks[2];
   ab.s.records = b.records; ab.s.index = b.index; ab.s.flags = nullptr; ab.s.cap = std::min(b.cap, *mirror_cap);
   ab.s.records2 = *mirror_rec; ab.s.counter = *mirror_cnt; ab.s.ext_counter = *mirror_cnt ? 1 : 0;
@@ -2089,6 +2293,7 @@ extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_
   b.settled = false; b.settle_rc = SF_OK;
   c->in_overlapped_step = lanes > 1;            // (sf_use_split: the form the verification takes)
   const bool device = c->step_device_walk && !c->overlap && c->store.slots > 0;
+  c->cur_lane = lane;
   if (lane > 0 && (rc = lane_enter(c, lane)) != SF_OK) { c->in_overlapped_step = false; return rc; }
   // state every lane reads (fp16 copies, coefficients, masks) prepared by another lane since this one last looked?
   if (c->lane_seen_prep[lane] != c->prep_epoch && c->ev_prep) {
@@ -2208,9 +2413,18 @@ extern "C" int sf_step_retire(sf_handle c, sf_step_result* out) {
   out->n_matches = n;
   out->record_of_match = b.record_of_match.data();
   out->records = b.records;
+  out->d_records = c->step_mirror_records[b.parity] ? nullptr : (const sf_result*)b.dev_records.p;
   out->n_records = n_records;
   out->n_accepted = n_accepted;
   out->streamed = b.streamed ? 1 : 0;
+  return SF_OK;
+}
+
+extern "C" int sf_memcpy_device_async(sf_handle c, void* d_dst, const void* d_src, size_t bytes, void* hip_stream) {
+  if (!c || (bytes > 0 && (!d_dst || !d_src))) return SF_EINVAL;
+  if (bytes == 0) return SF_OK;
+  SF_HIP(c, hipSetDevice(c->device));
+  SF_HIP(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, hip_stream ? (hipStream_t)hip_stream : c->stream));
   return SF_OK;
 }
 

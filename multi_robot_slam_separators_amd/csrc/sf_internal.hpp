@@ -312,6 +312,7 @@ struct sf_context {
     int32_t* walk_status = nullptr;    // ... and the NN stage's status (0, or 1 = candidate set denser than the filter level allows)
     int32_t cap = 0;
     Buf dev;                           // device: 64-byte counter block {matches, -, -, -, accept slot counter} + (row, column)[cap]
+    Buf dev_records;                   // device: [cap] the accepted records once more, same slots as `records` (sf_step_result.d_records)
     std::vector<sf_match> matches;     // host walk: the matches
     std::vector<int32_t> slot_of_match, record_of_match, rec_of_slot;
     int32_t n = 0, pairs = 0;
@@ -346,6 +347,19 @@ struct sf_context {
     void* compact_state_ptr = nullptr;
     uint64_t seen_db_epoch = ~0ull;
   } lanes[SF_STEP_MAX_LANES - 1];
+  // Where the pipeline's streams sit on the hardware (sf_api.hip: place_streams).  Measured once, at the first step that
+  // needs a second stream: a launch that does not fit on the chip keeps the dispatcher of its queue's PIPE busy until
+  // its last workgroup is placed, and every other queue of that pipe waits -- so the lanes' main streams are picked
+  // from candidates on different pipes and the second streams (short chains of small launches) from a pipe none of
+  // them uses.  Streams are handed out once; what is left over is destroyed with the handle.
+  struct StreamPlacement {
+    bool tried = false, done = false;
+    hipStream_t main[SF_STEP_MAX_LANES] = {};   // [0] unused: lane 0 runs on the handle's stream
+    hipStream_t aux[SF_STEP_MAX_LANES] = {};
+    hipStream_t copy = nullptr;                  // the second stream of the synchronous speculative call
+    char report[384] = {0};
+  } placement;
+  int cur_lane = 0;                        // the lane sf_step_issue is issuing on
   Buf step_nn;                             // device walk: row minima (f64) | row arg (i32) | row candidate (i32) | packed arg (u64) | status
   hipStream_t aux = nullptr;               // (lane 0's; swapped with the lanes' like `stream`)
   hipEvent_t ev_filter = nullptr, ev_walk = nullptr;

@@ -105,6 +105,7 @@ def load():
         "sf_compact_accepted_device_async": (C.c_int, [vp, vp, i32, vp, vp, vp]),
         "sf_step_issue": (C.c_int, [vp, i32, i32]),
         "sf_step_retire": (C.c_int, [vp, P(_abi.StepResult)]),
+        "sf_memcpy_device_async": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
         "sf_step_mirror": (C.c_int, [vp, vp, vp, i32]),
         "sf_step_mirror_pair": (C.c_int, [vp, vp, vp, vp, vp, i32]),
         "sf_step_mirror_streams": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -131,6 +132,7 @@ def load():
                                                                    P(i32), vp, vp, vp, vp]),
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_select": (C.c_int, [vp, C.c_uint32]),
+        "sf_stream_placement": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
         "sf_prof_reset": (C.c_int, [vp]),
         "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
         "sf_kernel_name": (C.c_char_p, [C.c_int]),
@@ -158,11 +160,11 @@ EXPORTED = [
     "sf_store_add_keyframes_device", "sf_store_size", "sf_store_clear",
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_netvlad_infer_batch_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
-    "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_step_mirror", "sf_step_mirror_pair", "sf_step_mirror_streams", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
+    "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_memcpy_device_async", "sf_step_mirror", "sf_step_mirror_pair", "sf_step_mirror_streams", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_nn_walk_device",
     "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
-    "sf_kernel_name",
+    "sf_kernel_name", "sf_stream_placement",
 ]
 
 
@@ -505,7 +507,14 @@ class SeparatorFinder:
             return a.copy() if copy else a
         return (view(r.matches, n, _abi.MATCH_DTYPE), view(r.record_of_match, n, np.int32),
                 view(r.records, nr, _abi.RESULT_DTYPE),
-                {"n_matches": n, "n_records": nr, "n_accepted": r.n_accepted, "streamed": bool(r.streamed)})
+                {"n_matches": n, "n_records": nr, "n_accepted": r.n_accepted, "streamed": bool(r.streamed),
+                 "d_records": r.d_records or 0})
+
+    def memcpy_device_async(self, d_dst, d_src, nbytes, stream=None):
+        """Device-to-device copy (raw pointers) on `stream` (a hipStream_t as an integer; None: the handle's stream), e.g. a
+        retired step's d_records -> a send buffer."""
+        self._check(self._L.sf_memcpy_device_async(self._h, C.c_void_p(d_dst), C.c_void_p(d_src), int(nbytes),
+                                                   C.c_void_p(stream) if stream else None))
 
     def step_mirror(self, d_records2, d_counter, cap):
         """Second (device) destination of every accepted record + the caller's slot counter; (None, None, 0) removes it."""
@@ -627,6 +636,12 @@ class SeparatorFinder:
                 if self._L.sf_kernel_name(k).decode() in names:
                     mask |= 1 << k
         self._check(self._L.sf_prof_select(self._h, mask))
+
+    def stream_placement(self):
+        """One line on where the step pipeline's streams sit on the dispatch pipes (include/sf_experimental.h)."""
+        buf = C.create_string_buffer(512)
+        self._check(self._L.sf_stream_placement(self._h, buf, 512))
+        return buf.value.decode()
 
     def prof_reset(self):
         self._check(self._L.sf_prof_reset(self._h))

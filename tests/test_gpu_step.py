@@ -501,3 +501,69 @@ def test_step_queries_across_the_form_and_chunk_boundaries(n):
             assert mm.tobytes() == m.tobytes()
             assert np.array_equal(rom >= 0, ok) and info["n_accepted"] == int(ok.sum())
             assert recs[rom[ok]].tobytes() == ref[ok].tobytes()
+
+
+def test_step_result_carries_a_device_copy_of_the_records():
+    """sf_step_result.d_records: the accepted records of a retired step once more in device memory, same slots as the
+    pinned host block (what a multi-GPU host hands to its all-gather after the retire); absent while a mirror is set."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(877, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+        for walk in (1, 0):
+            f.set_option(_abi.SF_OPT_STEP_DEVICE_WALK, walk)
+            for _ in range(3):
+                f.step_issue(sa, sb)
+            for _ in range(3):
+                out = f.step_retire(copy=True)
+                _check_step(out, m_ref, res_ref, True)
+                n = out[3]["n_records"]
+                assert out[3]["d_records"] != 0 and n > 0
+                d = torch.zeros((n, RB), dtype=torch.uint8, device=DEV)
+                f.memcpy_device_async(d.data_ptr(), out[3]["d_records"], n * RB)      # (None: the handle's stream)
+                f.synchronize()
+                assert d.cpu().numpy().tobytes() == out[2].tobytes()
+        send = torch.zeros((n_kf + n_kf // 8 + 257, RB), dtype=torch.uint8, device=DEV)
+        f.step_mirror(send[1:].data_ptr(), send.data_ptr(), n_kf + n_kf // 8 + 256)
+        f.step_issue(sa, sb)
+        assert f.step_retire()[3]["d_records"] == 0
+        f.step_mirror(None, None, 0)
+
+
+def test_streams_of_the_step_pipeline_are_placed_by_measurement():
+    """The step pipeline's streams are picked from candidates by measuring which of them dispatch beside each other
+    (sf_api.hip place_streams): the report says so once steps on several streams have run, names a class for every lane's
+    main stream, and the steps' bytes are the separate calls' -- also with the streams given in another order (a foreign
+    stream used first shifts every later stream's hardware queue)."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(977, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    foreign = torch.cuda.Stream()
+    with torch.cuda.stream(foreign):
+        torch.zeros(1 << 16, dtype=torch.uint8, device=DEV).clone()
+    foreign.synchronize()
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        assert "not measured" in f.stream_placement()
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        m_ref, res_ref = _two_calls(f, sa, sb, n_kf)
+        for _ in range(6):
+            f.step_issue(sa, sb)
+        for _ in range(6):
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        rep = f.stream_placement()
+        assert rep.startswith("placement:"), rep
+        if "classes," in rep:             # (measured: at least two classes, a class per lane's main stream)
+            assert int(rep.split("placement: ")[1].split(" classes")[0]) >= 2, rep
+            assert "main classes" in rep and "second streams: class" in rep, rep
