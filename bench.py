@@ -926,7 +926,7 @@ def main():
     retired = [0]
     # the exchanges' own stream, at the highest priority like RCCL's (TORCH_NCCL_HIGH_PRIORITY, set in main()): their
     # launches are a handful of small copies per step that must not wait behind a verification's dispatch (with both at
-    # the default priority a step took 0.488 ms at world size 1, with both raised 0.462 -- profiles/r05p; N = 1: 0.446)
+    # the default priority a step took 0.488 ms at world size 1, with both raised 0.462 -- profiles/r04v_placement, run p; N = 1: 0.446)
     xstream = torch.cuda.Stream(priority=-1) if dist_on and coll_dev.type == "cuda" else None
     if pipelined and dist_cuda and os.environ.get("BENCH_ONE_EXCHANGE_BUFFER") is None:
         exchs.append(dist.RecordExchange(_abi.RESULT_DTYPE.itemsize, n_kf + n_kf // 8 + 256, n_kf // 4 + 256, coll_dev))

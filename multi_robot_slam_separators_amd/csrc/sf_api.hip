@@ -1496,7 +1496,7 @@ extern "C" int sf_find_matches_and_verify_device(sf_handle c, int32_t slot_base_
       // Streams of another priority level get queues of their own, so unless the process raised the queue budget
       // (bench.py sets GPU_MAX_HW_QUEUES=8, measured slightly better than the priority) this stream is created
       // with the highest priority; its work (exact NN re-evaluation, small copies) is what the host waits for.
-      // (round 5: the stream's place is measured -- place_streams, further down -- and only if that fails created blind)
+      // (round 4, late: the stream's place is measured -- place_streams, further down -- and only if that fails created blind)
       int prio_least = 0, prio_greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
       const char* hwq = getenv("GPU_MAX_HW_QUEUES");
@@ -1920,10 +1920,10 @@ static int step_issue_sync(sf_context* c, sf_context::StepBlock& b, int32_t slot
 // the queues onto the FOUR dispatch pipes of the command processor.  A launch whose workgroups do not all fit on the
 // chip (every verification launch of a batch step) keeps its pipe's dispatcher busy until the last workgroup is placed:
 // a launch on another queue of the SAME pipe waits for that, one on another pipe starts at once
-// (tools/ubench/pipe_probe.hip, profiles/r05m_pipe_probe_*.txt: 0.93-1.01 of the blocking launch's duration against
+// (tools/ubench/pipe_probe.hip, profiles/r04v_placement/pipe_probe_*.txt: 0.93-1.01 of the blocking launch's duration against
 // 0.07).  Which pipe a new stream lands on depends on every stream the process created before -- torch's, RCCL's, the
 // caller's -- so the same library ran a step in 0.44 ms or 0.50-0.56 ms depending on whether ONE other stream had been
-// used first (profiles/r05k).  Hence: measure.  Twelve candidate streams (six per priority level) are sorted into
+// used first (profiles/r04v_placement, run k).  Hence: measure.  Twelve candidate streams (six per priority level) are sorted into
 // classes by "a long launch on X delays a one-wavefront launch on Y"; the lanes' main streams are taken from classes
 // other than the handle's own stream's (and each other's), the second streams -- the nine small dependent launches of
 // the device walk, which must never sit behind a verification's dispatch -- from a class no main stream uses,
