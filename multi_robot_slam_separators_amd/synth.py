@@ -116,6 +116,11 @@ def make_true_partner(rng, fa, T_gt, overlap=0.4, noise=0.02, flip=0.05):
     return _abi.FeatureArrays(desc, xyz, _keypoints(u, v)), gt
 
 
+def without_3d(fa):
+    """The same keyframe without 3D points (keypoints and descriptors only)."""
+    return _abi.FeatureArrays(fa.desc, np.zeros((0, 3), np.float32), fa.kpts)
+
+
 def float_descriptors(fa, dims, rng=None, jitter=0.0):
     """The float32-descriptor twin of a keyframe with binary descriptors (sf_params.desc_type 1): dimension d of a row is
     +-1 by bit d of the binary descriptor (+ Gaussian jitter), so a true partner's rows stay close to their originals

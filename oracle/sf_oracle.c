@@ -987,70 +987,101 @@ static int sfo_registration_pass(const sf_params* p, const sf_features* from, co
   /* :928 if (wordsTo.size()) ... else "Missing correspondences" */
   if (n_words_to_2d > 0) {
     const int calibrated = p->image_width > 0 && p->image_height > 0 && p->fx > 0.0 && p->fy > 0.0;
-    /* 3D-3D gate :1117-1118 ; PnP gate :1059 (isValidForProjection) and :1070-1071 */
-    const int gate = p->estimation_type == 1
-                         ? (calibrated && n_words_from >= p->min_inliers && n_words_to_2d >= p->min_inliers)
-                         : (n_words_from >= p->min_inliers && n_words_to >= p->min_inliers);
-    if (gate) {
-      sfo_motion mo;
-      uint8_t* imask = (uint8_t*)calloc((size_t)(*nc > 0 ? *nc : 1), 1);
-      if (!imask) return SF_ENOMEM;
-      rc = p->estimation_type == 1
-               ? sfo_estimate_motion_3d2d(p, from->xyz, to->kpts, to->n3d > 0 ? to->xyz : NULL, cf, ct, *nc, &mo, imask)
-               : sfo_estimate_motion_3d3d(p, from->xyz, to->xyz, cf, ct, *nc, &mo, imask);
-      if (rc != SF_OK) { free(imask); return rc; }
-      out->cov_diag = mo.variance;
-      out->cov_diag_ang = mo.variance_ang;
-      out->inliers = mo.inliers;
-      out->matches = mo.matches;
-      if (!mo.is_null) {
-        memcpy(out->transform, mo.transform, sizeof(out->transform));
-        out->is_null = 0;
-        if (p->force_3dof) sfo_to3dof(out->transform);      /* :1100-1102, :1141-1143 */
-      }
-      if (!p->forward_est_only && p->estimation_type == 0) {
-        /* dir = 1 (:936-978, :1113-1152): A = to, B = from; same words, same id order */
-        sfo_motion m1;
-        uint8_t* imask1 = (uint8_t*)calloc((size_t)(*nc > 0 ? *nc : 1), 1);
-        if (!imask1) { free(imask); return SF_ENOMEM; }
-        rc = sfo_estimate_motion_3d3d(p, to->xyz, from->xyz, ct, cf, *nc, &m1, imask1);
-        if (rc != SF_OK) { free(imask); free(imask1); return rc; }
-        if (!m1.is_null && p->force_3dof) sfo_to3dof(m1.transform);
-        /* :1155-1189 union of the two directions' inlier ids (matches: the same ids in both directions) */
-        int uni = 0;
-        for (int i = 0; i < *nc; ++i) uni += (imask[i] | imask1[i]) ? 1 : 0;
-        out->inliers = uni;
-        out->matches = mo.matches > m1.matches ? mo.matches : m1.matches;
-        /* :1376-1394 */
-        if (!m1.is_null) {
-          float inv[12];
-          sfo_rigid_inverse(m1.transform, inv);
-          if (out->is_null) {
-            memcpy(out->transform, inv, sizeof(inv));
-            out->is_null = 0;
-            out->cov_diag = m1.variance;
-            out->cov_diag_ang = m1.variance_ang;
-          } else {
-            float mid[12];
-            sfo_interpolate_half(out->transform, inv, mid);
-            memcpy(out->transform, mid, sizeof(mid));
-            out->cov_diag = (mo.variance + m1.variance) / 2.0;
-            out->cov_diag_ang = (mo.variance_ang + m1.variance_ang) / 2.0;
-          }
+    const int pnp = p->estimation_type == 1;
+    /* wordsFrom.size(): every "from" row is a word of the global matcher (:856-875, ids distinct by construction); the
+     * guided matcher makes a word of every row with a finite 3D point (:766-774, :793-802) */
+    const int n_words_from_2d = *guided ? n_words_from : kf;
+    /* dir = 0 (:936-960 A = from, B = to): 3D-3D gate :1117-1118 ; PnP gate :1059 (isValidForProjection) and :1070-1071.
+     * dir = 1 (:961-977 A = to, B = from; Vis/ForwardEstOnly = false only): the same gates with the roles swapped */
+    const int gate[2] = {
+        pnp ? (calibrated && n_words_from >= p->min_inliers && n_words_to_2d >= p->min_inliers)
+            : (n_words_from >= p->min_inliers && n_words_to >= p->min_inliers),
+        p->forward_est_only ? 0
+            : pnp ? (calibrated && n_words_to >= p->min_inliers && n_words_from_2d >= p->min_inliers)
+                  : (n_words_to >= p->min_inliers && n_words_from >= p->min_inliers)};
+    sfo_motion mo[2];
+    uint8_t* imask[2] = {NULL, NULL};
+    for (int dir = 0; dir < 2; ++dir) {
+      memset(&mo[dir], 0, sizeof(mo[dir]));
+      mo[dir].is_null = 1;
+      mo[dir].variance = 1.0;            /* :934-935 covariances[dir] = eye(6) */
+      mo[dir].variance_ang = 1.0;
+      imask[dir] = (uint8_t*)calloc((size_t)(*nc > 0 ? *nc : 1), 1);
+      if (!imask[dir]) { free(imask[0]); return SF_ENOMEM; }
+    }
+    rc = SF_OK;
+    for (int dir = 0; dir < 2 && rc == SF_OK; ++dir) {
+      if (!gate[dir]) continue;
+      const sf_features* A = dir == 0 ? from : to;
+      const sf_features* B = dir == 0 ? to : from;
+      const uint16_t* ca = dir == 0 ? cf : ct;
+      const uint16_t* cb = dir == 0 ? ct : cf;
+      /* (PnP, dir = 1: the guess -- transforms[0].inverse(), :1087 -- does not enter this restatement's solver, see
+       *  sf_oracle_pnp.c; the camera model is the one camera of sf_params for both frames) */
+      rc = pnp ? sfo_estimate_motion_3d2d(p, A->xyz, B->kpts, B->n3d > 0 ? B->xyz : NULL, ca, cb, *nc, &mo[dir], imask[dir])
+               : sfo_estimate_motion_3d3d(p, A->xyz, B->xyz, ca, cb, *nc, &mo[dir], imask[dir]);
+      if (rc == SF_OK && !mo[dir].is_null && p->force_3dof) sfo_to3dof(mo[dir].transform);   /* :1100-1102, :1141-1143 */
+    }
+    if (rc != SF_OK) { free(imask[0]); free(imask[1]); return rc; }
+    if (gate[0] || gate[1]) {
+      /* :1155-1189 union of the two directions' inlier and match ids.  3D-3D: both directions match the ids whose two
+       * points are finite; PnP: direction d matches the ids whose A-side point is finite. */
+      int uni = 0, uni_m = 0;
+      for (int i = 0; i < *nc; ++i) {
+        uni += (imask[0][i] | imask[1][i]) ? 1 : 0;
+        if (pnp) {
+          const int m0 = gate[0] && sfo_finite3(from->xyz + 3 * (size_t)cf[i]);
+          const int m1 = gate[1] && sfo_finite3(to->xyz + 3 * (size_t)ct[i]);
+          uni_m += (m0 | m1) ? 1 : 0;
         }
-        free(imask1);
       }
-      /* :1192-1197 bundle adjustment of the forward transform (the covariance keeps the motion estimate's value) */
-      if (p->bundle_adjustment > 0 && !mo.is_null && mo.inliers > 0 && n_words_from > 0 && n_words_to_2d > 0) {
-        int n_inl = mo.inliers, null2 = 0;
-        rc = sfo_bundle_adjust(p, from->xyz, from->kpts, to->n3d > 0 ? to->xyz : NULL, to->kpts, cf, ct, imask, *nc,
+      out->inliers = uni;
+      out->matches = pnp ? uni_m : (mo[0].matches > mo[1].matches ? mo[0].matches : mo[1].matches);
+      out->cov_diag = mo[0].variance;
+      out->cov_diag_ang = mo[0].variance_ang;
+      if (!mo[0].is_null) {
+        memcpy(out->transform, mo[0].transform, sizeof(out->transform));
+        out->is_null = 0;
+      }
+      /* :1192-1197 bundle adjustment of the forward transform over the union of the inliers; it ends with
+       * transforms[1].setNull() (:1369), so the backward estimate then only contributed its inliers */
+      /* (a word that is an inlier of the backward PnP only may have no finite point in the "from" frame; the
+       *  reference hands that point to g2o as it is -- [upstream] behaviour undefined -- here such words stay out of the
+       *  adjustment and of the inlier count behind it: DESIGN.md section 3) */
+      int ba_ran = 0, uni_ba = 0;
+      for (int i = 0; i < *nc && from->n3d > 0; ++i)
+        uni_ba += ((imask[0][i] | imask[1][i]) && sfo_finite3(from->xyz + 3 * (size_t)cf[i])) ? 1 : 0;
+      if (p->bundle_adjustment > 0 && !mo[0].is_null && uni_ba > 0 && n_words_from > 0 && n_words_to_2d > 0) {
+        uint8_t* um = imask[0];
+        for (int i = 0; i < *nc; ++i)
+          um[i] = (uint8_t)((imask[0][i] | imask[1][i]) && sfo_finite3(from->xyz + 3 * (size_t)cf[i]));
+        int n_inl = uni_ba, null2 = 0;
+        rc = sfo_bundle_adjust(p, from->xyz, from->kpts, to->n3d > 0 ? to->xyz : NULL, to->kpts, cf, ct, um, *nc,
                                out->transform, &n_inl, &null2, NULL);
-        if (rc != SF_OK) { free(imask); return rc; }
+        if (rc != SF_OK) { free(imask[0]); free(imask[1]); return rc; }
         out->inliers = n_inl;
         out->is_null = null2;
+        ba_ran = 1;
       }
-      free(imask);
+      /* :1376-1394 */
+      if (!ba_ran && !mo[1].is_null) {
+        float inv[12];
+        sfo_rigid_inverse(mo[1].transform, inv);
+        if (out->is_null) {
+          memcpy(out->transform, inv, sizeof(inv));
+          out->is_null = 0;
+          out->cov_diag = mo[1].variance;
+          out->cov_diag_ang = mo[1].variance_ang;
+        } else {
+          float mid[12];
+          sfo_interpolate_half(out->transform, inv, mid);
+          memcpy(out->transform, mid, sizeof(mid));
+          out->cov_diag = (mo[0].variance + mo[1].variance) / 2.0;
+          out->cov_diag_ang = (mo[0].variance_ang + mo[1].variance_ang) / 2.0;
+        }
+      }
     }
+    free(imask[0]); free(imask[1]);
   }
   if (!out->is_null && p->force_3dof) sfo_to3dof(out->transform);   /* myRegistration.cpp:269-276 */
   return SF_OK;
@@ -1095,7 +1126,6 @@ int sfo_estimate_transform_dbg(const sf_params* p, const sf_features* from, cons
   if (p->estimation_type != 0 && p->estimation_type != 1) return SF_EINVAL;
   if (p->desc_type != 0 && p->desc_type != 1) return SF_EINVAL;
   if (p->desc_type == 1 && ((from->rows > 0 && from->cols % 4) || (to->rows > 0 && to->cols % 4))) return SF_EINVAL;
-  if (!p->forward_est_only && (p->estimation_type != 0 || p->bundle_adjustment != 0)) return SF_EINVAL;
   if (p->estimation_type == 1 && (p->pnp_flags != 0 || p->pnp_refine_iterations < 0)) return SF_EINVAL;
   if (p->bundle_adjustment != 0 &&
       (p->bundle_adjustment != 1 || !(p->image_width > 0 && p->image_height > 0 && p->fx > 0.0 && p->fy > 0.0) ||

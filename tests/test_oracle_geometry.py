@@ -401,7 +401,41 @@ def test_bidirectional_estimate(oracle):
             both += 1
             assert np.linalg.norm(r0["position"] - r1["position"]) < 0.05
     assert both >= 6
-    p2 = _abi.copy_params(p1)
-    p2.estimation_type = 1
-    with pytest.raises(RuntimeError):
-        oracle.estimate_transform(p2, A[0], B[0])
+
+
+@pytest.mark.parametrize("est,ba", [(1, 0), (0, 1), (1, 1)])
+def test_bidirectional_estimate_with_pnp_and_bundle_adjustment(oracle, est, ba):
+    """Vis/ForwardEstOnly = false with the PnP estimator and / or bundle adjustment (myRegistrationVis.cpp:936-978,
+    1155-1197, 1369, 1376-1394): the backward estimate swaps the frames' roles; inliers and matches are unions; with
+    bundle adjustment the forward transform is refined over the union and the backward transform is dropped, without it
+    the result is the half-way interpolation.  A frame without 3D points takes one direction out (PnP: the one whose 3D
+    side it would be)."""
+    A, B, is_true, Ts = synth.make_pairs(79, 16, k=300, true_frac=0.75)
+    p0 = synth.camera_params()
+    p0.iterations = 200
+    p0.estimation_type = est
+    p0.bundle_adjustment = ba
+    p1 = _abi.copy_params(p0)
+    p1.forward_est_only = 0
+    both = moved = 0
+    for a, b in zip(A, B):
+        r0, r1 = oracle.estimate_transform(p0, a, b), oracle.estimate_transform(p1, a, b)
+        assert r1["matches_pass1"] >= r0["matches_pass1"]
+        if not ba:
+            assert r1["inliers_pass1"] >= r0["inliers_pass1"]
+        if r0["success"] and r1["success"]:
+            both += 1
+            assert np.linalg.norm(r0["position"] - r1["position"]) < (0.15 if est else 0.08)
+            moved += int(r0["position"].tobytes() != r1["position"].tobytes())
+    assert both >= 6 and (ba or moved >= 4)       # (with bundle adjustment the backward estimate only adds inliers)
+    if est == 1:
+        # "to" without 3D points: only the forward PnP can run -> the forward-only result, bit for bit; "from" without:
+        # only the backward one -> the inverse of the backward transform (forward-only finds nothing)
+        n_back = 0
+        for a, b in zip(A[:8], B[:8]):
+            b2 = synth.without_3d(b)
+            assert oracle.estimate_transform(p1, a, b2).tobytes() == oracle.estimate_transform(p0, a, b2).tobytes()
+            a2 = synth.without_3d(a)
+            assert not oracle.estimate_transform(p0, a2, b)["success"]
+            n_back += int(oracle.estimate_transform(p1, a2, b)["success"])
+        assert n_back >= 3 or ba
