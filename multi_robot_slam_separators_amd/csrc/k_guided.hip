@@ -554,9 +554,13 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   const int words_to_2d = outside ? 0 : Kt;
   const int words_to = (outside || mT.y <= 0) ? 0 : Kt;
   const bool pnp = P.estimation_type == 1;   // guided matching implies a calibrated camera
-  const bool motion = words_to_2d > 0 && words_from >= P.min_inliers &&
-                      (pnp ? words_to_2d : words_to) >= P.min_inliers;      // :1117-1118 / :1070-1071
-  const bool survivor = motion && n_corr >= P.min_inliers && n_corr >= (pnp ? 4 : 3);
+  // (PnP with Vis/ForwardEstOnly = false: either direction's gate, and every pair with a correspondence goes on -- as
+  //  in the global matcher, k_match.hip)
+  const bool both = pnp && P.bidirectional;
+  const bool motion = words_to_2d > 0 &&
+                      ((words_from >= P.min_inliers && (pnp ? words_to_2d : words_to) >= P.min_inliers) ||    // :1117-1118 / :1070-1071
+                       (both && words_to >= P.min_inliers && words_from >= P.min_inliers));
+  const bool survivor = both ? (motion && n_corr > 0) : (motion && n_corr >= P.min_inliers && n_corr >= (pnp ? 4 : 3));
   if (motion && !survivor) {
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
     for (int i = tid; i < n_corr; i += NT) {

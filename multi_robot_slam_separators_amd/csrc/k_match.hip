@@ -232,9 +232,13 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
   const int words_to = (mT.y > 0) ? unique_to : 0;
   // est: 0 = 3D->3D gate (:1117-1118); 1 = PnP gate (:1070-1071, 2D words of the "to" frame);
   //      2 = PnP without a calibrated camera (:1059-1065): the estimation never runs
+  //      3 = PnP, both directions (Vis/ForwardEstOnly = false): either gate; every pair with a correspondence goes on,
+  //          the estimates count their own matches (the union of the two is not this kernel's to know)
   const bool motion = est == 0 ? (unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers)
-                               : (est == 1 && unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers);
-  const bool survivor = motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4);
+                    : est == 1 ? (unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers)
+                               : (est == 3 && unique_to > 0 && ((words_from >= min_inliers && unique_to >= min_inliers) ||
+                                                                (words_to >= min_inliers && Kf >= min_inliers)));
+  const bool survivor = est == 3 ? (motion && n_corr > 0) : (motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4));
   if (motion && !survivor) {
     const float* xF = st.xyz + (size_t)sF * kcap * 3;
     const float* xT = st.xyz + (size_t)sT * kcap * 3;
@@ -730,9 +734,13 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
   const int words_to = (mT.y > 0) ? unique_to : 0;
   // est: 0 = 3D->3D gate (:1117-1118); 1 = PnP gate (:1070-1071, 2D words of the "to" frame);
   //      2 = PnP without a calibrated camera (:1059-1065): the estimation never runs
+  //      3 = PnP, both directions (Vis/ForwardEstOnly = false): either gate; every pair with a correspondence goes on,
+  //          the estimates count their own matches (the union of the two is not this kernel's to know)
   const bool motion = est == 0 ? (unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers)
-                               : (est == 1 && unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers);
-  const bool survivor = motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4);
+                    : est == 1 ? (unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers)
+                               : (est == 3 && unique_to > 0 && ((words_from >= min_inliers && unique_to >= min_inliers) ||
+                                                                (words_to >= min_inliers && Kf >= min_inliers)));
+  const bool survivor = est == 3 ? (motion && n_corr > 0) : (motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4));
   if (motion && !survivor) {
     const float* xF = st.xyz + (size_t)sF * kcap * 3;
     const float* xT = st.xyz + (size_t)sT * kcap * 3;

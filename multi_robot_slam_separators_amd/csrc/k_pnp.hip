@@ -304,10 +304,16 @@ struct PnpTail {
 };
 
 // Body of one PnP pass for ONE pair (the calling 256-thread workgroup); smem_raw is the workgroup's dynamic LDS.
+// DIR = 1: the backward estimate of Vis/ForwardEstOnly = false (myRegistrationVis.cpp:961-977: A = "to", B = "from" --
+// the 3D points of "to" against the keypoints of "from"; the stage kernel only).  `mask_out` (stage kernel, both
+// directions): one byte per "from" feature of the pair, set for this estimate's inliers; `guided` (with mask_out): the
+// pass's correspondences come from guided matching (decides what the 2D words of "from" are, sf_pnp_dir_gate).
+template <int DIR = 0>
 __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                          const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                          const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
-                                         const DeviceParams& P, unsigned char* smem_raw, int trace_base = 0) {
+                                         const DeviceParams& P, unsigned char* smem_raw, int trace_base = 0,
+                                         uint8_t* mask_out = nullptr, bool guided = false) {
   // (trace_base: first of five timestamp slots of the diagnostic build -- gather, RANSAC, first solve, refinement
   //  rounds, pose + covariance; SF_TRACE_MARK compiles to nothing in the product)
   const int tid = threadIdx.x;
@@ -317,7 +323,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   const PnpTail none = {nullptr, nullptr, nullptr, 0, false};
   (void)trace_base;
   const int max_it = P.iterations > 0 ? P.iterations : 0;
-  const bool to_has_3d = st.meta[sT].y > 0;   // the "to" frame carries 3D points (selects the covariance form)
+  const bool to_has_3d = st.meta[DIR ? sF : sT].y > 0;   // the B frame carries 3D points (selects the covariance form)
 
   PnpLds L;
   {
@@ -345,8 +351,19 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   const uint32_t* cl = corr + (size_t)pair * kcap;
   const float* xF = st.xyz + (size_t)sF * kcap * 3;
   const float* xT = st.xyz + (size_t)sT * kcap * 3;
-  const float4* kT = st.kp + (size_t)sT * kcap;
+  const float4* kT = st.kp + (size_t)(DIR ? sF : sT) * kcap;      // (keypoints of the B frame)
   const float cxf = (float)P.cx, cyf = (float)P.cy;
+  if (P.bidirectional && !sf_pnp_dir_gate(DIR, hdr[pair], st.meta[sF].x, guided, P.min_inliers)) {
+    // this direction's gate (:1059, :1070-1071) is closed: covariances[dir] stays the identity, no matches, no inliers
+    if (tid == 0) {
+      PassState z;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) z.T[i] = 0.f;
+      z.var = 1.0; z.var_ang = 1.0; z.is_null = 1; z.inliers = 0; z.matches = 0; z.pad = 0;
+      pass[pair] = z;
+    }
+    return none;
+  }
   if (tid < 16) L.misc[tid] = 0;
   __syncthreads();
   int m = 0;
@@ -357,9 +374,9 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     uint32_t c = 0;
     if (i < n_corr) {
       c = cl[i];
-      const float* a = xF + 3 * (c & 0xFFFFu);
+      const float* a = DIR ? xT + 3 * (c >> 16) : xF + 3 * (c & 0xFFFFu);
       ax = a[0]; ay = a[1]; az = a[2];
-      const float4 kp = kT[c >> 16];
+      const float4 kp = kT[DIR ? (c & 0xFFFFu) : (c >> 16)];
       ox = kp.x - cxf; oy = kp.y - cyf;
       ok = sfd::finite3(ax, ay, az);
     }
@@ -565,6 +582,9 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
 
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return none; }
   if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 3);
+  if (mask_out)
+    for (int i = tid; i < m; i += SF_BLOCK)
+      if (inl[i]) mask_out[L.cidx[i] & 0xFFFFu] = 1;
   ps.inliers = n_inl;
   if (n_inl < P.min_inliers) {
     if (tid == 0) pass[pair] = ps;
@@ -607,7 +627,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     for (int i = tid; i < m4; i += SF_BLOCK) {
       float v1 = __int_as_float(0x7F800000), v2 = __int_as_float(0x7F800000);
       if (i < m && inl[i]) {
-        const float* b = xT + 3 * (L.cidx[i] >> 16);
+        const float* b = DIR ? xF + 3 * (L.cidx[i] & 0xFFFFu) : xT + 3 * (L.cidx[i] >> 16);
         const float bx = b[0], by = b[1], bz = b[2];
         if (sfd::finite3(bx, by, bz)) {
           const float4 a = L.obj[i];
@@ -648,16 +668,19 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   return PnpTail{L.obj, L.cidx, inl, m, true};
 }
 
-template <bool BA>
+template <bool BA, int DIR = 0>
 __global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
 k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
-      PassState* __restrict__ pass, int extra_3dof, DeviceParams P) {
+      PassState* __restrict__ pass, int extra_3dof, DeviceParams P, uint8_t* __restrict__ mask = nullptr,
+      const uint8_t* __restrict__ guided_flag = nullptr) {
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = list[blockIdx.x];
-  const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr, hdr, pass, P, smem_raw);
+  const PnpTail tail = pnp_body<DIR>(st, pair, pair_from, pair_to, corr, hdr, pass, P, smem_raw, 0,
+                                     mask ? mask + (size_t)pair * st.kcap : nullptr,
+                                     guided_flag != nullptr && guided_flag[pair] != 0);
   if constexpr (BA) {
     // myRegistrationVis.cpp:1192-1370: two-view bundle adjustment of this pass's estimate
     if (P.bundle_adjustment && tail.ran)
@@ -669,6 +692,66 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
     for (int t = 0; t < extra_3dof; ++t) sfd::to3dof_canon(pass[pair].T);
 }
 
+// Vis/ForwardEstOnly = false with the PnP estimator: the two directions' estimates of a pass merged as
+// myRegistrationVis.cpp:1155-1189 (union of the inlier ids and of the match ids -- direction d matches the ids whose
+// A-side point is finite, if its gate was open) and :1376-1394 (inverse of the backward transform; interpolate(0.5) when
+// both exist, covariance their mean).  One wavefront per pair.
+__global__ void __launch_bounds__(64)
+k_merge_directions_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+                       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+                       const uint8_t* __restrict__ guided_flag, PassState* __restrict__ fwd,
+                       const PassState* __restrict__ back, const uint8_t* __restrict__ mask_f,
+                       const uint8_t* __restrict__ mask_b, int min_inliers, int extra_3dof) {
+  if ((int)blockIdx.x >= *counter) return;
+  const int pair = list[blockIdx.x], lane = threadIdx.x, kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  const CorrHeader h = hdr[pair];
+  const bool guided = guided_flag != nullptr && guided_flag[pair] != 0;
+  const bool g0 = sf_pnp_dir_gate(0, h, st.meta[sF].x, guided, min_inliers);
+  const bool g1 = sf_pnp_dir_gate(1, h, st.meta[sF].x, guided, min_inliers);
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const uint32_t* cl = corr + (size_t)pair * kcap;
+  int uni = 0, uni_m = 0;
+  for (int i = lane; i < kcap; i += 64) uni += (mask_f[(size_t)pair * kcap + i] | mask_b[(size_t)pair * kcap + i]) ? 1 : 0;
+  for (int i = lane; i < h.n_corr; i += 64) {
+    const uint32_t c = cl[i];
+    bool m = false;
+    if (g0) { const float* a = xF + 3 * (c & 0xFFFFu); m = sfd::finite3(a[0], a[1], a[2]); }
+    if (g1 && !m) { const float* b = xT + 3 * (c >> 16); m = sfd::finite3(b[0], b[1], b[2]); }
+    uni_m += m ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { uni += __shfl_xor(uni, off); uni_m += __shfl_xor(uni_m, off); }
+  if (lane != 0) return;
+  PassState a = fwd[pair];
+  const PassState b = back[pair];
+  a.inliers = uni;
+  a.matches = uni_m;
+  if (!b.is_null) {
+    float inv[12];
+    sfd::rigid_inverse_canon(b.T, inv);
+    if (a.is_null) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.T[i] = inv[i];
+      a.is_null = 0;
+      a.var = b.var;
+      a.var_ang = b.var_ang;
+    } else {
+      float mid[12];
+      sfd::interpolate_half_canon(a.T, inv, mid);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.T[i] = mid[i];
+      a.var = (a.var + b.var) / 2.0;
+      a.var_ang = (a.var_ang + b.var_ang) / 2.0;
+    }
+  }
+  if (!a.is_null)
+    for (int t = 0; t < extra_3dof; ++t) sfd::to3dof_canon(a.T);
+  fwd[pair] = a;
+}
+
 }  // namespace
 
 size_t sf_pnp_lds_bytes(int kcap, int iterations) { return sf_pnp_lds_bytes_dev(kcap, iterations); }
@@ -678,24 +761,50 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
   const bool ba = c->dparams.bundle_adjustment != 0;
   const size_t lds = ((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "PnP workgroup needs %zu B of LDS (> 160 KiB)", lds);
+  const bool bidir = c->dparams.bidirectional != 0;       // (never together with bundle adjustment: sf_create)
   bool& attr = ba ? c->pnp_ba_attr_set : c->pnp_attr_set;
   if (!attr) {   // per handle = per device
     if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else {
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
+  const int32_t* list = (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p);
+  const int32_t* counter = counters + (pass == 1 ? 0 : 2);
+  const uint32_t* corr = (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p);
+  const CorrHeader* hdr = (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p);
+  PassState* ps = (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p);
+  const int end_3dof = c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0;
+  // (pass 1 always matches globally; pass 2's correspondences are the guided matcher's where its flag says so)
+  const uint8_t* guided_flag = pass == 2 ? (const uint8_t*)c->flags.p : nullptr;
+  uint8_t *mask_f = nullptr, *mask_b = nullptr;
+  if (bidir) {
+    int rc;
+    const size_t mb = (size_t)n * st.kcap;
+    if ((rc = sf_buf_reserve(c, c->dir_mask, 2 * mb)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->pass_back, (size_t)n * sizeof(PassState))) != SF_OK) return rc;
+    mask_f = (uint8_t*)c->dir_mask.p;
+    mask_b = mask_f + mb;
+    SF_HIP(c, hipMemsetAsync(mask_f, 0, 2 * mb, c->stream));
+  }
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
-  auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
-                       (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p), counters + (pass == 1 ? 0 : 2),
-                       (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
-                       (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p),
-                       (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p),
-                       c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0, c->dparams);
+  auto launch = [&](auto kern, PassState* out, uint8_t* mask, int extra) {
+    hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter, corr, hdr, out, extra,
+                       c->dparams, mask, guided_flag);
   };
-  if (ba) launch(k_pnp<true>); else launch(k_pnp<false>);
+  if (ba) launch(k_pnp<true>, ps, nullptr, end_3dof);
+  else if (!bidir) launch(k_pnp<false, 0>, ps, nullptr, end_3dof);
+  else {
+    launch(k_pnp<false, 0>, ps, mask_f, 0);
+    launch(k_pnp<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    hipLaunchKernelGGL(k_merge_directions_pnp, dim3(n), dim3(64), 0, c->stream, st, d_from, d_to, list, counter, corr, hdr,
+                       guided_flag, ps, (const PassState*)c->pass_back.p, (const uint8_t*)mask_f, (const uint8_t*)mask_b,
+                       c->dparams.min_inliers, end_3dof);
+  }
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
   return SF_OK;

@@ -344,6 +344,7 @@ bool sf_split_applicable(const sf_context* c, const StoreView& st) {
 // the PnP form: k_match_split + k_chain_pnp
 bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st) {
   if (c->dparams.estimation_type != 1 || !c->fused || c->match_variant != 0 || c->params.desc_type != 0) return false;
+  if (c->dparams.bidirectional) return false;      // (both directions: stage kernels)
   if (!(c->match_mfma && st.kcap <= MF_MAX_ROWS)) return false;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t lds = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +

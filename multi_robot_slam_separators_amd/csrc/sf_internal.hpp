@@ -405,9 +405,19 @@ StoreView sf_store_view(const Store& s);
 void sf_prof_begin(sf_context* c, int kernel);
 void sf_prof_end(sf_context* c, int kernel);
 
-// gate selector of the matching kernels: 0 = 3D->3D, 1 = PnP, 2 = PnP without a calibrated camera
+// gate selector of the matching kernels: 0 = 3D->3D, 1 = PnP, 2 = PnP without a calibrated camera, 3 = PnP with
+// Vis/ForwardEstOnly = false (either direction's gate sends the pair on; each estimate then checks its own)
 inline int sf_est_mode(const sf_context* c) {
-  return c->dparams.estimation_type == 1 ? (c->dparams.calibrated ? 1 : 2) : 0;
+  return c->dparams.estimation_type == 1 ? (c->dparams.calibrated ? (c->dparams.bidirectional ? 3 : 1) : 2) : 0;
+}
+
+// Gate of one direction of the PnP estimate (myRegistrationVis.cpp:1059, :1070-1071 with A / B as :936-977 set them):
+// dir 0: 3D words of "from" and 2D words of "to"; dir 1: 3D words of "to" and 2D words of "from" -- every "from" row
+// after global matching (:856-875), the rows with a finite point after guided matching (:766-774).
+__host__ __device__ inline bool sf_pnp_dir_gate(int dir, const CorrHeader& h, int rows_from, bool guided, int min_inliers) {
+  if (h.words_to_2d <= 0) return false;                                   // :928
+  if (dir == 0) return h.words_from >= min_inliers && h.words_to_2d >= min_inliers;
+  return h.words_to >= min_inliers && (guided ? h.words_from : rows_from) >= min_inliers;
 }
 
 #define SF_HIP(c, expr)                                                                      \

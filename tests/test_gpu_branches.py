@@ -59,12 +59,20 @@ def test_force_3dof_parity(monkeypatch, oracle, est, ba, fused):
     assert n_ok >= 5
 
 
-def test_bidirectional_parity(oracle):
+@pytest.mark.parametrize("est", [0, 1])
+def test_bidirectional_parity(oracle, est):
+    """Vis/ForwardEstOnly = false (myRegistrationVis.cpp:936-978, 1155-1189, 1376-1394) with both estimators: the backward
+    estimate (frames' roles swapped), the unions of inliers and matches, the half-way interpolation -- byte for byte the
+    oracle's; with the PnP estimator also pairs one of whose frames has no 3D points (one direction's gate closed)."""
     from multi_robot_slam_separators_amd import lib
     A, B, is_true, _ = synth.make_pairs(92, 40, k=300, true_frac=0.6)
+    if est == 1:
+        A = A + [synth.without_3d(a) for a in A[:6]] + A[6:12]
+        B = B + B[:6] + [synth.without_3d(b) for b in B[6:12]]
     for f3 in (0, 1):
         p = synth.camera_params()
         p.iterations = 200
+        p.estimation_type = est
         p.forward_est_only = 0
         p.force_3dof = f3
         with lib.SeparatorFinder(p) as f:
@@ -74,21 +82,23 @@ def test_bidirectional_parity(oracle):
         assert prof["k_verify_fused"][0] == 0        # both directions run on the stage kernels
         p_fwd = _abi.copy_params(p)
         p_fwd.forward_est_only = 1
-        n_ok = grew = 0
+        n_ok = grew = back_only = 0
         for i in range(len(A)):
             o = oracle.estimate_transform(p, A[i], B[i])
-            assert_result_parity(got[i], o, "3dof %d pair %d" % (f3, i))
+            assert_result_parity(got[i], o, "est %d 3dof %d pair %d" % (est, f3, i))
             n_ok += int(o["success"])
             of = oracle.estimate_transform(p_fwd, A[i], B[i])
             assert o["inliers_pass1"] >= of["inliers_pass1"]        # a union
             grew += int(o["success"] and o["position"].tobytes() != of["position"].tobytes())
+            back_only += int(o["success"] and not of["success"])
         assert n_ok >= (3 if f3 else 15)
         assert f3 or grew >= 10                      # the backward estimate really enters the pose (interpolation)
+        assert est == 0 or f3 or back_only >= 2      # "from" without 3D points: only the backward PnP can run
 
 
 def test_bidirectional_is_refused_where_it_is_not_implemented():
     from multi_robot_slam_separators_amd import lib
-    for kw in (dict(estimation_type=1), dict(bundle_adjustment=1)):
+    for kw in (dict(bundle_adjustment=1),):
         p = synth.camera_params()
         p.forward_est_only = 0
         for k, v in kw.items():
