@@ -129,10 +129,11 @@ typedef struct sf_params {
      false): guess and estimates are reduced to (x, y, yaw) -- Transform::to3DoF [upstream] = Transform(x, y, 0, 0, 0,
      yaw) with yaw = atan2(r21, r11), computed here as the rotation (r11, r21) / |(r11, r21)| about z.            */
   int32_t force_3dof;              /* 0 */
-  /* Vis/ForwardEstOnly (myRegistrationVis.cpp:936,1155-1189,1376-1394; rtabmap default true).  0: every pass also
-     estimates to -> from; the pass's transform is interpolate(0.5) of the forward estimate and the inverse of the
-     backward one, its covariance their mean, inliers / matches the union of both directions' ids.  Implemented for
-     estimation_type 0 without bundle adjustment (sf_create -> SF_EINVAL otherwise).                             */
+  /* Vis/ForwardEstOnly (myRegistrationVis.cpp:936-978,1155-1197,1369,1376-1394; rtabmap default true).  0: every pass
+     also estimates to -> from (the frames' roles swapped, each direction behind its own gate); the pass's transform is
+     interpolate(0.5) of the forward estimate and the inverse of the backward one, its covariance their mean, inliers /
+     matches the union of both directions' ids.  With bundle_adjustment the forward transform is adjusted over the union
+     of the inliers and the backward transform is dropped (:1369).  Both estimators; runs on the stage kernels.   */
   int32_t forward_est_only;        /* 1 */
   /* Descriptor type of every keyframe of this handle (rtabmap Vis/FeatureType is fixed per run).  0 = binary rows
      (CV_8U: BRIEF / ORB, Hamming distance -- the only kind the reference's own wire carries, MsgConversion.cpp:113-129);

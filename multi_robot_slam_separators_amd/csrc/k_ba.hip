@@ -446,8 +446,159 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
   }
 }
 
+// Vis/ForwardEstOnly = false WITH bundle adjustment (myRegistrationVis.cpp:1155-1197, :1369, :1376-1394): the two
+// directions' estimates of a pass (stage kernels k_ransac<.,0/1> / k_pnp<.,0/1>, which left their inlier masks -- one
+// byte per "from" feature -- in HBM) are merged here.  The adjustment refines the FORWARD transform over the UNION of the
+// inliers and ends with transforms[1].setNull(): the backward estimate then only contributed inliers.  Where its gate is
+// closed (no forward transform, no inlier) the directions merge as without it (inverse of the backward transform,
+// interpolate(0.5), mean covariance).  Words of the union without a finite point in the "from" frame (inliers of the
+// backward PnP only) stay out of the adjustment and of the inlier count behind it.
+// LDS: [kcap] float4 points | [kcap] u32 packed indices | [kcap] u8 ones | 16 ints, then ba_body's working set.
+__host__ __device__ inline size_t sf_merge_ba_head_bytes(int kcap) {
+  return (((size_t)kcap * 16 + (size_t)kcap * 4 + (size_t)kcap + 16 * 4) + 15) & ~(size_t)15;
+}
+
+template <bool PNP>
+__global__ void __launch_bounds__(SF_BLOCK, 2)
+k_merge_directions_ba(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+                      const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
+                      const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
+                      const uint8_t* __restrict__ guided_flag, PassState* __restrict__ fwd,
+                      const PassState* __restrict__ back, const uint8_t* __restrict__ mask_f,
+                      const uint8_t* __restrict__ mask_b, int extra_3dof, DeviceParams P) {
+  if ((int)blockIdx.x >= *counter) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int pair = list[blockIdx.x], tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, kcap = st.kcap;
+  const int sF = pair_from[pair], sT = pair_to[pair];
+  float4* pts = (float4*)smem_raw;
+  uint32_t* cidx = (uint32_t*)(smem_raw + (size_t)kcap * 16);
+  uint8_t* ones = smem_raw + (size_t)kcap * 20;
+  int* misc = (int*)(smem_raw + ((((size_t)kcap * 21) + 3) & ~(size_t)3));
+  const CorrHeader h = hdr[pair];
+  const bool guided = guided_flag != nullptr && guided_flag[pair] != 0;
+  const bool g0 = !PNP || sf_pnp_dir_gate(0, h, st.meta[sF].x, guided, P.min_inliers);
+  const bool g1 = !PNP || sf_pnp_dir_gate(1, h, st.meta[sF].x, guided, P.min_inliers);
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const uint32_t* cl = corr + (size_t)pair * kcap;
+  const uint8_t* mf = mask_f + (size_t)pair * kcap;
+  const uint8_t* mb = mask_b + (size_t)pair * kcap;
+  if (tid < 16) misc[tid] = 0;
+  __syncthreads();
+  // the union of the inliers (all of it) and, in correspondence order, its words with a finite "from" point
+  int uni = 0, uni_m = 0, n_ba = 0;
+  for (int base = 0; base < h.n_corr; base += SF_BLOCK) {
+    const int i = base + tid;
+    bool in = false, ok = false;
+    uint32_t c = 0;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < h.n_corr) {
+      c = cl[i];
+      in = (mf[c & 0xFFFFu] | mb[c & 0xFFFFu]) != 0;
+      const float* a = xF + 3 * (c & 0xFFFFu);
+      ax = a[0]; ay = a[1]; az = a[2];
+      const bool fa = sfd::finite3(ax, ay, az);
+      ok = in && fa;
+      if (PNP) {
+        bool m = g0 && fa;
+        if (g1 && !m) { const float* b = xT + 3 * (c >> 16); m = sfd::finite3(b[0], b[1], b[2]); }
+        uni_m += m ? 1 : 0;
+      }
+    }
+    uni += in ? 1 : 0;
+    const unsigned long long bal = __ballot(ok);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+      const int cw = misc[4 + w];
+      if (w < wave) woff += cw;
+      total += cw;
+    }
+    if (ok) {
+      const int k = n_ba + woff + before;
+      pts[k] = make_float4(ax, ay, az, 0.f);
+      cidx[k] = c;
+      ones[k] = 1;
+    }
+    n_ba += total;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { uni += __shfl_xor(uni, off); uni_m += __shfl_xor(uni_m, off); }
+  if (lane == 0) { atomicAdd(&misc[0], uni); atomicAdd(&misc[1], uni_m); }
+  __syncthreads();
+  uni = misc[0];
+  uni_m = misc[1];
+  if (tid == 0) {
+    PassState a = fwd[pair];
+    const PassState b = back[pair];
+    a.matches = PNP ? uni_m : (a.matches > b.matches ? a.matches : b.matches);
+    // :1192-1197 (the words3From / wordsTo conditions hold whenever a forward transform exists)
+    const bool adjust = P.bundle_adjustment != 0 && !a.is_null && n_ba > 0;
+    misc[2] = adjust ? 1 : 0;
+    if (adjust) {
+      a.inliers = n_ba;
+    } else {
+      a.inliers = uni;
+      if (!b.is_null) {
+        float inv[12];
+        sfd::rigid_inverse_canon(b.T, inv);
+        if (a.is_null) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) a.T[i] = inv[i];
+          a.is_null = 0;
+          a.var = b.var;
+          a.var_ang = b.var_ang;
+        } else {
+          float mid[12];
+          sfd::interpolate_half_canon(a.T, inv, mid);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) a.T[i] = mid[i];
+          a.var = (a.var + b.var) / 2.0;
+          a.var_ang = (a.var_ang + b.var_ang) / 2.0;
+        }
+      }
+    }
+    fwd[pair] = a;
+  }
+  __syncthreads();
+  if (misc[2]) ba_body(st, sF, sT, pts, cidx, ones, n_ba, fwd[pair], P, smem_raw + sf_merge_ba_head_bytes(kcap));
+  if (extra_3dof && tid == 0 && !fwd[pair].is_null)
+    for (int t = 0; t < extra_3dof; ++t) sfd::to3dof_canon(fwd[pair].T);
+}
+
 }  // namespace
 
 size_t sf_ba_lds_bytes(int kcap) {
   return (size_t)kcap * (24 + 24 + 12 + 12) + 128 * 8 + 2 * 32 * 8 + 16 * 4;
+}
+
+// (both launchers of the stage pipeline end here when both options are on)
+int sf_launch_merge_directions_ba(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass,
+                                  bool pnp, const uint8_t* mask_f, const uint8_t* mask_b) {
+  const size_t lds = sf_merge_ba_head_bytes(st.kcap) + sf_ba_lds_bytes(st.kcap);
+  if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "bundle adjustment of both directions needs %zu B of LDS (> 160 KiB)", lds);
+  if (!c->merge_ba_attr_set) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_merge_directions_ba<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_merge_directions_ba<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->merge_ba_attr_set = true;
+  }
+  int32_t* counters = (int32_t*)c->counters.p;
+  const int32_t* list = (const int32_t*)(pass == 1 ? c->list1.p : c->list3.p);
+  const int32_t* counter = counters + (pass == 1 ? 0 : 2);
+  const uint32_t* corr = (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p);
+  const CorrHeader* hdr = (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p);
+  PassState* ps = (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p);
+  const int end_3dof = c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0;
+  const uint8_t* guided_flag = pass == 2 ? (const uint8_t*)c->flags.p : nullptr;
+  if (pnp)
+    hipLaunchKernelGGL(k_merge_directions_ba<true>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter,
+                       corr, hdr, guided_flag, ps, (const PassState*)c->pass_back.p, mask_f, mask_b, end_3dof, c->dparams);
+  else
+    hipLaunchKernelGGL(k_merge_directions_ba<false>, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter,
+                       corr, hdr, guided_flag, ps, (const PassState*)c->pass_back.p, mask_f, mask_b, end_3dof, c->dparams);
+  return SF_OK;
 }

@@ -759,12 +759,14 @@ size_t sf_pnp_lds_bytes(int kcap, int iterations) { return sf_pnp_lds_bytes_dev(
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
   const bool ba = c->dparams.bundle_adjustment != 0;
-  const size_t lds = ((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
+  // (both directions WITH the adjustment: plain estimates, then k_merge_directions_ba adjusts over the union)
+  const size_t lds = ((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
+                     ((ba && !c->dparams.bidirectional) ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "PnP workgroup needs %zu B of LDS (> 160 KiB)", lds);
-  const bool bidir = c->dparams.bidirectional != 0;       // (never together with bundle adjustment: sf_create)
-  bool& attr = ba ? c->pnp_ba_attr_set : c->pnp_attr_set;
+  const bool bidir = c->dparams.bidirectional != 0;
+  bool& attr = (ba && !bidir) ? c->pnp_ba_attr_set : c->pnp_attr_set;
   if (!attr) {   // per handle = per device
-    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (ba && !bidir) SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else {
       SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -796,11 +798,15 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
     hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter, corr, hdr, out, extra,
                        c->dparams, mask, guided_flag);
   };
-  if (ba) launch(k_pnp<true>, ps, nullptr, end_3dof);
+  if (ba && !bidir) launch(k_pnp<true>, ps, nullptr, end_3dof);
   else if (!bidir) launch(k_pnp<false, 0>, ps, nullptr, end_3dof);
   else {
     launch(k_pnp<false, 0>, ps, mask_f, 0);
     launch(k_pnp<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    if (ba) {
+      const int rc = sf_launch_merge_directions_ba(c, st, d_from, d_to, n, pass, true, mask_f, mask_b);
+      if (rc != SF_OK) return rc;
+    } else
     hipLaunchKernelGGL(k_merge_directions_pnp, dim3(n), dim3(64), 0, c->stream, st, d_from, d_to, list, counter, corr, hdr,
                        guided_flag, ps, (const PassState*)c->pass_back.p, (const uint8_t*)mask_f, (const uint8_t*)mask_b,
                        c->dparams.min_inliers, end_3dof);

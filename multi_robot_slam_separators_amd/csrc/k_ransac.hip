@@ -770,12 +770,14 @@ size_t sf_ransac_lds_bytes(int kcap, int iterations) {
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
   const bool ba = c->dparams.bundle_adjustment != 0;
-  const size_t lds = ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) + (ba ? sf_ba_lds_bytes(st.kcap) : 0);
+  // (both directions WITH the adjustment: plain estimates, then k_merge_directions_ba adjusts over the union)
+  const size_t lds = ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
+                     ((ba && !c->dparams.bidirectional) ? sf_ba_lds_bytes(st.kcap) : 0);
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
-  const bool bidir = c->dparams.bidirectional != 0;       // (never together with bundle adjustment: sf_create)
-  bool& attr = ba ? c->ransac_ba_attr_set : c->ransac_attr_set;
+  const bool bidir = c->dparams.bidirectional != 0;
+  bool& attr = (ba && !bidir) ? c->ransac_ba_attr_set : c->ransac_attr_set;
   if (!attr) {   // per handle = per device
-    if (ba) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (ba && !bidir) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else {
       SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -805,11 +807,15 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
                        (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
                        (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p), out, mask, extra, c->dparams);
   };
-  if (ba) launch(k_ransac<true, 0>, ps, nullptr, end_3dof);
+  if (ba && !bidir) launch(k_ransac<true, 0>, ps, nullptr, end_3dof);
   else if (!bidir) launch(k_ransac<false, 0>, ps, nullptr, end_3dof);
   else {
     launch(k_ransac<false, 0>, ps, mask_f, 0);
     launch(k_ransac<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    if (ba) {
+      const int rc = sf_launch_merge_directions_ba(c, st, d_from, d_to, n, pass, false, mask_f, mask_b);
+      if (rc != SF_OK) return rc;
+    } else
     hipLaunchKernelGGL(k_merge_directions, dim3(n), dim3(64), 0, c->stream, list, counter, ps,
                        (const PassState*)c->pass_back.p, (const uint8_t*)mask_f, (const uint8_t*)mask_b, st.kcap, end_3dof);
   }

@@ -674,8 +674,6 @@ static int fill_device_params(sf_context* c) {
   if (p.desc_type != 0 && p.desc_type != 1) return sf_fail(c, SF_EINVAL, "desc_type %d unknown (0 = binary rows, 1 = float32 rows)", p.desc_type);
   if (p.desc_type == 1 && p.desc_bytes != 256 && p.desc_bytes != 512 && p.desc_bytes != 32)
     return sf_fail(c, SF_EINVAL, "desc_type 1: desc_bytes %d (float32 rows of 64 or 128 dimensions: 256 or 512)", p.desc_bytes);
-  if (p.forward_est_only == 0 && p.bundle_adjustment != 0)
-    return sf_fail(c, SF_EINVAL, "forward_est_only = 0 is implemented without bundle adjustment");
   DeviceParams& d = c->dparams;
   memset(&d, 0, sizeof(d));
   d.force_3dof = p.force_3dof != 0;

@@ -225,7 +225,7 @@ struct sf_context {
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
   bool fused_attr[2][2][2] = {};   // [W == 16][matrix-core matcher][bundle adjustment]: LDS attribute set
-  bool ransac_ba_attr_set = false, pnp_ba_attr_set = false;
+  bool ransac_ba_attr_set = false, pnp_ba_attr_set = false, merge_ba_attr_set = false;
   bool debug_corr = false;      // SF_OPT_DEBUG_CORR: the fused kernel also writes lists / headers / states to HBM
   bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
   bool fused = true;        // fused per-pair verification kernel (SF_FUSED=0 selects the stage kernels)
@@ -435,6 +435,9 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass);
 // Guided matching for pairs whose pass 1 succeeded; builds the pass-2 RANSAC work list.
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
+// Vis/ForwardEstOnly = false with bundle adjustment: merge of a pass's two estimates + adjustment over the union (k_ba.hip)
+int sf_launch_merge_directions_ba(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass,
+                                  bool pnp, const uint8_t* mask_f, const uint8_t* mask_b);
 // Fused per-pair pipeline (k_verify.hip): match -> RANSAC -> guided -> RANSAC -> result in one launch.
 size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st);
 bool sf_split_applicable(const sf_context* c, const StoreView& st);

@@ -96,12 +96,36 @@ def test_bidirectional_parity(oracle, est):
         assert est == 0 or f3 or back_only >= 2      # "from" without 3D points: only the backward PnP can run
 
 
-def test_bidirectional_is_refused_where_it_is_not_implemented():
+@pytest.mark.parametrize("est", [0, 1])
+def test_bidirectional_with_bundle_adjustment_parity(oracle, est):
+    """Vis/ForwardEstOnly = false with bundle adjustment (myRegistrationVis.cpp:1155-1197, :1369): the forward transform
+    refined over the union of both directions' inliers, the backward transform dropped; where there is no forward
+    transform the directions merge as without the adjustment.  Byte for byte the oracle's."""
     from multi_robot_slam_separators_amd import lib
-    for kw in (dict(bundle_adjustment=1),):
-        p = synth.camera_params()
-        p.forward_est_only = 0
-        for k, v in kw.items():
-            setattr(p, k, v)
-        with pytest.raises(lib.SepfinderError):
-            lib.SeparatorFinder(p)
+    A, B, is_true, _ = synth.make_pairs(93, 32, k=300, true_frac=0.6)
+    if est == 1:
+        A = A + [synth.without_3d(a) for a in A[:5]] + A[5:10]
+        B = B + B[:5] + [synth.without_3d(b) for b in B[5:10]]
+    p = synth.camera_params()
+    p.iterations = 200
+    p.estimation_type = est
+    p.forward_est_only = 0
+    p.bundle_adjustment = 1
+    p.stereo_baseline = 0.12
+    with lib.SeparatorFinder(p) as f:
+        got = f.estimate_transform_batch(A, B)
+    p_fwd = _abi.copy_params(p)
+    p_fwd.forward_est_only = 1
+    p_noba = _abi.copy_params(p)
+    p_noba.bundle_adjustment = 0
+    n_ok = differs_fwd = differs_noba = 0
+    for i in range(len(A)):
+        o = oracle.estimate_transform(p, A[i], B[i])
+        assert_result_parity(got[i], o, "est %d pair %d" % (est, i))
+        n_ok += int(o["success"])
+        differs_fwd += int(o.tobytes() != oracle.estimate_transform(p_fwd, A[i], B[i]).tobytes())
+        differs_noba += int(o.tobytes() != oracle.estimate_transform(p_noba, A[i], B[i]).tobytes())
+    assert n_ok >= 12
+    # both options really act (3D-3D on clean synthetic pairs: the two directions find the same inliers, so the union --
+    # and with it the adjusted transform -- is the forward-only one)
+    assert differs_noba >= 8 and (est == 0 or differs_fwd >= 8)
