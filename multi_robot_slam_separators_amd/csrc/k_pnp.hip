@@ -90,7 +90,14 @@ __device__ __forceinline__ bool pnp_inlier(const PnpLds& L, const PnpCam& cam, c
   const float A = __fmaf_rn(-o.x, Z, cam.fxf * X);
   const float B = __fmaf_rn(-o.y, Z, cam.fyf * Y);
   const float lhs = __fmaf_rn(B, B, A * A);
-  const float rhs = cam.thr2f * (Z * Z);
+  // (the threshold through a vector register: the loop vectoriser tests two points per lane with packed-f32
+  //  instructions, and as a uniform the threshold pair sat in SGPRs restored by v_readlane right in front of the
+  //  packed multiply in k_chain_pnp<8, true> -- the shape tools/pk_isa_scan.py gates on)
+  float thr2 = cam.thr2f;
+#ifndef SF_NO_PK_BARRIERS
+  asm volatile("" : "+v"(thr2));
+#endif
+  const float rhs = thr2 * (Z * Z);
   return (Z > 0.0f) && (lhs <= rhs);
 }
 
