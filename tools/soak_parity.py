@@ -38,8 +38,12 @@ for rd in range(rounds):
     # the adjacent branches (Reg/Force3DoF, Vis/ForwardEstOnly = false) in a third of the rounds each
     if rng.random() < 0.33:
         p.force_3dof = 1
-    if p.estimation_type == 0 and rng.random() < 0.33:
-        p.forward_est_only = 0
+    if rng.random() < 0.33:
+        p.forward_est_only = 0       # (both estimators; with the adjustment below in a quarter of those rounds)
+    if p.image_width > 0 and rng.random() < 0.25:
+        p.bundle_adjustment = 1
+        p.stereo_baseline = float(rng.choice([0.0, 0.12]))
+        p.ba_iterations = int(rng.choice([0, 1, 5, 20]))
     A, B = [], []
     for i in range(npairs):
         k = int(rng.choice([0, 1, 3, 9, 64, 100, 255, 256, 257, 500, 777, 1024]))
