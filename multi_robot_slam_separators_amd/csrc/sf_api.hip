@@ -1987,8 +1987,10 @@ static int place_streams(sf_context* c) {
   }
   if (hipMalloc((void**)&pr.d, 64) != hipSuccess || hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess ||
       hipEventCreate(&pr.e2) != hipSuccess) return cleanup(SF_OK);
-  // every stream's hardware queue exists before anything is measured (the runtime creates it at the stream's first use)
-  (void)hipStreamSynchronize(c->stream);
+  // every stream's hardware queue exists before anything is measured (the runtime creates it at the stream's first use);
+  // and nothing else of this process runs on the device meanwhile (another handle's steps in flight would read as
+  // "blocked" here): one device-wide wait, once per handle
+  (void)hipDeviceSynchronize();
   for (int i = 1; i <= NC; ++i) {
     hipLaunchKernelGGL(k_place_probe, dim3(1), dim3(64), 0, S[i], pr.d);
     (void)hipStreamSynchronize(S[i]);
