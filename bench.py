@@ -703,6 +703,32 @@ def run_cfg3(args, rank, world, dev, dev_index, coll_dev, dist_on):
         f.close()
 
 
+def wait_ranks(procs):
+    """Exit code of a set of rank processes.  A rank that dies (e.g. fewer GPUs than ranks) leaves the others waiting in
+    the rendezvous or in a collective: as soon as one exits with an error the rest are ended (these exact children, by
+    their handles) and its code is returned."""
+    import time as _time
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:
+                    q.terminate()
+        if live:
+            _time.sleep(0.05 if rc == 0 else 0.5)
+            if rc != 0:
+                for q in live:
+                    if q.poll() is None:
+                        q.kill()
+    return rc
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` with no launcher: one child process per GPU with the torchrun environment
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rank 0's stdout (the JSON line) passed through.  The parent has not
@@ -725,10 +751,7 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-    raise SystemExit(rc)
+    raise SystemExit(wait_ranks(procs))
 
 
 def main():

@@ -269,3 +269,21 @@ def test_no_packed_f32_reads_of_rewritten_sgprs():
     assert "total: 0 packed-f32 reads" in r.stdout
     mk = open(os.path.join(ROOT, "multi_robot_slam_separators_amd", "csrc", "Makefile")).read()
     assert "-fno-slp-vectorize" in mk.split("COMMON =")[1].split("\n")[0]        # every translation unit is built with it
+
+
+def test_bench_ends_the_other_ranks_when_one_fails():
+    """bench.py's own launcher (`--gpus N` without torchrun): a rank that exits with an error must not leave the others
+    waiting in a rendezvous for ever (seen on a one-GPU box with --gpus 2: rank 1 has no device, rank 0 waited)."""
+    import subprocess
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(120)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(3)"])]
+    t0 = time.time()
+    rc = bench.wait_ranks(procs)
+    assert rc == 3 and time.time() - t0 < 10
+    assert all(p.poll() is not None for p in procs)
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
+    assert bench.wait_ranks(ok) == 0
