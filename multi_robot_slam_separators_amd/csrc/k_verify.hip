@@ -17,6 +17,13 @@
 // workspace.  The stage kernels remain for the PnP estimator (k_pnp: ~170 VGPRs, 3 workgroups per CU) and as
 // the A/B reference (SF_FUSED=0): both paths run the same bodies and produce identical bytes.
 // Compiled with -ffp-contract=off (canonical arithmetic of the RANSAC / guided bodies).
+// Workgroups of k_chain_pnp per CU the compiler budgets registers for.  Measured on the bench's PnP line (round 4,
+// profiles/r04z_pnp_chain_occupancy.txt): 2 (256 registers, no scratch) 11.8 M pairs/s, 3 (168 registers, 116 B of
+// scratch per lane) 13.7 M, 4 (128 registers, 296 B) 13.4 M -- the chains are latency-bound, more of them side by side
+// is worth more than their spills cost, until the matching launch beside them loses the slots.
+#ifndef SF_PNP_CHAIN_OCC
+#define SF_PNP_CHAIN_OCC 3
+#endif
 #include "k_match.hip"
 #include "k_ransac.hip"
 #include "k_guided.hip"
@@ -274,7 +281,7 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
 // the 3D-3D chain); what the fusion saves is three launches, the guided kernel's 10 000 workgroups that find nothing
 // to do, and the gaps between them.  Same bodies, same bytes.
 template <int W, bool BA>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
+__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : SF_PNP_CHAIN_OCC)
 k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
             const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
             uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
