@@ -211,7 +211,9 @@ int  sf_create(const sf_params* p, int device, sf_handle* out);
 void sf_destroy(sf_handle h);
 const char* sf_last_error(sf_handle h);   /* h may be NULL: last create() error              */
 int  sf_get_params(sf_handle h, sf_params* out);
-/* Make the handle issue all work on a caller-owned hipStream_t (e.g. torch's current stream). */
+/* Make the handle issue all work on a caller-owned hipStream_t (e.g. torch's current stream).  Call it before the first
+   sf_step_issue: the step pipeline picks its further streams relative to this one, once (see sf_stream_placement in
+   sf_experimental.h); a stream set later is used, but the other streams are not picked again. */
 int  sf_set_stream(sf_handle h, void* hip_stream);
 int  sf_synchronize(sf_handle h);
 
