@@ -538,7 +538,9 @@ int  sf_step_issue(sf_handle h, int32_t slot_base_other, int32_t slot_base_local
 int  sf_step_retire(sf_handle h, sf_step_result* out);      /* the OLDEST step in flight; waits for its verification */
 /* bytes from device memory to device memory, asynchronous on `hip_stream` (NULL: the handle's stream) -- e.g. a retired
    step's sf_step_result.d_records -> the send buffer of the caller's collective, on the stream the caller runs its
-   collectives from (a stream of its own keeps that traffic out of the way of the steps in flight) */
+   collectives from (a stream of its own keeps that traffic out of the way of the steps in flight).  A copy out of a
+   step's d_records is remembered: the step that next uses that block waits for it before it writes the buffer again,
+   whatever stream the copy was queued on. */
 int  sf_memcpy_device_async(sf_handle h, void* d_dst, const void* d_src, size_t bytes, void* hip_stream);
 /* Optional second destination of every accepted record, on the device -- e.g. the send buffer of the all-gather that
    follows (sf_allgather_separators_device: slot 0 = header, records from slot 1): d_records2[slot] receives the record

@@ -837,6 +837,7 @@ extern "C" void sf_destroy(sf_handle c) {
   for (auto& sb : c->step_blocks) {
     if (sb.pinned) (void)hipHostFree(sb.pinned);
     if (sb.done) (void)hipEventDestroy(sb.done);
+    if (sb.copied) (void)hipEventDestroy(sb.copied);
     buf_free(sb.dev);
     buf_free(sb.dev_records);
   }
@@ -2295,6 +2296,11 @@ extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_
   const bool device = c->step_device_walk && !c->overlap && c->store.slots > 0;
   c->cur_lane = lane;
   if (lane > 0 && (rc = lane_enter(c, lane)) != SF_OK) { c->in_overlapped_step = false; return rc; }
+  if (b.copy_pending) {            // (sf_memcpy_device_async out of this block's records, possibly on a stream of the caller's)
+    hipError_t e = hipStreamWaitEvent(c->stream, b.copied, 0);
+    if (e != hipSuccess) rc = sf_fail(c, SF_EHIP, "hipStreamWaitEvent(copy of d_records) -> %s", hipGetErrorString(e));
+    b.copy_pending = false;
+  }
   // state every lane reads (fp16 copies, coefficients, masks) prepared by another lane since this one last looked?
   if (c->lane_seen_prep[lane] != c->prep_epoch && c->ev_prep) {
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_prep, 0);
@@ -2424,7 +2430,17 @@ extern "C" int sf_memcpy_device_async(sf_handle c, void* d_dst, const void* d_sr
   if (!c || (bytes > 0 && (!d_dst || !d_src))) return SF_EINVAL;
   if (bytes == 0) return SF_OK;
   SF_HIP(c, hipSetDevice(c->device));
-  SF_HIP(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, hip_stream ? (hipStream_t)hip_stream : c->stream));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  SF_HIP(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, s));
+  // out of a step block's record buffer: the block's next step must not overwrite it before this copy has run
+  for (auto& b : c->step_blocks) {
+    const char* lo = (const char*)b.dev_records.p;
+    if (!lo || (const char*)d_src < lo || (const char*)d_src >= lo + b.dev_records.bytes) continue;
+    if (!b.copied) SF_HIP(c, hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+    SF_HIP(c, hipEventRecord(b.copied, s));
+    b.copy_pending = true;
+    break;
+  }
   return SF_OK;
 }
 

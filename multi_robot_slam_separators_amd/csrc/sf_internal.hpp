@@ -323,6 +323,10 @@ struct sf_context {
     int32_t slot_other = 0, slot_local = 0, parity = 0;   // (what a fallback needs to run the query again)
     int settle_rc = 0;
     hipEvent_t done = nullptr;
+    // a caller's copy out of dev_records (sf_memcpy_device_async, on ANY stream) is recorded here; the step that next
+    // uses the block waits for it before its kernels may write the buffer again
+    hipEvent_t copied = nullptr;
+    bool copy_pending = false;
   } step_blocks[SF_STEP_MAX_DEPTH + 1];
   int step_depth = 6;                      // SF_OPT_STEP_DEPTH: steps in flight
   int step_lanes = 3;                      // SF_OPT_STEP_LANES: streams the steps in flight are dealt over (step k on lane k mod lanes)

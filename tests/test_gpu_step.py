@@ -567,3 +567,46 @@ def test_streams_of_the_step_pipeline_are_placed_by_measurement():
         if "classes," in rep:             # (measured: at least two classes, a class per lane's main stream)
             assert int(rep.split("placement: ")[1].split(" classes")[0]) >= 2, rep
             assert "main classes" in rep and "second streams: class" in rep, rep
+
+
+def test_a_copy_out_of_d_records_is_ordered_before_the_blocks_reuse():
+    """sf_memcpy_device_async out of sf_step_result.d_records on a stream of the caller's that runs LATE (a long launch
+    queued in front of every copy): the step that reuses the block must wait for the copy.  Two queries with different
+    separators alternate through a ring of two, so a block is rewritten with OTHER records one retire later."""
+    n_kf, k, dim = 96, 200, 512
+    feats, nv_a, nv_b = _world(1077, n_kf, k, dim)
+    p = synth.camera_params()
+    p.iterations = 200
+    p.netvlad_dimensions = dim
+    p.netvlad_max_matches_nb = n_kf
+    p.max_features = k
+    side = torch.cuda.Stream()
+    ballast = torch.zeros((4096, 4096), dtype=torch.float32, device=DEV)
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.set_option(_abi.SF_OPT_STEP_DEPTH, 2)
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        # the second query: the keyframes' roles swapped (the same matches, the inverse poses: other record bytes); a
+        # block is reused three steps later, i.e. by the OTHER query
+        copies, want = [], []
+        for it in range(24):
+            if it % 2 == 0:
+                f.step_issue(sa, sb)
+            else:
+                f.step_issue(sb, sa)
+            if it >= 1:
+                out = f.step_retire(copy=True)
+                n = out[3]["n_records"]
+                assert n > 0
+                d = torch.zeros((n, RB), dtype=torch.uint8, device=DEV)
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        ballast @ ballast                      # ~ms of work in front of the copy
+                    f.memcpy_device_async(d.data_ptr(), out[3]["d_records"], n * RB, side.cuda_stream)
+                copies.append(d)
+                want.append(out[2].tobytes())
+        f.step_retire()
+        torch.cuda.synchronize()
+        assert len(set(want)) >= 2                             # (the two queries' records really differ)
+        for d, w in zip(copies, want):
+            assert d.cpu().numpy().tobytes() == w
