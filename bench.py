@@ -338,6 +338,22 @@ def upload_store(f, feats, dev, n_kf, k, cols):
     return first["a"], first["b"]
 
 
+def set_estimator(p, args):
+    """--estimator / --bundle-adjustment / --forward-est-only -> sf_params (myRegistrationVis.cpp:52-71 reads these as
+    rtabmap's Vis/EstimationType, Vis/BundleAdjustment, Vis/ForwardEstOnly).  The adjustment takes stereo residuals
+    (baseline 0.12 m: the reference's camera is a stereo pair, stereoCamGeometricTools.cpp:56-76)."""
+    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    if args.bundle_adjustment:
+        p.bundle_adjustment = 1
+        p.stereo_baseline = 0.12
+    p.forward_est_only = int(args.forward_est_only)
+
+
+def estimator_text(args):
+    return ("3D-3D" if args.estimator == "3d3d" else "PnP") + (" + two-view bundle adjustment" if args.bundle_adjustment else "") + \
+        (", both directions (Vis/ForwardEstOnly = false)" if not args.forward_est_only else "")
+
+
 def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
     """the step(s) of R(R-1)/2 robot pairs cut over the ranks (strong scaling).  Prints its own
     JSON line (rank 0)."""
@@ -348,7 +364,7 @@ def run_partition_8e(args, rank, world, dev, dev_index, coll_dev, dist_on):
     n_rp = args.robots * (args.robots - 1) // 2
     p = synth.camera_params()
     p.iterations = args.iterations
-    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    set_estimator(p, args)
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf
     p.nn_precision = args.nn_precision
@@ -440,7 +456,7 @@ def run_cfg4(args, rank, world, dev, dev_index, coll_dev, dist_on):
     n_kf, k, cols = args.keyframes, args.features, args.desc_bytes
     p = synth.camera_params()
     p.iterations = args.iterations
-    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    set_estimator(p, args)
     p.max_features = k
     p.desc_bytes = cols
     p.store_capacity = 2 * n_kf
@@ -538,7 +554,7 @@ def run_cfg3(args, rank, world, dev, dev_index, coll_dev, dist_on):
     n_rp = args.robots * (args.robots - 1) // 2
     p = synth.camera_params()
     p.iterations = args.iterations
-    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    set_estimator(p, args)
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf
     p.nn_precision = args.nn_precision
@@ -772,6 +788,12 @@ def main():
     ap.add_argument("--estimator", choices=("3d3d", "pnp"), default="3d3d",
                     help="motion estimator of both registration passes: 3d3d = RANSAC 3D->3D (north_star, "
                          "myRegistrationVis.cpp:1113-1152), pnp = RANSAC 3D->2D (:1055-1112, rtabmap's default)")
+    ap.add_argument("--bundle-adjustment", action="store_true",
+                    help="two-view bundle adjustment behind each pass's estimate (myRegistrationVis.cpp:1192-1370; rtabmap's "
+                         "Vis/BundleAdjustment = 1, its default where g2o is present); with --estimator pnp this is the flow "
+                         "the reference most likely runs as shipped (SURVEY.md section 9)")
+    ap.add_argument("--forward-est-only", type=int, choices=(0, 1), default=1,
+                    help="0: Vis/ForwardEstOnly = false (both directions estimated and merged, myRegistrationVis.cpp:936-978)")
     ap.add_argument("--netvlad-f16", action="store_true",
                     help="NetVLAD descriptors handed over in fp16 (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -858,7 +880,7 @@ def main():
     n_kf, k, cols, dim = args.keyframes, args.features, args.desc_bytes, args.dim
     p = synth.camera_params()
     p.iterations = args.iterations
-    p.estimation_type = 1 if args.estimator == "pnp" else 0
+    set_estimator(p, args)
     p.netvlad_dimensions = dim
     p.netvlad_max_matches_nb = n_kf            # batch operation: walk every row
     p.nn_precision = args.nn_precision
@@ -1532,7 +1554,7 @@ def main():
                             "candidates); NN filter contracted %s of %d dimensions (adaptive prefix ladder -- the "
                             "full-length figure is value_full_length_filter)" % (
                                 n_kf, dim, "fp16" if args.netvlad_f16 else "fp32", k, cols * 8, args.iterations,
-                                "3D-3D" if args.estimator == "3d3d" else "PnP", 100 * args.true_frac, n_kf,
+                                estimator_text(args), 100 * args.true_frac, n_kf,
                                 (filter_dims or dim) if args.nn_precision == 1 else dim, dim),
                 "pairs_per_step_per_gpu": pairs_per_step,
                 "parallelism": "pairs sharded by robot pair, 1 rank per GPU" if world > 1 else "single GPU",

@@ -55,7 +55,9 @@ extern "C" {
 /* 4: sf_step_mirror_pair, sf_step_mirror_streams, SF_OPT_STEP_SPLIT added (nothing existing changed).                */
 /* 5: sf_step_issue no longer waits for the device (SF_OPT_STEP_DEVICE_WALK, _DEPTH, _LANES), sf_nn_walk_device added; 
       sf_step_result pointers stay valid until the next sf_step_retire; sf_params grew desc_type (appended).         */
-#define SF_ABI_VERSION 5
+/* 6: SF_K_BA added to the kernel ids of sf_prof_get (SF_K_COUNT 10 -> 11): the bundle adjustment is a launch of its
+      own; sf_step_issue refuses more steps in flight than a mirror has buffers for.                                */
+#define SF_ABI_VERSION 6
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -575,7 +577,8 @@ enum {
   SF_K_NN_REFINE = 7,  /* exact f64 distance of every filter survivor                         */
   SF_K_FUSED = 8,      /* fused per-pair pipeline: match + RANSAC + guided + RANSAC + result    */
   SF_K_NN_WALK = 9,    /* argsort of the row minima + the walk (data_handler.py:191-205), on the device */
-  SF_K_COUNT = 10
+  SF_K_BA = 10,        /* two-view bundle adjustment of a pass's estimate (a launch of its own since ABI 6) */
+  SF_K_COUNT = 11
 };
 /* When enabled every kernel launch is bracketed by hipEvents on the handle's stream.          */
 int  sf_prof_enable(sf_handle h, int on);

@@ -14,7 +14,7 @@ SF_MAX_DESC_BYTES = 64
 SF_MAX_DESC_BYTES_F32 = 512
 
 (SF_K_MATCH, SF_K_RANSAC1, SF_K_GUIDED, SF_K_RANSAC2, SF_K_NN, SF_K_NN_SELECT, SF_K_NN_FILTER,
- SF_K_NN_REFINE, SF_K_FUSED, SF_K_NN_WALK, SF_K_COUNT) = range(11)
+ SF_K_NN_REFINE, SF_K_FUSED, SF_K_NN_WALK, SF_K_BA, SF_K_COUNT) = range(12)
 (SF_OPT_MATCH_MFMA, SF_OPT_FUSED, SF_OPT_OVERLAP, SF_OPT_CHAIN_WAVES, SF_OPT_DEBUG_CORR, SF_OPT_NN_FULL_FILTER,
  SF_OPT_STEP_OVERLAP, SF_OPT_STEP_SPLIT, SF_OPT_STEP_DEPTH, SF_OPT_STEP_LANES, SF_OPT_STEP_DEVICE_WALK,
  SF_OPT_STEP_SPECULATE) = range(12)      # sf_set_option
@@ -223,7 +223,7 @@ class StepResult(C.Structure):
                 ("d_records", C.c_void_p)]
 
 
-SF_ABI_VERSION = 5      # include/sepfinder.h
+SF_ABI_VERSION = 6      # include/sepfinder.h
 
 
 def default_params() -> Params:

@@ -155,14 +155,12 @@ __device__ __forceinline__ void ba_sym3_mul(const double (&Ai)[6], const double*
 }
 
 // Schur-reduced normal equations at (q, t, points Xs): totals in `out` (LDS, [28])
+template <int NW>
 __device__ inline void ba_normal_eq(const BaLds& L, const BaCam& cam, int m, const double* Xs, const double (&q)[4],
                                     const double (&t)[3], double lambda, double* out, int tid) {
   double R2[9];
   sfd::quat_to_R(q, R2);
-  double ne[BA_NSUM];
-#pragma unroll
-  for (int k = 0; k < BA_NSUM; ++k) ne[k] = 0.0;
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  sfd::canon_reduce_to_lds<BA_NSUM, 32, NW>(m, tid, L.red, out, [&](int i, double (&ne)[BA_NSUM]) {
     BaBlocks B;
     ba_point_blocks(cam, Xs + 3 * i, L.o1 + 3 * i, L.o2 + 3 * i, R2, t, B);
     double term[BA_NSUM];
@@ -190,16 +188,16 @@ __device__ inline void ba_normal_eq(const BaLds& L, const BaCam& cam, int m, con
     }
 #pragma unroll
     for (int k = 0; k < BA_NSUM; ++k) ne[k] += term[k];
-  }
-  sfd::block_sum_canon_to_lds<BA_NSUM, 32>(ne, L.red, out, tid);
+  });
 }
 
 // candidate points Xc = X - A'^-1 (bp + C^T dc) at the current state
+template <int NW>
 __device__ inline void ba_backsub(const BaLds& L, const BaCam& cam, int m, const double (&q)[4], const double (&t)[3],
                                   double lambda, const double (&dc)[6], int tid) {
   double R2[9];
   sfd::quat_to_R(q, R2);
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  for (int i = tid; i < m; i += 64 * NW) {
     BaBlocks B;
     ba_point_blocks(cam, L.X + 3 * i, L.o1 + 3 * i, L.o2 + 3 * i, R2, t, B);
     double Ai[6];
@@ -233,22 +231,7 @@ __device__ __forceinline__ BaLds ba_carve(unsigned char* p, int kcap) {
   return L;
 }
 
-// Bundle adjustment of one pass.  pts[i] / cidx[i] / inl[i] (LDS, i < m): the estimate's compacted correspondences --
-// the "from" 3D point, the packed (from | to << 16) feature indices, the inlier flag.  `ps` (the pass state the
-// estimate just wrote; thread 0's view is authoritative): T, inliers and is_null are updated in place.
-__device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, const float4* pts, const uint32_t* cidx,
-                                        const uint8_t* inl, int m, PassState& ps, const DeviceParams& P,
-                                        unsigned char* lds) {
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int kcap = st.kcap;
-  const BaLds L = ba_carve(lds, kcap);
-  __syncthreads();                       // the estimate's result (ps) is visible
-  const PassState p0 = ps;
-  // :1192-1197 gate (the words3From / wordsTo conditions hold whenever the estimate ran)
-  if (p0.is_null || p0.inliers <= 0) return;
-
-  BaCam cam;
+__device__ __forceinline__ void ba_cam_setup(const DeviceParams& P, BaCam& cam) {
   cam.fx = P.fx; cam.fy = P.fy; cam.b = (double)P.stereo_baseline;
   cam.info = 1.0 / (double)P.ba_pixel_variance;
   cam.delta = (double)P.ba_robust_kernel_delta;
@@ -258,52 +241,34 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
     for (int j = 0; j < 3; ++j) cam.R1[3 * i + j] = (double)P.L[4 * j + i];
     cam.t1[i] = -(((double)P.L[i] * (double)P.L[3] + (double)P.L[4 + i] * (double)P.L[7]) + (double)P.L[8 + i] * (double)P.L[11]);
   }
+}
 
-  // ---- the inlier words, in correspondence order -----------------------------------------------------------------------
-  const float4* kF = st.kp + (size_t)sF * kcap;
-  const float4* kT = st.kp + (size_t)sT * kcap;
-  const float* xT = st.xyz + (size_t)sT * kcap * 3;
-  const bool to3d = st.meta[sT].y > 0;
-  const float cxf = (float)P.cx, cyf = (float)P.cy;
-  if (tid < 16) L.misc[tid] = 0;
-  __syncthreads();
-  int n = 0;
-  for (int base = 0; base < m; base += SF_BLOCK) {
-    const int i = base + tid;
-    const bool in = i < m && inl[i] != 0;
-    const unsigned long long bal = __ballot(in);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int c = L.misc[4 + w];
-      if (w < wave) woff += c;
-      total += c;
-    }
-    if (in) {
-      const int k = n + woff + before;
-      const float4 a = pts[i];
-      const uint32_t c = cidx[i];
-      const float4 k1 = kF[c & 0xFFFFu], k2 = kT[c >> 16];
-      L.X[3 * k] = (double)a.x; L.X[3 * k + 1] = (double)a.y; L.X[3 * k + 2] = (double)a.z;
-      const float d1 = (float)(((cam.R1[6] * (double)a.x + cam.R1[7] * (double)a.y) + cam.R1[8] * (double)a.z) + cam.t1[2]);
-      L.o1[3 * k] = k1.x - cxf; L.o1[3 * k + 1] = k1.y - cyf; L.o1[3 * k + 2] = d1;
-      float d2 = 0.0f;
-      if (to3d) {
-        const float* bq = xT + 3 * (size_t)(c >> 16);
-        const float bx = bq[0], by = bq[1], bz = bq[2];
-        if (sfd::finite3(bx, by, bz))
-          d2 = (float)(((cam.R1[6] * (double)bx + cam.R1[7] * (double)by) + cam.R1[8] * (double)bz) + cam.t1[2]);
-      }
-      L.o2[3 * k] = k2.x - cxf; L.o2[3 * k + 1] = k2.y - cyf; L.o2[3 * k + 2] = d2;
-    }
-    n += total;
-    __syncthreads();
+// one inlier word -> its slot k of the adjustment's working set: the point, both observations with their depths
+__device__ __forceinline__ void ba_put_word(const BaLds& L, const BaCam& cam, int k, float ax, float ay, float az, uint32_t c,
+                                            const float4* kF, const float4* kT, const float* xT, bool to3d, float cxf,
+                                            float cyf) {
+  const float4 k1 = kF[c & 0xFFFFu], k2 = kT[c >> 16];
+  L.X[3 * k] = (double)ax; L.X[3 * k + 1] = (double)ay; L.X[3 * k + 2] = (double)az;
+  const float d1 = (float)(((cam.R1[6] * (double)ax + cam.R1[7] * (double)ay) + cam.R1[8] * (double)az) + cam.t1[2]);
+  L.o1[3 * k] = k1.x - cxf; L.o1[3 * k + 1] = k1.y - cyf; L.o1[3 * k + 2] = d1;
+  float d2 = 0.0f;
+  if (to3d) {
+    const float* bq = xT + 3 * (size_t)(c >> 16);
+    const float bx = bq[0], by = bq[1], bz = bq[2];
+    if (sfd::finite3(bx, by, bz))
+      d2 = (float)(((cam.R1[6] * (double)bx + cam.R1[7] * (double)by) + cam.R1[8] * (double)bz) + cam.t1[2]);
   }
-  if (n == 0) return;
+  L.o2[3 * k] = k2.x - cxf; L.o2[3 * k + 1] = k2.y - cyf; L.o2[3 * k + 2] = d2;
+}
 
+// The adjustment itself over the n words already in L.X / L.o1 / L.o2 (correspondence order), from the estimate p0;
+// thread 0 writes the adjusted state to `ps`.
+template <int NW>
+__device__ __forceinline__ void ba_solve(const BaLds& L, const BaCam& cam, int n, const PassState& p0, PassState& ps,
+                                         const DeviceParams& P) {
+  constexpr int NT = 64 * NW;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   // camera 2: M = (T L)^-1 from float matrices (rtabmap::Transform), then double
   double q[4], t[3];
   {
@@ -329,13 +294,13 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
   double* cur = L.ne_a;
   double* cnd = L.ne_b;
   double lambda = 1e-3;
-  ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+  ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
   for (int iter = 0; iter < P.ba_iterations; ++iter) {
     double d[6];
     if (!sfd::solve6(cur, lambda, d)) {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
-      ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+      ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
       continue;
     }
     const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
@@ -351,10 +316,10 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
     for (int i = 0; i < 4; ++i) qc[i] = qc[i] * qn;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tc[i] = t[i] + d[3 + i];
-    ba_backsub(L, cam, n, q, t, lambda, d, tid);
+    ba_backsub<NW>(L, cam, n, q, t, lambda, d, tid);
     const double lambda_acc = lambda * 0.1 < 1e-16 ? 1e-16 : lambda * 0.1;
     __syncthreads();                                   // candidate points written
-    ba_normal_eq(L, cam, n, L.Xc, qc, tc, lambda_acc, cnd, tid);
+    ba_normal_eq<NW>(L, cam, n, L.Xc, qc, tc, lambda_acc, cnd, tid);
     const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
     const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
     if (cnd[27] < cur[27]) {
@@ -362,14 +327,14 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
       for (int i = 0; i < 4; ++i) q[i] = qc[i];
 #pragma unroll
       for (int i = 0; i < 3; ++i) t[i] = tc[i];
-      for (int i = tid; i < 3 * n; i += SF_BLOCK) L.X[i] = L.Xc[i];
+      for (int i = tid; i < 3 * n; i += NT) L.X[i] = L.Xc[i];
       double* sw = cur; cur = cnd; cnd = sw;
       lambda = lambda_acc;
       __syncthreads();
     } else {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
-      ba_normal_eq(L, cam, n, L.X, q, t, lambda, cur, tid);
+      ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
     }
     if (dd <= 1.4e-14 * tt) break;
   }
@@ -379,7 +344,7 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
   sfd::quat_to_R(q, R2);
   const double lim = cam.delta * cam.delta;
   int n_out = 0;
-  for (int i = tid; i < n; i += SF_BLOCK) {
+  for (int i = tid; i < n; i += NT) {
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -407,7 +372,9 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
   __syncthreads();
   if (lane == 0) L.misc[8 + wave] = n_out;
   __syncthreads();
-  n_out = ((L.misc[8] + L.misc[9]) + L.misc[10]) + L.misc[11];
+  n_out = L.misc[8];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) n_out += L.misc[8 + w];
 
   if (tid == 0) {
     PassState o = p0;
@@ -444,6 +411,126 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
     }
     ps = o;
   }
+}
+
+// Bundle adjustment of one pass.  pts[i] / cidx[i] / inl[i] (LDS, i < m): the estimate's compacted correspondences --
+// the "from" 3D point, the packed (from | to << 16) feature indices, the inlier flag.  `ps` (the pass state the
+// estimate just wrote; thread 0's view is authoritative): T, inliers and is_null are updated in place.
+template <int NW = 4>
+__device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, const float4* pts, const uint32_t* cidx,
+                                        const uint8_t* inl, int m, PassState& ps, const DeviceParams& P,
+                                        unsigned char* lds) {
+  constexpr int NT = 64 * NW;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const BaLds L = ba_carve(lds, kcap);
+  __syncthreads();                       // the estimate's result (ps) is visible
+  const PassState p0 = ps;
+  // :1192-1197 gate (the words3From / wordsTo conditions hold whenever the estimate ran)
+  if (p0.is_null || p0.inliers <= 0) return;
+
+  BaCam cam;
+  ba_cam_setup(P, cam);
+
+  // ---- the inlier words, in correspondence order -----------------------------------------------------------------------
+  const float4* kF = st.kp + (size_t)sF * kcap;
+  const float4* kT = st.kp + (size_t)sT * kcap;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const bool to3d = st.meta[sT].y > 0;
+  const float cxf = (float)P.cx, cyf = (float)P.cy;
+  if (tid < 16) L.misc[tid] = 0;
+  __syncthreads();
+  int n = 0;
+  for (int base = 0; base < m; base += NT) {
+    const int i = base + tid;
+    const bool in = i < m && inl[i] != 0;
+    const unsigned long long bal = __ballot(in);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int c = L.misc[4 + w];
+      if (w < wave) woff += c;
+      total += c;
+    }
+    if (in) {
+      const float4 a = pts[i];
+      ba_put_word(L, cam, n + woff + before, a.x, a.y, a.z, cidx[i], kF, kT, xT, to3d, cxf, cyf);
+    }
+    n += total;
+    __syncthreads();
+  }
+  if (n == 0) return;
+  ba_solve<NW>(L, cam, n, p0, ps, P);
+}
+
+// The adjustment of one pass as a launch of its own (round 5): the estimate's kernel left its inlier set as one byte
+// per "from" feature (`mask`, [kcap] of this pair) next to the pass's correspondence list, and the words are rebuilt
+// from those -- the correspondences whose "from" point is finite (PnP) / whose two points are finite and non-zero
+// (3D-3D), i.e. the estimate's own compaction, in list order, restricted to the inliers: the sequence ba_body takes
+// from the estimate's LDS.  Same arithmetic, same bytes; what it buys is that the estimators are no longer compiled
+// for the adjustment's ~60 live fp64 values (256 registers + 700 B of scratch per lane at 2 workgroups per CU in
+// rounds 2-4) and the adjustment runs at the width its ~100 words fill.
+template <int NW, bool PNP>
+__device__ __forceinline__ void ba_pass_body(const StoreView& st, int sF, int sT, const uint32_t* __restrict__ cl,
+                                             int n_corr, const uint8_t* __restrict__ mask, PassState& ps,
+                                             const DeviceParams& P, unsigned char* lds) {
+  constexpr int NT = 64 * NW;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int kcap = st.kcap;
+  const BaLds L = ba_carve(lds, kcap);
+  const PassState p0 = ps;
+  if (p0.is_null || p0.inliers <= 0) return;      // :1192-1197 (block-uniform: every lane read the same state)
+  BaCam cam;
+  ba_cam_setup(P, cam);
+  const float4* kF = st.kp + (size_t)sF * kcap;
+  const float4* kT = st.kp + (size_t)sT * kcap;
+  const float* xF = st.xyz + (size_t)sF * kcap * 3;
+  const float* xT = st.xyz + (size_t)sT * kcap * 3;
+  const bool to3d = st.meta[sT].y > 0;
+  const float cxf = (float)P.cx, cyf = (float)P.cy;
+  if (tid < 16) L.misc[tid] = 0;
+  __syncthreads();
+  int n = 0;
+  for (int base = 0; base < n_corr; base += NT) {
+    const int i = base + tid;
+    bool in = false;
+    uint32_t c = 0;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < n_corr) {
+      c = cl[i];
+      if (mask[c & 0xFFFFu]) {
+        const float* a = xF + 3 * (c & 0xFFFFu);
+        ax = a[0]; ay = a[1]; az = a[2];
+        in = sfd::finite3(ax, ay, az);
+        if (!PNP && in) {      // util3d::findCorrespondences: both points finite and non-zero
+          const float* b = xT + 3 * (size_t)(c >> 16);
+          const float bx = b[0], by = b[1], bz = b[2];
+          in = sfd::finite3(bx, by, bz) && (ax != 0.f || ay != 0.f || az != 0.f) && (bx != 0.f || by != 0.f || bz != 0.f);
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(in);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) L.misc[4 + wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int cw = L.misc[4 + w];
+      if (w < wave) woff += cw;
+      total += cw;
+    }
+    if (in) ba_put_word(L, cam, n + woff + before, ax, ay, az, c, kF, kT, xT, to3d, cxf, cyf);
+    n += total;
+    __syncthreads();
+  }
+  if (n == 0) return;
+  ba_solve<NW>(L, cam, n, p0, ps, P);
 }
 
 // Vis/ForwardEstOnly = false WITH bundle adjustment (myRegistrationVis.cpp:1155-1197, :1369, :1376-1394): the two

@@ -24,6 +24,8 @@ namespace {
 // recorded (from, to) combinations per thread of the candidate-parallel search (list = GUIDED_CPT * 256 entries); a
 // frame with more takes the per-lane loop
 #define GUIDED_CPT 8
+// ... and the list's length: the same for every workgroup width (a narrower workgroup walks it in more trips)
+#define GUIDED_CAND_CAP (GUIDED_CPT * 256)
 
 // Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
@@ -33,12 +35,12 @@ namespace {
 // compared by their L2 distance -- sqrtf of the float32 sum of squared differences in dimension order, as
 // cv::BFMatcher(NORM_L2) reports it (:739-749) -- in the per-lane search loop (same tests, same decisions; the
 // candidate-parallel pass with its packed 32-bit keys is the binary descriptors').
-template <int W, bool L2 = false>
+template <int W, bool L2 = false, int NW = 4>
 __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int sF, int sT, const PassState& pass1,
                                             PassState& pass2_out, uint8_t& guided_flag_out, uint32_t* out,
                                             CorrHeader& hdr_out, int32_t* __restrict__ list,
                                             int32_t* __restrict__ counter, const DeviceParams& P, int* smem) {
-  constexpr int NW = 4, NT = 64 * NW;
+  constexpr int NT = 64 * NW;      // NW = 4: the 256-thread workgroups; 1, 2: the low-occupancy chains (k_verify.hip)
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
@@ -249,7 +251,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;      // (the fill counters are dead; ordered before the decisions by
                                                           //  the barrier behind the search's first pass)
   int n_finite = 0, n_proj = 0;
-  const int cand_cap = GUIDED_CPT * NT;
+  const int cand_cap = NW == 4 ? GUIDED_CAND_CAP : min(GUIDED_CAND_CAP, 4 * kcap);   // (NW < 4: the keys are parked in the grid's items)
   // projection of a finite "from" point with the guess (:503-512): pixel position and "inside the image, in front"
   auto project = [&](float x, float y, float z, float& u, float& v) -> bool {
     const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
@@ -398,6 +400,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   if (tid == 0 && P.dbg_trace) P.dbg_trace[(size_t)pair * SF_TRACE_SLOTS + 27] = (unsigned long long)n_cand;
 #endif
   if (!L2 && n_cand <= cand_cap) {
+    if constexpr (NW == 4) {
     // pass B: one combination per lane (<= GUIDED_CPT per thread, kept in registers between the two atomic passes)
     uint32_t ck[GUIDED_CPT], ci[GUIDED_CPT];
 #pragma unroll
@@ -427,6 +430,48 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
     for (int j = 0; j < GUIDED_CPT; ++j)
       if (ck[j] != 0xFFFFFFFFu && ck[j] != key1[ci[j]]) atomicMin(&key2[ci[j]], ck[j]);   // keys of a point are distinct
     __syncthreads();
+    } else {
+    // pass B on one or two wavefronts: the same keys, but a lane takes GUIDED_CAND_CAP / NT combinations and parks their
+    // keys in LDS -- the grid's items (4 kcap words) are dead once the candidates are recorded -- instead of in registers;
+    // U combinations per trip, so that their descriptor loads are in flight together
+    constexpr int U = 2;
+    uint32_t* ckey = reinterpret_cast<uint32_t*>(item4);
+    for (int c0 = U * tid; c0 < n_cand; c0 += U * NT) {
+      uint32_t ck[U], ci[U];
+      uint4 fa[U][W / 4], fb[U][W / 4];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const uint32_t it = cand[min(c0 + j, n_cand - 1)];
+        ci[j] = it >> 16;
+        ck[j] = it & 0xFFFFu;
+        const uint4* pf = reinterpret_cast<const uint4*>(dF + (size_t)ci[j] * W);
+        const uint4* pt = reinterpret_cast<const uint4*>(dT + (size_t)ck[j] * W);
+#pragma unroll
+        for (int q4 = 0; q4 < W / 4; ++q4) { fa[j][q4] = pf[q4]; fb[j][q4] = pt[q4]; }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < W / 4; ++q4) {
+          const uint4 a = fa[j][q4], b = fb[j][q4];
+          d += __popc(a.x ^ b.x) + __popc(a.y ^ b.y) + __popc(a.z ^ b.z) + __popc(a.w ^ b.w);
+        }
+        if (c0 + j < n_cand) {
+          const uint32_t key = (d << 16) | ck[j];
+          ckey[c0 + j] = key;
+          atomicMin(&key1[ci[j]], key);
+        }
+      }
+    }
+    __syncthreads();
+    SF_TRACE_MARK(P, pair, 25);   // Hamming distances + best keys
+    for (int c = tid; c < n_cand; c += NT) {
+      const uint32_t key = ckey[c], i = cand[c] >> 16;
+      if (key != key1[i]) atomicMin(&key2[i], key);   // keys of a point are distinct
+    }
+    __syncthreads();
+    }
     SF_TRACE_MARK(P, pair, 26);   // second-best keys
     for (int i = tid; i < Kf; i += NT) {
       const uint32_t ol = oilast[i];

@@ -675,8 +675,8 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   return PnpTail{L.obj, L.cidx, inl, m, true};
 }
 
-template <bool BA, int DIR = 0>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 3)
+template <int DIR = 0>
+__global__ void __launch_bounds__(SF_BLOCK, 3)
 k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
       const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
       const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
@@ -688,12 +688,7 @@ k_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __rest
   const PnpTail tail = pnp_body<DIR>(st, pair, pair_from, pair_to, corr, hdr, pass, P, smem_raw, 0,
                                      mask ? mask + (size_t)pair * st.kcap : nullptr,
                                      guided_flag != nullptr && guided_flag[pair] != 0);
-  if constexpr (BA) {
-    // myRegistrationVis.cpp:1192-1370: two-view bundle adjustment of this pass's estimate
-    if (P.bundle_adjustment && tail.ran)
-      ba_body(st, pair_from[pair], pair_to[pair], tail.obj, tail.cidx, tail.inl, tail.m, pass[pair], P,
-              smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15));
-  }
+  (void)tail;      // (myRegistrationVis.cpp:1192-1370, the adjustment of this estimate: k_ba_pass, its own launch)
   // myRegistration.cpp:269-276, and for pass 1 the application its result meets as the guess of pass 2 (:245-248)
   if (extra_3dof && threadIdx.x == 0 && !pass[pair].is_null)
     for (int t = 0; t < extra_3dof; ++t) sfd::to3dof_canon(pass[pair].T);
@@ -766,18 +761,15 @@ size_t sf_pnp_lds_bytes(int kcap, int iterations) { return sf_pnp_lds_bytes_dev(
 int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
   const bool ba = c->dparams.bundle_adjustment != 0;
-  // (both directions WITH the adjustment: plain estimates, then k_merge_directions_ba adjusts over the union)
-  const size_t lds = ((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
-                     ((ba && !c->dparams.bidirectional) ? sf_ba_lds_bytes(st.kcap) : 0);
+  // (the adjustment is a launch of its own behind the estimate: sf_launch_ba_pass; both directions WITH the adjustment:
+  //  plain estimates, then k_merge_directions_ba adjusts over the union)
+  const size_t lds = (sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15;
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "PnP workgroup needs %zu B of LDS (> 160 KiB)", lds);
   const bool bidir = c->dparams.bidirectional != 0;
-  bool& attr = (ba && !bidir) ? c->pnp_ba_attr_set : c->pnp_attr_set;
+  bool& attr = c->pnp_attr_set;
   if (!attr) {   // per handle = per device
-    if (ba && !bidir) SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else {
-      SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_pnp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
@@ -798,6 +790,12 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
     mask_f = (uint8_t*)c->dir_mask.p;
     mask_b = mask_f + mb;
     SF_HIP(c, hipMemsetAsync(mask_f, 0, 2 * mb, c->stream));
+  } else if (ba) {      // the estimate's inlier set, one byte per "from" feature: what the adjustment's launch rebuilds its words from
+    int rc;
+    const size_t mb = (size_t)n * st.kcap;
+    if ((rc = sf_buf_reserve(c, c->dir_mask, mb)) != SF_OK) return rc;
+    mask_f = (uint8_t*)c->dir_mask.p;
+    SF_HIP(c, hipMemsetAsync(mask_f, 0, mb, c->stream));
   }
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
@@ -805,11 +803,11 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
     hipLaunchKernelGGL(kern, dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to, list, counter, corr, hdr, out, extra,
                        c->dparams, mask, guided_flag);
   };
-  if (ba && !bidir) launch(k_pnp<true>, ps, nullptr, end_3dof);
-  else if (!bidir) launch(k_pnp<false, 0>, ps, nullptr, end_3dof);
+  if (ba && !bidir) launch(k_pnp<0>, ps, mask_f, 0);      // (Reg/Force3DoF's end-of-pass application: behind the adjustment)
+  else if (!bidir) launch(k_pnp<0>, ps, nullptr, end_3dof);
   else {
-    launch(k_pnp<false, 0>, ps, mask_f, 0);
-    launch(k_pnp<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    launch(k_pnp<0>, ps, mask_f, 0);
+    launch(k_pnp<1>, (PassState*)c->pass_back.p, mask_b, 0);
     if (ba) {
       const int rc = sf_launch_merge_directions_ba(c, st, d_from, d_to, n, pass, true, mask_f, mask_b);
       if (rc != SF_OK) return rc;
@@ -820,5 +818,6 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
   }
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
+  if (ba && !bidir) return sf_launch_ba_pass(c, st, d_from, d_to, n, pass, pass == 1 ? 1 : 3, mask_f, nullptr, false, nullptr);
   return SF_OK;
 }

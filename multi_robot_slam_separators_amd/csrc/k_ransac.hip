@@ -113,10 +113,11 @@ __device__ inline void fit3(const RansacLds& L, uint32_t s0, uint32_t s1, uint32
 
 // optimizeModelCoefficients over the members of `mask` (block-order reductions); the fit of the reduced moments is
 // solved by wavefront 0 and left in L.bc (visible to the workgroup after the caller's next barrier)
+template <int NW>
 __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask, int n_in, int tid) {
   const double inv_n = 1.0 / (double)n_in;
   double s6[6];
-  sfd::canon_reduce<6, 16, 4>(m, tid, L.red, s6, [&](int i, double (&a)[6]) {
+  sfd::canon_reduce<6, 16, NW>(m, tid, L.red, s6, [&](int i, double (&a)[6]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
       a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
@@ -126,7 +127,7 @@ __device__ inline void fit_masked(const RansacLds& L, int m, const uint8_t* mask
   double mp[3] = {s6[0] * inv_n, s6[1] * inv_n, s6[2] * inv_n};
   double mq[3] = {s6[3] * inv_n, s6[4] * inv_n, s6[5] * inv_n};
   double s9[11];   // S (9), ga, gb
-  sfd::canon_reduce<11, 16, 4>(m, tid, L.red, s9, [&](int i, double (&acc)[11]) {
+  sfd::canon_reduce<11, 16, NW>(m, tid, L.red, s9, [&](int i, double (&acc)[11]) {
     if (mask[i]) {
       float4 p = L.src[i], q = L.dst[i];
       const double a[3] = {(double)p.x - mp[0], (double)p.y - mp[1], (double)p.z - mp[2]};
@@ -167,6 +168,7 @@ struct SelCounts { int n, low, diff; };
 // selectWithinDistance under the model at `cf` (LDS): membership mask, the members' squared residuals in L.d2
 // (non-members and the padding up to a multiple of 4 hold +inf, so order statistics over the selected set can
 // scan the array without consulting the mask), and the three counts above in ONE block reduction.
+template <int NW>
 __device__ inline SelCounts select_within(const RansacLds& L, int m, const float* cf, double thr2, uint8_t* mask,
                                           const uint8_t* prev, double sigma, double thr, int tid) {
   float coef[12];
@@ -174,7 +176,7 @@ __device__ inline SelCounts select_within(const RansacLds& L, int m, const float
   for (int k = 0; k < 12; ++k) coef[k] = cf[k];
   unsigned long long acc = 0;
   const int m4 = (m + 3) & ~3;
-  for (int i = tid; i < m4; i += SF_BLOCK) {
+  for (int i = tid; i < m4; i += 64 * NW) {
     float r2 = __int_as_float(0x7F800000);
     if (i < m) {
       float4 p = L.src[i], q = L.dst[i];
@@ -194,7 +196,9 @@ __device__ inline SelCounts select_within(const RansacLds& L, int m, const float
   __syncthreads();
   if (lane == 0) L.sums[wave] = acc;
   __syncthreads();
-  const unsigned long long t = ((L.sums[0] + L.sums[1]) + L.sums[2]) + L.sums[3];
+  unsigned long long t = L.sums[0];            // (integer fields: the order of the fold is free)
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += L.sums[w];
   SelCounts c;
   c.n = (int)(t & 0x1FFFull);
   c.low = (int)((t >> 13) & 0x1FFFull);
@@ -215,16 +219,17 @@ __device__ inline SelCounts select_within(const RansacLds& L, int m, const float
 typedef __attribute__((address_space(3))) const float* lds_cfloat_p;
 typedef __attribute__((address_space(3))) unsigned* lds_uint_p;
 typedef __attribute__((address_space(3))) int* lds_int_p;
+template <int NT>
 __device__ __attribute__((noinline)) float radix_select_rank(lds_cfloat_p d2, lds_uint_p hist, lds_int_p misc, int m4,
                                                              int rank, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  for (int b = tid; b < 4 * 256; b += SF_BLOCK) hist[b] = 0u;
+  for (int b = tid; b < 4 * 256; b += NT) hist[b] = 0u;
   __syncthreads();                                       // histograms cleared, the selection's d2 visible
   unsigned prefix = 0u;
 #pragma unroll 1
   for (int p = 0; p < 4; ++p) {
     const int shift = 24 - 8 * p;
-    for (int i = tid; i < m4; i += SF_BLOCK) {
+    for (int i = tid; i < m4; i += NT) {
       const unsigned bits = __float_as_uint(d2[i]);
       if (p == 0 || (bits >> (shift + 8)) == prefix)
         __hip_atomic_fetch_add(&hist[p * 256 + ((bits >> shift) & 255u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -256,8 +261,9 @@ __device__ __attribute__((noinline)) float radix_select_rank(lds_cfloat_p d2, ld
   return __uint_as_float(prefix);
 }
 
+template <int NW>
 __device__ __forceinline__ double variance_of(const RansacLds& L, int m, int n, int tid) {
-  const float medv = radix_select_rank((lds_cfloat_p)L.d2, (lds_uint_p) reinterpret_cast<unsigned*>(L.hyp),
+  const float medv = radix_select_rank<64 * NW>((lds_cfloat_p)L.d2, (lds_uint_p) reinterpret_cast<unsigned*>(L.hyp),
                                        (lds_int_p)L.misc, (m + 3) & ~3, n >> 1, tid);
   return 2.1981 * (double)medv;
 }
@@ -394,11 +400,11 @@ __device__ __forceinline__ void write_null_pass(PassState& out, int matches) {
 // `out` by thread 0.
 // DIR = 1: the backward estimate of Vis/ForwardEstOnly = false (myRegistrationVis.cpp:936-978: A = "to", B = "from");
 // `mask_out` (stage kernel, DIR form only): one byte per "from" feature of the pair, set for this estimate's inliers.
-template <bool BA = false, int DIR = 0>
+template <int DIR = 0, int NW = 4>
 __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int sF, int sT, const uint32_t* cl, int n_corr,
                                             PassState& out, const DeviceParams& P, unsigned char* lds,
                                             int trace_base = 2, uint8_t* mask_out = nullptr) {
-  constexpr int NT = SF_BLOCK;
+  constexpr int NT = 64 * NW;      // NW = 4: the 256-thread workgroup of the fused / stage kernels; 1, 2: the low-occupancy chains
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
@@ -429,7 +435,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       int c = L.misc[4 + w];
       if (w < wave) woff += c;
       total += c;
@@ -451,7 +457,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
 
   // the wavefront that samples, fits and replays rotates with the pair, so that the workgroups sharing a CU do
   // not all put this serial fp64 section on the same SIMD
-  const int fit_wave = pair & 3;
+  const int fit_wave = pair & (NW - 1);
 
   // ---- computeSampleDistanceThreshold (PCA of the source cloud) ----------------------------------
   const double inv_m = 1.0 / (double)m;
@@ -461,13 +467,13 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   {
     double mean[3];
     double s3[3];
-    sfd::canon_reduce<3, 16, 4>(m, tid, L.red, s3, [&](int i, double (&a)[3]) {
+    sfd::canon_reduce<3, 16, NW>(m, tid, L.red, s3, [&](int i, double (&a)[3]) {
       float4 p = L.src[i];
       a[0] += (double)p.x; a[1] += (double)p.y; a[2] += (double)p.z;
     });
     mean[0] = s3[0] * inv_m; mean[1] = s3[1] * inv_m; mean[2] = s3[2] * inv_m;
     double c6[6];  // xx xy xz yy yz zz
-    sfd::canon_reduce<6, 16, 4>(m, tid, L.red, c6, [&](int i, double (&a)[6]) {
+    sfd::canon_reduce<6, 16, NW>(m, tid, L.red, c6, [&](int i, double (&a)[6]) {
       float4 p = L.src[i];
       const double a0 = (double)p.x - mean[0], a1 = (double)p.y - mean[1], a2 = (double)p.z - mean[2];
       a[0] += a0 * a0; a[1] += a0 * a1; a[2] += a0 * a2;
@@ -536,7 +542,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       const double thr2 = P.inlier_thr * P.inlier_thr;
       float thr2f = (float)thr2;                             // largest float strictly below thr^2
       if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
-      const int slice = (m + 3) / 4;                           // points counted by each wavefront
+      const int slice = (m + NW - 1) / NW;                     // points counted by each wavefront
       const int i0 = min(m, wave_c * slice), i1 = min(m, i0 + slice);
       L.hyp_cnt[wave_c * 64 + lane_c] = R == 16 ? count_round<16>(L, hv, i0, i1, lane_c, thr2f)
                                                 : count_round<64>(L, hv, i0, i1, lane_c, thr2f);
@@ -549,12 +555,12 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       if (R == 16) {
         const int h = lane_r & 15;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
 #pragma unroll
           for (int g = 0; g < 4; ++g) tot += L.hyp_cnt[w * 64 + g * 16 + h];
       } else {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot += L.hyp_cnt[w * 64 + lane_r];
+        for (int w = 0; w < NW; ++w) tot += L.hyp_cnt[w * 64 + lane_r];
       }
       const bool present = lane_r < R && it <= max_it;
       const int c = (present && hv[lane_r]) ? tot : -1;
@@ -591,7 +597,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   const double thr = P.inlier_thr;
   const double thr2 = thr * thr;
   const double sigma = P.refine_sigma;
-  SelCounts sc = select_within(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid_b);
+  SelCounts sc = select_within<NW>(L, m, L.best, thr2, L.mask_a, nullptr, sigma, thr, tid_b);
   int n_inl = sc.n;
   const uint8_t* inl = L.mask_a;     // the final inlier set (std::swap(inliers_, new_inliers) below)
   int n_last = n_inl;
@@ -612,13 +618,13 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     if (tid_b < 12) L.bc[tid_b] = L.best[tid_b];            // new_model_coefficients = model_coefficients
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;  // last four pushed sizes (z1 newest)
     do {
-      if (n_prev >= 3) fit_masked(L, m, prev, n_prev, tid_b);
+      if (n_prev >= 3) fit_masked<NW>(L, m, prev, n_prev, tid_b);
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
       __syncthreads();                                // L.bc (and the cleared `neu`) visible
       // membership changes are counted against `prev`, the set selected one round ago, while `neu` (the set of
       // two rounds ago) is overwritten
-      sc = select_within(L, m, L.bc, error_threshold * error_threshold, neu, prev, sigma, thr, tid_b);
+      sc = select_within<NW>(L, m, L.bc, error_threshold * error_threshold, neu, prev, sigma, thr, tid_b);
       n_new = sc.n;
       n_last = n_new;
       if (n_new == 0) {
@@ -629,7 +635,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       // error_threshold = min(thr, sigma * sqrt(variance)), variance = 2.1981 * median: the median is only needed
       // when it is one of the `low` members (see SelCounts)
       if ((n_new >> 1) < sc.low) {
-        const double variance = variance_of(L, m, n_new, tid_b);
+        const double variance = variance_of<NW>(L, m, n_new, tid_b);
         const double sthr = sigma * sqrt(variance);
         error_threshold = thr < sthr ? thr : sthr;
       } else {
@@ -655,7 +661,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
     if (mask_out)
       for (int i = tid; i < m; i += NT)
         if (inl[i]) mask_out[L.cidx[i] & 0xFFFFu] = 1;
-    const double variance = variance_of(L, m, n_last, tid_b);
+    const double variance = variance_of<NW>(L, m, n_last, tid_b);
     if (tid_b == 0) {
       PassState ps;
 #pragma unroll
@@ -691,11 +697,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   } else if (tid_b == 0) {
     write_null_pass(out, m);
   }
-  if constexpr (BA) {
-    // :1192-1370 two-view bundle adjustment of this pass's estimate (its working set sits behind this stage's)
-    if (P.bundle_adjustment)
-      ba_body(st, sF, sT, L.src, L.cidx, inl, m, out, P, lds + ((sf_ransac_lds_bytes_dev(kcap) + 15) & ~(size_t)15));
-  }
+  // (:1192-1370, the two-view bundle adjustment of this estimate: k_ba_pass, a launch of its own -- k_verify.hip)
   SF_TRACE_MARK(P, pair, trace_base + 5);
 }
 
@@ -706,8 +708,8 @@ __device__ inline void pass_to3dof(PassState& ps, int times) {
   for (int t = 0; t < times; ++t) sfd::to3dof_canon(ps.T);
 }
 
-template <bool BA, int DIR>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
+template <int DIR>
+__global__ void __launch_bounds__(SF_BLOCK, 4)
 k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
          const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
          const uint32_t* __restrict__ corr, const CorrHeader* __restrict__ hdr,
@@ -715,7 +717,7 @@ k_ransac(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __r
   if ((int)blockIdx.x >= *counter) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int pair = list[blockIdx.x];
-  ransac_body<BA, DIR>(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr,
+  ransac_body<DIR>(st, pair, pair_from[pair], pair_to[pair], corr + (size_t)pair * st.kcap, hdr[pair].n_corr,
                        pass[pair], P, smem_raw, 2, mask ? mask + (size_t)pair * st.kcap : nullptr);
   if (extra_3dof && threadIdx.x == 0) pass_to3dof(pass[pair], extra_3dof);
 }
@@ -770,18 +772,15 @@ size_t sf_ransac_lds_bytes(int kcap, int iterations) {
 int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass) {
   if (n <= 0) return SF_OK;
   const bool ba = c->dparams.bundle_adjustment != 0;
-  // (both directions WITH the adjustment: plain estimates, then k_merge_directions_ba adjusts over the union)
-  const size_t lds = ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
-                     ((ba && !c->dparams.bidirectional) ? sf_ba_lds_bytes(st.kcap) : 0);
+  // (the adjustment is a launch of its own behind the estimate: sf_launch_ba_pass; both directions WITH the adjustment:
+  //  plain estimates, then k_merge_directions_ba adjusts over the union)
+  const size_t lds = (sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15;
   if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "RANSAC workgroup needs %zu B of LDS (> 160 KiB)", lds);
   const bool bidir = c->dparams.bidirectional != 0;
-  bool& attr = (ba && !bidir) ? c->ransac_ba_attr_set : c->ransac_attr_set;
+  bool& attr = c->ransac_attr_set;
   if (!attr) {   // per handle = per device
-    if (ba && !bidir) SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else {
-      SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_ransac<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
@@ -799,6 +798,12 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
     mask_f = (uint8_t*)c->dir_mask.p;
     mask_b = mask_f + mb;
     SF_HIP(c, hipMemsetAsync(mask_f, 0, 2 * mb, c->stream));
+  } else if (ba) {      // the estimate's inlier set, one byte per "from" feature: what the adjustment's launch rebuilds its words from
+    int rc;
+    const size_t mb = (size_t)n * st.kcap;
+    if ((rc = sf_buf_reserve(c, c->dir_mask, mb)) != SF_OK) return rc;
+    mask_f = (uint8_t*)c->dir_mask.p;
+    SF_HIP(c, hipMemsetAsync(mask_f, 0, mb, c->stream));
   }
   const int kid = pass == 1 ? SF_K_RANSAC1 : SF_K_RANSAC2;
   sf_prof_begin(c, kid);
@@ -807,11 +812,11 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
                        (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p),
                        (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p), out, mask, extra, c->dparams);
   };
-  if (ba && !bidir) launch(k_ransac<true, 0>, ps, nullptr, end_3dof);
-  else if (!bidir) launch(k_ransac<false, 0>, ps, nullptr, end_3dof);
+  if (ba && !bidir) launch(k_ransac<0>, ps, mask_f, 0);     // (Reg/Force3DoF's end-of-pass application: behind the adjustment)
+  else if (!bidir) launch(k_ransac<0>, ps, nullptr, end_3dof);
   else {
-    launch(k_ransac<false, 0>, ps, mask_f, 0);
-    launch(k_ransac<false, 1>, (PassState*)c->pass_back.p, mask_b, 0);
+    launch(k_ransac<0>, ps, mask_f, 0);
+    launch(k_ransac<1>, (PassState*)c->pass_back.p, mask_b, 0);
     if (ba) {
       const int rc = sf_launch_merge_directions_ba(c, st, d_from, d_to, n, pass, false, mask_f, mask_b);
       if (rc != SF_OK) return rc;
@@ -821,5 +826,6 @@ int sf_launch_ransac(sf_context* c, StoreView st, const int32_t* d_from, const i
   }
   sf_prof_end(c, kid);
   SF_HIP(c, hipGetLastError());
+  if (ba && !bidir) return sf_launch_ba_pass(c, st, d_from, d_to, n, pass, pass == 1 ? 1 : 3, mask_f, nullptr, false, nullptr);
   return SF_OK;
 }

@@ -14,8 +14,15 @@
 // (368 B).  Round 1 round-tripped all of it through HBM between stages of the SAME workgroup (a write, a
 // vmcnt(0) wait, a barrier and a dependent read per hand-over, 60 MB of writes per 10 000-pair launch).
 // SF_OPT_DEBUG_CORR (sf_debug_correspondences, tests) additionally copies lists and headers to the global
-// workspace.  The stage kernels remain for the PnP estimator (k_pnp: ~170 VGPRs, 3 workgroups per CU) and as
-// the A/B reference (SF_FUSED=0): both paths run the same bodies and produce identical bytes.
+// workspace.  The stage kernels remain for the shapes the fused / split forms do not take and as the A/B
+// reference (SF_FUSED=0): all paths run the same bodies and produce identical bytes.
+//
+// Round 5: the bundle adjustment (myRegistrationVis.cpp:1192-1370) is a launch of its own (k_ba_pass) in every
+// pipeline.  Inside the estimators' kernels it had forced a second instantiation of each of them -- 256 registers +
+// 700 B of scratch per lane at two workgroups per CU -- and the reference's as-shipped flow (PnP + adjustment) ran
+// at 3.1 M pairs/s against 13.7 M without it.  With the adjustment on, a survivor's chain is cut in two:
+// [estimate 1] -> k_ba_pass -> [guided matching + estimate 2] -> k_ba_pass (+ result), the estimates leaving their
+// inlier sets as one byte per "from" feature.
 // Compiled with -ffp-contract=off (canonical arithmetic of the RANSAC / guided bodies).
 // Workgroups of k_chain_pnp per CU the compiler budgets registers for.  Measured on the bench's PnP line (round 4,
 // profiles/r04z_pnp_chain_occupancy.txt): 2 (256 registers, no scratch) 11.8 M pairs/s, 3 (168 registers, 116 B of
@@ -39,72 +46,105 @@ struct FusedTail {
   int32_t stream_slot;       // accepted-result stream: this pair's slot in the host block (-1: not accepted / full)
 };
 
+// What the two halves of a chain cut around the bundle adjustment leave in HBM besides lists, headers and pass states
+struct BaHandover {
+  uint8_t* mask1;     // [pairs][kcap] inlier bytes of the first estimate, per "from" feature (zeroed before the launch)
+  uint8_t* mask2;     // ... of the second
+  uint8_t* est2;      // [pairs] 1 = the pair's second estimate ran (its state is to be adjusted)
+};
+
+// the accepted result of a finished pair leaves for the host NOW (posted PCIe writes beside the other pairs' work)
+// instead of through a compaction kernel behind the launch: thread 0 takes the slot, 23 lanes move the 368 bytes
+__device__ __forceinline__ void stream_accepted(int pair, const sf_result* __restrict__ out, const DeviceParams& P,
+                                                int32_t& s_slot) {
+  const AcceptStream& S = P.accept;
+  const int tid = (int)threadIdx.x;
+  if (tid == 0) {
+    const bool ok = out[pair].success != 0;
+    if (S.flags) S.flags[pair] = ok ? 1 : 0;
+    int slot = -1;
+    if (ok) {
+      const unsigned sl = atomicAdd(S.counter, 1u);
+      if (sl < (unsigned)S.cap) { slot = (int)sl; S.index[sl] = pair; }
+    }
+    s_slot = slot;
+  }
+  __syncthreads();
+  const int slot = s_slot;
+  if (slot >= 0 && tid < (int)(sizeof(sf_result) / 16)) {
+    const uint4 v = reinterpret_cast<const uint4*>(out + pair)[tid];
+    reinterpret_cast<uint4*>(S.records + slot)[tid] = v;
+    if (S.records2) reinterpret_cast<uint4*>(S.records2 + slot)[tid] = v;
+  }
+}
+
 // Everything after the pass-1 correspondence list of a pair: RANSAC, guess-guided matching, RANSAC, result.
-template <int W, bool BA>
+// PART 0: the whole chain.  With the bundle adjustment on the chain is cut around its two launches (k_ba_pass):
+// PART 1 = the first estimate (its state and inlier bytes go to HBM), PART 2 = guided matching + the second estimate
+// from the ADJUSTED first state (list, header, flag, state, inlier bytes to HBM; the result is assembled by the second
+// adjustment's launch).
+template <int W, int NW = 4, int PART = 0>
 __device__ __forceinline__ void chain_after_match(const StoreView& st, int pair, int sF, int sT, bool est1, FusedTail& T,
                                                   uint32_t* cl, unsigned char* chain_lds, uint32_t* __restrict__ corr2,
                                                   CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass1,
                                                   PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
-                                                  sf_result* __restrict__ out, const DeviceParams& P) {
+                                                  sf_result* __restrict__ out, const DeviceParams& P,
+                                                  const BaHandover& H) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int kcap = st.kcap;
   // from here on this workgroup is a short chain of dependent fp64 steps: let its wavefronts win the
   // issue arbitration against the matching wavefronts it shares SIMDs with (they are throughput-bound
   // and lose nothing measurable), so the chain -- the tail of the launch -- finishes sooner
   __builtin_amdgcn_s_setprio(3);
-  if (est1) {
-    ransac_body<BA>(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2);
-    if (P.force_3dof && tid == 0) pass_to3dof(T.pass1, 2);      // myRegistration.cpp:269-276, then :245-248 as pass 2's guess
-    __syncthreads();
+  if constexpr (PART != 2) {
+    if (est1) {
+      ransac_body<0, NW>(st, pair, sF, sT, cl, T.hdr1.n_corr, T.pass1, P, chain_lds, 2,
+                         PART == 1 ? H.mask1 + (size_t)pair * kcap : nullptr);
+      if constexpr (PART == 0) {
+        if (P.force_3dof && tid == 0) pass_to3dof(T.pass1, 2);    // myRegistration.cpp:269-276, then :245-248 as pass 2's guess
+      }
+      __syncthreads();
+    }
+    if constexpr (PART == 1) {
+      if (tid == 0) pass1[pair] = T.pass1;        // (Reg/Force3DoF's applications: behind the adjustment, k_ba_pass)
+      return;
+    }
   }
   // pass 2: guess-guided matching (:476-825) seeded with the pass-1 pose, RANSAC again
-  const bool est2 = guided_body<W>(st, pair, sF, sT, T.pass1, T.pass2, T.guided_flag, cl, T.hdr2, nullptr, nullptr, P,
-                                   reinterpret_cast<int*>(chain_lds));
+  const bool est2 = guided_body<W, false, NW>(st, pair, sF, sT, T.pass1, T.pass2, T.guided_flag, cl, T.hdr2, nullptr, nullptr,
+                                              P, reinterpret_cast<int*>(chain_lds));
   __syncthreads();
-  if (P.dbg_corr) {
+  if (P.dbg_corr || PART == 2) {
     const int n = T.hdr2.n_corr;
-    for (int i = tid; i < n; i += SF_BLOCK) corr2[(size_t)pair * kcap + i] = cl[i];
+    for (int i = tid; i < n; i += NT) corr2[(size_t)pair * kcap + i] = cl[i];
     if (tid == 0) hdr2[pair] = T.hdr2;
   }
   if (est2) {
-    ransac_body<BA>(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11);
-    if (P.force_3dof && tid == 0) pass_to3dof(T.pass2, 1);
+    ransac_body<0, NW>(st, pair, sF, sT, cl, T.hdr2.n_corr, T.pass2, P, chain_lds, 11,
+                       PART == 2 ? H.mask2 + (size_t)pair * kcap : nullptr);
+    if constexpr (PART == 0) {
+      if (P.force_3dof && tid == 0) pass_to3dof(T.pass2, 1);
+    }
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);
+  if constexpr (PART == 2) {
+    if (tid == 0) { pass2[pair] = T.pass2; guided_flag[pair] = T.guided_flag; H.est2[pair] = est2 ? 1 : 0; }
+    return;
+  }
   if (tid == 0) {
     if (P.dbg_corr) { pass1[pair] = T.pass1; pass2[pair] = T.pass2; guided_flag[pair] = T.guided_flag; }
     finalize_one(T.pass1, T.pass2, T.guided_flag, out[pair]);
   }
-  if (P.accept_on) {
-    // the accepted result leaves for the host NOW (posted PCIe writes beside the other pairs' work) instead of through
-    // a compaction kernel behind the launch: thread 0 takes the slot, 23 lanes move the 368 bytes
-    const AcceptStream& S = P.accept;
-    if (tid == 0) {
-      const bool ok = out[pair].success != 0;
-      if (S.flags) S.flags[pair] = ok ? 1 : 0;
-      int slot = -1;
-      if (ok) {
-        const unsigned sl = atomicAdd(S.counter, 1u);
-        if (sl < (unsigned)S.cap) { slot = (int)sl; S.index[sl] = pair; }
-      }
-      T.stream_slot = slot;
-    }
-    __syncthreads();
-    const int slot = T.stream_slot;
-    if (slot >= 0 && tid < (int)(sizeof(sf_result) / 16)) {
-      const uint4 v = reinterpret_cast<const uint4*>(out + pair)[tid];
-      reinterpret_cast<uint4*>(S.records + slot)[tid] = v;
-      if (S.records2) reinterpret_cast<uint4*>(S.records2 + slot)[tid] = v;
-    }
-  }
+  if (P.accept_on) stream_accepted(pair, out, P, T.stream_slot);
 }
 
 // WIDE: the instantiation for frames whose LDS working set does not let four workgroups share a CU anyway (K = 1000
 // features: 52 KB, three per CU): compiled for two workgroups per CU it takes 162 registers -- three still fit -- and
 // keeps FOUR resident "to" tiles per wavefront in the scan (one spread of a "from" tile per four tiles instead of two).
-template <int W, int NQ, bool BA, bool WIDE = false>
-__global__ void __launch_bounds__(SF_BLOCK, (BA || WIDE) ? 2 : 4)
+template <int W, int NQ, bool WIDE = false>
+__global__ void __launch_bounds__(SF_BLOCK, WIDE ? 2 : 4)
 k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
                uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
@@ -142,7 +182,8 @@ k_verify_fused(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     for (int i = tid; i < n; i += SF_BLOCK) corr1[(size_t)pair * kcap + i] = cl[i];
     if (tid == 0) hdr1[pair] = T.hdr1;
   }
-  chain_after_match<W, BA>(st, pair, sF, sT, est1, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P);
+  chain_after_match<W>(st, pair, sF, sT, est1, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P,
+                       BaHandover{nullptr, nullptr, nullptr});
 }
 
 // ---- the split pipeline: ONE matching launch over all pairs, ONE chain launch over the survivors -------------
@@ -181,13 +222,22 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
   }
 }
 
-template <int W, bool BA>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : 4)
+// NW: wavefronts per chain.  4 = the round-2 form (one 256-thread workgroup per survivor, 128 registers: a chain holds
+// a quarter of a CU's wave slots and registers while three of its four wavefronts wait at barriers most of the time).
+// 1 / 2 (round 5): one or two WAVEFRONTS per survivor -- with one, no barrier is left in the chain (a single-wavefront
+// workgroup's __syncthreads is a wait on its own LDS traffic) and no wavefront waits for the one that solves.  The sums
+// keep the canonical 256-lane order (sfd::canon_reduce plays the four wavefronts one after the other), so the results
+// are the same bytes (tests/test_gpu_verify.py::test_chain_widths_give_the_same_bytes).  Measured on the bench step
+// (profiles/r05a_chain_width.txt): a chain takes ~1.8 x as long on one wavefront as on four, and what caps the chains
+// per CU is their LDS (32 KB each: five per CU whatever their width), not registers or wave slots -- 20.1 / 22.0 / 22.3 M
+// pairs/s for 1 / 2 / 4.  The narrow forms stay selectable (SF_CHAIN_NW) for shapes whose working set is small.
+template <int W, int NW, int PART>
+__global__ void __launch_bounds__(64 * NW, 4)
 k_chain(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
         const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
         uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
         uint8_t* __restrict__ guided_flag, const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
-        sf_result* __restrict__ out, DeviceParams P, int tail_off) {
+        sf_result* __restrict__ out, DeviceParams P, int tail_off, BaHandover H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if ((int)blockIdx.x >= *counter) return;           // (the grid is sized for every pair surviving)
   const int pair = list[blockIdx.x];
@@ -197,24 +247,28 @@ k_chain(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __re
   FusedTail& T = *reinterpret_cast<FusedTail*>(smem_raw + tail_off);
   uint32_t* cl = reinterpret_cast<uint32_t*>(smem_raw);
   unsigned char* chain_lds = smem_raw + (size_t)kcap * 4;
-  const CorrHeader h1 = hdr1[pair];
-  if (tid == 0) { T.hdr1 = h1; T.pass1 = pass1[pair]; }
-  for (int i = tid; i < h1.n_corr; i += SF_BLOCK) cl[i] = corr1[(size_t)pair * kcap + i];
+  if constexpr (PART != 2) {
+    const CorrHeader h1 = hdr1[pair];
+    if (tid == 0) { T.hdr1 = h1; T.pass1 = pass1[pair]; }
+    for (int i = tid; i < h1.n_corr; i += 64 * NW) cl[i] = corr1[(size_t)pair * kcap + i];
+  } else {
+    if (tid == 0) T.pass1 = pass1[pair];              // (the adjusted first estimate)
+  }
   __syncthreads();
   SF_TRACE_MARK(P, pair, 1);
-  chain_after_match<W, BA>(st, pair, sF, sT, true, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P);
+  chain_after_match<W, NW, PART>(st, pair, sF, sT, true, T, cl, chain_lds, corr2, hdr2, pass1, pass2, guided_flag, out, P, H);
 }
 
-template <int W, int NQ, bool BA, bool WIDE = false>
+template <int W, int NQ, bool WIDE = false>
 int launch_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                  size_t lds, int tail_off) {
-  bool& attr_set = c->fused_attr[W == 16][NQ == 0][BA || WIDE];   // one flag per instantiation (WIDE only without BA)
+  bool& attr_set = c->fused_attr[W == 16][NQ == 0][WIDE];   // one flag per instantiation
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, BA, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_verify_fused<W, NQ, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_verify_fused<W, NQ, BA, WIDE>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_verify_fused<W, NQ, WIDE>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (uint32_t*)c->corr2.p,
                      (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p, d_out, c->dparams,
                      tail_off, c->pair_src);
@@ -226,8 +280,7 @@ size_t fused_tail_offset(const sf_context* c, const StoreView& st, bool with_mat
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t match = with_match ? sf_match_lds_bytes(st.kcap, st.w) : 0;
   const size_t guided = (size_t)st.kcap * 4 + sf_guided_lds_bytes(st.kcap, nc);
-  const size_t ransac = (size_t)st.kcap * 4 + ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
-                        (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0);
+  const size_t ransac = (size_t)st.kcap * 4 + ((sf_ransac_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15);
   return (std::max(match, std::max(guided, ransac)) + 15) & ~(size_t)15;
 }
 
@@ -246,106 +299,163 @@ size_t sf_fused_lds_bytes(const sf_context* c, const StoreView& st) {
   return lds <= 160 * 1024 ? lds : 0;
 }
 
+// (with the bundle adjustment on the fused kernel does not apply: the chain is cut around the adjustment's launches,
+//  sf_launch_verify_split, or the stage kernels run)
 int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n,
                            sf_result* d_out) {
   if (n <= 0) return SF_OK;
   const size_t lds = sf_fused_lds_bytes(c, st);
-  if (lds == 0) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
+  if (lds == 0 || c->dparams.bundle_adjustment) return sf_fail(c, SF_EINVAL, "fused verification pipeline not applicable");
   const int tail_off = (int)fused_tail_offset(c, st);
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
   const bool mf = c->match_mfma && st.kcap <= MF_MAX_ROWS;
-  const bool ba = c->dparams.bundle_adjustment != 0;   // (own instantiation: 2 workgroups per CU, ~60 live fp64 values)
-#define SF_FUSED_CASE(W_, NQ_)                                                               \
-  rc = ba ? launch_fused<W_, NQ_, true>(c, st, d_from, d_to, n, d_out, lds, tail_off)         \
-          : launch_fused<W_, NQ_, false>(c, st, d_from, d_to, n, d_out, lds, tail_off)
   // more than a quarter of a CU's LDS per workgroup: four do not fit, so the build for fewer workgroups (162 registers:
   // up to three per CU) with four resident tiles
   static const bool wide_off = getenv("SF_FUSED_WIDE_OFF") != nullptr;      // (A/B runs)
   static const bool wide_all = getenv("SF_FUSED_WIDE_ALL") != nullptr;    // (experiment: the wide build for every shape)
-  if (mf && !ba && st.w == 8 && (lds * 4 > 160 * 1024 || wide_all) && !wide_off)
-    rc = launch_fused<8, 0, false, true>(c, st, d_from, d_to, n, d_out, lds, tail_off);
-  else
-  if (mf) { if (st.w == 8) SF_FUSED_CASE(8, 0); else SF_FUSED_CASE(16, 0); }
-  else { if (st.w == 8) SF_FUSED_CASE(8, 2); else SF_FUSED_CASE(16, 2); }
-#undef SF_FUSED_CASE
+  if (mf && st.w == 8 && (lds * 4 > 160 * 1024 || wide_all) && !wide_off)
+    rc = launch_fused<8, 0, true>(c, st, d_from, d_to, n, d_out, lds, tail_off);
+  else if (mf) rc = st.w == 8 ? launch_fused<8, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+                              : launch_fused<16, 0>(c, st, d_from, d_to, n, d_out, lds, tail_off);
+  else rc = st.w == 8 ? launch_fused<8, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off)
+                      : launch_fused<16, 2>(c, st, d_from, d_to, n, d_out, lds, tail_off);
   sf_prof_end(c, SF_K_FUSED);
   if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());
   return SF_OK;
 }
 
+namespace {
+
 // The PnP estimator's chain for the survivors of k_match_split: PnP -> guess-guided matching -> PnP -> result in ONE
 // launch (the stage path: k_pnp, k_guided over ALL pairs, k_pnp, k_finalize).  The bodies keep handing their lists
 // and pass states over through the global workspace (k_pnp's 168 registers leave no room for the LDS-resident form of
 // the 3D-3D chain); what the fusion saves is three launches, the guided kernel's 10 000 workgroups that find nothing
-// to do, and the gaps between them.  Same bodies, same bytes.
-template <int W, bool BA>
-__global__ void __launch_bounds__(SF_BLOCK, BA ? 2 : SF_PNP_CHAIN_OCC)
+// to do, and the gaps between them.  Same bodies, same bytes.  PART as in chain_after_match (bundle adjustment on:
+// 1 = the first estimate, 2 = guided matching + the second estimate; the adjustments' launches in between and behind).
+template <int W, int PART>
+__global__ void __launch_bounds__(SF_BLOCK, SF_PNP_CHAIN_OCC)
 k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
             const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
             uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
             uint8_t* __restrict__ guided_flag, const int32_t* __restrict__ list, const int32_t* __restrict__ counter,
-            sf_result* __restrict__ out, DeviceParams P) {
+            sf_result* __restrict__ out, DeviceParams P, BaHandover H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if ((int)blockIdx.x >= *counter) return;
   const int pair = list[blockIdx.x];
   const int sF = pair_from[pair], sT = pair_to[pair];
-  unsigned char* ba_lds = smem_raw + ((sf_pnp_lds_bytes_dev(st.kcap, P.iterations) + 15) & ~(size_t)15);
+  const int kcap = st.kcap;
   __builtin_amdgcn_s_setprio(3);
   SF_TRACE_MARK(P, pair, 1);
-  {
-    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw, 37);
-    if constexpr (BA) {
-      if (P.bundle_adjustment && tail.ran)
-        ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass1[pair], P, ba_lds);
-    }
+  if constexpr (PART != 2) {
+    pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw, 37,
+             PART == 1 ? H.mask1 + (size_t)pair * kcap : nullptr);
+    if constexpr (PART == 1) return;       // (Reg/Force3DoF's applications: behind the adjustment, k_ba_pass)
     if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass1[pair], 2);
+    __syncthreads();     // pass1[pair] (written by thread 0) is read by every lane below
   }
-  __syncthreads();     // pass1[pair] (written by thread 0) is read by every lane below
   const bool est2 = guided_body<W>(st, pair, sF, sT, pass1[pair], pass2[pair], guided_flag[pair],
-                                   corr2 + (size_t)pair * st.kcap, hdr2[pair], nullptr, nullptr, P,
+                                   corr2 + (size_t)pair * kcap, hdr2[pair], nullptr, nullptr, P,
                                    reinterpret_cast<int*>(smem_raw));
   __syncthreads();
   SF_TRACE_MARK(P, pair, 42);
   if (est2) {
-    const PnpTail tail = pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 43);
-    if constexpr (BA) {
-      if (P.bundle_adjustment && tail.ran)
-        ba_body(st, sF, sT, tail.obj, tail.cidx, tail.inl, tail.m, pass2[pair], P, ba_lds);
+    pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 43,
+             PART == 2 ? H.mask2 + (size_t)pair * kcap : nullptr, true);
+    if constexpr (PART == 0) {
+      if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass2[pair], 1);
     }
-    if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass2[pair], 1);
     __syncthreads();
   }
   SF_TRACE_MARK(P, pair, 17);
+  if constexpr (PART == 2) {
+    if (threadIdx.x == 0) H.est2[pair] = est2 ? 1 : 0;
+    return;
+  }
   if (threadIdx.x == 0) finalize_one(pass1[pair], pass2[pair], guided_flag[pair], out[pair]);
   if (P.accept_on) {              // accepted-result stream (see chain_after_match)
     __syncthreads();              // (the bodies are done with the LDS: its first word carries the slot)
-    int& s_slot = *reinterpret_cast<int*>(smem_raw);
-    const AcceptStream& S = P.accept;
-    if (threadIdx.x == 0) {
-      const bool ok = out[pair].success != 0;
-      if (S.flags) S.flags[pair] = ok ? 1 : 0;
-      int slot = -1;
-      if (ok) {
-        const unsigned sl = atomicAdd(S.counter, 1u);
-        if (sl < (unsigned)S.cap) { slot = (int)sl; S.index[sl] = pair; }
-      }
-      s_slot = slot;
-    }
-    __syncthreads();
-    const int slot = s_slot;
-    if (slot >= 0 && threadIdx.x < sizeof(sf_result) / 16) {
-      const uint4 v = reinterpret_cast<const uint4*>(out + pair)[threadIdx.x];
-      reinterpret_cast<uint4*>(S.records + slot)[threadIdx.x] = v;
-      if (S.records2) reinterpret_cast<uint4*>(S.records2 + slot)[threadIdx.x] = v;
-    }
+    stream_accepted(pair, out, P, *reinterpret_cast<int32_t*>(smem_raw));
   }
+}
+
+// ---- bundle adjustment as a launch of its own (k_ba.hip: ba_pass_body) ----------------------------------------------------
+// One workgroup of NW wavefronts per entry of the pass's work list.  `run` (may be null): one byte per pair, 0 = this
+// pair's pass has no estimate to adjust (pass 2 of a pair whose guided matching did not go on to the estimation).
+// fin: the adjustment of pass 2 also assembles the pair's result (finalize_one) and, where the accepted-result stream is
+// armed, hands it to the host -- the tail of the chain kernels.
+template <int NW, bool PNP>
+__global__ void __launch_bounds__(64 * NW, 1)
+k_ba_pass(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
+          const int32_t* __restrict__ list, const int32_t* __restrict__ counter, const uint32_t* __restrict__ corr,
+          const CorrHeader* __restrict__ hdr, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ run,
+          PassState* __restrict__ pass, int extra_3dof, int fin, const PassState* __restrict__ pass1,
+          const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((int)blockIdx.x >= *counter) return;
+  const int pair = list[blockIdx.x];
+  const int kcap = st.kcap;
+  if (!run || run[pair]) {
+    ba_pass_body<NW, PNP>(st, pair_from[pair], pair_to[pair], corr + (size_t)pair * kcap, hdr[pair].n_corr,
+                          mask + (size_t)pair * kcap, pass[pair], P, smem_raw);
+    // myRegistration.cpp:269-276, and for pass 1 the application its result meets as the guess of pass 2 (:245-248)
+    // (thread 0 wrote the adjusted state: same thread, program order)
+    if (extra_3dof && threadIdx.x == 0) pass_to3dof(pass[pair], extra_3dof);
+  }
+  if (!fin) return;
+  __syncthreads();
+  if (threadIdx.x == 0) finalize_one(pass1[pair], pass[pair], guided_flag[pair], out[pair]);
+  if (P.accept_on) {
+    __syncthreads();              // (the adjustment is done with the LDS: its first word carries the slot)
+    stream_accepted(pair, out, P, *reinterpret_cast<int32_t*>(smem_raw));
+  }
+}
+
+}  // namespace
+
+// The adjustment of pass `pass` (1 / 2) of the n pairs of a launch sequence, over that pass's work list.  mask: the
+// estimates' inlier bytes [n][kcap]; run: see k_ba_pass; list_sel: which work list (1: the matching's survivors,
+// 3: the pass-2 survivors of the stage pipeline).
+int sf_launch_ba_pass(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass, int list_sel,
+                      const uint8_t* mask, const uint8_t* run, bool fin, sf_result* d_out) {
+  if (n <= 0) return SF_OK;
+  const size_t lds = sf_ba_lds_bytes(st.kcap);
+  if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "bundle adjustment needs %zu B of LDS (> 160 KiB)", lds);
+  const bool pnp = c->dparams.estimation_type == 1;
+  const int nw = c->ba_nw;
+  bool& attr = c->ba_pass_attr[pnp][nw == 4 ? 2 : nw - 1];
+  int32_t* counters = (int32_t*)c->counters.p;
+  const int32_t* list = (const int32_t*)(list_sel == 1 ? c->list1.p : c->list3.p);
+  const int32_t* counter = counters + (list_sel == 1 ? 0 : 2);
+  const uint32_t* corr = (const uint32_t*)(pass == 1 ? c->corr1.p : c->corr2.p);
+  const CorrHeader* hdr = (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p);
+  PassState* ps = (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p);
+  const int end_3dof = c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0;
+  sf_prof_begin(c, SF_K_BA);
+#define SF_BA_CASE(NW_, PNP_)                                                                                             \
+  do {                                                                                                                    \
+    if (lds > 64 * 1024 && !attr) {                                                                                       \
+      SF_HIP(c, hipFuncSetAttribute((const void*)k_ba_pass<NW_, PNP_>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                    160 * 1024));                                                                         \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((k_ba_pass<NW_, PNP_>), dim3(n), dim3(64 * NW_), lds, c->stream, st, d_from, d_to, list, counter,   \
+                       corr, hdr, mask, run, ps, end_3dof, fin ? 1 : 0, (const PassState*)c->pass1.p,                      \
+                       (const uint8_t*)c->flags.p, d_out, c->dparams);                                                    \
+  } while (0)
+  if (pnp) { if (nw == 1) SF_BA_CASE(1, true); else if (nw == 2) SF_BA_CASE(2, true); else SF_BA_CASE(4, true); }
+  else { if (nw == 1) SF_BA_CASE(1, false); else if (nw == 2) SF_BA_CASE(2, false); else SF_BA_CASE(4, false); }
+#undef SF_BA_CASE
+  sf_prof_end(c, SF_K_BA);
+  SF_HIP(c, hipGetLastError());
+  return SF_OK;
 }
 
 // The split pipeline (k_match_split + k_chain); applies where the fused kernel does.
 bool sf_split_applicable(const sf_context* c, const StoreView& st) {
-  return sf_fused_lds_bytes(c, st) != 0 && c->match_mfma && st.kcap <= MF_MAX_ROWS;
+  return sf_fused_lds_bytes(c, st) != 0 && c->match_mfma && st.kcap <= MF_MAX_ROWS &&
+         (!c->dparams.bundle_adjustment || sf_ba_lds_bytes(st.kcap) <= 160 * 1024);
 }
 
 // the PnP form: k_match_split + k_chain_pnp
@@ -354,26 +464,69 @@ bool sf_split_pnp_applicable(const sf_context* c, const StoreView& st) {
   if (c->dparams.bidirectional) return false;      // (both directions: stage kernels)
   if (!(c->match_mfma && st.kcap <= MF_MAX_ROWS)) return false;
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t lds = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
-                                  (c->dparams.bundle_adjustment ? sf_ba_lds_bytes(st.kcap) : 0),
+  const size_t lds = std::max((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15,
                               sf_guided_lds_bytes(st.kcap, nc));
-  return lds <= 160 * 1024 && sf_match_lds_bytes(st.kcap, st.w) <= 160 * 1024;
+  return lds <= 160 * 1024 && sf_match_lds_bytes(st.kcap, st.w) <= 160 * 1024 &&
+         (!c->dparams.bundle_adjustment || sf_ba_lds_bytes(st.kcap) <= 160 * 1024);
 }
 
 namespace {
-template <int W, bool BA>
+template <int W, int NW, int PART>
 int launch_chain(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
-                 size_t lds, int tail_off) {
-  bool& attr_set = c->chain_attr[W == 16][BA];
+                 size_t lds, int tail_off, const BaHandover& H) {
+  bool& attr_set = c->chain_attr[W == 16][PART][NW == 4 ? 2 : NW - 1];
   if (lds > 64 * 1024 && !attr_set) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain<W, BA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain<W, NW, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
-  hipLaunchKernelGGL((k_chain<W, BA>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_chain<W, NW, PART>), dim3(n), dim3(64 * NW), lds, c->stream, st, d_from, d_to,
                      (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,
                      (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
-                     (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams, tail_off);
+                     (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams, tail_off, H);
+  return SF_OK;
+}
+
+template <int W, int PART>
+int launch_chain_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
+                     size_t lds, const BaHandover& H) {
+  bool& attr = c->chain_pnp_attr[W == 16][PART];
+  if (lds > 64 * 1024 && !attr) {
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  int32_t* counters = (int32_t*)c->counters.p;
+  hipLaunchKernelGGL((k_chain_pnp<W, PART>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+                     (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,
+                     (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
+                     (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams, H);
+  return SF_OK;
+}
+
+template <int PART>
+int launch_chain_part(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
+                      bool pnp, const BaHandover& H) {
+  int rc;
+  sf_prof_begin(c, SF_K_FUSED);
+  if (pnp) {
+    const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+    const size_t lds_p = std::max((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15,
+                                  sf_guided_lds_bytes(st.kcap, nc));
+    rc = st.w == 8 ? launch_chain_pnp<8, PART>(c, st, d_from, d_to, n, d_out, lds_p, H)
+                   : launch_chain_pnp<16, PART>(c, st, d_from, d_to, n, d_out, lds_p, H);
+  } else {
+    const int tail_off = (int)fused_tail_offset(c, st, false);
+    const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);
+#define SF_CHAIN_CASE(W_)                                                                                             \
+    rc = c->chain_nw == 1   ? launch_chain<W_, 1, PART>(c, st, d_from, d_to, n, d_out, lds_c, tail_off, H)            \
+         : c->chain_nw == 2 ? launch_chain<W_, 2, PART>(c, st, d_from, d_to, n, d_out, lds_c, tail_off, H)            \
+                            : launch_chain<W_, 4, PART>(c, st, d_from, d_to, n, d_out, lds_c, tail_off, H)
+    if (st.w == 8) SF_CHAIN_CASE(8); else SF_CHAIN_CASE(16);
+#undef SF_CHAIN_CASE
+  }
+  sf_prof_end(c, SF_K_FUSED);
+  if (rc != SF_OK) return rc;
+  SF_HIP(c, hipGetLastError());
   return SF_OK;
 }
 }  // namespace
@@ -404,43 +557,17 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
 #undef SF_SPLIT_MATCH
   sf_prof_end(c, SF_K_MATCH);
   SF_HIP(c, hipGetLastError());
-  const bool ba = c->dparams.bundle_adjustment != 0;
+  if (!c->dparams.bundle_adjustment)
+    return launch_chain_part<0>(c, st, d_from, d_to, n, d_out, pnp, BaHandover{nullptr, nullptr, nullptr});
+  // bundle adjustment on: [estimate 1] -> adjustment -> [guided matching + estimate 2] -> adjustment + result
   int rc;
-  if (pnp) {
-    const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-    const size_t lds_p = std::max(((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15) +
-                                      (ba ? sf_ba_lds_bytes(st.kcap) : 0),
-                                  sf_guided_lds_bytes(st.kcap, nc));
-    sf_prof_begin(c, SF_K_FUSED);
-#define SF_CHAIN_PNP(W_, BA_)                                                                                         \
-    do {                                                                                                              \
-      bool& attr = c->chain_pnp_attr[W_ == 16][BA_];                                                                  \
-      if (lds_p > 64 * 1024 && !attr) {                                                                               \
-        SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W_, BA_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      160 * 1024));                                                                   \
-        attr = true;                                                                                                  \
-      }                                                                                                               \
-      hipLaunchKernelGGL((k_chain_pnp<W_, BA_>), dim3(n), dim3(SF_BLOCK), lds_p, c->stream, st, d_from, d_to,          \
-                         (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,            \
-                         (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,  \
-                         (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams);               \
-    } while (0)
-    if (st.w == 8) { if (ba) SF_CHAIN_PNP(8, true); else SF_CHAIN_PNP(8, false); }
-    else { if (ba) SF_CHAIN_PNP(16, true); else SF_CHAIN_PNP(16, false); }
-#undef SF_CHAIN_PNP
-    sf_prof_end(c, SF_K_FUSED);
-    SF_HIP(c, hipGetLastError());
-    return SF_OK;
-  }
-  const int tail_off = (int)fused_tail_offset(c, st, false);
-  const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);
-  sf_prof_begin(c, SF_K_FUSED);
-  if (st.w == 8) rc = ba ? launch_chain<8, true>(c, st, d_from, d_to, n, d_out, lds_c, tail_off)
-                         : launch_chain<8, false>(c, st, d_from, d_to, n, d_out, lds_c, tail_off);
-  else rc = ba ? launch_chain<16, true>(c, st, d_from, d_to, n, d_out, lds_c, tail_off)
-               : launch_chain<16, false>(c, st, d_from, d_to, n, d_out, lds_c, tail_off);
-  sf_prof_end(c, SF_K_FUSED);
-  if (rc != SF_OK) return rc;
-  SF_HIP(c, hipGetLastError());
-  return SF_OK;
+  const size_t mb = (size_t)n * st.kcap;
+  if ((rc = sf_buf_reserve(c, c->dir_mask, 2 * mb + (size_t)n)) != SF_OK) return rc;
+  uint8_t* m1 = (uint8_t*)c->dir_mask.p;
+  const BaHandover H = {m1, m1 + mb, m1 + 2 * mb};
+  SF_HIP(c, hipMemsetAsync(m1, 0, 2 * mb + (size_t)n, c->stream));
+  if ((rc = launch_chain_part<1>(c, st, d_from, d_to, n, d_out, pnp, H)) != SF_OK) return rc;
+  if ((rc = sf_launch_ba_pass(c, st, d_from, d_to, n, 1, 1, H.mask1, nullptr, false, d_out)) != SF_OK) return rc;
+  if ((rc = launch_chain_part<2>(c, st, d_from, d_to, n, d_out, pnp, H)) != SF_OK) return rc;
+  return sf_launch_ba_pass(c, st, d_from, d_to, n, 2, 1, H.mask2, H.est2, true, d_out);
 }

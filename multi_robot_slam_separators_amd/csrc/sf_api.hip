@@ -74,7 +74,7 @@ StoreView sf_store_view(const Store& s) {
 // ---- profiling ------------------------------------------------------------------------------
 static const char* k_names[SF_K_COUNT] = {"k_match_global", "k_ransac(pass1)", "k_guided",
                                           "k_ransac(pass2)", "k_nn_argmin", "k_nn_select",
-                                          "k_nn_filter_f16", "k_nn_refine", "k_verify_fused", "k_nn_walk"};
+                                          "k_nn_filter_f16", "k_nn_refine", "k_verify_fused", "k_nn_walk", "k_ba_pass"};
 const char* sf_kernel_name(int k) { return (k >= 0 && k < SF_K_COUNT) ? k_names[k] : "?"; }
 
 // Brackets that have completed are booked and their events reused without waiting for anything: a long profiled
@@ -748,6 +748,8 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_STEP_SPLIT_MIN")) c->split_auto_min = std::max(1, atoi(v));
   if (const char* v = getenv("SF_STEP_SPLIT")) c->split_auto = atoi(v) != 0;   // 0: overlapped steps keep the fused kernel
   if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;      // 0: PnP on the five stage launches
+  if (const char* v = getenv("SF_BA_NW")) { const int nw = atoi(v); c->ba_nw = (nw == 1 || nw == 2) ? nw : 4; }
+  if (const char* v = getenv("SF_CHAIN_NW")) { const int nw = atoi(v); c->chain_nw = (nw == 1 || nw == 2) ? nw : 4; }
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
   if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;         // 1: two-stream halves (verify_device)
@@ -1233,6 +1235,9 @@ static const int SF_CHUNK = 131072;  // pairs per launch sequence (bounds the wo
 // candidates per tick: one launch instead of three).  SF_FUSED=2 forces the split form everywhere.
 static bool sf_use_split(const sf_context* c, const StoreView& v, int n) {
   if (c->split) return sf_split_applicable(c, v);
+  // bundle adjustment on: the fused kernel does not apply (the adjustment is a launch of its own, the chain is cut around
+  // it); the split form wherever it exists, else the stage kernels
+  if (c->dparams.bundle_adjustment && c->dparams.estimation_type == 0 && c->fused) return sf_split_applicable(c, v);
   if (!c->split_auto || !c->in_overlapped_step) return false;
   if (c->dparams.estimation_type != 0 || v.w != 8 || n > 65536 || n < c->split_auto_min || !sf_split_applicable(c, v))
     return false;
@@ -1257,7 +1262,7 @@ static VerifyPlan verify_plan(const sf_context* c, const StoreView& v, int n) {
   p.single = n <= SF_CHUNK;
   if (c->chain_pnp && sf_split_pnp_applicable(c, v)) { p.form = VerifyPlan::SPLIT_PNP; p.lists = true; }
   else if (sf_use_split(c, v, n)) { p.form = VerifyPlan::SPLIT; p.lists = true; }
-  else if (sf_fused_lds_bytes(c, v) != 0) { p.form = VerifyPlan::FUSED; p.lists = c->debug_corr; }
+  else if (sf_fused_lds_bytes(c, v) != 0 && !c->dparams.bundle_adjustment) { p.form = VerifyPlan::FUSED; p.lists = c->debug_corr; }
   else { p.form = VerifyPlan::STAGES; p.lists = true; }
   return p;
 }
@@ -1272,7 +1277,8 @@ static int verify_sequence(sf_context* ctx, const StoreView& view, const int32_t
       ctx->last_lists_valid = true;
       return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
     case VerifyPlan::SPLIT:
-      ctx->last_lists_valid = ctx->debug_corr;   // (pass-2 lists only with the option; pass-1 lists always)
+      // (pass-2 lists only with the option or the bundle adjustment, whose launches read them; pass-1 lists always)
+      ctx->last_lists_valid = ctx->debug_corr || ctx->dparams.bundle_adjustment != 0;
       return sf_launch_verify_split(ctx, view, d_from, d_to, m, d_out);
     case VerifyPlan::FUSED:
       // one launch: every pair's whole two-pass pipeline inside its workgroup (k_verify.hip); no work lists
@@ -1317,6 +1323,8 @@ static int ensure_twin(sf_context* c) {
   t->fused = c->fused;
   t->split = c->split;
   t->chain_pnp = c->chain_pnp;
+  t->chain_nw = c->chain_nw;
+  t->ba_nw = c->ba_nw;
   t->debug_corr = c->debug_corr;
   t->prof = c->prof;
   return SF_OK;

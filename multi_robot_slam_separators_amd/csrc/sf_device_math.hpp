@@ -388,6 +388,52 @@ __device__ __forceinline__ void block_sum_canon_to_lds(const double (&v)[N], dou
   __syncthreads();
 }
 
+// canon_reduce with the N totals left in LDS (out[0..N), out must not alias red): the 256-thread form accumulates
+// per lane and calls block_sum_canon_to_lds; one or two wavefronts play the four of the canonical scheme one after
+// the other (see canon_reduce).  `acc(i, v)` adds element i's terms to v[0..N).
+template <int N, int STRIDE, int NW, class F>
+__device__ __forceinline__ void canon_reduce_to_lds(int m, int tid, double* red, double* out, F acc) {
+  if constexpr (NW == 4) {
+    double v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0.0;
+    for (int i = tid; i < m; i += 256) acc(i, v);
+    block_sum_canon_to_lds<N, STRIDE>(v, red, out, tid);
+  } else {
+    static_assert(NW == 1 || NW == 2, "one, two or four wavefronts");
+    constexpr int P = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : 32;
+    static_assert(STRIDE >= P, "scratch rows must hold the padded count");
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();  // previous users of `red` / `out` are done
+#pragma unroll 1
+    for (int j = 0; j < 4 / NW; ++j) {
+      const int vw = wave * (4 / NW) + j;
+      double w[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w[k] = 0.0;
+      {
+        double v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0.0;
+        for (int i = lane + 64 * vw; i < m; i += 256) acc(i, v);
+#pragma unroll
+        for (int k = 0; k < N; ++k) w[k] = v[k];
+      }
+      int idx = 0;
+      sum_stage<P>(w, idx, lane, 32);
+      sum_stage<(P / 2 > 1 ? P / 2 : 1)>(w, idx, lane, 16);
+      sum_stage<(P / 4 > 1 ? P / 4 : 1)>(w, idx, lane, 8);
+      sum_stage<(P / 8 > 1 ? P / 8 : 1)>(w, idx, lane, 4);
+      sum_stage<(P / 16 > 1 ? P / 16 : 1)>(w, idx, lane, 2);
+      sum_stage<(P / 32 > 1 ? P / 32 : 1)>(w, idx, lane, 1);
+      red[vw * STRIDE + idx] = w[0];
+    }
+    __syncthreads();
+    if (tid < N) out[tid] = ((red[tid] + red[STRIDE + tid]) + red[2 * STRIDE + tid]) + red[3 * STRIDE + tid];
+    __syncthreads();
+  }
+}
+
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
   return isfinite(x) && isfinite(y) && isfinite(z);
 }

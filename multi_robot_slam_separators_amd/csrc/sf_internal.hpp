@@ -224,7 +224,7 @@ struct sf_context {
   int match_variant = 0;   // 0 = default geometry; see sf_launch_match_global
   bool ransac_attr_set = false;
   bool pnp_attr_set = false;
-  bool fused_attr[2][2][2] = {};   // [W == 16][matrix-core matcher][bundle adjustment]: LDS attribute set
+  bool fused_attr[2][2][2] = {};   // [W == 16][matrix-core matcher][WIDE]: LDS attribute set
   bool ransac_ba_attr_set = false, pnp_ba_attr_set = false, merge_ba_attr_set = false;
   bool debug_corr = false;      // SF_OPT_DEBUG_CORR: the fused kernel also writes lists / headers / states to HBM
   bool last_lists_valid = false;   // the last verification left correspondence lists in the global workspace
@@ -236,9 +236,13 @@ struct sf_context {
   bool split_auto = false;  // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip); off since round 4
   int split_auto_min = 2048;   // ... for queries of at least this many candidates (SF_STEP_SPLIT_MIN): below, one launch wins
   bool in_overlapped_step = false;   // set around sf_step_issue's body while the steps alternate between two streams
-  bool chain_attr[2][2] = {};      // k_chain [W == 16][bundle adjustment]: LDS attribute set
+  bool chain_attr[2][3][3] = {};   // k_chain [W == 16][part 0 / 1 / 2][wavefronts per chain 1 / 2 / 4]: LDS attribute set
+  int chain_nw = 4;                // wavefronts per motion-estimation chain of the split forms: 1, 2 (round 5), or 4 = the
+                                   // 256-thread workgroup of rounds 2-4 (SF_CHAIN_NW)
   bool split_match_attr[2] = {};   // k_match_split [W == 16]
-  bool chain_pnp_attr[2][2] = {};  // k_chain_pnp [W == 16][bundle adjustment]
+  bool chain_pnp_attr[2][3] = {};  // k_chain_pnp [W == 16][part 0 / 1 / 2]
+  bool ba_pass_attr[2][3] = {};    // k_ba_pass [PnP][wavefronts 1 / 2 / 4]
+  int ba_nw = 2;                   // wavefronts per bundle adjustment (k_ba_pass; SF_BA_NW)
   bool chain_pnp = true;           // PnP estimator: k_match_split + k_chain_pnp instead of the five stage launches
                                    // (SF_CHAIN_PNP=0: the stage launches)
   bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)
@@ -440,6 +444,8 @@ int sf_launch_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int3
 // Guided matching for pairs whose pass 1 succeeded; builds the pass-2 RANSAC work list.
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n);
 // Vis/ForwardEstOnly = false with bundle adjustment: merge of a pass's two estimates + adjustment over the union (k_ba.hip)
+int sf_launch_ba_pass(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass, int list_sel,
+                      const uint8_t* mask, const uint8_t* run, bool fin, sf_result* d_out);
 int sf_launch_merge_directions_ba(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass,
                                   bool pnp, const uint8_t* mask_f, const uint8_t* mask_b);
 // Fused per-pair pipeline (k_verify.hip): match -> RANSAC -> guided -> RANSAC -> result in one launch.

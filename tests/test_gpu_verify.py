@@ -445,10 +445,50 @@ def test_split_pipeline_equals_fused_kernel(monkeypatch):
                 corr = [f.debug_correspondences(i, w) for i in range(len(AA)) for w in (1, 2)]
                 prof = f.prof_get()
             out[mode] = (res, corr, prof)
-        assert out["1"][2]["k_match_global"][0] == 0 and out["2"][2]["k_match_global"][0] >= 1   # (the split's matching launch)
+        # (the split's matching launch; with the bundle adjustment on, a launch of its own since round 5, the chain is cut
+        #  around it and the handle's default form is the split one too)
+        assert out["2"][2]["k_match_global"][0] >= 1 and (out["1"][2]["k_match_global"][0] == 0) == (ba == 0)
+        if ba:
+            assert out["1"][2]["k_ba_pass"][0] >= 2 and out["2"][2]["k_ba_pass"][0] >= 2
         assert out["1"][0].tobytes() == out["2"][0].tobytes()
         for c1, c2 in zip(out["1"][1], out["2"][1]):
             assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1])
+
+
+@pytest.mark.parametrize("ba", [0, 1])
+def test_chain_widths_give_the_same_bytes(monkeypatch, ba):
+    """The survivors' chains on one, two or four wavefronts (SF_CHAIN_NW; k_chain<W, NW, PART>) and the bundle adjustment
+    on one, two or four (SF_BA_NW; k_ba_pass<NW, .>): the sums keep the canonical 256-lane order whatever the width, so
+    results and pass-2 lists are the same bytes -- and equal the oracle's."""
+    from multi_robot_slam_separators_amd import lib
+    from oracle import pyoracle
+    from test_gpu_fuzz import random_frame
+    rng = np.random.default_rng(17)
+    A, B, _, _ = synth.make_pairs(715, 40, k=500, cols=32, true_frac=0.5)
+    A += [random_frame(rng, 0, 32), random_frame(rng, 37, 32), A[0], A[1]]
+    B += [random_frame(rng, 20, 32), random_frame(rng, 0, 32), A[0], B[1]]
+    p = synth.camera_params()
+    p.iterations = 300
+    p.bundle_adjustment = ba
+    p.stereo_baseline = 0.12 if ba else 0.0
+    monkeypatch.setenv("SF_FUSED", "2")
+    monkeypatch.setenv("SF_DEBUG_CORR", "1")
+    out = {}
+    for nw in ("4", "2", "1"):
+        monkeypatch.setenv("SF_CHAIN_NW", nw)
+        monkeypatch.setenv("SF_BA_NW", nw)
+        with lib.SeparatorFinder(p) as f:
+            res = f.estimate_transform_batch(A, B)
+            corr = [f.debug_correspondences(i, 2) for i in range(len(A))]
+        out[nw] = (res, corr)
+    for nw in ("2", "1"):
+        assert out[nw][0].tobytes() == out["4"][0].tobytes(), nw
+        for c4, cn in zip(out["4"][1], out[nw][1]):
+            assert np.array_equal(c4[0], cn[0]) and np.array_equal(c4[1], cn[1])
+    ref = pyoracle.estimate_transform_batch(p, A, B, pyoracle.num_threads())
+    for i in range(len(A)):
+        assert out["1"][0][i].tobytes() == ref[i].tobytes(), i
+    assert int(out["1"][0]["success"].sum()) >= 15
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
