@@ -155,12 +155,13 @@ __device__ __forceinline__ void ba_sym3_mul(const double (&Ai)[6], const double*
 }
 
 // Schur-reduced normal equations at (q, t, points Xs): totals in `out` (LDS, [28])
-template <int NW>
+// SMALL: at most 256 words (k_ba_pass's first launch): one word per lane of the canonical 256-lane scheme
+template <int NW, bool SMALL = false>
 __device__ inline void ba_normal_eq(const BaLds& L, const BaCam& cam, int m, const double* Xs, const double (&q)[4],
                                     const double (&t)[3], double lambda, double* out, int tid) {
   double R2[9];
   sfd::quat_to_R(q, R2);
-  sfd::canon_reduce_to_lds<BA_NSUM, 32, NW>(m, tid, L.red, out, [&](int i, double (&ne)[BA_NSUM]) {
+  sfd::canon_reduce_to_lds<BA_NSUM, 32, NW, SMALL>(m, tid, L.red, out, [&](int i, double (&ne)[BA_NSUM]) {
     BaBlocks B;
     ba_point_blocks(cam, Xs + 3 * i, L.o1 + 3 * i, L.o2 + 3 * i, R2, t, B);
     double term[BA_NSUM];
@@ -263,7 +264,7 @@ __device__ __forceinline__ void ba_put_word(const BaLds& L, const BaCam& cam, in
 
 // The adjustment itself over the n words already in L.X / L.o1 / L.o2 (correspondence order), from the estimate p0;
 // thread 0 writes the adjusted state to `ps`.
-template <int NW>
+template <int NW, bool SMALL = false>
 __device__ __forceinline__ void ba_solve(const BaLds& L, const BaCam& cam, int n, const PassState& p0, PassState& ps,
                                          const DeviceParams& P) {
   constexpr int NT = 64 * NW;
@@ -294,13 +295,13 @@ __device__ __forceinline__ void ba_solve(const BaLds& L, const BaCam& cam, int n
   double* cur = L.ne_a;
   double* cnd = L.ne_b;
   double lambda = 1e-3;
-  ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
+  ba_normal_eq<NW, SMALL>(L, cam, n, L.X, q, t, lambda, cur, tid);
   for (int iter = 0; iter < P.ba_iterations; ++iter) {
     double d[6];
     if (!sfd::solve6(cur, lambda, d)) {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
-      ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
+      ba_normal_eq<NW, SMALL>(L, cam, n, L.X, q, t, lambda, cur, tid);
       continue;
     }
     const double hx = 0.5 * d[0], hy = 0.5 * d[1], hz = 0.5 * d[2];
@@ -319,7 +320,7 @@ __device__ __forceinline__ void ba_solve(const BaLds& L, const BaCam& cam, int n
     ba_backsub<NW>(L, cam, n, q, t, lambda, d, tid);
     const double lambda_acc = lambda * 0.1 < 1e-16 ? 1e-16 : lambda * 0.1;
     __syncthreads();                                   // candidate points written
-    ba_normal_eq<NW>(L, cam, n, L.Xc, qc, tc, lambda_acc, cnd, tid);
+    ba_normal_eq<NW, SMALL>(L, cam, n, L.Xc, qc, tc, lambda_acc, cnd, tid);
     const double dd = ((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]) + d[5] * d[5];
     const double tt = ((tc[0] * tc[0] + tc[1] * tc[1]) + tc[2] * tc[2]) + 1.0;
     if (cnd[27] < cur[27]) {
@@ -334,7 +335,7 @@ __device__ __forceinline__ void ba_solve(const BaLds& L, const BaCam& cam, int n
     } else {
       lambda = lambda * 10.0;
       if (lambda > 1e12) break;
-      ba_normal_eq<NW>(L, cam, n, L.X, q, t, lambda, cur, tid);
+      ba_normal_eq<NW, SMALL>(L, cam, n, L.X, q, t, lambda, cur, tid);
     }
     if (dd <= 1.4e-14 * tt) break;
   }
@@ -474,17 +475,18 @@ __device__ __forceinline__ void ba_body(const StoreView& st, int sF, int sT, con
 // from the estimate's LDS.  Same arithmetic, same bytes; what it buys is that the estimators are no longer compiled
 // for the adjustment's ~60 live fp64 values (256 registers + 700 B of scratch per lane at 2 workgroups per CU in
 // rounds 2-4) and the adjustment runs at the width its ~100 words fill.
-template <int NW, bool PNP>
+// `cap`: words the workgroup's LDS holds (sf_ba_lds_bytes(cap)); the caller has checked the estimate's inlier count
+// (an upper bound of the words) against it, and the gate of :1192-1197 (a non-null estimate with inliers).
+// SMALL: cap <= 256.
+template <int NW, bool PNP, bool SMALL>
 __device__ __forceinline__ void ba_pass_body(const StoreView& st, int sF, int sT, const uint32_t* __restrict__ cl,
-                                             int n_corr, const uint8_t* __restrict__ mask, PassState& ps,
-                                             const DeviceParams& P, unsigned char* lds) {
+                                             int n_corr, const uint8_t* __restrict__ mask, const PassState& p0,
+                                             PassState& ps, const DeviceParams& P, unsigned char* lds, int cap) {
   constexpr int NT = 64 * NW;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
-  const BaLds L = ba_carve(lds, kcap);
-  const PassState p0 = ps;
-  if (p0.is_null || p0.inliers <= 0) return;      // :1192-1197 (block-uniform: every lane read the same state)
+  const BaLds L = ba_carve(lds, cap);
   BaCam cam;
   ba_cam_setup(P, cam);
   const float4* kF = st.kp + (size_t)sF * kcap;
@@ -525,12 +527,12 @@ __device__ __forceinline__ void ba_pass_body(const StoreView& st, int sF, int sT
       if (w < wave) woff += cw;
       total += cw;
     }
-    if (in) ba_put_word(L, cam, n + woff + before, ax, ay, az, c, kF, kT, xT, to3d, cxf, cyf);
+    if (in && n + woff + before < cap) ba_put_word(L, cam, n + woff + before, ax, ay, az, c, kF, kT, xT, to3d, cxf, cyf);
     n += total;
     __syncthreads();
   }
-  if (n == 0) return;
-  ba_solve<NW>(L, cam, n, p0, ps, P);
+  if (n == 0 || n > cap) return;      // (n <= the estimate's inlier count <= cap by the caller's check)
+  ba_solve<NW, SMALL>(L, cam, n, p0, ps, P);
 }
 
 // Vis/ForwardEstOnly = false WITH bundle adjustment (myRegistrationVis.cpp:1155-1197, :1369, :1376-1394): the two

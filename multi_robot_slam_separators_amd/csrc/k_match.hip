@@ -477,22 +477,14 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
     nxt += 32 * W;
     load_raw<KS>(nxt, raw);
   }
-  // the scores kept so far move with the origin (the first row of the current tile); pairs of them in one packed add
-  if constexpr (NTL % 2 == 0) {
-    typedef float mf_v2f __attribute__((ext_vector_type(2)));
-    const mf_v2f step = {32.f * MF_FR, 32.f * MF_FR};
+  // the scores kept so far move with the origin (the first row of the current tile).  Plain adds: rounds 2-4 paired them
+  // in v_pk_add_f32 with the step in an SGPR pair -- packed f32 beside MFMAs costs more issue time than the two adds it
+  // replaces (MI355X_MICROARCH.md, cycle constants), and since round 5 no packed-f32 instruction with a scalar source is
+  // left in this translation unit (tools/pk_isa_scan.py --strict: the build gate of DESIGN.md section 3).
 #pragma unroll
-    for (int j = 0; j < NTL; j += 2) {
-      mf_v2f bb = {b[j], b[j + 1]}, ss = {s[j], s[j + 1]};
-      bb += step; ss += step;
-      b[j] = bb[0]; b[j + 1] = bb[1]; s[j] = ss[0]; s[j + 1] = ss[1];
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-      b[j] += 32.f * MF_FR;
-      s[j] += 32.f * MF_FR;
-    }
+  for (int j = 0; j < NTL; ++j) {
+    b[j] += 32.f * MF_FR;
+    s[j] += 32.f * MF_FR;
   }
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {

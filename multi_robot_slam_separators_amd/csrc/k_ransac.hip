@@ -41,7 +41,8 @@ struct RansacLds {
   unsigned long long* sums;   // [4] packed per-wavefront counters of a selection
   int* misc;        // [16]
   float* hyp;       // [12][64] models of the current round of hypotheses
-  int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
+  int* hyp_cnt;     // [4][64] inlier counts (first round: one row of partial counts per wavefront; later rounds: the
+                    // counts of the 64 hypotheses each wavefront fitted itself, -1 = no sample) + [64] valid flags of the first round
   float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the scan)
   float* bc;        // [12] model being refined (broadcast from the solving wavefront)
   uint32_t* cidx;   // [kcap] packed (from | to << 16) feature indices of the gathered correspondences (bundle adjustment)
@@ -302,6 +303,26 @@ __device__ __forceinline__ int count_round(const RansacLds& L, const int* hv, in
   return cnt;
 }
 
+// Inlier count of THIS lane's hypothesis (coefficients in registers) over all m points: the rounds behind the first,
+// where every wavefront fits and counts 64 hypotheses of its own.  Point loads four at a time (LDS broadcast).
+__device__ __forceinline__ int count_own(const RansacLds& L, const float (&coef)[12], int m, float thr2f) {
+  int cnt = 0;
+  int i = 0;
+#pragma unroll 1
+  for (; i + 1 < m; i += 2) {
+    const float4 p0 = L.src[i], q0 = L.dst[i], p1 = L.src[i + 1], q1 = L.dst[i + 1];
+    const float r0 = sfd::residual2(coef, p0.x, p0.y, p0.z, q0.x, q0.y, q0.z);
+    const float r1 = sfd::residual2(coef, p1.x, p1.y, p1.z, q1.x, q1.y, q1.z);
+    cnt += ((r0 <= thr2f) ? 1 : 0) + ((r1 <= thr2f) ? 1 : 0);
+  }
+  if (i < m) {
+    const float4 p = L.src[i], q = L.dst[i];
+    const float r2 = sfd::residual2(coef, p.x, p.y, p.z, q.x, q.y, q.z);
+    cnt += (r2 <= thr2f) ? 1 : 0;
+  }
+  return cnt;
+}
+
 // State of PCL's sequential loop between rounds (wave-uniform in the solving wavefront)
 struct ScanState {
   int best;      // best inlier count so far (-1: none)
@@ -332,9 +353,11 @@ __device__ __forceinline__ double shfl_up_from(double v, int off, int lane) {
 // k is a function of the best count alone, so the value it has after iteration j is f(max(best, c_0 .. c_j)): every
 // lane evaluates f on its inclusive prefix maximum, the top-of-loop test of lane j uses lane j-1's value, and the
 // first lane whose test fails is where the sequential loop stops.  Returns true when the loop has terminated.
+// park: the round's models sit in L.hyp (first round) and the winner's is copied to L.best here; otherwise the lane
+// that owns the winning iteration writes it after the replay (ransac_body).
 __device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, int base, int R, int lane, int c,
                                              bool present, int max_it, bool adaptive, double inv_m,
-                                             double log_probability) {
+                                             double log_probability, bool park = true) {
   int x = present ? c : -1;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -367,7 +390,7 @@ __device__ __forceinline__ bool replay_round(const RansacLds& L, ScanState& S, i
       const int lb = __ffsll((long long)at) - 1;        // first iteration that reached the final best
       S.best = nb;
       S.best_it = base + lb;
-      if (lane < 12) L.best[lane] = L.hyp[lane * 64 + lb];   // keep the winning model
+      if (park && lane < 12) L.best[lane] = L.hyp[lane * 64 + lb];   // keep the winning model
     }
     S.k = nk;
   }
@@ -501,17 +524,21 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
   if (P.dbg_stop == 1) { if (tid == 0) write_null_pass(out, m); return; }   // diagnostic truncation (SF_RANSAC_STOP)
   SF_TRACE_MARK(P, pair, trace_base + 1);
 
-  // ---- hypotheses: one lane each, rounds of 16 then 64 ----------------------------------------------
+  // ---- hypotheses: one lane each; a first round of 16, then rounds of 64 per WAVEFRONT -----------------------------
   // (values only needed behind this loop -- thr, thr2, sigma -- are formed there, and the replay's constants inside
   //  the replay: the fit in the middle of the loop wants every register it can get)
   const int max_it = P.iterations;
   int* hv = L.hyp_cnt + 4 * 64;
-  int R = 16;
-  for (int base = 0; base <= max_it; base += R, R = 64) {   // (the increment uses the R of the round just finished)
+  {
+    // First round: iterations 0..15, fitted by ONE wavefront and counted by all of them, four lanes per hypothesis (PCL's
+    // adaptive rule stops after a handful of iterations when the correspondences are good: everything is laid out for
+    // that round to be short).
     // The lane / wavefront numbers of a round go through an empty asm: everything derived from them (LDS addresses,
     // the point slice) is then computed INSIDE the round instead of being hoisted in front of the loop and kept alive
     // across the fit, where the register allocator had to spill it (96-128 bytes of scratch per lane, and spill
     // stores are HBM writes: 125 MB per 10 000-pair launch).
+    constexpr int R = 16;
+    const int base = 0;
     int lane_r = lane, wave_r = wave;
     asm volatile("" : "+v"(lane_r), "+v"(wave_r));
     const int it = base + lane_r;
@@ -535,7 +562,7 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       hv[lane_s] = valid;
     }
     __syncthreads();
-    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 18 : 21);   // first round: models parked
+    SF_TRACE_MARK(P, pair, trace_base == 2 ? 18 : 21);   // first round: models parked
     {
       int lane_c = lane, wave_c = wave;
       asm volatile("" : "+v"(lane_c), "+v"(wave_c));
@@ -544,24 +571,18 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
       const int slice = (m + NW - 1) / NW;                     // points counted by each wavefront
       const int i0 = min(m, wave_c * slice), i1 = min(m, i0 + slice);
-      L.hyp_cnt[wave_c * 64 + lane_c] = R == 16 ? count_round<16>(L, hv, i0, i1, lane_c, thr2f)
-                                                : count_round<64>(L, hv, i0, i1, lane_c, thr2f);
+      L.hyp_cnt[wave_c * 64 + lane_c] = count_round<16>(L, hv, i0, i1, lane_c, thr2f);
     }
     __syncthreads();
-    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 19 : 22);   // ... inliers counted
+    SF_TRACE_MARK(P, pair, trace_base == 2 ? 19 : 22);   // ... inliers counted
     if (wave_r == fit_wave) {
       asm volatile("" : "+v"(lane_r));
       int tot = 0;
-      if (R == 16) {
-        const int h = lane_r & 15;
+      const int h = lane_r & 15;
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
+      for (int w = 0; w < NW; ++w)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) tot += L.hyp_cnt[w * 64 + g * 16 + h];
-      } else {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) tot += L.hyp_cnt[w * 64 + lane_r];
-      }
+        for (int g = 0; g < 4; ++g) tot += L.hyp_cnt[w * 64 + g * 16 + h];
       const bool present = lane_r < R && it <= max_it;
       const int c = (present && hv[lane_r]) ? tot : -1;
       ScanState S;
@@ -578,8 +599,71 @@ __device__ __forceinline__ void ransac_body(const StoreView& st, int pair, int s
       }
     }
     __syncthreads();
-    if (base == 0) SF_TRACE_MARK(P, pair, trace_base == 2 ? 20 : 23);   // ... PCL's loop replayed
-    if (L.misc[1]) break;
+    SF_TRACE_MARK(P, pair, trace_base == 2 ? 20 : 23);   // ... PCL's loop replayed
+  }
+  // The rounds behind the first (round 5): EVERY wavefront fits 64 hypotheses of its own -- iterations base + 64 w + lane
+  // -- and counts them over all points itself, the model staying in the lane's registers; one wavefront then replays PCL's
+  // loop over the 64 NW counts in iteration order (the same replay_round calls as with rounds of 64), and the lane that
+  // owns a new best parks its model.  Rounds 2-4 had ONE wavefront fit 64 hypotheses while the others waited: with every
+  // hypothesis evaluated (ransac_adaptive_stop = 0: the configuration read to the letter, 501 per pass) the fits were
+  // three quarters of a chain.  Which iteration draws which sample does not depend on the round structure, so the
+  // results are the same bytes.
+  if (!L.misc[1]) {
+    for (int base = 16; base <= max_it; base += 64 * NW) {
+      int lane_r = lane, wave_r = wave;
+      asm volatile("" : "+v"(lane_r), "+v"(wave_r));
+      const int it = base + 64 * wave_r + lane_r;
+      float coef[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) coef[k] = 0.f;
+      int cnt = -1;                                    // (-1: no such iteration, or getSamples failed)
+      if (it <= max_it) {
+        uint32_t s0, s1, s2;
+        if (draw_sample(L, P.seed, (uint32_t)it, P.max_sample_checks, (uint32_t)m, reinterpret_cast<const double*>(L.sums)[0],
+                        s0, s1, s2)) {
+          fit3(L, s0, s1, s2, coef);
+          const double thr2 = P.inlier_thr * P.inlier_thr;
+          float thr2f = (float)thr2;                           // largest float strictly below thr^2
+          if ((double)thr2f >= thr2) thr2f = __uint_as_float(__float_as_uint(thr2f) - 1u);
+          cnt = count_own(L, coef, m, thr2f);
+        }
+      }
+      {
+        int lane_s = lane, wave_s = wave;
+        asm volatile("" : "+v"(lane_s), "+v"(wave_s));
+        L.hyp_cnt[wave_s * 64 + lane_s] = cnt;
+      }
+      __syncthreads();
+      if (wave_r == fit_wave) {
+        asm volatile("" : "+v"(lane_r));
+        ScanState S;
+        S.best = L.misc[12]; S.best_it = L.misc[13]; S.it = L.misc[14];
+        S.k = reinterpret_cast<const double*>(L.sums)[1];
+        bool stop = false;
+#pragma unroll 1
+        for (int sub = 0; sub < NW && !stop; ++sub) {
+          const int b = base + 64 * sub;
+          if (b > max_it) break;                       // (the sequential loop's own end: no further round exists)
+          const bool present = b + lane_r <= max_it;
+          const int c = present ? L.hyp_cnt[sub * 64 + lane_r] : -1;
+          stop = replay_round(L, S, b, 64, lane_r, c, present, max_it, P.adaptive_stop != 0,
+                              reinterpret_cast<const double*>(L.sums)[2], sfd::canon_log(1.0 - 0.99), false);
+        }
+        if (lane_r == 0) {
+          L.misc[12] = S.best; L.misc[13] = S.best_it; L.misc[14] = S.it;
+          reinterpret_cast<double*>(L.sums)[1] = S.k;
+          L.misc[0] = S.best_it;
+          L.misc[1] = stop ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (cnt >= 0 && L.misc[0] == it) {               // this lane's iteration is the new best: keep its model
+#pragma unroll
+        for (int k = 0; k < 12; ++k) L.best[k] = coef[k];
+      }
+      __syncthreads();
+      if (L.misc[1]) break;
+    }
   }
   // (same for everything behind the loop: addresses are re-derived from a laundered thread index instead of
   //  being shared with -- and kept alive since -- the gather in front of it)

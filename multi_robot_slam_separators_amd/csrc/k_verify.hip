@@ -385,20 +385,34 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
 // pair's pass has no estimate to adjust (pass 2 of a pair whose guided matching did not go on to the estimation).
 // fin: the adjustment of pass 2 also assembles the pair's result (finalize_one) and, where the accepted-result stream is
 // armed, hands it to the host -- the tail of the chain kernels.
-template <int NW, bool PNP>
-__global__ void __launch_bounds__(64 * NW, 1)
+// Two launches per pass where a keyframe holds more than SF_BA_SMALL_CAP features: the SMALL one takes every pair
+// whose estimate has at most that many inliers (the adjustment's words) with an LDS working set sized for them -- 20 KB
+// instead of 38 KB at K = 500: eight workgroups per CU instead of four, and one word per lane of the canonical 256-lane
+// sums, so no accumulator stays live across a loop -- the other launch the pairs with more (none on typical frames: its
+// workgroups read a pass state and leave).  A pair is handled, and its result assembled, by exactly one of the two.
+#define SF_BA_SMALL_CAP 256
+template <int NW, bool PNP, bool SMALL, int OCC = 1>
+__global__ void __launch_bounds__(64 * NW, OCC)
 k_ba_pass(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
           const int32_t* __restrict__ list, const int32_t* __restrict__ counter, const uint32_t* __restrict__ corr,
           const CorrHeader* __restrict__ hdr, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ run,
           PassState* __restrict__ pass, int extra_3dof, int fin, const PassState* __restrict__ pass1,
-          const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P) {
+          const uint8_t* __restrict__ guided_flag, sf_result* __restrict__ out, DeviceParams P, int cap, int both) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if ((int)blockIdx.x >= *counter) return;
   const int pair = list[blockIdx.x];
   const int kcap = st.kcap;
+  const PassState p0 = pass[pair];
+  // :1192-1197 gate (the words3From / wordsTo conditions hold whenever the estimate ran); block-uniform
+  const bool adjust = (!run || run[pair]) && !p0.is_null && p0.inliers > 0;
+  const bool big = adjust && p0.inliers > SF_BA_SMALL_CAP;
+  if (both && big == SMALL) return;            // the other launch's pair
+  if (adjust) {
+    if (p0.inliers <= cap)
+      ba_pass_body<NW, PNP, SMALL>(st, pair_from[pair], pair_to[pair], corr + (size_t)pair * kcap, hdr[pair].n_corr,
+                                   mask + (size_t)pair * kcap, p0, pass[pair], P, smem_raw, cap);
+  }
   if (!run || run[pair]) {
-    ba_pass_body<NW, PNP>(st, pair_from[pair], pair_to[pair], corr + (size_t)pair * kcap, hdr[pair].n_corr,
-                          mask + (size_t)pair * kcap, pass[pair], P, smem_raw);
     // myRegistration.cpp:269-276, and for pass 1 the application its result meets as the guess of pass 2 (:245-248)
     // (thread 0 wrote the adjusted state: same thread, program order)
     if (extra_3dof && threadIdx.x == 0) pass_to3dof(pass[pair], extra_3dof);
@@ -420,11 +434,10 @@ k_ba_pass(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __
 int sf_launch_ba_pass(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, int pass, int list_sel,
                       const uint8_t* mask, const uint8_t* run, bool fin, sf_result* d_out) {
   if (n <= 0) return SF_OK;
-  const size_t lds = sf_ba_lds_bytes(st.kcap);
-  if (lds > 160 * 1024) return sf_fail(c, SF_ERANGE, "bundle adjustment needs %zu B of LDS (> 160 KiB)", lds);
+  if (sf_ba_lds_bytes(st.kcap) > 160 * 1024)
+    return sf_fail(c, SF_ERANGE, "bundle adjustment needs %zu B of LDS (> 160 KiB)", sf_ba_lds_bytes(st.kcap));
   const bool pnp = c->dparams.estimation_type == 1;
   const int nw = c->ba_nw;
-  bool& attr = c->ba_pass_attr[pnp][nw == 4 ? 2 : nw - 1];
   int32_t* counters = (int32_t*)c->counters.p;
   const int32_t* list = (const int32_t*)(list_sel == 1 ? c->list1.p : c->list3.p);
   const int32_t* counter = counters + (list_sel == 1 ? 0 : 2);
@@ -432,22 +445,33 @@ int sf_launch_ba_pass(sf_context* c, StoreView st, const int32_t* d_from, const 
   const CorrHeader* hdr = (const CorrHeader*)(pass == 1 ? c->hdr1.p : c->hdr2.p);
   PassState* ps = (PassState*)(pass == 1 ? c->pass1.p : c->pass2.p);
   const int end_3dof = c->dparams.force_3dof ? (pass == 1 ? 2 : 1) : 0;
+  const bool both = st.kcap > SF_BA_SMALL_CAP;       // (a keyframe cannot give more words than it has features)
   sf_prof_begin(c, SF_K_BA);
-#define SF_BA_CASE(NW_, PNP_)                                                                                             \
-  do {                                                                                                                    \
-    if (lds > 64 * 1024 && !attr) {                                                                                       \
-      SF_HIP(c, hipFuncSetAttribute((const void*)k_ba_pass<NW_, PNP_>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                    160 * 1024));                                                                         \
-      attr = true;                                                                                                        \
-    }                                                                                                                     \
-    hipLaunchKernelGGL((k_ba_pass<NW_, PNP_>), dim3(n), dim3(64 * NW_), lds, c->stream, st, d_from, d_to, list, counter,   \
-                       corr, hdr, mask, run, ps, end_3dof, fin ? 1 : 0, (const PassState*)c->pass1.p,                      \
-                       (const uint8_t*)c->flags.p, d_out, c->dparams);                                                    \
+  auto launch = [&](auto kern, int cap, bool& attr) -> int {
+    const size_t lds = sf_ba_lds_bytes(cap);
+    if (lds > 64 * 1024 && !attr) {
+      SF_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n), dim3(64 * nw), lds, c->stream, st, d_from, d_to, list, counter, corr, hdr, mask, run,
+                       ps, end_3dof, fin ? 1 : 0, (const PassState*)c->pass1.p, (const uint8_t*)c->flags.p, d_out,
+                       c->dparams, cap, both ? 1 : 0);
+    return SF_OK;
+  };
+  int rc = SF_OK;
+  bool dummy = true;      // (the SMALL launch's LDS is under 64 KB: no attribute to set)
+  const int cap_small = std::min(st.kcap, SF_BA_SMALL_CAP);
+#define SF_BA_CASE(NW_, PNP_)                                                                              \
+  do {                                                                                                     \
+    rc = (c->ba_occ ? c->ba_occ : (PNP_ ? 1 : 2)) == 2 ? launch(k_ba_pass<NW_, PNP_, true, 2>, cap_small, dummy)                          \
+                        : launch(k_ba_pass<NW_, PNP_, true, 1>, cap_small, dummy);                         \
+    if (rc == SF_OK && both) rc = launch(k_ba_pass<NW_, PNP_, false>, st.kcap, c->ba_pass_attr[PNP_][NW_ == 4 ? 2 : NW_ - 1]); \
   } while (0)
   if (pnp) { if (nw == 1) SF_BA_CASE(1, true); else if (nw == 2) SF_BA_CASE(2, true); else SF_BA_CASE(4, true); }
   else { if (nw == 1) SF_BA_CASE(1, false); else if (nw == 2) SF_BA_CASE(2, false); else SF_BA_CASE(4, false); }
 #undef SF_BA_CASE
   sf_prof_end(c, SF_K_BA);
+  if (rc != SF_OK) return rc;
   SF_HIP(c, hipGetLastError());
   return SF_OK;
 }

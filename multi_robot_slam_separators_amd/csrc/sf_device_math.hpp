@@ -336,6 +336,10 @@ __device__ __forceinline__ void canon_reduce(int m, int tid, double* red, double
 #pragma unroll 1
     for (int j = 0; j < 4 / NW; ++j) {
       const int vw = wave * (4 / NW) + j;     // the wavefront of the 256-thread scheme this pass stands in for
+      if (64 * vw >= m) {                     // no element for this wavefront: its partials are all +0.0, and so are their sums
+        if (lane < P) red[vw * STRIDE + lane] = 0.0;
+        continue;
+      }
       double w[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) w[k] = 0.0;
@@ -391,13 +395,16 @@ __device__ __forceinline__ void block_sum_canon_to_lds(const double (&v)[N], dou
 // canon_reduce with the N totals left in LDS (out[0..N), out must not alias red): the 256-thread form accumulates
 // per lane and calls block_sum_canon_to_lds; one or two wavefronts play the four of the canonical scheme one after
 // the other (see canon_reduce).  `acc(i, v)` adds element i's terms to v[0..N).
-template <int N, int STRIDE, int NW, class F>
+// ONCE: the caller guarantees m <= 256 -- every lane of the canonical scheme has at most one element, so its partial is
+// 0.0 + that element's terms and no accumulator stays live across a loop.
+template <int N, int STRIDE, int NW, bool ONCE = false, class F>
 __device__ __forceinline__ void canon_reduce_to_lds(int m, int tid, double* red, double* out, F acc) {
   if constexpr (NW == 4) {
     double v[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = 0.0;
-    for (int i = tid; i < m; i += 256) acc(i, v);
+    if constexpr (ONCE) { if (tid < m) acc(tid, v); }
+    else { for (int i = tid; i < m; i += 256) acc(i, v); }
     block_sum_canon_to_lds<N, STRIDE>(v, red, out, tid);
   } else {
     static_assert(NW == 1 || NW == 2, "one, two or four wavefronts");
@@ -408,6 +415,10 @@ __device__ __forceinline__ void canon_reduce_to_lds(int m, int tid, double* red,
 #pragma unroll 1
     for (int j = 0; j < 4 / NW; ++j) {
       const int vw = wave * (4 / NW) + j;
+      if (64 * vw >= m) {                     // no element for this wavefront: its partials are all +0.0, and so are their sums
+        if (lane < P) red[vw * STRIDE + lane] = 0.0;
+        continue;
+      }
       double w[32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) w[k] = 0.0;
@@ -415,7 +426,8 @@ __device__ __forceinline__ void canon_reduce_to_lds(int m, int tid, double* red,
         double v[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = 0.0;
-        for (int i = lane + 64 * vw; i < m; i += 256) acc(i, v);
+        if constexpr (ONCE) { if (lane + 64 * vw < m) acc(lane + 64 * vw, v); }
+        else { for (int i = lane + 64 * vw; i < m; i += 256) acc(i, v); }
 #pragma unroll
         for (int k = 0; k < N; ++k) w[k] = v[k];
       }

@@ -242,7 +242,10 @@ struct sf_context {
   bool split_match_attr[2] = {};   // k_match_split [W == 16]
   bool chain_pnp_attr[2][3] = {};  // k_chain_pnp [W == 16][part 0 / 1 / 2]
   bool ba_pass_attr[2][3] = {};    // k_ba_pass [PnP][wavefronts 1 / 2 / 4]
-  int ba_nw = 2;                   // wavefronts per bundle adjustment (k_ba_pass; SF_BA_NW)
+  int ba_occ = 0;                  // wavefronts per SIMD the SMALL adjustment kernel is compiled for (SF_BA_OCC; 1 = 512 registers,
+                                   // no scratch; 2 = 256 registers + 256 B of scratch; 0 = by estimator: PnP 1, 3D-3D 2 -- measured,
+                                   // profiles/r05e_ba_occupancy.txt)
+  int ba_nw = 1;                   // wavefronts per bundle adjustment (k_ba_pass; SF_BA_NW): 1 measured fastest (profiles/r05c_ba_width.txt)
   bool chain_pnp = true;           // PnP estimator: k_match_split + k_chain_pnp instead of the five stage launches
                                    // (SF_CHAIN_PNP=0: the stage launches)
   bool match_mfma = true;   // Hamming table on the fp4 matrix cores (SF_MATCH_MFMA=0 selects the VALU matcher)

@@ -4,9 +4,14 @@ lanes on gfx950) that read an SGPR operand which a scalar instruction REWRITES w
 whose SGPR operand was written by v_readlane within the previous few -- the two shapes found around the pose composition
 of the guided pass in the build that produced the position-dependent pose of round 3.  Runs without
 a GPU (hipcc -S).
-  tools/pk_isa_scan.py [--tu k_verify.hip] [--slp] [--pre-fix] [--window 4] [--fail]
+  tools/pk_isa_scan.py [--tu k_verify.hip] [--slp] [--pre-fix] [--window 4] [--fail] [--strict]
 --slp: compile WITHOUT -fno-slp-vectorize; --pre-fix: also without the register barriers of guided_body (the build of
-the symptom); --fail: exit 1 when the product flags leave any hit (the build gate tests/test_host_logic.py runs)."""
+the symptom); --fail: exit 1 when the product flags leave any hit (the build gate tests/test_host_logic.py runs).
+--strict (round 5, the invariant the product build holds): list EVERY packed-f32 instruction (v_pk_*_f32) of the
+translation unit that has a scalar register among its sources -- not only those whose register is rewritten nearby.  The
+mechanism of round 3's symptom was never isolated, so the gate no longer leans on a guess about it: the canonical-
+arithmetic translation units are built with -fno-slp-vectorize AND -fno-vectorize, the matcher's explicit packed adds are
+gone, and the product flags leave no such instruction at all (0 packed-f32 instructions of any kind in k_verify.hip)."""
 import argparse, collections, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +26,7 @@ def sregs(tok):
     return [int(m.group(1))] if m else []
 
 
-def scan(asm_path, window):
+def scan(asm_path, window, strict=False):
     funcs, cur = collections.OrderedDict(), None
     for ln in open(asm_path):
         m = re.match(r"^(_Z\w+):", ln)
@@ -33,11 +38,14 @@ def scan(asm_path, window):
     for name, ins in funcs.items():
         for i, l in enumerate(ins):
             op = l.split()[0]
-            if not re.match(r"v_pk_(mul|fma|add)_f32", op):
+            if not re.match(r"v_pk_\w+_f32", op):
                 continue
             toks = [t.strip(",") for t in re.split(r"[ ,]+", l)[1:]]
             src = set(r for t in toks[1:] for r in sregs(t))
             if not src:
+                continue
+            if strict:
+                out.append((name, i, "scalar source", l, "-"))
                 continue
             for j in range(i + 1, min(len(ins), i + 1 + window)):       # rewritten right behind the read
                 o2 = ins[j].split()[0]
@@ -59,10 +67,13 @@ def main():
     ap.add_argument("--pre-fix", action="store_true")
     ap.add_argument("--window", type=int, default=4)
     ap.add_argument("--fail", action="store_true")
+    ap.add_argument("--strict", action="store_true")
     a = ap.parse_args()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed"]
     if a.tu in ("k_verify.hip", "k_extract.hip", "k_gftt.hip", "k_lk.hip"):
         flags.append("-ffp-contract=off")
+        if not (a.slp or a.pre_fix):
+            flags.append("-fno-vectorize")      # (csrc/Makefile: CANON)
     if not (a.slp or a.pre_fix):
         flags.append("-fno-slp-vectorize")
     if a.pre_fix:
@@ -71,7 +82,7 @@ def main():
         asm = os.path.join(td, "tu.s")
         subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-S", "--cuda-device-only", os.path.join(CSRC, a.tu), "-o", asm],
                        check=True, stderr=subprocess.DEVNULL)
-        hits, n_ins = scan(asm, a.window)
+        hits, n_ins = scan(asm, a.window, a.strict)
     names = subprocess.run(["c++filt"] + [h[0] for h in hits], capture_output=True, text=True).stdout.split("\n")
     print("%s  flags: %s  (%d instructions)" % (a.tu, " ".join(flags[6:]) or "-", n_ins))
     per = collections.Counter()
@@ -79,7 +90,10 @@ def main():
         short = re.sub(r"\(anonymous namespace\)::", "", n).split("(")[0].replace("void ", "")
         per[short] += 1
         print("  %-44s @%-6d %-22s %s   <-  %s" % (short[:44], h[1], h[2], h[3], h[4]))
-    print("  total: %d packed-f32 reads of an SGPR that is rewritten / was lane-read within %d instructions" % (len(hits), a.window))
+    if a.strict:
+        print("  total: %d packed-f32 instructions with a scalar source register" % len(hits))
+    else:
+        print("  total: %d packed-f32 reads of an SGPR that is rewritten / was lane-read within %d instructions" % (len(hits), a.window))
     if a.fail and hits:
         sys.exit(1)
 

@@ -24,7 +24,7 @@ python tools/summarize_prof.py $tag $out/stats $out/fetch $out/write > $out/summ
 python tools/pmc_kernel.py $out/sq > $out/sq.txt
 # (the verification's kernels: the fused form, or -- inside overlapped steps, the default since round 3's last session --
 #  the split form's matching and chain kernels; a kernel that did not run leaves no file)
-for kern in k_verify_fused k_match_split k_chain; do python tools/sq_json.py $tag $kern $out/sq $out/sqw; done
+for kern in k_verify_fused k_match_split "k_chain<" k_chain_pnp "k_ba_pass<1, true, true>" "k_ba_pass<1, false, true>"; do python tools/sq_json.py $tag "$kern" $out/sq $out/sqw; done
 cp profiles/${tag}_summary.json profiles/${tag}_kernel_stats.csv profiles/${tag}_sq_*.json $out/
 grep "^{" $out/stats.log > $out/${tag}_bench_stdout.log
-tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_split|k_chain|k_match_global_mf" $out/sq.txt
+tail -30 $out/summary.txt; grep -E "k_verify_fused|k_match_split|k_chain|k_match_global_mf|k_ba_pass" $out/sq.txt

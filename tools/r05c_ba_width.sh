@@ -1,0 +1,18 @@
+#!/bin/bash
+# PnP + bundle adjustment / 3D-3D + bundle adjustment bench lines by width of the adjustment's workgroups (SF_BA_NW)
+A="--steps 100 --warmup 10 --no-extras --no-cpu-baseline"
+mkdir -p gpurun_out/r05c
+run() { tag=$1; shift; envs=$1; shift; echo "== $tag: $envs $*"; env $envs timeout -k 10 400 python bench.py $A "$@" > gpurun_out/r05c/$tag.json 2> gpurun_out/r05c/$tag.err || { echo FAILED; tail -5 gpurun_out/r05c/$tag.err; return 1; }
+python - gpurun_out/r05c/$tag.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value %.3f M  ms_per_step %.4f  ok %s/%s" % (d["value"] / 1e6, d["ms_per_step"], d["check"]["decisions_matching_ground_truth"], d["check"]["of"]))
+print("   kernels", {k: round(v, 3) for k, v in d["kernel_ms_per_step"].items() if v > 0})
+PY
+}
+for nw in 4 2 1; do
+run pnp_ba_nw$nw SF_BA_NW=$nw --estimator pnp --bundle-adjustment || exit 1
+done
+for nw in 4 2 1; do
+run 3d3d_ba_nw$nw SF_BA_NW=$nw --bundle-adjustment || exit 1
+done

@@ -1,0 +1,16 @@
+#!/bin/bash
+A="--steps 100 --warmup 10 --no-extras --no-cpu-baseline"
+mkdir -p gpurun_out/r05e
+run() { tag=$1; shift; envs=$1; shift; echo "== $tag: $envs $*"; env $envs timeout -k 10 400 python bench.py $A "$@" > gpurun_out/r05e/$tag.json 2> gpurun_out/r05e/$tag.err || { echo FAILED; tail -5 gpurun_out/r05e/$tag.err; return 1; }
+python - gpurun_out/r05e/$tag.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value %.3f M  ms_per_step %.4f  ok %s/%s" % (d["value"] / 1e6, d["ms_per_step"], d["check"]["decisions_matching_ground_truth"], d["check"]["of"]))
+print("   kernels", {k: round(v, 3) for k, v in d["kernel_ms_per_step"].items() if v > 0})
+PY
+}
+for occ in 2 1; do for nw in 1 2; do
+run pnp_ba_occ${occ}_nw$nw "SF_BA_OCC=$occ SF_BA_NW=$nw" --estimator pnp --bundle-adjustment || exit 1
+done; done
+run 3d3d_ba_occ1_nw1 "SF_BA_OCC=1 SF_BA_NW=1" --bundle-adjustment
+run 3d3d_ba_occ2_nw1 "SF_BA_OCC=2 SF_BA_NW=1" --bundle-adjustment

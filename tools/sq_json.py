@@ -22,13 +22,15 @@ def averages(dirname, kernel):
 
 
 tag, kernel, sq = sys.argv[1], sys.argv[2], sys.argv[3]
+import re
+fname = re.sub(r"_+$", "", re.sub(r"[^A-Za-z0-9]+", "_", kernel))      # ("k_ba_pass<1, true, true>" -> k_ba_pass_1_true_true)
 d, n = averages(sq, kernel)
 if d:
     simd_cycles = 1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0
     d["valu_busy_estimate"] = d["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
     d["mfma_busy_estimate"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
     d["_note"] = "%s, averages over %d launches of one rocprofv3 --pmc pass (tools/profile_round.sh)" % (kernel, n)
-    json.dump(d, open("profiles/%s_sq_%s.json" % (tag, kernel), "w"), indent=1)
+    json.dump(d, open("profiles/%s_sq_%s.json" % (tag, fname), "w"), indent=1)
 if len(sys.argv) > 4:
     w, n = averages(sys.argv[4], kernel)
     if w:
@@ -37,4 +39,4 @@ if len(sys.argv) > 4:
         w["frac_wait_inst_any (issue stall)"] = w["SQ_WAIT_INST_ANY"] / wc
         w["frac_active_inst_any"] = w["SQ_ACTIVE_INST_ANY"] / wc
         w["_note"] = "%s, wavefront-cycle accounting (quad-cycles), averages over %d launches" % (kernel, n)
-        json.dump(w, open("profiles/%s_sq_waits_%s.json" % (tag, kernel), "w"), indent=1)
+        json.dump(w, open("profiles/%s_sq_waits_%s.json" % (tag, fname), "w"), indent=1)

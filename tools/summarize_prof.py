@@ -5,7 +5,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 def short(name):
-    m = re.search(r"(k_[a-z0-9_]+(?:<[0-9, ]+>)?)", name)
+    m = re.search(r"(k_[a-z0-9_]+(?:<[0-9a-z, ]+>)?)", name)
     return m.group(1) if m else name[:40]
 
 def pmc(dirname):
