@@ -232,7 +232,11 @@ int  sf_nn_append_received_f32_device(sf_handle h, const float* d_desc, int32_t 
 int  sf_nn_append_local_f16_device(sf_handle h, const uint16_t* d_desc, int32_t n, int32_t dim);
 int  sf_nn_append_received_f16_device(sf_handle h, const uint16_t* d_desc, int32_t n, int32_t dim);
 int  sf_nn_sizes(sf_handle h, int32_t* n_local, int32_t* n_received);
-/* local_kf_already_used.append / other_kf_already_used.append / add_frames_kept_pairs_to_ignore */
+/* local_kf_already_used.append / other_kf_already_used.append / add_frames_kept_pairs_to_ignore
+   These three change the state every query reads: while sf_step_issue has steps in flight they first wait for ALL of
+   them on the host (the steps were issued on the masks as they were) -- a caller that marks after every accepted
+   match serialises the step pipeline; mark between retiring a batch of steps and issuing the next.  Arguments are
+   validated before that wait; a step whose re-run failed makes the call return that error (the mask is untouched). */
 int  sf_nn_mark_local_used(sf_handle h, int32_t idx_local);
 int  sf_nn_mark_other_used(sf_handle h, int32_t idx_other);
 int  sf_nn_ignore_pair(sf_handle h, int32_t idx_local, int32_t idx_other);
@@ -549,7 +553,10 @@ int  sf_memcpy_device_async(sf_handle h, void* d_dst, const void* d_src, size_t 
    the host block receives at the same slot and *d_counter (a device word the CALLER zeroes before each sf_step_issue,
    e.g. the count in that header) counts the slots taken.  cap = record slots behind d_records2; a cap below the number
    of verified candidates of a query (local rows * 9 / 8 + 256) switches that query to the compaction (nothing is ever
-   dropped).  NULL, NULL, 0 removes the mirror.  Not while a step is in flight.                                    */
+   dropped).  NULL, NULL, 0 removes the mirror.  Not while a step is in flight.
+   While a mirror is set sf_step_issue admits as many steps in flight as the mirror has buffers (1 here, 2 with
+   sf_step_mirror_pair) and fails with SF_EINVAL beyond -- step k + 2 would zero and overwrite what step k wrote:
+   the loop is issue, [issue,] retire + hand the buffer to the collective, issue, ... (ABI 6).                       */
 int  sf_step_mirror(sf_handle h, sf_result* d_records2, uint32_t* d_counter, int32_t cap);
 /* The same with TWO destinations that alternate with the steps (the first sf_step_issue after this call writes the
    even pair, the next one the odd pair, ...): with two send buffers the all-gather of step k runs beside the

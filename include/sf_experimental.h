@@ -72,7 +72,18 @@ int  sf_debug_counters(sf_handle h, unsigned long long* out, int32_t n);
 int  sf_debug_guided_points(sf_handle h, int32_t pair, unsigned long long* plane0, unsigned long long* plane1,
                             int32_t* kcap_out);
 
+/* The launch plan of a verification call of n_pairs pairs on keyframes of `kcap` feature slots (a multiple of 64) and
+   `desc_words` dwords per descriptor row, and its workspace -- computed on the host, no device needed (a test without a
+   GPU holds the reservation against what each launch form writes: the out-of-bounds write of round 3 was a form that
+   writes correspondence lists on a workspace reserved without them).  out (>= 22 values): [0] form (0 stages, 1 fused,
+   2 split, 3 split PnP, 4 two-stream halves), [1] lists in HBM, [2] one chunk, [3] pairs of the largest launch
+   sequence, [4..12] bytes reserved for corr1, corr2, hdr1, hdr2, pass1, pass2, list1, list3, flags, [13..21] bytes the
+   form's launches write to them.                                                                                 */
+int  sf_debug_plan_workspace(const sf_params* p, int32_t kcap, int32_t desc_words, int32_t n_pairs,
+                             int32_t in_overlapped_step, int32_t debug_corr, int64_t* out, int32_t n_out);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif /* SF_EXPERIMENTAL_H */

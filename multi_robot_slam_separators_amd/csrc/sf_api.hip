@@ -674,6 +674,10 @@ static int fill_device_params(sf_context* c) {
   if (p.desc_type != 0 && p.desc_type != 1) return sf_fail(c, SF_EINVAL, "desc_type %d unknown (0 = binary rows, 1 = float32 rows)", p.desc_type);
   if (p.desc_type == 1 && p.desc_bytes != 256 && p.desc_bytes != 512 && p.desc_bytes != 32)
     return sf_fail(c, SF_EINVAL, "desc_type 1: desc_bytes %d (float32 rows of 64 or 128 dimensions: 256 or 512)", p.desc_bytes);
+  // float32 descriptors with the width left at sf_default_params' 32 (a binary width): 64 dimensions.  The width only
+  // matters before the first non-empty keyframe arrives -- an EMPTY first keyframe (the reference tolerates them: the
+  // fake-words path) takes it for its row pitch, and 32 bytes per float row was refused by the store (round 4).
+  if (p.desc_type == 1 && p.desc_bytes == 32) c->params.desc_bytes = 256;
   DeviceParams& d = c->dparams;
   memset(&d, 0, sizeof(d));
   d.force_3dof = p.force_3dof != 0;
@@ -1187,20 +1191,35 @@ extern "C" int sf_store_clear(sf_handle c) {
 // ---- verification pipeline ------------------------------------------------------------------------
 // lists: the correspondence lists live in HBM (stage kernels, or the fused kernel with SF_OPT_DEBUG_CORR); the fused
 // kernel otherwise keeps them in LDS and the two kcap-entry arrays per pair are not needed
+// Bytes of each workspace array for a launch sequence of n pairs: what ws_reserve reserves, as a pure function (also what
+// sf_debug_plan_workspace reports, so that a test without a GPU can hold it against what each launch form writes).
+struct WsBytes { size_t corr1, corr2, hdr1, hdr2, pass1, pass2, list1, list3, flags; };
+static WsBytes ws_bytes(int n, int kcap, bool lists) {
+  const size_t np = (size_t)n;
+  WsBytes w;
+  w.corr1 = w.corr2 = lists ? np * kcap * 4 : 0;
+  w.hdr1 = w.hdr2 = np * sizeof(CorrHeader);
+  w.pass1 = w.pass2 = np * sizeof(PassState);
+  w.list1 = w.list3 = np * 4;
+  w.flags = np;
+  return w;
+}
+
 static int ws_reserve(sf_context* c, int n, int kcap, bool lists) {
   int rc;
   const size_t np = (size_t)n;
+  const WsBytes w = ws_bytes(n, kcap, lists);
   if (lists) {
-    if ((rc = sf_buf_reserve(c, c->corr1, np * kcap * 4)) != SF_OK) return rc;
-    if ((rc = sf_buf_reserve(c, c->corr2, np * kcap * 4)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->corr1, w.corr1)) != SF_OK) return rc;
+    if ((rc = sf_buf_reserve(c, c->corr2, w.corr2)) != SF_OK) return rc;
   }
-  if ((rc = sf_buf_reserve(c, c->hdr1, np * sizeof(CorrHeader))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->hdr2, np * sizeof(CorrHeader))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->pass1, np * sizeof(PassState))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->pass2, np * sizeof(PassState))) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->list1, np * 4)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->list3, np * 4)) != SF_OK) return rc;
-  if ((rc = sf_buf_reserve(c, c->flags, np)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->hdr1, w.hdr1)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->hdr2, w.hdr2)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pass1, w.pass1)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->pass2, w.pass2)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->list1, w.list1)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->list3, w.list3)) != SF_OK) return rc;
+  if ((rc = sf_buf_reserve(c, c->flags, w.flags)) != SF_OK) return rc;
 #ifndef SF_CHAIN_TRACE
   if (getenv("SF_DIAG")) {     // experiment: eight 64-bit diagnostic counters the kernels may bump (sf_debug_counters)
     // [0..511]: counters; then two 64-bit planes of [pair][kcap] per-point records of the guided pass
@@ -1266,6 +1285,68 @@ static VerifyPlan verify_plan(const sf_context* c, const StoreView& v, int n) {
   else if (sf_fused_lds_bytes(c, v) != 0 && !c->dparams.bundle_adjustment) { p.form = VerifyPlan::FUSED; p.lists = c->debug_corr; }
   else { p.form = VerifyPlan::STAGES; p.lists = true; }
   return p;
+}
+
+// What the launches of a form WRITE into the workspace for a sequence of m pairs -- stated here independently of
+// ws_bytes / ws_reserve, from the kernels' own indexing (k_verify.hip, k_match.hip, k_ransac.hip, k_pnp.hip,
+// k_guided.hip): lists are [pair][kcap] words, headers / states / flags one entry per pair, work lists one int per pair.
+// (The `4822be5` fault of round 3 was a form that writes lists on a workspace reserved without them.)
+static WsBytes form_writes(VerifyPlan::Form form, int m, int kcap, bool debug_corr, bool ba) {
+  const size_t np = (size_t)m, list = np * (size_t)kcap * 4;
+  WsBytes w = {};
+  switch (form) {
+    case VerifyPlan::FUSED:            // lists / headers / states only with SF_OPT_DEBUG_CORR; flags with it too
+      if (debug_corr) { w.corr1 = w.corr2 = list; w.hdr1 = w.hdr2 = np * sizeof(CorrHeader); w.pass1 = w.pass2 = np * sizeof(PassState); w.flags = np; }
+      break;
+    case VerifyPlan::SPLIT:            // k_match_split: corr1, hdr1, pass1, list1 (+ hdr2 / pass2 / flags of non-survivors with
+      w.corr1 = list; w.hdr1 = np * sizeof(CorrHeader); w.pass1 = np * sizeof(PassState); w.list1 = np * 4;   // the debug option)
+      if (debug_corr || ba) { w.corr2 = list; w.hdr2 = np * sizeof(CorrHeader); w.pass2 = np * sizeof(PassState); w.flags = np; }
+      break;
+    case VerifyPlan::SPLIT_PNP:        // k_chain_pnp hands everything over through the workspace
+    case VerifyPlan::STAGES:
+    case VerifyPlan::HALVES:
+      w.corr1 = w.corr2 = list; w.hdr1 = w.hdr2 = np * sizeof(CorrHeader); w.pass1 = w.pass2 = np * sizeof(PassState);
+      w.list1 = w.list3 = np * 4; w.flags = np;
+      break;
+  }
+  return w;
+}
+
+// include/sf_experimental.h: the plan of a verification call and its workspace, computed WITHOUT a device (no HIP call):
+// out[0] = form, out[1] = lists, out[2] = single, out[3] = pairs of the largest launch sequence, out[4..12] = bytes
+// ws_reserve reserves (corr1, corr2, hdr1, hdr2, pass1, pass2, list1, list3, flags), out[13..21] = bytes the form's
+// launches write for that sequence.
+extern "C" int sf_debug_plan_workspace(const sf_params* p, int32_t kcap, int32_t desc_words, int32_t n_pairs,
+                                       int32_t in_overlapped_step, int32_t debug_corr, int64_t* out, int32_t n_out) {
+  if (!p || !out || n_out < 22 || kcap <= 0 || (kcap & 63) || (desc_words != 8 && desc_words != 16 && desc_words != 64 && desc_words != 128) || n_pairs <= 0)
+    return SF_EINVAL;
+  sf_context* c = new (std::nothrow) sf_context();
+  if (!c) return SF_ENOMEM;
+  c->params = *p;
+  int rc = fill_device_params(c);
+  if (rc == SF_OK) {
+    if (const char* v = getenv("SF_FUSED")) { c->fused = atoi(v) != 0; c->split = atoi(v) == 2; }
+    if (const char* v = getenv("SF_STEP_SPLIT")) c->split_auto = atoi(v) != 0;
+    if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;
+    if (const char* v = getenv("SF_OVERLAP")) c->overlap = atoi(v) != 0;
+    c->in_overlapped_step = in_overlapped_step != 0;
+    c->debug_corr = debug_corr != 0;
+    StoreView v = {};
+    v.kcap = kcap; v.w = desc_words; v.n_slots = 1;
+    const VerifyPlan plan = verify_plan(c, v, n_pairs);
+    const int seq = plan.form == VerifyPlan::HALVES ? std::min((std::min(n_pairs, 2 * SF_CHUNK) + 1) / 2, SF_CHUNK)
+                                                    : std::min(n_pairs, SF_CHUNK);
+    const bool lists = plan.form == VerifyPlan::HALVES ? true : plan.lists;
+    const WsBytes r = ws_bytes(seq, kcap, lists);
+    const WsBytes w = form_writes(plan.form == VerifyPlan::HALVES ? VerifyPlan::STAGES : plan.form, seq, kcap, c->debug_corr,
+                                  c->dparams.bundle_adjustment != 0);
+    out[0] = (int64_t)plan.form; out[1] = plan.lists; out[2] = plan.single; out[3] = seq;
+    const size_t rs[9] = {r.corr1, r.corr2, r.hdr1, r.hdr2, r.pass1, r.pass2, r.list1, r.list3, r.flags};
+    const size_t ws[9] = {w.corr1, w.corr2, w.hdr1, w.hdr2, w.pass1, w.pass2, w.list1, w.list3, w.flags};
+    for (int i = 0; i < 9; ++i) { out[4 + i] = (int64_t)rs[i]; out[13 + i] = (int64_t)ws[i]; }
+  }
+  delete c;
+  return rc;
 }
 
 // One launch sequence for m <= SF_CHUNK pairs on ctx's stream and workspace, in the form the call's plan names.
@@ -1834,11 +1915,11 @@ static void lane_swap(sf_context* c, int k) {
 // write and a fallback still sees the state its step was issued on.  `drain` also waits for the lanes' streams.
 int sf_lanes_touch(sf_context* c, bool drain) {
   c->db_epoch += 1;
-  (void)step_settle_all(c);
+  const int rc = step_settle_all(c);      // (a step whose fallback re-run failed: the error is the caller's to see)
   if (drain)
     for (auto& L : c->lanes)
       if (L.stream) SF_HIP(c, hipStreamSynchronize(L.stream));
-  return SF_OK;
+  return rc;
 }
 
 static int stream_with_own_queue(sf_context* c, hipStream_t* out, bool aux);
@@ -2290,6 +2371,16 @@ extern "C" int sf_step_issue(sf_handle c, int32_t slot_base_other, int32_t slot_
     return sf_fail(c, SF_EINVAL, "empty descriptor database (data_handler.py:308 guards this case)");
   SF_HIP(c, hipSetDevice(c->device));
   const bool mirrored = c->step_mirror_records[0] != nullptr;
+  if (mirrored) {
+    // A mirror has ONE caller buffer (and one caller-zeroed counter) per parity: step k + 2 writes where step k wrote.  The
+    // ring's depth (default 6) would let step k + 2 zero and overwrite the mirror before step k is retired and its collective
+    // enqueued, so with a mirror set no more steps may be in flight than the mirror has buffers.
+    const int mirror_buffers = (c->step_mirror_records[1] && c->step_mirror_records[1] != c->step_mirror_records[0]) ? 2 : 1;
+    if (c->step_inflight >= mirror_buffers)
+      return sf_fail(c, SF_EINVAL, "%d step(s) in flight with a %d-buffer mirror set (sf_step_mirror%s): retire before issuing -- "
+                                   "step k + %d would overwrite the records of step k", c->step_inflight, mirror_buffers,
+                     mirror_buffers == 2 ? "_pair" : "", mirror_buffers);
+  }
   int lanes = (c->step_overlap && !c->overlap && (!mirrored || c->step_mirror_lanes)) ? c->step_lanes : 1;
   if (mirrored) lanes = std::min(lanes, 2);          // (a mirror's buffer and its collective live on the stream of its parity)
   if (c->params.nn_precision == 0) lanes = 1;        // (the fp32-ranking path keeps its partial minima in ONE workspace)
@@ -2362,7 +2453,9 @@ static int step_settle(sf_context* c, sf_context::StepBlock& b) {
     rc = sf_fail(c, SF_EHIP, "hipEventSynchronize(step fallback) -> %s", hipGetErrorString(e));
   if (rc == SF_OK && mirrored)
     rc = sf_fail(c, SF_ERANGE, "sf_step_retire: the NN candidate set outgrew the filter level while a mirror was set -- the "
-                               "mirror missed this step's records (the level is settled now: issue the step again)");
+                               "mirror (parity %d) missed this step's records.  The level is settled now; the step counter has "
+                               "advanced, so a re-issued step writes the mirror of parity %d: retire everything in flight, "
+                               "re-zero both counters and issue the step again", b.parity, (int)(c->step_seq & 1));
   return b.settle_rc = rc;
 }
 
@@ -2769,8 +2862,10 @@ extern "C" int sf_nn_sizes(sf_handle c, int32_t* n_local, int32_t* n_received) {
 
 extern "C" int sf_nn_mark_local_used(sf_handle c, int32_t idx) {
   if (!c) return SF_EINVAL;
-  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (idx < 0 || idx >= c->nn_local.n) return sf_fail(c, SF_ERANGE, "local index %d outside [0,%d)", idx, c->nn_local.n);
+  // steps in flight were issued on the masks as they are: they are waited for first (arguments validated before the drain;
+  // a settle error -- a step whose re-run failed -- is this call's error: the mask is not touched then)
+  if (c->step_inflight) { const int rc = sf_lanes_touch(c, false); if (rc != SF_OK) return rc; }
   if ((int)c->mask_local.size() < c->nn_local.n) c->mask_local.resize(c->nn_local.n, 0);
   c->mask_local[idx] = 1;
   c->masks_dirty = true;
@@ -2779,8 +2874,8 @@ extern "C" int sf_nn_mark_local_used(sf_handle c, int32_t idx) {
 
 extern "C" int sf_nn_mark_other_used(sf_handle c, int32_t idx) {
   if (!c) return SF_EINVAL;
-  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (idx < 0 || idx >= c->nn_recv.n) return sf_fail(c, SF_ERANGE, "other index %d outside [0,%d)", idx, c->nn_recv.n);
+  if (c->step_inflight) { const int rc = sf_lanes_touch(c, false); if (rc != SF_OK) return rc; }
   if ((int)c->mask_other.size() < c->nn_recv.n) c->mask_other.resize(c->nn_recv.n, 0);
   c->mask_other[idx] = 1;
   c->masks_dirty = true;
@@ -2789,9 +2884,9 @@ extern "C" int sf_nn_mark_other_used(sf_handle c, int32_t idx) {
 
 extern "C" int sf_nn_ignore_pair(sf_handle c, int32_t il, int32_t io) {
   if (!c) return SF_EINVAL;
-  if (c->step_inflight) (void)sf_lanes_touch(c, false);   // (steps in flight were issued on the masks as they are)
   if (il < 0 || il >= c->nn_local.n || io < 0 || io >= c->nn_recv.n)
     return sf_fail(c, SF_ERANGE, "pair (%d,%d) outside the %d x %d distance matrix", il, io, c->nn_local.n, c->nn_recv.n);
+  if (c->step_inflight) { const int rc = sf_lanes_touch(c, false); if (rc != SF_OK) return rc; }
   c->ignored.push_back(il);
   c->ignored.push_back(io);
   c->masks_dirty = true;

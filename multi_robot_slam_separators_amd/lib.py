@@ -119,6 +119,7 @@ def load():
         "sf_debug_pass_state": (C.c_int, [vp, i32, i32, vp, P(i32), P(i32), P(i32)]),
         "sf_debug_counters": (C.c_int, [vp, vp, i32]),
         "sf_debug_guided_points": (C.c_int, [vp, i32, vp, vp, P(i32)]),
+        "sf_debug_plan_workspace": (C.c_int, [P(_abi.Params), i32, i32, i32, i32, i32, P(i64), i32]),
         "sf_pack_separators": (C.c_int, [vp, i32, C.c_int8, C.c_int8, vp, vp, vp, vp, vp]),
         "sf_comm_unique_id": (C.c_int, [vp, i32]),
         "sf_comm_init": (C.c_int, [vp, vp, i32, i32]),
@@ -161,7 +162,7 @@ EXPORTED = [
     "sf_brief_set_pattern", "sf_brief_get_pattern", "sf_extract_keyframe_device", "sf_detect_corners_device", "sf_stereo_flow_defaults", "sf_stereo_correspondences_device", "sf_detector_defaults", "sf_get_features_and_descriptor", "sf_netvlad_load", "sf_netvlad_infer_device", "sf_netvlad_infer_batch_device", "sf_estimate_transform",
     "sf_estimate_transform_batch", "sf_verify_pairs", "sf_verify_pairs_device", "sf_verify_matches_device", "sf_find_matches_and_verify_device", "sf_compact_accepted_device",
     "sf_compact_accepted_device_async", "sf_step_issue", "sf_step_retire", "sf_memcpy_device_async", "sf_step_mirror", "sf_step_mirror_pair", "sf_step_mirror_streams", "sf_accept_stream_set", "sf_accept_stream_select", "sf_accept_stream_status", "sf_last_match_results", "sf_compact_accepted_indexed_device_async", "sf_compact_accepted_indexed_mirrored_device_async",
-    "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
+    "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_debug_plan_workspace", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_nn_walk_device",
     "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
     "sf_kernel_name", "sf_stream_placement",
@@ -488,7 +489,8 @@ class SeparatorFinder:
     # -- the caller's loop body as a begin / retire pair (find_separators.py:59-133) ----------------------------------
     def step_issue(self, slot_base_other, slot_base_local):
         """Queue one find-and-verify step (NN search, walk, verification of every returned candidate, all on the
-        device); does not wait for any of it.  At most SF_OPT_STEP_DEPTH (default 4) steps in flight."""
+        device); does not wait for any of it.  At most SF_OPT_STEP_DEPTH (default 6) steps in flight; with a mirror set
+        (step_mirror / step_mirror_pair) as many as the mirror has buffers."""
         self._check(self._L.sf_step_issue(self._h, int(slot_base_other), int(slot_base_local)))
 
     def step_retire(self, copy=False):

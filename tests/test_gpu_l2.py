@@ -75,3 +75,23 @@ def test_float_descriptor_edge_cases(oracle):
         bad = _abi.FeatureArrays(np.zeros((10, 48), np.float32), a.xyz[:10], a.kpts[:10])
         with pytest.raises(lib.SepfinderError):
             f.store_add_keyframe(bad)
+
+
+def test_empty_first_keyframe_on_a_default_width_float_handle(oracle):
+    """A float-descriptor handle created with the width sf_default_params leaves (32, a binary width) must accept an EMPTY
+    keyframe as its first store entry (the reference tolerates empty keyframes: the fake-words path) -- round 4 derived a
+    32-byte float row from it and the store refused the keyframe.  The width is taken as 64 dimensions until the first
+    non-empty keyframe arrives."""
+    dims = 64
+    p = _params(dims)
+    p.desc_bytes = 32                       # (what sf_default_params writes)
+    A, B, _, _ = _pairs(78, 2, 120, dims, 0.02, true_frac=1.0)
+    empty = _abi.FeatureArrays(np.zeros((0, 0), np.float32), A[0].xyz[:0], A[0].kpts[:0])
+    with lib.SeparatorFinder(p) as f:
+        s0 = f.store_add_keyframe(empty)
+        s1 = f.store_add_keyframe(A[0])
+        s2 = f.store_add_keyframe(B[0])
+        got = f.verify_pairs(np.array([s1, s0], np.int32), np.array([s2, s2], np.int32))
+        o = oracle.estimate_transform(_params(dims), A[0], B[0])
+        assert got[0].tobytes() == o.tobytes() and got[0]["success"] == 1
+        assert got[1]["success"] == 0 and got[1]["matches"] == 0

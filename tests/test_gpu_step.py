@@ -278,6 +278,24 @@ def test_step_with_two_alternating_mirrors():
         torch.cuda.synchronize()
         check_buffer(1, out_odd)
         check_buffer(0, out_even)
+        # the ring's default depth (6) must not apply with a mirror set: a THIRD step in flight would zero and overwrite the
+        # buffer of the oldest one before its collective has read it -- the library refuses it (round 4 admitted it)
+        send[1].zero_()
+        f.step_issue(sa, sb)
+        send[0].zero_()
+        f.step_issue(sa, sb)
+        with pytest.raises(lib.SepfinderError, match="2-buffer mirror"):
+            f.step_issue(sa, sb)
+        out_odd = f.step_retire(copy=True)
+        send[1].zero_()
+        f.step_issue(sa, sb)                      # (one retired: one may enter)
+        out_even = f.step_retire(copy=True)
+        out_odd2 = f.step_retire(copy=True)
+        for out in (out_odd, out_even, out_odd2):
+            _check_step(out, m_ref, res_ref, True)
+        torch.cuda.synchronize()
+        check_buffer(0, out_even)
+        check_buffer(1, out_odd2)
         with pytest.raises(lib.SepfinderError):
             f.step_mirror_pair((send[0][1:].data_ptr(), send[0].data_ptr()), (0, 0), cap)     # both pairs or none
         # sf_step_mirror_streams: the odd steps on the handle's second stream; the caller's fills go to the same streams

@@ -290,3 +290,45 @@ def test_bench_ends_the_other_ranks_when_one_fails():
     assert all(p.poll() is not None for p in procs)
     ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(2)]
     assert bench.wait_ranks(ok) == 0
+
+
+@pytest.mark.parametrize("n_pairs", [1, 2047, 20000, 65536, 65537, 131072, 131073, 140000, 300000])
+def test_workspace_reservation_covers_what_every_launch_form_writes(monkeypatch, n_pairs):
+    """The only pin of round 3's out-of-bounds fix that needs no GPU: for every form the plan of a verification call can
+    take (fused / split / split PnP / stage kernels / two-stream halves; with and without the debug lists, the bundle
+    adjustment, the float descriptors; inside and outside overlapped steps; forced by SF_FUSED / SF_STEP_SPLIT), the
+    bytes ws_reserve reserves for the call's largest launch sequence cover the bytes that form's kernels write --
+    sf_debug_plan_workspace (include/sf_experimental.h) computes both on the host, the writes from a table kept apart
+    from the reservation's.  The shapes are the ones around the form and chunk boundaries (65 536 candidates, the
+    131 072-pair chunk) that tests/test_gpu_step.py runs on the device."""
+    import ctypes as C
+    import itertools
+    from multi_robot_slam_separators_amd import _abi, lib, synth
+    L = lib.load()
+    names = ("corr1", "corr2", "hdr1", "hdr2", "pass1", "pass2", "list1", "list3", "flags")
+    seen = set()
+    envs = ({}, {"SF_FUSED": "0"}, {"SF_FUSED": "2"}, {"SF_STEP_SPLIT": "1"}, {"SF_OVERLAP": "1"}, {"SF_CHAIN_PNP": "0"})
+    for env in envs:
+        for k in ("SF_FUSED", "SF_STEP_SPLIT", "SF_OVERLAP", "SF_CHAIN_PNP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for est, ba, bidir, dtype, kcap, overl, dbg in itertools.product((0, 1), (0, 1), (0, 1), (0, 1), (512, 1024, 2560),
+                                                                         (0, 1), (0, 1)):
+            p = synth.camera_params()
+            p.estimation_type = est
+            p.bundle_adjustment = ba
+            p.stereo_baseline = 0.12 if ba else 0.0
+            p.forward_est_only = 0 if bidir else 1
+            p.desc_type = dtype
+            p.desc_bytes = 256 if dtype else 32
+            out = (C.c_int64 * 22)()
+            rc = L.sf_debug_plan_workspace(C.byref(p), kcap, 64 if dtype else 8, n_pairs, overl, dbg, out, 22)
+            assert rc == 0, (env, est, ba, bidir, dtype, kcap)
+            form, seq = int(out[0]), int(out[3])
+            assert 1 <= seq <= 131072
+            seen.add(form)
+            for i, nm in enumerate(names):
+                assert out[4 + i] >= out[13 + i], (env, "form %d" % form, nm, int(out[4 + i]), int(out[13 + i]),
+                                                   dict(est=est, ba=ba, bidir=bidir, dtype=dtype, kcap=kcap, overl=overl, dbg=dbg))
+    assert seen >= ({0, 1, 2, 3, 4} if n_pairs >= 20000 else {0, 1, 3})     # every form was planned at least once
