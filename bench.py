@@ -1689,6 +1689,15 @@ def main():
         out["stream_placement"] = f.stream_placement()
         if dist_cuda:
             out["exchange_buffers"] = len(exchs)
+        if exch is not None:
+            # who took part in the separator exchange, read from the gathered header rows of the last step's all-gather
+            # (every rank stamps its own number there), and what one collective moves
+            seen = exch.ranks_seen()
+            out["collective"] = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend,
+                                 "op": "all_gather_into_tensor, one per step, started at retire",
+                                 "ranks_in_allgather": len(seen), "ranks_seen": seen,
+                                 "bytes_per_step": exch.bytes_per_exchange(),
+                                 "records_per_rank_last_step": exch.counts()}
         out["accepted_separators_streamed_from_the_kernel"] = bool(state.get("streamed_last", False))
         if alt_sync is not None:
             out["value_one_synchronisation_per_step"] = alt_sync

@@ -169,7 +169,9 @@ class RecordExchange:
             self._n_local = None
         else:
             self._n_local = int(n_local)
-            self._hdr.fill_(self._n_local)
+            # low word: the count; high word: this rank's number + 1 -- evidence, in the gathered headers themselves, of
+            # which ranks took part in the collective (ranks_seen)
+            self._hdr.fill_(self._n_local | ((self.td.get_rank(self.group) + 1) << 32))
         self._work = self.td.all_gather_into_tensor(self.recv.view(self.world * self.blk, self.rec),
                                                     self.send[: self.blk], group=self.group, async_op=True)
         if finish:
@@ -199,6 +201,20 @@ class RecordExchange:
                 raise RuntimeError("record exchange: rank %d reports %d records (limit %s): the producer's count is invalid"
                                    % (r, c, limit))
         return out
+
+    def ranks_seen(self):
+        """Ranks whose header row arrived in the last finished all-gather, read from the high words of the gathered
+        headers (each rank stamps rank + 1 there when it stamps its count on the host): what a bench line reports as
+        `ranks_in_allgather` -- counted from the data, not from WORLD_SIZE.  Empty when the producer stamped the count on
+        the device (the high word stays zero)."""
+        import torch
+        h = self._h_counts if self.h_recv is None else self.h_recv[:, 0, :8].contiguous()
+        hi = h.view(torch.int32).reshape(-1, 2)[:, 1].tolist()
+        return sorted(int(x) - 1 for x in hi if int(x) > 0)
+
+    def bytes_per_exchange(self):
+        """Bytes one all-gather moves into every rank's receive buffer (world x block rows x record bytes)."""
+        return int(self.world * self.blk * self.rec)
 
     def gathered(self, r, counts=None):
         c = (counts or self.counts())[r]

@@ -184,6 +184,8 @@ for cap in (8, 2):
         want_counts = [len(dist.shard_pairs(n_pairs, r, world)) if step == 0 else
                        max(0, len(dist.shard_pairs(n_pairs, r, world)) - 1 - r) for r in range(world)]
         assert cts == want_counts, (cap, step, cts)
+        # (who took part, read from the gathered headers themselves: what bench.py reports as ranks_in_allgather)
+        assert ex.ranks_seen() == list(range(world)) and ex.bytes_per_exchange() == world * (min(cap, n_pairs) + 1) * B
         off = 0
         for r in range(world):
             theirs = dist.shard_pairs(n_pairs, r, world)[: cts[r]]
