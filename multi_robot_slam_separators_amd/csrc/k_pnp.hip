@@ -35,9 +35,12 @@ namespace {
 
 #define PNP_NSUM 28
 
-__host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations) {
+// bear: the observations' unit bearings are kept in LDS (the 256-thread form; 24 B per correspondence) -- the narrow
+// chains recompute the three a hypothesis needs (the same operations on the same inputs: the same bits) and fit
+// five to a CU instead of four
+__host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations, bool bear = true) {
   const int it = iterations > 0 ? iterations : 0;
-  return (size_t)kcap * (16 + 24 + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
+  return (size_t)kcap * (16 + (bear ? 24 : 0) + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
          5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
 }
 
@@ -60,11 +63,7 @@ struct PnpLds {
   double* ne_b;     // [32] normal equations of the candidate pose
 };
 
-template <int N>
-__device__ __forceinline__ void block_sum_vec32(double (&v)[N], double* red, int tid) {
-  sfd::block_sum_canon<N, 32>(v, red, tid);
-}
-
+template <int NW = 4>
 __device__ __forceinline__ int block_sum_i(int v, int* misc, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -72,7 +71,10 @@ __device__ __forceinline__ int block_sum_i(int v, int* misc, int tid) {
   __syncthreads();
   if (lane == 0) misc[8 + wave] = v;
   __syncthreads();
-  return ((misc[8] + misc[9]) + misc[10]) + misc[11];
+  int t = misc[8];                          // (integers: the order of the fold is free)
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += misc[8 + w];
+  return t;
 }
 
 struct PnpCam {
@@ -102,6 +104,7 @@ __device__ __forceinline__ bool pnp_inlier(const PnpLds& L, const PnpCam& cam, c
 }
 
 // model of RANSAC iteration `it`: keyed 4-sample, P3P on the first three, the 4th picks the root
+template <bool BEAR>
 __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64_t seed, uint32_t it, uint32_t m,
                                       float (&coef)[12]) {
   uint32_t s0, s1, s2, s3;
@@ -112,8 +115,15 @@ __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64
   for (int k = 0; k < 3; ++k) {
     const float4 p = L.obj[sk[k]];
     P[k][0] = (double)p.x; P[k][1] = (double)p.y; P[k][2] = (double)p.z;
-    const double* b = L.bear + 3 * sk[k];
-    f[k][0] = b[0]; f[k][1] = b[1]; f[k][2] = b[2];
+    if constexpr (BEAR) {
+      const double* b = L.bear + 3 * sk[k];
+      f[k][0] = b[0]; f[k][1] = b[1]; f[k][2] = b[2];
+    } else {                               // (the operations of the precomputation in pnp_body, on the same inputs)
+      const float2 o = L.img[sk[k]];
+      const double un = (double)o.x / cam.fx, vn = (double)o.y / cam.fy;
+      const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
+      f[k][0] = un * inv; f[k][1] = vn * inv; f[k][2] = inv;
+    }
   }
   const float4 p4 = L.obj[s3];
   const float2 o4 = L.img[s3];
@@ -122,15 +132,13 @@ __device__ inline bool pnp_hypothesis(const PnpLds& L, const PnpCam& cam, uint64
 }
 
 // Normal equations of the reprojection error over the members of L.mask at pose (q, t).
+template <int NW>
 __device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask,
                                      const double (&q)[4], const double (&t)[3], double* out, int tid) {
   double R[9];
   sfd::quat_to_R(q, R);
-  double ne[PNP_NSUM];
-#pragma unroll
-  for (int k = 0; k < PNP_NSUM; ++k) ne[k] = 0.0;
-  for (int i = tid; i < m; i += SF_BLOCK) {
-    if (!mask[i]) continue;
+  sfd::canon_reduce_to_lds<PNP_NSUM, 32, NW>(m, tid, L.red, out, [&](int i, double (&ne)[PNP_NSUM]) {
+    if (!mask[i]) return;
     const float4 p = L.obj[i];
     const float2 o = L.img[i];
     const double Px = (double)p.x, Py = (double)p.y, Pz = (double)p.z;
@@ -163,19 +171,19 @@ __device__ inline void pnp_normal_eq(const PnpLds& L, const PnpCam& cam, int m, 
     } else {
       ne[27] += 1e30;   // a member behind the camera makes the pose unacceptable
     }
-  }
-  sfd::block_sum_canon_to_lds<PNP_NSUM, 32>(ne, L.red, out, tid);
+  });
 }
 
 // Levenberg-Marquardt over the members of `mask` from pose (q, t): at most 20 evaluations, diagonal
 // scaled by 1 + lambda [upstream cvFindExtrinsicCameraParams2 / CvLevMarq].  Every lane runs the same
 // scalar control flow on the block-reduced sums.  ne returns the normal equations at the final pose.
+template <int NW>
 __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const uint8_t* mask, double (&q)[4],
                               double (&t)[3], int tid) {
   // L.ne_a holds the normal equations of the accepted pose on return
   double* cur = L.ne_a;
   double* cand = L.ne_b;
-  pnp_normal_eq(L, cam, m, mask, q, t, cur, tid);
+  pnp_normal_eq<NW>(L, cam, m, mask, q, t, cur, tid);
   double lambda = 1e-3;
   // The damped 6 x 6 solve and the candidate pose are a short scalar computation on the reduced sums: ONE wavefront
   // does it and hands the candidate over through L.red (free between two reductions); round 2 had all four wavefronts
@@ -223,7 +231,7 @@ __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const u
     qc[0] = L.red[1]; qc[1] = L.red[2]; qc[2] = L.red[3]; qc[3] = L.red[4];
     tc[0] = L.red[5]; tc[1] = L.red[6]; tc[2] = L.red[7];
     const double dd = L.red[8], tt = L.red[9];
-    pnp_normal_eq(L, cam, m, mask, qc, tc, cand, tid);     // (its first barrier: the hand-over has been read by everyone)
+    pnp_normal_eq<NW>(L, cam, m, mask, qc, tc, cand, tid);     // (its first barrier: the hand-over has been read by everyone)
     if (cand[27] < cur[27]) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) q[i] = qc[i];
@@ -247,6 +255,7 @@ __device__ inline void pnp_lm(const PnpLds& L, const PnpCam& cam, int m, const u
 
 // rtabmap computeReprojErrors: members = points in front of the camera with reprojection error (px,
 // not squared) <= thr under the float-rounded pose; L.e1[i] receives member i's error.
+template <int NW>
 __device__ inline int pnp_select(const PnpLds& L, const PnpCam& cam, int m, const double (&q)[4],
                                  const double (&t)[3], float thr, uint8_t* mask, int tid) {
   double Rd[9];
@@ -259,7 +268,7 @@ __device__ inline int pnp_select(const PnpLds& L, const PnpCam& cam, int m, cons
     c[4 * i + 3] = (float)t[i];
   }
   int n = 0;
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  for (int i = tid; i < m; i += 64 * NW) {
     const float4 P = L.obj[i];
     const float2 o = L.img[i];
     const float X = __fmaf_rn(c[2], P.z, __fmaf_rn(c[1], P.y, __fmaf_rn(c[0], P.x, c[3])));
@@ -276,14 +285,15 @@ __device__ inline int pnp_select(const PnpLds& L, const PnpCam& cam, int m, cons
     mask[i] = in ? 1 : 0;
     n += in ? 1 : 0;
   }
-  return block_sum_i(n, L.misc, tid);
+  return block_sum_i<NW>(n, L.misc, tid);
 }
 
 // value of rank `rank` among the finite entries of arr[0..m4) (+inf padded): rank counting, 4 per read
+template <int NT>
 __device__ inline float rank_value(const float* arr, int m, int rank, double* slot, int tid) {
   const int m4 = (m + 3) & ~3;
   __syncthreads();
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  for (int i = tid; i < m; i += NT) {
     const float v = arr[i];
     if (v < __int_as_float(0x7F800000)) {
       int lt = 0, eq = 0;
@@ -315,7 +325,7 @@ struct PnpTail {
 // the 3D points of "to" against the keypoints of "from"; the stage kernel only).  `mask_out` (stage kernel, both
 // directions): one byte per "from" feature of the pair, set for this estimate's inliers; `guided` (with mask_out): the
 // pass's correspondences come from guided matching (decides what the 2D words of "from" are, sf_pnp_dir_gate).
-template <int DIR = 0>
+template <int DIR = 0, int NW = 4>
 __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const int32_t* __restrict__ pair_from,
                                          const int32_t* __restrict__ pair_to, const uint32_t* __restrict__ corr,
                                          const CorrHeader* __restrict__ hdr, PassState* __restrict__ pass,
@@ -323,6 +333,8 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
                                          uint8_t* mask_out = nullptr, bool guided = false) {
   // (trace_base: first of five timestamp slots of the diagnostic build -- gather, RANSAC, first solve, refinement
   //  rounds, pose + covariance; SF_TRACE_MARK compiles to nothing in the product)
+  constexpr int NT = 64 * NW;
+  constexpr bool BEAR = NW == 4;          // (sf_pnp_lds_bytes_dev)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int kcap = st.kcap;
@@ -337,7 +349,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     unsigned char* p = smem_raw;
     L.obj = (float4*)p; p += (size_t)kcap * 16;
     L.red = (double*)p; p += 128 * 8;
-    L.bear = (double*)p; p += (size_t)kcap * 24;
+    L.bear = (double*)p; p += BEAR ? (size_t)kcap * 24 : 0;
     L.img = (float2*)p; p += (size_t)kcap * 8;
     L.e1 = (float*)p; p += (size_t)kcap * 4;
     L.e2 = (float*)p; p += (size_t)kcap * 4;
@@ -374,7 +386,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   if (tid < 16) L.misc[tid] = 0;
   __syncthreads();
   int m = 0;
-  for (int base = 0; base < n_corr; base += SF_BLOCK) {
+  for (int base = 0; base < n_corr; base += NT) {
     const int i = base + tid;
     bool ok = false;
     float ax = 0, ay = 0, az = 0, ox = 0, oy = 0;
@@ -393,7 +405,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     __syncthreads();
     int woff = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < SF_BLOCK / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const int cw = L.misc[4 + w];
       if (w < wave) woff += cw;
       total += cw;
@@ -408,11 +420,13 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   }
 
   // unit bearings of the observations, once per point (the P3P of every hypothesis reads three of them)
-  for (int i = tid; i < m; i += SF_BLOCK) {
-    const float2 o = L.img[i];
-    const double un = (double)o.x / P.fx, vn = (double)o.y / P.fy;
-    const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
-    L.bear[3 * i] = un * inv; L.bear[3 * i + 1] = vn * inv; L.bear[3 * i + 2] = inv;
+  if constexpr (BEAR) {
+    for (int i = tid; i < m; i += NT) {
+      const float2 o = L.img[i];
+      const double un = (double)o.x / P.fx, vn = (double)o.y / P.fy;
+      const double inv = 1.0 / sqrt((un * un + vn * vn) + 1.0);
+      L.bear[3 * i] = un * inv; L.bear[3 * i + 1] = vn * inv; L.bear[3 * i + 2] = inv;
+    }
   }
   __syncthreads();
 
@@ -441,17 +455,17 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   {
     int niters = max_it, best = 0, best_it = -1, sc_it = 0;   // thread 0 only
     if (tid == 0) { L.misc[0] = -1; L.misc[1] = 1; }
-    const int slice = (m + 3) >> 2;                        // points counted by each wavefront
+    const int slice = (m + NW - 1) / NW;                   // points counted by each wavefront
     const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
     int* hv = L.hyp_cnt + 4 * 64;
-    const int fit_wave = pair & 3;   // rotate the solving wavefront (SIMD) with the pair
+    const int fit_wave = pair & (NW - 1);   // rotate the solving wavefront (SIMD) with the pair
     for (int base = 0; base < max_it; base += 64) {
       const int it = base + lane;
       if (wave == fit_wave) {
         int valid = 0;
         if (it < max_it) {
           float coef[12];
-          if (pnp_hypothesis(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
+          if (pnp_hypothesis<BEAR>(L, cam, P.seed, (uint32_t)it, (uint32_t)m, coef)) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) L.hyp[k * 64 + lane] = coef[k];
             valid = 1;
@@ -471,8 +485,12 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
         L.hyp_cnt[wave * 64 + lane] = cnt;
       }
       __syncthreads();
-      if (wave == fit_wave && it < max_it)
-        L.counts[it] = ((L.hyp_cnt[lane] + L.hyp_cnt[64 + lane]) + L.hyp_cnt[128 + lane]) + L.hyp_cnt[192 + lane];
+      if (wave == fit_wave && it < max_it) {
+        int tot = L.hyp_cnt[lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tot += L.hyp_cnt[64 * w + lane];
+        L.counts[it] = tot;
+      }
       __syncthreads();
       if (tid == 0) {
         const int lim = min(max_it, base + 64);   // counts exist for iterations < lim
@@ -509,12 +527,12 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
 #pragma unroll
   for (int k = 0; k < 12; ++k) coef[k] = L.best[k];
   int n_inl = 0;
-  for (int i = tid; i < m; i += SF_BLOCK) {
+  for (int i = tid; i < m; i += NT) {
     const bool in = pnp_inlier(L, cam, coef, i);
     L.mask[i] = in ? 1 : 0;
     n_inl += in ? 1 : 0;
   }
-  n_inl = block_sum_i(n_inl, L.misc, tid);   // also orders the mask writes before the reads below
+  n_inl = block_sum_i<NW>(n_inl, L.misc, tid);   // also orders the mask writes before the reads below
 
   if (P.dbg_stop == 3) { if (tid == 0) pass[pair] = ps; return none; }
   // ---- final solve on the inliers: Levenberg-Marquardt, at most 20 evaluations ------------------------
@@ -529,7 +547,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     }
     sfd::R_to_quat(Rb, q);
   }
-  pnp_lm(L, cam, m, L.mask, q, t, tid);
+  pnp_lm<NW>(L, cam, m, L.mask, q, t, tid);
   if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 2);
 
   // ---- rtabmap util3d::solvePnPRansac refinement rounds (Vis/PnPRefineIterations > 0) ---------------------
@@ -543,14 +561,14 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     uint8_t* prev = L.mask;
     uint8_t* neu = L.mask_b;
     int n_prev = n_inl, n_new = 0;
-    for (int i = tid; i < m; i += SF_BLOCK) neu[i] = 0;
+    for (int i = tid; i < m; i += NT) neu[i] = 0;
     int n_sizes = 0, z1 = 0, z2 = 0, z3 = 0, z4 = 0;   // last four pushed sizes (z1 newest)
     do {
-      pnp_lm(L, cam, m, prev, q, t, tid);                // solvePnP from the current model
+      pnp_lm<NW>(L, cam, m, prev, q, t, tid);                // solvePnP from the current model
       z4 = z3; z3 = z2; z2 = z1; z1 = n_prev;
       ++n_sizes;
       __syncthreads();
-      n_new = pnp_select(L, cam, m, q, t, error_threshold, neu, tid);
+      n_new = pnp_select<NW>(L, cam, m, q, t, error_threshold, neu, tid);
       if (n_new < min_count) {
         ++refine_iterations;
         if (refine_iterations >= P.pnp_refine_iterations) break;
@@ -558,16 +576,26 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
       }
       // uMean / uVariance of the members' errors (block-order sums, float results)
       double s1[1] = {0.0};
-      for (int i = tid; i < m; i += SF_BLOCK) if (neu[i]) s1[0] += (double)L.e1[i];
-      block_sum_vec32<1>(s1, L.red, tid);
+      if constexpr (NW == 4) {
+        for (int i = tid; i < m; i += NT) if (neu[i]) s1[0] += (double)L.e1[i];
+        sfd::block_sum_canon<1, 32>(s1, L.red, tid);
+      } else {
+        sfd::canon_reduce<1, 32, NW>(m, tid, L.red, s1, [&](int i, double (&a)[1]) { if (neu[i]) a[0] += (double)L.e1[i]; });
+      }
       const float mean = (float)(s1[0] / (double)n_new);
       float variance = 0.0f;
       if (n_new > 1) {
         double s2[1] = {0.0};
-        for (int i = tid; i < m; i += SF_BLOCK) {
-          if (neu[i]) { const float dlt = L.e1[i] - mean; s2[0] += (double)(dlt * dlt); }
+        if constexpr (NW == 4) {
+          for (int i = tid; i < m; i += NT) {
+            if (neu[i]) { const float dlt = L.e1[i] - mean; s2[0] += (double)(dlt * dlt); }
+          }
+          sfd::block_sum_canon<1, 32>(s2, L.red, tid);
+        } else {
+          sfd::canon_reduce<1, 32, NW>(m, tid, L.red, s2, [&](int i, double (&a)[1]) {
+            if (neu[i]) { const float dlt = L.e1[i] - mean; a[0] += (double)(dlt * dlt); }
+          });
         }
-        block_sum_vec32<1>(s2, L.red, tid);
         variance = (float)(s2[0] / (double)(n_new - 1));
       }
       const float sthr = (float)P.refine_sigma * sqrtf(variance);
@@ -580,8 +608,8 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
         continue;
       }
       int diff = 0;
-      for (int i = tid; i < m; i += SF_BLOCK) diff |= (prev[i] != neu[i]) ? 1 : 0;
-      inlier_changed = block_sum_i(diff, L.misc, tid) != 0;
+      for (int i = tid; i < m; i += NT) diff |= (prev[i] != neu[i]) ? 1 : 0;
+      inlier_changed = block_sum_i<NW>(diff, L.misc, tid) != 0;
     } while (inlier_changed && ++refine_iterations < P.pnp_refine_iterations);
     inl = neu;
     n_inl = n_new;
@@ -590,7 +618,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   if (P.dbg_stop == 4) { if (tid == 0) pass[pair] = ps; return none; }
   if (trace_base) SF_TRACE_MARK(P, pair, trace_base + 3);
   if (mask_out)
-    for (int i = tid; i < m; i += SF_BLOCK)
+    for (int i = tid; i < m; i += NT)
       if (inl[i]) mask_out[L.cidx[i] & 0xFFFFu] = 1;
   ps.inliers = n_inl;
   if (n_inl < P.min_inliers) {
@@ -631,7 +659,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
   if (to_has_3d) {
     const int m4 = (m + 3) & ~3;
     int cnt = 0;
-    for (int i = tid; i < m4; i += SF_BLOCK) {
+    for (int i = tid; i < m4; i += NT) {
       float v1 = __int_as_float(0x7F800000), v2 = __int_as_float(0x7F800000);
       if (i < m && inl[i]) {
         const float* b = DIR ? xF + 3 * (L.cidx[i] & 0xFFFFu) : xT + 3 * (L.cidx[i] >> 16);
@@ -654,13 +682,13 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
       L.e1[i] = v1;
       L.e2[i] = v2;
     }
-    const int oi = block_sum_i(cnt, L.misc, tid);
+    const int oi = block_sum_i<NW>(cnt, L.misc, tid);
     if (oi > 0) {
-      ps.var = 2.1981 * (double)rank_value(L.e1, m, oi >> 2, &L.red[120], tid);
-      ps.var_ang = 2.1981 * (double)rank_value(L.e2, m, oi >> 2, &L.red[121], tid);
+      ps.var = 2.1981 * (double)rank_value<NT>(L.e1, m, oi >> 2, &L.red[120], tid);
+      ps.var_ang = 2.1981 * (double)rank_value<NT>(L.e2, m, oi >> 2, &L.red[121], tid);
     }
   } else {
-    pnp_normal_eq(L, cam, m, inl, q, t, L.ne_a, tid);
+    pnp_normal_eq<NW>(L, cam, m, inl, q, t, L.ne_a, tid);
     // sqrtf and operator/ are IEEE-exact on gfx950; __fsqrt_rn is NOT (native v_sqrt_f32, ~1 ulp:
     // tools/ubench/fp_case.hip) and must not appear in canonical arithmetic
     const double v = (double)sqrtf((float)L.ne_a[27] / (float)n_inl);

@@ -334,8 +334,19 @@ namespace {
 // the 3D-3D chain); what the fusion saves is three launches, the guided kernel's 10 000 workgroups that find nothing
 // to do, and the gaps between them.  Same bodies, same bytes.  PART as in chain_after_match (bundle adjustment on:
 // 1 = the first estimate, 2 = guided matching + the second estimate; the adjustments' launches in between and behind).
-template <int W, int PART>
-__global__ void __launch_bounds__(SF_BLOCK, SF_PNP_CHAIN_OCC)
+// NW: wavefronts per chain (SF_CHAIN_NW).  The narrow forms recompute the three bearings a P3P hypothesis needs instead
+// of keeping one per correspondence in LDS (28 KB instead of 40 KB at K = 500: five chains per CU instead of four by LDS,
+// six by registers), and no wavefront waits while another one solves.
+// Register budget: the two-wavefront form (the default, 14.5 against 13.4 M pairs/s on the bench's PnP line,
+// profiles/r05i_pnp_chain_width.txt) is compiled for SF_PNP_CHAIN_OCC = 3 wavefronts per SIMD (168 registers, ~120 B of
+// scratch per lane) like round 4's chain.  The FOUR-wavefront form is compiled for 2 (256 registers, no scratch): at 3
+// this round's build of it -- same bodies as the stage kernel k_pnp, which is correct at that budget -- returned wrong
+// inlier sets from rtabmap's refinement rounds (tests/test_gpu_pnp.py::test_pnp_refinement_rounds with
+// SF_CHAIN_PNP_NW=4; 7 inliers against the oracle's 35), and correct ones at 2.  The cause is not established (the
+// kernel holds 106 SGPRs with ~170 v_writelane / ~420 v_readlane spill moves next to its scratch spills); the build
+// that showed it is not shipped, and the parity soak (tools/soak_parity.py pnp) runs on the shipped widths.
+template <int W, int PART, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : SF_PNP_CHAIN_OCC)
 k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
             const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
             uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
@@ -349,20 +360,20 @@ k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* 
   __builtin_amdgcn_s_setprio(3);
   SF_TRACE_MARK(P, pair, 1);
   if constexpr (PART != 2) {
-    pnp_body(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw, 37,
-             PART == 1 ? H.mask1 + (size_t)pair * kcap : nullptr);
+    pnp_body<0, NW>(st, pair, pair_from, pair_to, corr1, hdr1, pass1, P, smem_raw, 37,
+                    PART == 1 ? H.mask1 + (size_t)pair * kcap : nullptr);
     if constexpr (PART == 1) return;       // (Reg/Force3DoF's applications: behind the adjustment, k_ba_pass)
     if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass1[pair], 2);
     __syncthreads();     // pass1[pair] (written by thread 0) is read by every lane below
   }
-  const bool est2 = guided_body<W>(st, pair, sF, sT, pass1[pair], pass2[pair], guided_flag[pair],
-                                   corr2 + (size_t)pair * kcap, hdr2[pair], nullptr, nullptr, P,
-                                   reinterpret_cast<int*>(smem_raw));
+  const bool est2 = guided_body<W, false, NW>(st, pair, sF, sT, pass1[pair], pass2[pair], guided_flag[pair],
+                                              corr2 + (size_t)pair * kcap, hdr2[pair], nullptr, nullptr, P,
+                                              reinterpret_cast<int*>(smem_raw));
   __syncthreads();
   SF_TRACE_MARK(P, pair, 42);
   if (est2) {
-    pnp_body(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 43,
-             PART == 2 ? H.mask2 + (size_t)pair * kcap : nullptr, true);
+    pnp_body<0, NW>(st, pair, pair_from, pair_to, corr2, hdr2, pass2, P, smem_raw, 43,
+                    PART == 2 ? H.mask2 + (size_t)pair * kcap : nullptr, true);
     if constexpr (PART == 0) {
       if (P.force_3dof && threadIdx.x == 0) pass_to3dof(pass2[pair], 1);
     }
@@ -511,16 +522,19 @@ int launch_chain(sf_context* c, StoreView st, const int32_t* d_from, const int32
   return SF_OK;
 }
 
-template <int W, int PART>
+template <int W, int PART, int NW>
 int launch_chain_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
-                     size_t lds, const BaHandover& H) {
-  bool& attr = c->chain_pnp_attr[W == 16][PART];
+                     const BaHandover& H) {
+  const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
+  const size_t lds = std::max((sf_pnp_lds_bytes_dev(st.kcap, c->dparams.iterations, NW == 4) + 15) & ~(size_t)15,
+                              sf_guided_lds_bytes(st.kcap, nc));
+  bool& attr = c->chain_pnp_attr[W == 16][PART][NW == 4 ? 2 : NW - 1];
   if (lds > 64 * 1024 && !attr) {
-    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W, PART, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   int32_t* counters = (int32_t*)c->counters.p;
-  hipLaunchKernelGGL((k_chain_pnp<W, PART>), dim3(n), dim3(SF_BLOCK), lds, c->stream, st, d_from, d_to,
+  hipLaunchKernelGGL((k_chain_pnp<W, PART, NW>), dim3(n), dim3(64 * NW), lds, c->stream, st, d_from, d_to,
                      (const uint32_t*)c->corr1.p, (const CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p,
                      (uint32_t*)c->corr2.p, (CorrHeader*)c->hdr2.p, (PassState*)c->pass2.p, (uint8_t*)c->flags.p,
                      (const int32_t*)c->list1.p, (const int32_t*)(counters + 0), d_out, c->dparams, H);
@@ -533,11 +547,12 @@ int launch_chain_part(sf_context* c, StoreView st, const int32_t* d_from, const 
   int rc;
   sf_prof_begin(c, SF_K_FUSED);
   if (pnp) {
-    const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-    const size_t lds_p = std::max((sf_pnp_lds_bytes(st.kcap, c->dparams.iterations) + 15) & ~(size_t)15,
-                                  sf_guided_lds_bytes(st.kcap, nc));
-    rc = st.w == 8 ? launch_chain_pnp<8, PART>(c, st, d_from, d_to, n, d_out, lds_p, H)
-                   : launch_chain_pnp<16, PART>(c, st, d_from, d_to, n, d_out, lds_p, H);
+#define SF_CHAIN_PNP_CASE(W_)                                                                            \
+    rc = c->chain_pnp_nw == 1   ? launch_chain_pnp<W_, PART, 1>(c, st, d_from, d_to, n, d_out, H)          \
+         : c->chain_pnp_nw == 2 ? launch_chain_pnp<W_, PART, 2>(c, st, d_from, d_to, n, d_out, H)          \
+                                : launch_chain_pnp<W_, PART, 4>(c, st, d_from, d_to, n, d_out, H)
+    if (st.w == 8) SF_CHAIN_PNP_CASE(8); else SF_CHAIN_PNP_CASE(16);
+#undef SF_CHAIN_PNP_CASE
   } else {
     const int tail_off = (int)fused_tail_offset(c, st, false);
     const size_t lds_c = (size_t)tail_off + ((sizeof(FusedTail) + 15) & ~(size_t)15);

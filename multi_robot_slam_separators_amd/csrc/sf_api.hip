@@ -754,6 +754,7 @@ extern "C" int sf_create(const sf_params* p, int device, sf_handle* out) {
   if (const char* v = getenv("SF_CHAIN_PNP")) c->chain_pnp = atoi(v) != 0;      // 0: PnP on the five stage launches
   if (const char* v = getenv("SF_BA_OCC")) c->ba_occ = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   if (const char* v = getenv("SF_BA_NW")) { const int nw = atoi(v); c->ba_nw = (nw == 1 || nw == 2) ? nw : 4; }
+  if (const char* v = getenv("SF_CHAIN_PNP_NW")) { const int nw = atoi(v); c->chain_pnp_nw = (nw == 1 || nw == 2) ? nw : 4; }
   if (const char* v = getenv("SF_CHAIN_NW")) { const int nw = atoi(v); c->chain_nw = (nw == 1 || nw == 2) ? nw : 4; }
   if (const char* v = getenv("SF_MATCH_MFMA")) c->match_mfma = atoi(v) != 0;   // 0: VALU matcher (A/B reference)
   if (const char* v = getenv("SF_DEBUG_CORR")) c->debug_corr = atoi(v) != 0;   // 1: correspondence lists kept in HBM
@@ -1406,6 +1407,7 @@ static int ensure_twin(sf_context* c) {
   t->split = c->split;
   t->chain_pnp = c->chain_pnp;
   t->chain_nw = c->chain_nw;
+  t->chain_pnp_nw = c->chain_pnp_nw;
   t->ba_nw = c->ba_nw;
   t->ba_occ = c->ba_occ;
   t->debug_corr = c->debug_corr;

@@ -240,7 +240,8 @@ struct sf_context {
   int chain_nw = 4;                // wavefronts per motion-estimation chain of the split forms: 1, 2 (round 5), or 4 = the
                                    // 256-thread workgroup of rounds 2-4 (SF_CHAIN_NW)
   bool split_match_attr[2] = {};   // k_match_split [W == 16]
-  bool chain_pnp_attr[2][3] = {};  // k_chain_pnp [W == 16][part 0 / 1 / 2]
+  bool chain_pnp_attr[2][3][3] = {};  // k_chain_pnp [W == 16][part 0 / 1 / 2][wavefronts 1 / 2 / 4]
+  int chain_pnp_nw = 2;            // wavefronts per PnP chain (SF_CHAIN_PNP_NW; 2 measured fastest: profiles/r05i_pnp_chain_width.txt)
   bool ba_pass_attr[2][3] = {};    // k_ba_pass [PnP][wavefronts 1 / 2 / 4]
   int ba_occ = 0;                  // wavefronts per SIMD the SMALL adjustment kernel is compiled for (SF_BA_OCC; 1 = 512 registers,
                                    // no scratch; 2 = 256 registers + 256 B of scratch; 0 = by estimator: PnP 1, 3D-3D 2 -- measured,

@@ -455,11 +455,13 @@ def test_split_pipeline_equals_fused_kernel(monkeypatch):
             assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1])
 
 
+@pytest.mark.parametrize("est", [0, 1])
 @pytest.mark.parametrize("ba", [0, 1])
-def test_chain_widths_give_the_same_bytes(monkeypatch, ba):
-    """The survivors' chains on one, two or four wavefronts (SF_CHAIN_NW; k_chain<W, NW, PART>) and the bundle adjustment
-    on one, two or four (SF_BA_NW; k_ba_pass<NW, .>): the sums keep the canonical 256-lane order whatever the width, so
-    results and pass-2 lists are the same bytes -- and equal the oracle's."""
+def test_chain_widths_give_the_same_bytes(monkeypatch, ba, est):
+    """The survivors' chains on one, two or four wavefronts (SF_CHAIN_NW: k_chain<W, NW, PART>; SF_CHAIN_PNP_NW:
+    k_chain_pnp<W, PART, NW>, whose narrow forms also recompute the bearings instead of keeping them in LDS) and the
+    bundle adjustment on one, two or four (SF_BA_NW; k_ba_pass<NW, ...>): the sums keep the canonical 256-lane order
+    whatever the width, so results and pass-2 lists are the same bytes -- and equal the oracle's."""
     from multi_robot_slam_separators_amd import lib
     from oracle import pyoracle
     from test_gpu_fuzz import random_frame
@@ -469,6 +471,7 @@ def test_chain_widths_give_the_same_bytes(monkeypatch, ba):
     B += [random_frame(rng, 20, 32), random_frame(rng, 0, 32), A[0], B[1]]
     p = synth.camera_params()
     p.iterations = 300
+    p.estimation_type = est
     p.bundle_adjustment = ba
     p.stereo_baseline = 0.12 if ba else 0.0
     monkeypatch.setenv("SF_FUSED", "2")
@@ -476,6 +479,7 @@ def test_chain_widths_give_the_same_bytes(monkeypatch, ba):
     out = {}
     for nw in ("4", "2", "1"):
         monkeypatch.setenv("SF_CHAIN_NW", nw)
+        monkeypatch.setenv("SF_CHAIN_PNP_NW", nw)
         monkeypatch.setenv("SF_BA_NW", nw)
         with lib.SeparatorFinder(p) as f:
             res = f.estimate_transform_batch(A, B)
