@@ -503,10 +503,14 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
 
 // kNN-2 of the "to" rows of NTL 32-column tiles over all "from" rows; on return lanes 0..31 hold, for
 // column tile[j] * 32 + lane: d1 / d2 (Hamming, 0xFFFF when absent) and the from index of d1.
-template <int W, int NTL>
+// after_b(): called once the resident "to" operands are in registers (their global loads consumed) and before the scan --
+// where the persistent matcher (k_match_persist, k_verify.hip) queues the LDS-DMA of the NEXT pair's "from" rows, so
+// that no ordinary load of this wavefront is waited for while the DMA is in flight.
+struct MfNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int W, int NTL, class Hook = MfNoHook>
 __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
                                           const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
-                                          int (&idx)[NTL]) {
+                                          int (&idx)[NTL], Hook after_b = Hook()) {
   constexpr int KS = W / 2;
   const int r = lane & 31, h = lane >> 5;
   uint32_t m88, c22;   // constants pinned in VGPRs (see fp4_spread)
@@ -530,6 +534,7 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
     p += __shfl_xor(p, 32);                 // both halves of the row
     tsum[j] = 24 * W - 2 * p;               // the column's constant (see fp4_spread_from)
   }
+  after_b();
   float cin[16], b[NTL], s[NTL];
 #pragma unroll
   for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) * MF_FR;
