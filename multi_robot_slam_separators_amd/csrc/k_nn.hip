@@ -50,6 +50,12 @@ __device__ __forceinline__ void nn_tile_of_block(int bid, int gx, int gy, int& t
   tx = in / gsz;
 }
 
+// SF_NN_T256 = 0: the 128 x 128-tile filter for every non-128 level (A/B runs)
+static bool nn_t256_on() {
+  static const bool on = !(getenv("SF_NN_T256") && atoi(getenv("SF_NN_T256")) == 0);
+  return on;
+}
+
 __global__ void __launch_bounds__(256)
 k_nn_cast_rows(const double* __restrict__ src, float* __restrict__ dst, float* __restrict__ norms, int n, int dim,
                int ld) {
@@ -489,6 +495,141 @@ k_nn_filter_f16(const _Float16* __restrict__ A, const _Float16* __restrict__ B, 
   }
 }
 
+// ---- the same filter on 256 x 256 tiles, LDS-DMA fed (round 5; the full-length contraction of --strict) ------------
+// k_nn_filter_f16 above is the classic structure -- 128 x 128 tile, register-staged, two barriers per 64-deep K step --
+// and sits at its ceiling (0.89 PF = 36 % of the fp16 peak on the 10 000 x 10 000 x 4096 contraction; fabric traffic
+// 3 GB per launch: each operand panel is re-read 79 times).  This form: eight wavefronts (2 x 4) own a 256 x 256 tile,
+// 128 x 64 of it each (8 x 4 accumulator tiles of v_mfma_f32_16x16x32_f16: 128 VGPRs); a K step of 64 is 64 KB of
+// operands in LDS, double buffered (128 KB: one workgroup per CU); the NEXT step's operands arrive by
+// global_load_lds_dwordx4 -- no staging registers, no ds_write -- issued a quarter per phase while the current step's
+// four quadrants (16 MFMAs each) are contracted, and ONE barrier per K step (behind the issuing wavefronts'
+// vmcnt(0)) publishes them.  The LDS image is [256 rows][8 x 16 B] per operand with the 16-byte column XORed by
+// (row >> 1) & 7 (a linear image puts rows r and r + 2 on the same banks: 8-way conflicts on every fragment read); the
+// DMA writes LDS linearly (wave-uniform base + lane x 16), so the permutation is applied to the SOURCE address and to the
+// fragment reads (cdna_hip_programming.md section 5, rule 21).  Same inequality, same candidates as k_nn_filter_f16.
+typedef __attribute__((address_space(3))) void* nn_lds_vp;
+typedef __attribute__((address_space(1))) const void* nn_glb_vp;
+#define NN256_LDS (2 * 2 * 256 * 128)
+typedef float nn_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(512, 2)
+k_nn_filter_f16_t256(const _Float16* __restrict__ A, const _Float16* __restrict__ B, const float2* __restrict__ rowc,
+                     const float2* __restrict__ colc, int ld, int kdims, int gx, int gy, int n_l_pad, int n_r_pad,
+                     uint2* __restrict__ cand, unsigned* __restrict__ cand_count, unsigned cand_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nn256_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int tile_x, tile_y;
+  nn_tile_of_block(blockIdx.x, gx, gy, tile_x, tile_y);
+  const int row0 = tile_y * 256, col0 = tile_x * 256;
+
+  // ---- DMA source addresses: piece (op, half, j) of a K step = 64 lanes x 16 B = 8 rows x 128 B of the LDS image -------
+  // slot s = j * 512 + tid of the half-tile: image row s >> 3, image column s & 7 <- source column (s & 7) ^ ((row >> 1) & 7)
+  const char* srcA[2][2];
+  const char* srcB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int sl = j * 512 + tid;
+      const int r = sl >> 3, cs = (sl & 7) ^ ((r >> 1) & 7);
+      const int ra = min(row0 + h * 128 + r, n_l_pad - 1), rb = min(col0 + h * 128 + r, n_r_pad - 1);   // (rows past the
+      srcA[h][j] = reinterpret_cast<const char*>(A + (size_t)ra * ld) + cs * 16;                          //  padding: masked below)
+      srcB[h][j] = reinterpret_cast<const char*>(B + (size_t)rb * ld) + cs * 16;
+    }
+  const int dma_dst = wave * 1024;                                     // + op * 32768 + h * 16384 + j * 8192 (+ buffer)
+  auto issue = [&](int buf, int k0, int quarter) {                     // quarter: 0 = A half 0, 1 = A half 1, 2 = B half 0, 3 = B half 1
+    const int op = quarter >> 1, h = quarter & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* src = (op ? srcB[h][j] : srcA[h][j]) + (size_t)k0 * 2;
+      __builtin_amdgcn_global_load_lds((nn_glb_vp)src,
+                                       (nn_lds_vp)(nn256_lds + buf * 65536 + op * 32768 + h * 16384 + j * 8192 + dma_dst), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside an operand's 32 KB image) ----------------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int offA = (wr * 128 + fr) * 128, offB = (wc * 64 + fr) * 128;
+  const int col_k0 = ((0 + fq) ^ swz) * 16, col_k1 = ((4 + fq) ^ swz) * 16;
+
+  nn_f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = nn_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = kdims / 64;
+#pragma unroll
+  for (int qtr = 0; qtr < 4; ++qtr) issue(0, 0, qtr);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const unsigned char* bA = nn256_lds + cur * 65536;
+    const unsigned char* bB = bA + 32768;
+    const bool more = t + 1 < nk;
+    half8 a[4][2], b[2][2];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      // quadrants in the order (m half, n half) = (0,0) (0,1) (1,1) (1,0): one operand's fragments change per phase
+      const int mh = ph >> 1, nh = (ph == 1 || ph == 2) ? 1 : 0;
+      if (more) issue(cur ^ 1, (t + 1) * 64, ph);
+      if (ph == 0 || ph == 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const unsigned char* p = bA + offA + (mh * 4 + m) * 2048;
+          a[m][0] = *reinterpret_cast<const half8*>(p + col_k0);
+          a[m][1] = *reinterpret_cast<const half8*>(p + col_k1);
+        }
+      }
+      if (ph != 2) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const unsigned char* p = bB + offB + (nh * 2 + n) * 2048;
+          b[n][0] = *reinterpret_cast<const half8*>(p + col_k0);
+          b[n][1] = *reinterpret_cast<const half8*>(p + col_k1);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[mh * 4 + m][nh * 2 + n] =
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m][ks], b[n][ks], acc[mh * 4 + m][nh * 2 + n], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's pieces of step t + 1 have landed ...
+    __builtin_amdgcn_s_barrier();                         // ... everyone's have, and everyone is done reading step t
+  }
+
+  // ---- epilogue: the filter inequality per element (coefficients of the tile staged in LDS) ------------------------------
+  float2* sRowC = reinterpret_cast<float2*>(nn256_lds);
+  float2* sColC = sRowC + 256;
+  if (tid < 256) sRowC[tid] = (row0 + tid < n_l_pad) ? rowc[row0 + tid] : make_float2(__int_as_float(0x7F800000), 0.f);
+  else sColC[tid - 256] = (col0 + tid - 256 < n_r_pad) ? colc[col0 + tid - 256] : make_float2(__int_as_float(0x7F800000), 0.f);
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int col = wc * 64 + n * 16 + fr;
+    const float2 cj = sColC[col];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wr * 128 + m * 16 + fq * 4 + j;
+        const float2 ci = sRowC[row];
+        const float rhs = __builtin_fmaf(-ci.y, cj.y, ci.x + cj.x);
+        if (acc[m][n][j] > rhs) {      // false for +inf / NaN (masked / padding)
+          const unsigned pos = atomicAdd(cand_count, 1u);
+          if (pos < cand_cap) cand[pos] = make_uint2((unsigned)(row0 + row), (unsigned)(col0 + col));
+        }
+      }
+    }
+  }
+}
+
 // ---- the same filter for a 128-dimension contraction, with the row panel resident ----------------------------
 // k_nn_filter_f16 at k = 128 spent its time outside the matrix cores: every 128 x 128 tile paid the global-load
 // latency of both operand panels (two barriers per 64-dimension step, nothing to overlap it with) and ~10 VALU
@@ -662,8 +803,6 @@ k_nn_filter_f16_k128(const _Float16* __restrict__ A, const _Float16* __restrict_
 // ds_read_b128 lane group (16 rows, one chunk each) hit 16 different bank quads.
 // Same arithmetic, same order of the contraction steps, same candidate set as the kernel above (a candidate's
 // position in the list is free: the consumers take row minima).
-typedef __attribute__((address_space(3))) void* nn_lds_vp;
-typedef __attribute__((address_space(1))) const void* nn_glb_vp;
 constexpr int NN_K128R_ROWS = NN_BN * 64;            // dwords of the rows of one column tile (128 rows x 256 B)
 constexpr int NN_K128R_TILE = NN_K128R_ROWS + 256;   // + the tile's 128 column coefficients (one more 1 KiB piece)
 
@@ -1326,6 +1465,16 @@ static int nn_filter_launch(sf_context* c, NnFilterBufs& fb, int level, int kdim
                            (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc, gx,
                            gy, tps, cand, count, cap, count_next);
       c->nn_count_primed = true;                 // (this launch zeroes the other block for the next one)
+    } else if (nn_t256_on() && kdims % 64 == 0 && kdims >= 256) {
+      static bool attr256 = false;      // (one device per process in every deployment of this library; set once)
+      if (!attr256) {
+        SF_HIP(c, hipFuncSetAttribute((const void*)k_nn_filter_f16_t256, hipFuncAttributeMaxDynamicSharedMemorySize, NN256_LDS));
+        attr256 = true;
+      }
+      const int gx256 = (n_r_pad + 255) / 256, gy256 = (n_l_pad + 255) / 256;
+      hipLaunchKernelGGL(k_nn_filter_f16_t256, dim3(gx256 * gy256), dim3(512), NN256_LDS, c->stream,
+                         (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
+                         pitch16, kdims, gx256, gy256, n_l_pad, n_r_pad, cand, count, cap);
     } else {
       hipLaunchKernelGGL(k_nn_filter_f16, dim3((n_r_pad / NN_BN) * (n_l_pad / NN_BM)), dim3(256), 0, c->stream,
                          (const _Float16*)c->nn_local.rows_h.p, (const _Float16*)c->nn_recv.rows_h.p, rowc, colc,
