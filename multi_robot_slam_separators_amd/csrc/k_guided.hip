@@ -26,6 +26,10 @@ namespace {
 #define GUIDED_CPT 8
 // ... and the list's length: the same for every workgroup width (a narrower workgroup walks it in more trips)
 #define GUIDED_CAND_CAP (GUIDED_CPT * 256)
+// The narrow chains (one or two wavefronts per workgroup) hold a shorter list -- 1 216 combinations: the bench's frames
+// have 760 on average, 1 080 at the 90th percentile -- so that the guided pass fits six PnP chains to a CU (26.4 KB at
+// K = 500); a frame with more takes the per-lane loop (same integers).
+#define GUIDED_CAND_CAP_NARROW 1216
 
 // Body of the pass-2 matching stage for ONE pair (the calling workgroup); returns whether the pair
 // needs the pass-2 motion estimation (block-uniform).  list == nullptr: no work-list append (fused).
@@ -251,7 +255,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;      // (the fill counters are dead; ordered before the decisions by
                                                           //  the barrier behind the search's first pass)
   int n_finite = 0, n_proj = 0;
-  const int cand_cap = NW == 4 ? GUIDED_CAND_CAP : min(GUIDED_CAND_CAP, 4 * kcap);   // (NW < 4: the keys are parked in the grid's items)
+  const int cand_cap = NW == 4 ? GUIDED_CAND_CAP : min(GUIDED_CAND_CAP_NARROW, 4 * kcap);   // (NW < 4: the keys are parked in the grid's items)
   // projection of a finite "from" point with the guess (:503-512): pixel position and "inside the image, in front"
   auto project = [&](float x, float y, float z, float& u, float& v) -> bool {
     const float zf = ((Rc[6] * x + Rc[7] * y) + Rc[8] * z) + tc[2];
@@ -739,13 +743,15 @@ k_finalize(int n, const PassState* __restrict__ pass1, const PassState* __restri
 
 }  // namespace
 
-size_t sf_guided_lds_bytes(int kcap, int n_cells) {
+size_t sf_guided_lds_bytes(int kcap, int n_cells, bool narrow) {
   // claim, matched, misc, cell_start, cell_fill, (+3: 16-byte alignment of the item block) item4, then the search's
   // projections (2), candidate summaries, best / second-best keys (3) and the combination list
   // claim, matched, misc, cell_start (the fill counters live in `matched` when they fit), alignment, item4, candidate
   // summaries, best / second-best keys and the combination list
   return (size_t)(2 * kcap + 16 + n_cells + 1 + (n_cells <= kcap ? 0 : n_cells) + 3 + 4 * kcap + 3 * kcap +
-                  GUIDED_CPT * SF_BLOCK + (kcap > 2048 ? kcap - 2048 : 0)) * sizeof(int);   // (+ the raw keypoints' overhang)
+                  (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) +
+                  (kcap > (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) ? kcap - (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) : 0)) *
+         sizeof(int);   // (+ the raw keypoints' overhang: they are staged over oilast / key1 / key2 / cand, 4 kcap words)
 }
 
 int sf_launch_guided(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n) {

@@ -38,9 +38,11 @@ namespace {
 // bear: the observations' unit bearings are kept in LDS (the 256-thread form; 24 B per correspondence) -- the narrow
 // chains recompute the three a hypothesis needs (the same operations on the same inputs: the same bits) and fit
 // five to a CU instead of four
+// The per-iteration inlier counts live one ROUND (64 iterations) at a time: the replay consumes a round's counts before
+// the next round overwrites them.
 __host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations, bool bear = true) {
-  const int it = iterations > 0 ? iterations : 0;
-  return (size_t)kcap * (16 + (bear ? 24 : 0) + 8 + 4 + 4 + 4 + 2) + 128 * 8 + (size_t)((it + 4) & ~3) * 4 + 16 * 4 + 12 * 64 * 4 +
+  (void)iterations;
+  return (size_t)kcap * (16 + (bear ? 24 : 0) + 8 + 4 + 4 + 4 + 2) + 128 * 8 + 64 * 4 + 16 * 4 + 12 * 64 * 4 +
          5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
 }
 
@@ -53,7 +55,7 @@ struct PnpLds {
   float* e2;        // [kcap] angular error
   uint8_t* mask;    // [kcap]
   uint8_t* mask_b;  // [kcap] second inlier set of the refinement rounds
-  int* counts;      // [iterations]
+  int* counts;      // [64] inlier counts of the current round's iterations
   double* red;      // [4][32]
   int* misc;        // [16]
   float* hyp;       // [12][64] models of the current round of hypotheses
@@ -354,7 +356,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     L.e1 = (float*)p; p += (size_t)kcap * 4;
     L.e2 = (float*)p; p += (size_t)kcap * 4;
     L.cidx = (uint32_t*)p; p += (size_t)kcap * 4;
-    L.counts = (int*)p; p += (size_t)((max_it + 4) & ~3) * 4;
+    L.counts = (int*)p; p += 64 * 4;
     L.misc = (int*)p; p += 16 * 4;
     L.mask = p; p += kcap;
     L.mask_b = p; p += kcap;
@@ -489,13 +491,13 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
         int tot = L.hyp_cnt[lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tot += L.hyp_cnt[64 * w + lane];
-        L.counts[it] = tot;
+        L.counts[lane] = tot;
       }
       __syncthreads();
       if (tid == 0) {
         const int lim = min(max_it, base + 64);   // counts exist for iterations < lim
         while (sc_it < niters && sc_it < lim) {
-          const int good = L.counts[sc_it];
+          const int good = L.counts[sc_it - base];
           const int bar = best > 3 ? best : 3;          // max(maxGoodCount, modelPoints - 1)
           if (good > bar) {
             best = good;

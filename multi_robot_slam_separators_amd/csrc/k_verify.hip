@@ -714,7 +714,7 @@ int launch_chain_pnp(sf_context* c, StoreView st, const int32_t* d_from, const i
                      const BaHandover& H) {
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
   const size_t lds = std::max((sf_pnp_lds_bytes_dev(st.kcap, c->dparams.iterations, NW == 4) + 15) & ~(size_t)15,
-                              sf_guided_lds_bytes(st.kcap, nc));
+                              sf_guided_lds_bytes(st.kcap, nc, NW != 4));
   bool& attr = c->chain_pnp_attr[W == 16][PART][NW == 4 ? 2 : NW - 1];
   if (lds > 64 * 1024 && !attr) {
     SF_HIP(c, hipFuncSetAttribute((const void*)k_chain_pnp<W, PART, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -463,7 +463,7 @@ int sf_launch_verify_fused(sf_context* c, StoreView st, const int32_t* d_from, c
 size_t sf_ransac_lds_bytes(int kcap, int iterations);
 size_t sf_ba_lds_bytes(int kcap);
 size_t sf_pnp_lds_bytes(int kcap, int iterations);
-size_t sf_guided_lds_bytes(int kcap, int n_cells);
+size_t sf_guided_lds_bytes(int kcap, int n_cells, bool narrow = false);   // narrow: the one- / two-wavefront chains' shorter candidate list
 void sf_brief_default_pattern(int8_t* tests, int bytes);
 int sf_launch_detect_corners_batch(sf_context* c, const uint8_t* d_images, size_t img_stride, int n_img, int width, int height,
                                    int pitch, int max_corners, double quality_level, double min_distance,
