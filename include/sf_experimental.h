@@ -61,6 +61,12 @@ int  sf_prof_select(sf_handle h, uint32_t kernel_mask);
    the first step that needs a second stream: sf_api.hip place_streams; SF_STREAM_PLACEMENT=0 in the environment turns the
    measurement off, =2 also prints the line to stderr). */
 int  sf_stream_placement(sf_handle h, char* buf, size_t n);
+/* Runs that measurement now instead of inside the first step that needs a second stream (60-100 ms once per handle:
+   ~100 short chip-filling launches on the handle's stream and on streams of the library's own; it waits for the
+   handle's own streams only).  Work of other streams or processes on the GPU at that moment changes what is measured:
+   call it at a quiet moment, read sf_stream_placement for what was picked or why it was abandoned.  Idempotent;
+   SF_STREAM_PLACEMENT=0 makes it a no-op.                                                                        */
+int  sf_streams_prepare(sf_handle h);
 
 /* Pass state of pair `pair` of the last verification (diagnostics, tools/diag_pair_index.py): pose of the pass (row-major
    3 x 4, p_from = T p_to; all zero when null), is_null / inliers / matches.  Needs SF_OPT_DEBUG_CORR like

@@ -2081,10 +2081,13 @@ static int place_streams(sf_context* c) {
   }
   if (hipMalloc((void**)&pr.d, 64) != hipSuccess || hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess ||
       hipEventCreate(&pr.e2) != hipSuccess) return cleanup(SF_OK);
-  // every stream's hardware queue exists before anything is measured (the runtime creates it at the stream's first use);
-  // and nothing else of this process runs on the device meanwhile (another handle's steps in flight would read as
-  // "blocked" here): one device-wide wait, once per handle
-  (void)hipDeviceSynchronize();
+  // every stream's hardware queue exists before anything is measured (the runtime creates it at the stream's first use).
+  // Only THIS handle's streams are waited for (rounds 3-4 waited for the whole device, which also stalled on the work of
+  // every other stream of the process -- RCCL's, torch's): work of other streams or processes that runs during the
+  // measurement reads as "blocked" and is what the once-more rule below and the abandon path are for; a host that wants the
+  // measurement at a quiet moment calls sf_streams_prepare (include/sf_experimental.h) when it has one.
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& L : c->lanes) if (L.stream) (void)hipStreamSynchronize(L.stream);
   for (int i = 1; i <= NC; ++i) {
     hipLaunchKernelGGL(k_place_probe, dim3(1), dim3(64), 0, S[i], pr.d);
     (void)hipStreamSynchronize(S[i]);
@@ -2181,6 +2184,14 @@ static int place_streams(sf_context* c) {
              aux_free_pipe ? "no main stream on it" : "SHARED with a main stream", n_aux, n_queues, P.copy ? " + 1 for the synchronous call" : "");
   if (const char* v = getenv("SF_STREAM_PLACEMENT")) if (atoi(v) >= 2) fprintf(stderr, "sepfinder: %s\n", P.report);
   return cleanup(SF_OK);
+}
+
+// Runs the stream placement measurement NOW (idempotent; otherwise it runs inside the first step that needs a second
+// stream): 60-100 ms, ~100 short chip-filling launches on the handle's stream and on twelve streams of the library's own.
+extern "C" int sf_streams_prepare(sf_handle c) {
+  if (!c) return SF_EINVAL;
+  SF_HIP(c, hipSetDevice(c->device));
+  return place_streams(c);
 }
 
 extern "C" int sf_stream_placement(sf_handle c, char* buf, size_t n) {

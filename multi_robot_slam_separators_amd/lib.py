@@ -134,6 +134,7 @@ def load():
         "sf_prof_enable": (C.c_int, [vp, C.c_int]),
         "sf_prof_select": (C.c_int, [vp, C.c_uint32]),
         "sf_stream_placement": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+        "sf_streams_prepare": (C.c_int, [vp]),
         "sf_prof_reset": (C.c_int, [vp]),
         "sf_prof_get": (C.c_int, [vp, C.c_int, P(i64), P(C.c_double)]),
         "sf_kernel_name": (C.c_char_p, [C.c_int]),
@@ -165,7 +166,7 @@ EXPORTED = [
     "sf_debug_correspondences", "sf_debug_pass_state", "sf_debug_counters", "sf_debug_guided_points", "sf_debug_plan_workspace", "sf_pack_separators", "sf_comm_unique_id", "sf_comm_init", "sf_comm_destroy",
     "sf_allgather_separators", "sf_allgather_separators_device", "sf_allgather_bytes_device", "sf_nn_row_minima_device", "sf_nn_walk_device",
     "sf_get_features_and_descriptor_batch_device", "sf_prof_enable", "sf_prof_select", "sf_prof_reset", "sf_prof_get",
-    "sf_kernel_name", "sf_stream_placement",
+    "sf_kernel_name", "sf_stream_placement", "sf_streams_prepare",
 ]
 
 
@@ -644,6 +645,10 @@ class SeparatorFinder:
         buf = C.create_string_buffer(512)
         self._check(self._L.sf_stream_placement(self._h, buf, 512))
         return buf.value.decode()
+
+    def streams_prepare(self):
+        """Run the stream placement measurement now (60-100 ms; otherwise inside the first overlapped step)."""
+        self._check(self._L.sf_streams_prepare(self._h))
 
     def prof_reset(self):
         self._check(self._L.sf_prof_reset(self._h))

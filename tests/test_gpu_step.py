@@ -585,6 +585,19 @@ def test_streams_of_the_step_pipeline_are_placed_by_measurement():
         if "classes," in rep:             # (measured: at least two classes, a class per lane's main stream)
             assert int(rep.split("placement: ")[1].split(" classes")[0]) >= 2, rep
             assert "main classes" in rep and "second streams: class" in rep, rep
+    # the explicit form: the host picks the (quiet) moment -- before the first step -- and the steps find the streams placed
+    with lib.SeparatorFinder(p) as f:
+        f.set_stream(torch.cuda.current_stream().cuda_stream)
+        f.streams_prepare()
+        rep0 = f.stream_placement()
+        assert rep0.startswith("placement:") and "not measured" not in rep0, rep0
+        f.streams_prepare()               # idempotent
+        sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
+        for _ in range(4):
+            f.step_issue(sa, sb)
+        for _ in range(4):
+            _check_step(f.step_retire(copy=True), m_ref, res_ref, True)
+        assert f.stream_placement() == rep0
 
 
 def test_a_copy_out_of_d_records_is_ordered_before_the_blocks_reuse():
