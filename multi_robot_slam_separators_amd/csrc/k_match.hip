@@ -360,6 +360,9 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
 //     orders by distance first (steps of 2) and by the LOWER from index second (fraction < 1): the
 //     BFMatcher tie rule with no separate index bookkeeping;
 //   * best / second best per column: v_max_f32 + v_med3_f32 per cell, then one cross-half merge.
+#ifndef SF_MATCH_PRELOAD
+#define SF_MATCH_PRELOAD 0     // measured, not adopted: see match_v2_body
+#endif
 typedef int mf_v8i __attribute__((ext_vector_type(8)));
 typedef float mf_v16f __attribute__((ext_vector_type(16)));
 constexpr float MF_FR = 1.f / 2048.f;        // index fraction (kcap <= 2048 rows on this path)
@@ -503,21 +506,22 @@ __device__ __forceinline__ void knn2_mfma_tile(const uint32_t* fromD, int Kf, in
 
 // kNN-2 of the "to" rows of NTL 32-column tiles over all "from" rows; on return lanes 0..31 hold, for
 // column tile[j] * 32 + lane: d1 / d2 (Hamming, 0xFFFF when absent) and the from index of d1.
-// after_b(): called once the resident "to" operands are in registers (their global loads consumed) and before the scan --
-// where the persistent matcher (k_match_persist, k_verify.hip) queues the LDS-DMA of the NEXT pair's "from" rows, so
-// that no ordinary load of this wavefront is waited for while the DMA is in flight.
-struct MfNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int W, int NTL, class Hook = MfNoHook>
-__device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
-                                          const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
-                                          int (&idx)[NTL], Hook after_b = Hook()) {
+// The resident "to" operands of one scan: NTL column tiles spread to fp4, the columns' constants.
+template <int W, int NTL>
+struct MfB {
+  mf_v8i Bf[NTL][W / 2];
+  int tsum[NTL];
+};
+
+// Loads and spreads the "to" rows of the tiles tile[0..NTL) (a tile past the frame's rows is empty).
+template <int W, int NTL>
+__device__ __forceinline__ void mf_load_b(const uint32_t* __restrict__ dT, int Kt, const int (&tile)[NTL], int lane,
+                                          MfB<W, NTL>& B) {
   constexpr int KS = W / 2;
   const int r = lane & 31, h = lane >> 5;
   uint32_t m88, c22;   // constants pinned in VGPRs (see fp4_spread)
   asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
   asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
-  mf_v8i Bf[NTL][KS];
-  int tsum[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     const int t = tile[j] * 32 + r;
@@ -528,13 +532,24 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
     int p = 0;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      Bf[j][k] = fp4_spread_to(raw[k], m88, c22);
+      B.Bf[j][k] = fp4_spread_to(raw[k], m88, c22);
       p += __popc(raw[k] & 0x77777777u);
     }
     p += __shfl_xor(p, 32);                 // both halves of the row
-    tsum[j] = 24 * W - 2 * p;               // the column's constant (see fp4_spread_from)
+    B.tsum[j] = 24 * W - 2 * p;             // the column's constant (see fp4_spread_from)
   }
-  after_b();
+}
+
+// kNN-2 of the resident "to" columns over all "from" rows; on return lanes 0..31 hold, for column tile[j] * 32 + lane:
+// d1 / d2 (Hamming, 0xFFFF when absent) and the from index of d1.
+template <int W, int NTL>
+__device__ __forceinline__ void mf_scan(const uint32_t* fromD, int Kf, const MfB<W, NTL>& B, int lane,
+                                        uint32_t (&d1)[NTL], uint32_t (&d2)[NTL], int (&idx)[NTL]) {
+  constexpr int KS = W / 2;
+  const int r = lane & 31, h = lane >> 5;
+  uint32_t m88, c22;
+  asm volatile("v_mov_b32 %0, 0x88888888" : "=v"(m88));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(c22));
   float cin[16], b[NTL], s[NTL];
 #pragma unroll
   for (int i = 0; i < 16; ++i) cin[i] = -(float)((i & 3) + 8 * (i >> 2) + 4 * h) * MF_FR;
@@ -544,8 +559,8 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
   uint32_t raw[KS];
   load_raw<KS>(fromD + (size_t)min(r, Kf - 1) * W + KS * h, raw);
   const uint32_t* nxt = fromD + (size_t)r * W + KS * h;
-  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, Bf, cin, b, s, m88, c22, raw, nxt);
-  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, Bf, cin, b, s, m88, c22, raw, nxt);
+  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, B.Bf, cin, b, s, m88, c22, raw, nxt);
+  if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, B.Bf, cin, b, s, m88, c22, raw, nxt);
   const float org = (float)(32 * (((Kf + 31) >> 5) - 1)) * MF_FR;
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -554,9 +569,23 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
     const float ns = fmaxf(fminf(b[j], ob), fmaxf(s[j], os)) - org;
     const float dot1 = 2.f * ceilf(nb * 0.5f), dot2 = 2.f * ceilf(ns * 0.5f);
     idx[j] = (int)((dot1 - nb) * 2048.f);
-    d1[j] = (uint32_t)((32 * W - tsum[j] - (int)dot1) >> 1);
-    d2[j] = ns == -INFINITY ? 0xFFFFu : (uint32_t)((32 * W - tsum[j] - (int)dot2) >> 1);
+    d1[j] = (uint32_t)((32 * W - B.tsum[j] - (int)dot1) >> 1);
+    d2[j] = ns == -INFINITY ? 0xFFFFu : (uint32_t)((32 * W - B.tsum[j] - (int)dot2) >> 1);
   }
+}
+
+// after_b(): called once the resident "to" operands are in registers (their global loads consumed) and before the scan --
+// where the persistent matcher (k_match_persist, k_verify.hip) queues the LDS-DMA of the NEXT pair's "from" rows, so
+// that no ordinary load of this wavefront is waited for while the DMA is in flight.
+struct MfNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int W, int NTL, class Hook = MfNoHook>
+__device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
+                                          const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
+                                          int (&idx)[NTL], Hook after_b = Hook()) {
+  MfB<W, NTL> B;
+  mf_load_b<W, NTL>(dT, Kt, tile, lane, B);
+  after_b();
+  mf_scan<W, NTL>(fromD, Kf, B, lane, d1, d2, idx);
 }
 
 // Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
@@ -596,14 +625,41 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
   int* owner = cnt + kcap;                                 // [kcap]
   int* misc = owner + kcap;                                // [16]
 
-  {
+  // SF_MATCH_PRELOAD (round 5, matrix-core path): the "from" rows are staged by LDS-DMA (global_load_lds_dwordx4: no
+  // staging registers, no ds_write) and, with nothing of the wavefront's register file tied up in the copy, the FIRST
+  // group's "to" rows are loaded and spread while the DMA is in flight -- one memory latency in front of a pair's first
+  // MFMA instead of two.  (Rounds 3-4 tried the early "to" loads on top of the register copy: the raw rows kept across the
+  // staging barrier cost the fused kernel its 128-register budget; this form keeps 128 registers and no scratch.)
+  // MEASURED (profiles/r05p_preload_ab.txt, three alternations on one box): 22.51 / 22.73 / 22.65 M pairs/s with it against
+  // 22.79 / 22.82 / 22.72 without (PnP 15.34 against 15.27) -- no gain: with four to five workgroups of other pairs on the
+  // CU a pair's own staging latency is already covered, the launch is bound by issue slots.  Off by default.
+  constexpr bool PRE = SF_MATCH_PRELOAD != 0 && NQ == 0;
+  constexpr int PRE_NTL = W == 8 ? MF_NTL : 1;
+  MfB<W, PRE_NTL> B0;
+  int tl0[PRE_NTL];
+#pragma unroll
+  for (int j = 0; j < PRE_NTL; ++j) tl0[j] = wave + j * NW;
+  if constexpr (PRE) {
+    typedef __attribute__((address_space(3))) void* lds_vp_t;
+    typedef __attribute__((address_space(1))) const void* glb_vp_t;
+    const uint4* src = reinterpret_cast<const uint4*>(dF);
+    const int n16 = Kf * (W / 4);
+    for (int i0 = wave * 64; i0 < n16; i0 += NT) {
+      if (i0 + lane < n16)
+        __builtin_amdgcn_global_load_lds((glb_vp_t)(src + i0 + lane), (lds_vp_t)(fromD + 4 * i0), 16, 0, 0);
+    }
+  } else {
     const uint4* src = reinterpret_cast<const uint4*>(dF);
     uint4* dst = reinterpret_cast<uint4*>(fromD);
     for (int i = tid; i < Kf * (W / 4); i += NT) dst[i] = src[i];
   }
   for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
   if (tid < 16) misc[tid] = 0;
-  __syncthreads();
+  if constexpr (PRE) {
+    if (Kf > 0 && wave < ((Kt + 31) >> 5)) mf_load_b<W, PRE_NTL>(dT, Kt, tl0, lane, B0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's pieces of the rows have landed ...
+  }
+  __syncthreads();                                       // ... and everyone's
   SF_TRACE_ROW_MARK(trace_row, 32);   // "from" rows staged
 
   int rejected = 0;
@@ -637,7 +693,29 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
           }
         }
       };
-      for (int t0 = wave; t0 < n_nt; t0 += NW * NTL) {
+      int t_first = wave;
+      if constexpr (PRE) {
+        if (wave < n_nt) {       // the first group: its "to" operands were loaded beside the staging DMA (full width; a tile
+          int f[NTL];            //  past the frame's rows is empty)
+          uint32_t a1[NTL], a2[NTL];
+          mf_scan<W, NTL>(fromD, Kf, B0, lane, a1, a2, f);
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+            const int t = tl0[j] * 32 + lane;
+            if (lane < 32 && t < Kt) {
+              const bool acc = (Kf >= 2) && !((float)a1[j] > nndr * (float)a2[j]);
+              if (acc) {
+                atomicAdd(&cnt[f[j]], 1);
+                owner[f[j]] = t;
+              } else {
+                ++rejected;
+              }
+            }
+          }
+        }
+        t_first = wave + NW * NTL;
+      }
+      for (int t0 = t_first; t0 < n_nt; t0 += NW * NTL) {
         const int avail = (n_nt - t0 + NW - 1) / NW;
         if (NTL >= 4 && avail >= 3) group(std::integral_constant<int, 4>{}, t0);
         else if (NTL >= 2 && avail >= 2) group(std::integral_constant<int, 2>{}, t0);

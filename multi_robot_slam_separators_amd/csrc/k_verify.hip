@@ -31,6 +31,9 @@
 #ifndef SF_PNP_CHAIN_OCC
 #define SF_PNP_CHAIN_OCC 3
 #endif
+#ifndef SF_PNP_CHAIN_OCC4
+#define SF_PNP_CHAIN_OCC4 2      // the four-wavefront form's budget (3 = the build that failed a parity test: see k_chain_pnp)
+#endif
 #include "k_match.hip"
 #include "k_ransac.hip"
 #include "k_guided.hip"
@@ -529,11 +532,15 @@ namespace {
 // scratch per lane) like round 4's chain.  The FOUR-wavefront form is compiled for 2 (256 registers, no scratch): at 3
 // this round's build of it -- same bodies as the stage kernel k_pnp, which is correct at that budget -- returned wrong
 // inlier sets from rtabmap's refinement rounds (tests/test_gpu_pnp.py::test_pnp_refinement_rounds with
-// SF_CHAIN_PNP_NW=4; 7 inliers against the oracle's 35), and correct ones at 2.  The cause is not established (the
-// kernel holds 106 SGPRs with ~170 v_writelane / ~420 v_readlane spill moves next to its scratch spills); the build
-// that showed it is not shipped, and the parity soak (tools/soak_parity.py pnp) runs on the shipped widths.
+// SF_CHAIN_PNP_NW=4; 7 inliers against the oracle's 35), and correct ones at 2.  profiles/r05r_pnp_chain_occ3.txt: the
+// same source at 3 is correct again with -mllvm -amdgpu-spill-sgpr-to-vgpr=0 and with -mllvm -no-stack-slot-sharing, so
+// the fault belongs to ONE register allocation (106 SGPRs, 156 v_writelane / 427 v_readlane spill moves beside 128 B of
+// scratch), not to the source; lane sharing, hazard wait states, foreign writers of the spill registers and lane moves
+// under EXEC = 0 were checked on that build's ISA and are not it (tools/spill_lane_check.py, tools/ubench/lane_exec0.hip).
+// Which instruction is wrong is not established; -DSF_PNP_CHAIN_OCC4=3 rebuilds the failing form, which is not shipped,
+// and the parity soak (tools/soak_parity.py pnp) runs on the shipped widths.
 template <int W, int PART, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : SF_PNP_CHAIN_OCC)
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? SF_PNP_CHAIN_OCC4 : SF_PNP_CHAIN_OCC)
 k_chain_pnp(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
             const uint32_t* __restrict__ corr1, const CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
             uint32_t* __restrict__ corr2, CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2,
