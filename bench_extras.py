@@ -38,6 +38,8 @@ def pmc_traffic(kernel_prefix, pairs_per_launch, any_size=False):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
     for path in reversed(files):
+        if "cfg3" in os.path.basename(path):     # (profiles of the other workload: K = 1000, 100 000 pairs per launch)
+            continue
         try:
             pm = json.load(open(path)).get("pmc_per_launch", {})
         except Exception:

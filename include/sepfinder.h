@@ -612,10 +612,10 @@ enum {
   SF_OPT_STEP_SPLIT = 7,  /* 1: while the steps are dealt over several streams (SF_OPT_STEP_OVERLAP) the 3D-3D verification
                              of a step runs as one matching launch over all candidates + one chain launch over the
                              survivors instead of the fused kernel (256-bit descriptors, K <= 512 features, 2 048 .. 65 536
-                             candidates -- other shapes keep the fused kernel).  Round 3's default (two streams whose
-                             launches fell into step: +5 %); 0 (default since round 4): always the fused kernel -- with
-                             three streams and no host in the step it is the faster form (22.0 against 20.3 M pairs/s,
-                             profiles/r04g).  Results unchanged.                                                     */
+                             candidates -- other shapes keep the fused kernel).  Default 1 again since round 5: the matching
+                             launch's scan is software-pipelined inside a wavefront and the form is the faster one by
+                             1-1.5 % (23.0 against 22.7 M pairs/s, profiles/r05u_*; round 4, before that: the fused
+                             kernel 22.0 against 20.3).  0: always the fused kernel.  Results unchanged.              */
   SF_OPT_STEP_DEPTH = 8,  /* steps sf_step_issue keeps in flight, 1 .. 16 (default 6).  Not while a step is in flight.  */
   SF_OPT_STEP_LANES = 9,  /* streams the steps in flight are dealt over, 1 .. 4 (default 3; step k runs on stream
                              k mod lanes; with a mirror set at most 2).  Not while a step is in flight.              */

@@ -540,9 +540,150 @@ __device__ __forceinline__ void mf_load_b(const uint32_t* __restrict__ dT, int K
   }
 }
 
+// ---- round 5: the scan software-pipelined inside a wavefront (256-bit descriptors) -------------------------------------
+// knn2_mfma_tile above runs, per column tile, 4 dependent MFMAs, waits for the result (s_nop 11), then 20 dependent
+// vector instructions that consume it, on ONE accumulator tuple: nothing of a wavefront's own stream overlaps, and measured
+// over whole launches a SIMD spends 200-230 cycles per 32 x 32 tile pair = the SUM of its matrix-pipe time (4 x 32) and
+// its vector issue time (4 x 8 + 26 x 4; MI355X_MICROARCH.md, cycle constants) although three or four wavefronts share it
+// (cfg3-shaped k_match_split: 10.8 ms per 100 000 pairs = 108 ns per tile pair and SIMD, profiles/r05q_*).
+// Here the top-2 update of tile j - 1 is issued in the gaps of tile j's MFMAs, from a SECOND accumulator tuple: five to six
+// vector instructions per 32-cycle gap (their issue cost 8 + 6 x 4 fits it), so a tile pair costs the matrix pipe's 128
+// cycles plus what stays outside (the spread of the "from" tile, the loop).  The MFMAs have to sit in the asm statements
+// with the vector instructions (the compiler does not interleave an asm block with builtins), so the wait states are
+// written out by hand (cdna_hip_programming.md section 5.7 item 2):
+//   * a VALU-written A operand -> MFMA: s_nop 1 opens the first half (the spread is compiler code right in front); the
+//     second half's A operands are inputs of the first half too, so they are written before it;
+//   * an MFMA result -> a VALU reader: 12 states after the LAST MFMA of the tuple.  The old tuple's last MFMA is followed
+//     by 6 vector instructions (the end of the second half), then s_nop 1 (2), the new tile's first MFMA (1), the two
+//     origin shifts (2) and s_nop 1 (2) stand in front of the first read: 13.  The drain opens with s_nop 11;
+//   * an accumulate chain (the MFMA takes the previous result whole as C) needs none.
+// A statement's operands are limited to 30, hence two halves per tile (2 MFMAs + the update over 8 accumulator registers
+// each).  Same operations in the same order on the same values as top2_update16: same bytes.
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mf_pipe_half1(mf_v16f& acc, const mf_v4i& a0, const mf_v4i& a1, const mf_v4i& a2,
+                                              const mf_v4i& a3, const mf_v4i& b0, const mf_v4i& b1, const mf_v16f& cin,
+                                              const mf_v16f& old, float& b, float& s, float& x0, float& ta, float& tb) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 %[acc], %[a0], %[b0], %[cin] cbsz:4 blgp:4\n\t"
+      "v_add_f32 %[b], 0x3c800000, %[b]\n\t"            // the origin moves by one tile: 32 / 2048
+      "v_add_f32 %[s], 0x3c800000, %[s]\n\t"
+      "s_nop 1\n\t"
+      "v_med3_f32 %[x0], %[b], %[o0], %[o1]\n\t"
+      "v_max3_f32 %[b], %[b], %[o0], %[o1]\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 %[acc], %[a1], %[b1], %[acc] cbsz:4 blgp:4\n\t"
+      "v_med3_f32 %[ta], %[b], %[o2], %[o3]\n\t"
+      "v_max3_f32 %[b], %[b], %[o2], %[o3]\n\t"
+      "v_max3_f32 %[s], %[s], %[x0], %[ta]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o4], %[o5]\n\t"
+      "v_max3_f32 %[b], %[b], %[o4], %[o5]\n\t"
+      "v_med3_f32 %[tb], %[b], %[o6], %[o7]"
+      : [acc] "=&v"(acc), [b] "+v"(b), [s] "+v"(s), [x0] "=&v"(x0), [ta] "=&v"(ta), [tb] "=&v"(tb)
+      : [a0] "v"(a0), [a1] "v"(a1), "v"(a2), "v"(a3), [b0] "v"(b0), [b1] "v"(b1), [cin] "v"(cin), [o0] "v"(old[0]),
+        [o1] "v"(old[1]), [o2] "v"(old[2]), [o3] "v"(old[3]), [o4] "v"(old[4]), [o5] "v"(old[5]), [o6] "v"(old[6]),
+        [o7] "v"(old[7]));
+}
+__device__ __forceinline__ void mf_pipe_half2(mf_v16f& acc, const mf_v4i& a2, const mf_v4i& a3, const mf_v4i& b2,
+                                              const mf_v4i& b3, const mf_v16f& old, float& b, float& s, float& ta,
+                                              float& tb) {
+  float x0;
+  asm volatile(
+      "v_mfma_f32_32x32x64_f8f6f4 %[acc], %[a2], %[b2], %[acc] cbsz:4 blgp:4\n\t"
+      "v_max3_f32 %[b], %[b], %[o6], %[o7]\n\t"
+      "v_max3_f32 %[s], %[s], %[ta], %[tb]\n\t"
+      "v_med3_f32 %[x0], %[b], %[o8], %[o9]\n\t"
+      "v_max3_f32 %[b], %[b], %[o8], %[o9]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o10], %[o11]\n\t"
+      "v_max3_f32 %[b], %[b], %[o10], %[o11]\n\t"
+      "v_mfma_f32_32x32x64_f8f6f4 %[acc], %[a3], %[b3], %[acc] cbsz:4 blgp:4\n\t"
+      "v_max3_f32 %[s], %[s], %[x0], %[ta]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o12], %[o13]\n\t"
+      "v_max3_f32 %[b], %[b], %[o12], %[o13]\n\t"
+      "v_med3_f32 %[tb], %[b], %[o14], %[o15]\n\t"
+      "v_max3_f32 %[b], %[b], %[o14], %[o15]\n\t"
+      "v_max3_f32 %[s], %[s], %[ta], %[tb]"
+      : [acc] "+v"(acc), [b] "+v"(b), [s] "+v"(s), [x0] "=&v"(x0), [ta] "+v"(ta), [tb] "+v"(tb)
+      : [a2] "v"(a2), [a3] "v"(a3), [b2] "v"(b2), [b3] "v"(b3), [o6] "v"(old[6]), [o7] "v"(old[7]), [o8] "v"(old[8]),
+        [o9] "v"(old[9]), [o10] "v"(old[10]), [o11] "v"(old[11]), [o12] "v"(old[12]), [o13] "v"(old[13]),
+        [o14] "v"(old[14]), [o15] "v"(old[15]));
+}
+// the pending tuple's update with no tile behind it (end of the full tiles)
+__device__ __forceinline__ void mf_pipe_drain(const mf_v16f& old, float& b, float& s) {
+  float x0, ta, tb;
+  asm volatile(
+      "s_nop 11\n\t"
+      "v_add_f32 %[b], 0x3c800000, %[b]\n\t"
+      "v_add_f32 %[s], 0x3c800000, %[s]\n\t"
+      "v_med3_f32 %[x0], %[b], %[o0], %[o1]\n\t"
+      "v_max3_f32 %[b], %[b], %[o0], %[o1]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o2], %[o3]\n\t"
+      "v_max3_f32 %[b], %[b], %[o2], %[o3]\n\t"
+      "v_max3_f32 %[s], %[s], %[x0], %[ta]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o4], %[o5]\n\t"
+      "v_max3_f32 %[b], %[b], %[o4], %[o5]\n\t"
+      "v_med3_f32 %[tb], %[b], %[o6], %[o7]\n\t"
+      "v_max3_f32 %[b], %[b], %[o6], %[o7]\n\t"
+      "v_max3_f32 %[s], %[s], %[ta], %[tb]\n\t"
+      "v_med3_f32 %[x0], %[b], %[o8], %[o9]\n\t"
+      "v_max3_f32 %[b], %[b], %[o8], %[o9]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o10], %[o11]\n\t"
+      "v_max3_f32 %[b], %[b], %[o10], %[o11]\n\t"
+      "v_max3_f32 %[s], %[s], %[x0], %[ta]\n\t"
+      "v_med3_f32 %[ta], %[b], %[o12], %[o13]\n\t"
+      "v_max3_f32 %[b], %[b], %[o12], %[o13]\n\t"
+      "v_med3_f32 %[tb], %[b], %[o14], %[o15]\n\t"
+      "v_max3_f32 %[b], %[b], %[o14], %[o15]\n\t"
+      "v_max3_f32 %[s], %[s], %[ta], %[tb]"
+      : [b] "+v"(b), [s] "+v"(s), [x0] "=&v"(x0), [ta] "=&v"(ta), [tb] "=&v"(tb)
+      : [o0] "v"(old[0]), [o1] "v"(old[1]), [o2] "v"(old[2]), [o3] "v"(old[3]), [o4] "v"(old[4]), [o5] "v"(old[5]),
+        [o6] "v"(old[6]), [o7] "v"(old[7]), [o8] "v"(old[8]), [o9] "v"(old[9]), [o10] "v"(old[10]), [o11] "v"(old[11]),
+        [o12] "v"(old[12]), [o13] "v"(old[13]), [o14] "v"(old[14]), [o15] "v"(old[15]));
+}
+
+// the full "from" tiles of a scan in the pipelined form (W = 8, NTL even: tile j writes tuple j & 1 and consumes the other)
+template <int NTL>
+__device__ __forceinline__ void mf_scan_full_tiles_pipe(const uint32_t* fromD, int n_full, const MfB<8, NTL>& B,
+                                                        const float (&cin)[16], float (&b)[NTL], float (&s)[NTL],
+                                                        uint32_t m88, uint32_t c22, uint32_t (&raw)[4],
+                                                        const uint32_t*& nxt) {
+  static_assert(NTL == 2 || NTL == 4, "tiles alternate between two accumulator tuples");
+  if (n_full <= 0) return;
+  mf_v4i B4[NTL][4];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) B4[j][k] = mf_v4i{B.Bf[j][k][0], B.Bf[j][k][1], B.Bf[j][k][2], B.Bf[j][k][3]};
+  }
+  mf_v16f c0, acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c0[i] = cin[i]; acc1[i] = -INFINITY; }     // nothing pending: an update that changes nothing
+  for (int mt = 0; mt < n_full; ++mt) {
+    mf_v4i A4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const mf_v8i a = fp4_spread_from(raw[k], m88, c22);
+      A4[k] = mf_v4i{a[0], a[1], a[2], a[3]};
+    }
+    nxt += 32 * 8;                       // the next tile's rows (see knn2_mfma_tile)
+    load_raw<4>(nxt, raw);
+#pragma unroll
+    for (int j = 0; j < NTL; j += 2) {
+      constexpr int JP = NTL - 1;        // tile 0 consumes the LAST tile of the previous "from" tile
+      float x0, ta, tb;
+      const int jp = j == 0 ? JP : j - 1;
+      mf_pipe_half1(acc0, A4[0], A4[1], A4[2], A4[3], B4[j][0], B4[j][1], c0, acc1, b[jp], s[jp], x0, ta, tb);
+      mf_pipe_half2(acc0, A4[2], A4[3], B4[j][2], B4[j][3], acc1, b[jp], s[jp], ta, tb);
+      mf_pipe_half1(acc1, A4[0], A4[1], A4[2], A4[3], B4[j + 1][0], B4[j + 1][1], c0, acc0, b[j], s[j], x0, ta, tb);
+      mf_pipe_half2(acc1, A4[2], A4[3], B4[j + 1][2], B4[j + 1][3], acc0, b[j], s[j], ta, tb);
+    }
+  }
+  mf_pipe_drain(acc1, b[NTL - 1], s[NTL - 1]);
+}
+
 // kNN-2 of the resident "to" columns over all "from" rows; on return lanes 0..31 hold, for column tile[j] * 32 + lane:
 // d1 / d2 (Hamming, 0xFFFF when absent) and the from index of d1.
-template <int W, int NTL>
+template <int W, int NTL, bool PIPE = false>
 __device__ __forceinline__ void mf_scan(const uint32_t* fromD, int Kf, const MfB<W, NTL>& B, int lane,
                                         uint32_t (&d1)[NTL], uint32_t (&d2)[NTL], int (&idx)[NTL]) {
   constexpr int KS = W / 2;
@@ -559,7 +700,11 @@ __device__ __forceinline__ void mf_scan(const uint32_t* fromD, int Kf, const MfB
   uint32_t raw[KS];
   load_raw<KS>(fromD + (size_t)min(r, Kf - 1) * W + KS * h, raw);
   const uint32_t* nxt = fromD + (size_t)r * W + KS * h;
-  for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, B.Bf, cin, b, s, m88, c22, raw, nxt);
+  if constexpr (PIPE && W == 8 && (NTL == 2 || NTL == 4)) {
+    mf_scan_full_tiles_pipe<NTL>(fromD, n_full, B, cin, b, s, m88, c22, raw, nxt);
+  } else {
+    for (int mt = 0; mt < n_full; ++mt) knn2_mfma_tile<W, NTL, false>(fromD, Kf, mt, r, h, B.Bf, cin, b, s, m88, c22, raw, nxt);
+  }
   if (Kf & 31) knn2_mfma_tile<W, NTL, true>(fromD, Kf, n_full, r, h, B.Bf, cin, b, s, m88, c22, raw, nxt);
   const float org = (float)(32 * (((Kf + 31) >> 5) - 1)) * MF_FR;
 #pragma unroll
@@ -578,14 +723,14 @@ __device__ __forceinline__ void mf_scan(const uint32_t* fromD, int Kf, const MfB
 // where the persistent matcher (k_match_persist, k_verify.hip) queues the LDS-DMA of the NEXT pair's "from" rows, so
 // that no ordinary load of this wavefront is waited for while the DMA is in flight.
 struct MfNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int W, int NTL, class Hook = MfNoHook>
+template <int W, int NTL, class Hook = MfNoHook, bool PIPE = false>
 __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
                                           const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
                                           int (&idx)[NTL], Hook after_b = Hook()) {
   MfB<W, NTL> B;
   mf_load_b<W, NTL>(dT, Kt, tile, lane, B);
   after_b();
-  mf_scan<W, NTL>(fromD, Kf, B, lane, d1, d2, idx);
+  mf_scan<W, NTL, PIPE>(fromD, Kf, B, lane, d1, d2, idx);
 }
 
 // Body of the matching stage for ONE pair (the calling workgroup); `smem` is the workgroup's dynamic
@@ -594,7 +739,7 @@ __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const u
 // `out` = the pair's correspondence list (kcap entries; global in the stage kernels, LDS -- it may alias the
 // staged "from" block, which is dead by the time the list is written -- in the fused kernel); hdr_out / pass_out
 // = the pair's header and pass-1 state (same two homes).
-template <int W, int NQ, int NT, int MF_NTL = 2>
+template <int W, int NQ, int NT, int MF_NTL = 2, bool MF_PIPE = false>
 __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int sF, int sT, float nndr, int min_inliers,
                                               int est, uint32_t* out, CorrHeader& hdr_out, PassState& pass_out,
                                               int32_t* __restrict__ list, int32_t* __restrict__ counter, int* smem,
@@ -678,7 +823,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
         uint32_t a1[G], a2[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) tl[j] = t0 + j * NW;
-        knn2_mfma<W, G>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
+        knn2_mfma<W, G, MfNoHook, MF_PIPE>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           const int t = tl[j] * 32 + lane;
@@ -698,7 +843,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
         if (wave < n_nt) {       // the first group: its "to" operands were loaded beside the staging DMA (full width; a tile
           int f[NTL];            //  past the frame's rows is empty)
           uint32_t a1[NTL], a2[NTL];
-          mf_scan<W, NTL>(fromD, Kf, B0, lane, a1, a2, f);
+          mf_scan<W, NTL, MF_PIPE>(fromD, Kf, B0, lane, a1, a2, f);
 #pragma unroll
           for (int j = 0; j < NTL; ++j) {
             const int t = tl0[j] * 32 + lane;

@@ -31,6 +31,9 @@
 #ifndef SF_PNP_CHAIN_OCC
 #define SF_PNP_CHAIN_OCC 3
 #endif
+#ifndef SF_MATCH_PIPE
+#define SF_MATCH_PIPE 1          // k_match_split: the scan software-pipelined inside a wavefront (k_match.hip, mf_pipe_*)
+#endif
 #ifndef SF_PNP_CHAIN_OCC4
 #define SF_PNP_CHAIN_OCC4 2      // the four-wavefront form's budget (3 = the build that failed a parity test: see k_chain_pnp)
 #endif
@@ -208,7 +211,7 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
   extern __shared__ __attribute__((aligned(16))) int smem_i[];
   const int pair = blockIdx.x;
   SF_TRACE_MARK(P, pair, 0);
-  const bool survivor = match_v2_body<W, 0, SF_BLOCK, NTL>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
+  const bool survivor = match_v2_body<W, 0, SF_BLOCK, NTL, SF_MATCH_PIPE != 0>(st, pair, pair_from[pair], pair_to[pair], P.nndr, P.min_inliers,
                                                          est, corr1 + (size_t)pair * st.kcap, hdr1[pair], pass1[pair],
                                                          list, counter, smem_i,
                                                          P.dbg_trace ? P.dbg_trace + (size_t)pair * SF_TRACE_SLOTS : nullptr);
@@ -800,6 +803,8 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
                        (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams,
                        sf_est_mode(c), n);
   } else
+  // (shapes measured on the pipelined scan, profiles/r05t_match_split_shapes.txt: 4 tiles / 3 workgroups per CU 22.5 M
+  //  pairs/s on the 3D-3D split step, 2 tiles / 4: 22.2, 2 tiles / 3: 21.3, 4 tiles / 2: 21.2; PnP 15.0 / 15.0 / 14.8 / 13.7)
   if (st.w == 8) SF_SPLIT_MATCH(8); else SF_SPLIT_MATCH(16);
 #undef SF_SPLIT_MATCH
   sf_prof_end(c, SF_K_MATCH);

@@ -233,7 +233,8 @@ struct sf_context {
   bool gf_select_attr = false; // k_gftt_select_lds: dynamic LDS attribute set
   bool nn_k128_attr = false;   // k_nn_filter_f16_k128: dynamic LDS attribute set
   bool split = false;       // SF_FUSED=2: one matching launch + one chain launch over the survivors (k_verify.hip)
-  bool split_auto = false;  // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip); off since round 4
+  bool split_auto = true;   // SF_OPT_STEP_SPLIT: the split form inside overlapped steps (sf_use_split, sf_api.hip); on again since
+                            // round 5 (its matcher is software-pipelined: 23.0 against 22.7 M pairs/s, profiles/r05u_*)
   int split_auto_min = 2048;   // ... for queries of at least this many candidates (SF_STEP_SPLIT_MIN): below, one launch wins
   bool in_overlapped_step = false;   // set around sf_step_issue's body while the steps alternate between two streams
   bool chain_attr[2][3][3] = {};   // k_chain [W == 16][part 0 / 1 / 2][wavefronts per chain 1 / 2 / 4]: LDS attribute set

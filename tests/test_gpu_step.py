@@ -116,12 +116,13 @@ def test_step_pair_equals_the_separate_calls(est, overlap, walk):
             _check_step(f.step_retire(copy=True), m2, res2, want_streamed)
 
 
-@pytest.mark.parametrize("form", ["forced_lanes", "forced_one_stream", "opt_in", "opt_in_one_stream", "default"])
+@pytest.mark.parametrize("form", ["forced_lanes", "forced_one_stream", "opt_in", "opt_in_one_stream", "default", "opt_out"])
 def test_step_pair_in_the_split_form(form, monkeypatch):
     """The 3D-3D verification as one matching launch + one chain launch over the survivors (k_match_split + k_chain)
     instead of the fused kernel: everywhere with SF_FUSED=2 (read at sf_create); with SF_OPT_STEP_SPLIT on, by the
-    library's own choice inside steps that are dealt over several streams -- not when the steps share one stream, and not
-    by default (since round 4 the fused kernel is the faster form there).  The chain kernel streams the accepted
+    library's own choice inside steps that are dealt over several streams -- not when the steps share one stream.  The
+    option is on by default (round 5: the matching launch's scan is software-pipelined); 0 keeps the fused kernel.  The
+    chain kernel streams the accepted
     separators like the fused one does, and a step's matches, flags and records are the separate calls', byte for byte,
     in every form."""
     n_kf, k, dim = 96, 200, 512
@@ -147,6 +148,8 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
         f.set_option(_abi.SF_OPT_STEP_OVERLAP, 0 if form.endswith("one_stream") else 1)
         if form.startswith("opt_in"):
             f.set_option(_abi.SF_OPT_STEP_SPLIT, 1)
+        if form == "opt_out":
+            f.set_option(_abi.SF_OPT_STEP_SPLIT, 0)
         sa, sb, keep = _fill(f, feats, nv_a, nv_b, n_kf, k)
         m2, res2 = _two_calls(f, sa, sb, n_kf)     # the separate calls in this handle's form: the same bytes
         assert m2.tobytes() == m_ref.tobytes() and res2.tobytes() == res_ref.tobytes()
@@ -163,7 +166,7 @@ def test_step_pair_in_the_split_form(form, monkeypatch):
         prof = f.prof_get()
         f.prof_enable(False)
         split_ran = prof["k_match_global"][0] > 0          # (the matching launch's profiling slot)
-        assert split_ran == (form in ("forced_lanes", "forced_one_stream", "opt_in")), (form, prof)
+        assert split_ran == (form in ("forced_lanes", "forced_one_stream", "opt_in", "default")), (form, prof)
         assert prof["k_verify_fused"][0] == 6              # the fused kernel, or the chain launch in its slot
 
 

@@ -309,7 +309,7 @@ def test_workspace_reservation_covers_what_every_launch_form_writes(monkeypatch,
     L = lib.load()
     names = ("corr1", "corr2", "hdr1", "hdr2", "pass1", "pass2", "list1", "list3", "flags")
     seen = set()
-    envs = ({}, {"SF_FUSED": "0"}, {"SF_FUSED": "2"}, {"SF_STEP_SPLIT": "1"}, {"SF_OVERLAP": "1"}, {"SF_CHAIN_PNP": "0"})
+    envs = ({}, {"SF_FUSED": "0"}, {"SF_FUSED": "2"}, {"SF_STEP_SPLIT": "1"}, {"SF_STEP_SPLIT": "0"}, {"SF_OVERLAP": "1"}, {"SF_CHAIN_PNP": "0"})
     for env in envs:
         for k in ("SF_FUSED", "SF_STEP_SPLIT", "SF_OVERLAP", "SF_CHAIN_PNP"):
             monkeypatch.delenv(k, raising=False)
