@@ -797,6 +797,8 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
       SF_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
       c->cu_count = cus > 0 ? cus : 256;
     }
+    // (round 5, profiles/r05y_pairs_per_workgroup.txt: short-lived workgroups of 2 or 4 pairs each on this kernel, with
+    //  the pipelined scan: 20.9 against 22.7 M pairs/s on the 3D-3D step, 14.4 against 15.1 on the PnP step -- not kept)
     const int grid = std::min(n, 3 * c->cu_count);
     hipLaunchKernelGGL((k_match_persist<8>), dim3(grid), dim3(SF_BLOCK), lds_p, c->stream, st, d_from, d_to,
                        (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p,
