@@ -93,13 +93,15 @@ def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
     if os.environ.get("SF_MATCH_MFMA", "1") != "0":
         flop = 2.0 * k * k * cols * 8          # one multiply-add per descriptor bit pair
         tf = pairs_per_launch * flop / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-        scan = ("four resident column tiles per wavefront (three workgroups per CU): per 32-row tile and SIMD the 16 MFMAs hold "
-                "the fp4 pipe for 226 ns; the vector issue port is held 1.06 ns by each of the scan's 102 vector instructions and "
-                "9.3 ns by each MFMA (tools/ubench/mfma_port.hip): 257 ns -- over the launch the port is ~70 % busy, the pipe "
-                "~50 %, the rest is dependent latency at three wavefronts per SIMD (DESIGN.md section 5)" if dom == "k_match_split" else
-                "per 32-row tile and SIMD the 8 MFMAs hold the fp4 pipe for 113 ns; the vector issue port is held 1.06 ns by each "
-                "of the scan's 60 vector instructions and 9.3 ns by each MFMA (tools/ubench/mfma_port.hip): 138 ns "
-                "(DESIGN.md section 5; profiles/r03m_fewer_valu_no_gain.log)")
+        scan = ("four resident column tiles per wavefront (three workgroups per CU), the top-2 update of tile j - 1 issued in the "
+                "gaps of tile j's four MFMAs from a second accumulator tuple (k_match.hip, mf_pipe_*): a tile pair holds the "
+                "matrix pipe for 4 x 32 cycles and the vector issue port for 4 x 8 + 26 x 4.  Counters of the launch alone on the "
+                "chip (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x GRBM_GUI_ACTIVE / 8): pipe 75 % busy at K = 1000 "
+                "(profiles/r05s_cfg3_split_sq_k_match_split.json, sustained clock 1.69 GHz), ~58 % at K = 500 where staging, "
+                "compaction and dispatch are a quarter of a pair's workgroup time" if dom == "k_match_split" else
+                "per 32-row tile and SIMD the 8 MFMAs hold the fp4 pipe for 8 x 32 cycles; the vector issue port is held 4 cycles "
+                "by each of the scan's 60 vector instructions and 8 by each MFMA (MI355X_MICROARCH.md, cycle constants; "
+                "tools/ubench/mfma_port.hip) (DESIGN.md section 5; profiles/r03m_fewer_valu_no_gain.log)")
         return {"note": "matching = v_mfma_f32_32x32x64_f8f6f4 over +-1-encoded descriptor bits (2*K*K*bits flop per pair, "
                         "rows unpadded) + 1.25 VALU ops per table cell for the top-2 scan: " + scan
                         + ("; the launch also holds both motion-estimation chains of the surviving pairs, which are "
@@ -109,6 +111,37 @@ def compute_note(dom, k, cols, pairs_per_launch, launch_ms):
     return {"note": "VALU matcher (SF_MATCH_MFMA=0): per 256-bit descriptor pair 8 v_xor (full rate) + 8 v_bcnt_u32_b32 "
                     "(HALF rate on gfx950, tools/ubench/valu_rate.hip) + 6 16-bit min/max",
             "descriptor_pairs_per_s": per_s, "valu_busy_from_counters": sq_evidence(dom)}
+
+
+def matrix_pipe_roofline(hbm_roof, k, cols):
+    """The dominant kernel of the 3D-3D lines (k_match_split, or k_verify_fused whose matching part it is) is bound by the
+    fp4 matrix pipe, not by HBM: its roofline object on THAT basis -- algorithmic flops (2 * K * K * bits per pair: one
+    multiply-add per pair of descriptor bits of the K x K Hamming table) of a launch over its average duration, against
+    the dense fp4 MFMA peak of MI355X_MICROARCH.md -- with SURVEY section 8(d)'s HBM basis (bytes per pair) kept whole
+    under "hbm_basis".  `traffic` stays the HBM bytes per launch of the PMC passes."""
+    mc = hbm_roof["compute"]["matrix_core"]
+    flop = 2.0 * k * k * cols * 8
+    alone = hbm_roof.get("alone")
+    out = {"kernel": hbm_roof["kernel"], "bound": "mfma", "achieved": mc["achieved"], "peak": mc["peak"],
+           "unit": "TFLOP/s", "frac": mc["frac"], "traffic": hbm_roof.get("traffic"),
+           "traffic_measured_in_this_run": False, "traffic_source": hbm_roof.get("traffic_source"),
+           "flop_per_pair": flop, "pairs_per_launch": hbm_roof["pairs_per_launch"],
+           "avg_launch_ms": hbm_roof["avg_launch_ms"], "launches_per_step": hbm_roof["launches_per_step"],
+           "launches_sharing_the_chip": hbm_roof["launches_sharing_the_chip"],
+           "basis": "v_mfma_f32_32x32x64_f8f6f4 on +-1-coded descriptor bits: 2*K*K*bits flop per pair (rows unpadded), "
+                    "peak = dense fp4 at the nominal clock; `achieved` inside the timed region, where the launches of the "
+                    "steps in flight share the chip -- `alone` is the same kernel by itself",
+           "alone": None if not alone else {
+               "avg_launch_ms": alone["avg_launch_ms"], "launches": alone["launches"],
+               "achieved": hbm_roof["pairs_per_launch"] * flop / (alone["avg_launch_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s",
+               "frac": hbm_roof["pairs_per_launch"] * flop / (alone["avg_launch_ms"] * 1e-3) / 1e12 / mc["peak"]},
+           "compute": hbm_roof["compute"],
+           "hbm_basis": {kk: hbm_roof[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "bytes_per_pair", "alone",
+                                                     "whole_step") if kk in hbm_roof}}
+    for kk in ("chain_kernel", "whole_verification"):
+        if kk in hbm_roof:
+            out[kk] = hbm_roof[kk]
+    return out
 
 
 def generate_inputs(seed, n_kf, k, cols, dim, true_frac):
@@ -676,14 +709,19 @@ def run_cfg3(args, rank, world, dev, dev_index, coll_dev, dist_on):
                                       100 * args.true_frac, base, kd, dim),
                        "pairs_per_step_per_gpu": total_pairs / args.steps / world, "parallelism": "single GPU" if world == 1 else
                        "one topology per rank"},
-            "roofline": {"kernel": "k_verify_fused (WIDE form: K = 1000)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_pair": bpp,
+            # the verification launch is bound by the fp4 matrix pipe (its matching part: 75 % busy alone on the chip in the
+            # split form's matcher, profiles/r05s_cfg3_split_sq_k_match_split.json); SURVEY 8(d)'s HBM basis beside it
+            "roofline": {"kernel": "k_verify_fused (WIDE form: K = 1000)", "bound": "mfma",
+                         "achieved": flop4 / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0, "peak": MFMA_FP4_PEAK_TF,
+                         "unit": "TFLOP/s",
+                         "frac": flop4 / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TF if launch_ms > 0 else 0.0,
+                         "traffic": None, "flop_per_pair": 2.0 * k * k * cols * 8,
                          "pairs_per_launch": float(n_kf), "avg_launch_ms": launch_ms,
-                         "compute": {"matrix_core": {"achieved": flop4 / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0,
-                                                      "peak": MFMA_FP4_PEAK_TF, "unit": "TFLOP/s",
-                                                      "frac": flop4 / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TF if launch_ms > 0 else 0.0},
-                                     "note": "K x K Hamming table on the fp4 matrix cores (2*K*K*bits flop per pair) + the "
-                                             "motion-estimation chains of the surviving fifth inside the same launch"}},
+                         "basis": "K x K Hamming table on the fp4 matrix cores (2*K*K*bits flop per pair, rows unpadded) + the "
+                                  "motion-estimation chains of the surviving fifth inside the same launch; three launches (one "
+                                  "per robot pair) share the chip inside the timed region",
+                         "hbm_basis": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": ach / HBM_PEAK_GBS, "bytes_per_pair": bpp}},
             "roofline_nn": {"kernel": "k_nn_filter_f16", "bound": "mfma", "avg_launch_ms": filt_ms, "contracted_dims": kd,
                             "achieved": 2.0 * n_kf * n_kf * kd / (filt_ms * 1e-3) / 1e12 if filt_ms > 0 else 0.0,
                             "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
