@@ -77,8 +77,11 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   // [NC] fill counters of the bucketing: only alive until the keypoints are in their cells, so they live in `matched`
   // (written by the decisions at the very end) when that is large enough -- round 3: the guided pass sizes the fused
   // kernel's LDS, and K = 1000 frames were 10 KB over what lets three workgroups share a CU
-  const bool fill_in_matched = NC <= kcap;
-  int* cell_fill = fill_in_matched ? matched : cell_start + NC + 1;
+  // Round 5: up to 2 kcap cells they live in `claim` + `matched` (contiguous; `claim` is initialised behind the bucketing
+  // now): the 768 cells of a 640 x 480 image over K = 500 frames cost 3 KB of their own -- what kept the two-wavefront PnP
+  // chain at five per CU instead of six.
+  const bool fill_in_matched = NC <= 2 * kcap;
+  int* cell_fill = fill_in_matched ? claim : cell_start + NC + 1;
   // [kcap] the "to" keypoints grouped by cell as {x, y, octave bits, index bits}: the window test never leaves
   // LDS and takes ONE 16-byte read per entry
   // (the 16-byte alignment is done on the int INDEX: rounding the pointer through uintptr_t, as round 1 did, hid the
@@ -90,7 +93,6 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   uint32_t* key1 = oilast + kcap;                                // [kcap] best (Hamming << 16 | to) of the point
   uint32_t* key2 = key1 + kcap;                                  // [kcap] second best
   uint32_t* cand = key2 + kcap;                                  // [GUIDED_CPT * 256] recorded combinations (from << 16 | to)
-  for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;
   for (int i = tid; i <= NC; i += NT) cell_start[i] = 0;
   for (int i = tid; i < NC; i += NT) cell_fill[i] = 0;
   if (tid < 16) misc[tid] = 0;
@@ -253,7 +255,7 @@ __device__ __forceinline__ bool guided_body(const StoreView& st, int pair, int s
   }
 #endif
   for (int i = tid; i < Kf; i += NT) matched[i] = -1;      // (the fill counters are dead; ordered before the decisions by
-                                                          //  the barrier behind the search's first pass)
+  for (int i = tid; i < Kt; i += NT) claim[i] = 0x7FFFFFFF;  //  the barrier behind the search's first pass)
   int n_finite = 0, n_proj = 0;
   const int cand_cap = NW == 4 ? GUIDED_CAND_CAP : min(GUIDED_CAND_CAP_NARROW, 4 * kcap);   // (NW < 4: the keys are parked in the grid's items)
   // projection of a finite "from" point with the guess (:503-512): pixel position and "inside the image, in front"
@@ -748,7 +750,7 @@ size_t sf_guided_lds_bytes(int kcap, int n_cells, bool narrow) {
   // projections (2), candidate summaries, best / second-best keys (3) and the combination list
   // claim, matched, misc, cell_start (the fill counters live in `matched` when they fit), alignment, item4, candidate
   // summaries, best / second-best keys and the combination list
-  return (size_t)(2 * kcap + 16 + n_cells + 1 + (n_cells <= kcap ? 0 : n_cells) + 3 + 4 * kcap + 3 * kcap +
+  return (size_t)(2 * kcap + 16 + n_cells + 1 + (n_cells <= 2 * kcap ? 0 : n_cells) + 3 + 4 * kcap + 3 * kcap +
                   (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) +
                   (kcap > (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) ? kcap - (narrow ? GUIDED_CAND_CAP_NARROW : GUIDED_CAND_CAP) : 0)) *
          sizeof(int);   // (+ the raw keypoints' overhang: they are staged over oilast / key1 / key2 / cand, 4 kcap words)

@@ -40,10 +40,12 @@ namespace {
 // five to a CU instead of four
 // The per-iteration inlier counts live one ROUND (64 iterations) at a time: the replay consumes a round's counts before
 // the next round overwrites them.
-__host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations, bool bear = true) {
+// nw: wavefronts of the chain (one row of partial counts each + the valid flags: 27 264 B at K = 500 on two wavefronts --
+// the largest working set that still lets SIX chains share a CU's 160 KB, tools/ubench/lds_granule.hip)
+__host__ __device__ inline size_t sf_pnp_lds_bytes_dev(int kcap, int iterations, bool bear = true, int nw = 4) {
   (void)iterations;
   return (size_t)kcap * (16 + (bear ? 24 : 0) + 8 + 4 + 4 + 4 + 2) + 128 * 8 + 64 * 4 + 16 * 4 + 12 * 64 * 4 +
-         5 * 64 * 4 + 16 * 4 + 2 * 32 * 8;
+         (size_t)(nw + 1) * 64 * 4 + 16 * 4 + 2 * 32 * 8;
 }
 
 struct PnpLds {
@@ -59,7 +61,7 @@ struct PnpLds {
   double* red;      // [4][32]
   int* misc;        // [16]
   float* hyp;       // [12][64] models of the current round of hypotheses
-  int* hyp_cnt;     // [4][64] partial inlier counts (one row per wavefront) + [64] valid flags
+  int* hyp_cnt;     // [NW][64] partial inlier counts (one row per wavefront) + [64] valid flags
   float* best;      // [12] model of the best hypothesis so far (copied out of `hyp` by the replay)
   double* ne_a;     // [32] normal equations of the current pose   (totals live in LDS, not in VGPRs)
   double* ne_b;     // [32] normal equations of the candidate pose
@@ -361,7 +363,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     L.mask = p; p += kcap;
     L.mask_b = p; p += kcap;
     L.hyp = (float*)p; p += 12 * 64 * 4;
-    L.hyp_cnt = (int*)p; p += 5 * 64 * 4;
+    L.hyp_cnt = (int*)p; p += (NW + 1) * 64 * 4;
     L.best = (float*)p; p += 16 * 4;
     L.ne_a = (double*)p; p += 32 * 8;
     L.ne_b = (double*)p;
@@ -459,7 +461,7 @@ __device__ __forceinline__ PnpTail pnp_body(const StoreView& st, int pair, const
     if (tid == 0) { L.misc[0] = -1; L.misc[1] = 1; }
     const int slice = (m + NW - 1) / NW;                   // points counted by each wavefront
     const int i0 = min(m, wave * slice), i1 = min(m, i0 + slice);
-    int* hv = L.hyp_cnt + 4 * 64;
+    int* hv = L.hyp_cnt + NW * 64;
     const int fit_wave = pair & (NW - 1);   // rotate the solving wavefront (SIMD) with the pair
     for (int base = 0; base < max_it; base += 64) {
       const int it = base + lane;

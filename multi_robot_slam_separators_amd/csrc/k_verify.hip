@@ -723,7 +723,7 @@ template <int W, int PART, int NW>
 int launch_chain_pnp(sf_context* c, StoreView st, const int32_t* d_from, const int32_t* d_to, int n, sf_result* d_out,
                      const BaHandover& H) {
   const int nc = c->dparams.grid_gx * c->dparams.grid_gy;
-  const size_t lds = std::max((sf_pnp_lds_bytes_dev(st.kcap, c->dparams.iterations, NW == 4) + 15) & ~(size_t)15,
+  const size_t lds = std::max((sf_pnp_lds_bytes_dev(st.kcap, c->dparams.iterations, NW == 4, NW) + 15) & ~(size_t)15,
                               sf_guided_lds_bytes(st.kcap, nc, NW != 4));
   bool& attr = c->chain_pnp_attr[W == 16][PART][NW == 4 ? 2 : NW - 1];
   if (lds > 64 * 1024 && !attr) {
