@@ -360,9 +360,6 @@ __device__ __forceinline__ void knn2_scan_lds(const uint32_t* fromD, int Kf, con
 //     orders by distance first (steps of 2) and by the LOWER from index second (fraction < 1): the
 //     BFMatcher tie rule with no separate index bookkeeping;
 //   * best / second best per column: v_max_f32 + v_med3_f32 per cell, then one cross-half merge.
-#ifndef SF_MATCH_PRELOAD
-#define SF_MATCH_PRELOAD 0     // measured, not adopted: see match_v2_body
-#endif
 typedef int mf_v8i __attribute__((ext_vector_type(8)));
 typedef float mf_v16f __attribute__((ext_vector_type(16)));
 constexpr float MF_FR = 1.f / 2048.f;        // index fraction (kcap <= 2048 rows on this path)
@@ -719,17 +716,12 @@ __device__ __forceinline__ void mf_scan(const uint32_t* fromD, int Kf, const MfB
   }
 }
 
-// after_b(): called once the resident "to" operands are in registers (their global loads consumed) and before the scan --
-// where the persistent matcher (k_match_persist, k_verify.hip) queues the LDS-DMA of the NEXT pair's "from" rows, so
-// that no ordinary load of this wavefront is waited for while the DMA is in flight.
-struct MfNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int W, int NTL, class Hook = MfNoHook, bool PIPE = false>
+template <int W, int NTL, bool PIPE = false>
 __device__ __forceinline__ void knn2_mfma(const uint32_t* fromD, int Kf, const uint32_t* __restrict__ dT, int Kt,
                                           const int (&tile)[NTL], int lane, uint32_t (&d1)[NTL], uint32_t (&d2)[NTL],
-                                          int (&idx)[NTL], Hook after_b = Hook()) {
+                                          int (&idx)[NTL]) {
   MfB<W, NTL> B;
   mf_load_b<W, NTL>(dT, Kt, tile, lane, B);
-  after_b();
   mf_scan<W, NTL, PIPE>(fromD, Kf, B, lane, d1, d2, idx);
 }
 
@@ -770,41 +762,18 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
   int* owner = cnt + kcap;                                 // [kcap]
   int* misc = owner + kcap;                                // [16]
 
-  // SF_MATCH_PRELOAD (round 5, matrix-core path): the "from" rows are staged by LDS-DMA (global_load_lds_dwordx4: no
-  // staging registers, no ds_write) and, with nothing of the wavefront's register file tied up in the copy, the FIRST
-  // group's "to" rows are loaded and spread while the DMA is in flight -- one memory latency in front of a pair's first
-  // MFMA instead of two.  (Rounds 3-4 tried the early "to" loads on top of the register copy: the raw rows kept across the
-  // staging barrier cost the fused kernel its 128-register budget; this form keeps 128 registers and no scratch.)
-  // MEASURED (profiles/r05p_preload_ab.txt, three alternations on one box): 22.51 / 22.73 / 22.65 M pairs/s with it against
-  // 22.79 / 22.82 / 22.72 without (PnP 15.34 against 15.27) -- no gain: with four to five workgroups of other pairs on the
-  // CU a pair's own staging latency is already covered, the launch is bound by issue slots.  Off by default.
-  constexpr bool PRE = SF_MATCH_PRELOAD != 0 && NQ == 0;
-  constexpr int PRE_NTL = W == 8 ? MF_NTL : 1;
-  MfB<W, PRE_NTL> B0;
-  int tl0[PRE_NTL];
-#pragma unroll
-  for (int j = 0; j < PRE_NTL; ++j) tl0[j] = wave + j * NW;
-  if constexpr (PRE) {
-    typedef __attribute__((address_space(3))) void* lds_vp_t;
-    typedef __attribute__((address_space(1))) const void* glb_vp_t;
-    const uint4* src = reinterpret_cast<const uint4*>(dF);
-    const int n16 = Kf * (W / 4);
-    for (int i0 = wave * 64; i0 < n16; i0 += NT) {
-      if (i0 + lane < n16)
-        __builtin_amdgcn_global_load_lds((glb_vp_t)(src + i0 + lane), (lds_vp_t)(fromD + 4 * i0), 16, 0, 0);
-    }
-  } else {
+  // (Round 5 measured the staging by LDS-DMA with the first group's "to" rows loaded and spread beside it -- one memory
+  //  latency in front of a pair's first MFMA instead of two, at 128 registers and no scratch: 22.6 against 22.8 M pairs/s,
+  //  profiles/r05p_preload_ab.txt.  With four to five workgroups of other pairs on the CU a pair's own staging latency is
+  //  already covered; not kept.)
+  {
     const uint4* src = reinterpret_cast<const uint4*>(dF);
     uint4* dst = reinterpret_cast<uint4*>(fromD);
     for (int i = tid; i < Kf * (W / 4); i += NT) dst[i] = src[i];
   }
   for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
   if (tid < 16) misc[tid] = 0;
-  if constexpr (PRE) {
-    if (Kf > 0 && wave < ((Kt + 31) >> 5)) mf_load_b<W, PRE_NTL>(dT, Kt, tl0, lane, B0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's pieces of the rows have landed ...
-  }
-  __syncthreads();                                       // ... and everyone's
+  __syncthreads();
   SF_TRACE_ROW_MARK(trace_row, 32);   // "from" rows staged
 
   int rejected = 0;
@@ -823,7 +792,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
         uint32_t a1[G], a2[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) tl[j] = t0 + j * NW;
-        knn2_mfma<W, G, MfNoHook, MF_PIPE>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
+        knn2_mfma<W, G, MF_PIPE>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           const int t = tl[j] * 32 + lane;
@@ -838,29 +807,7 @@ __device__ __forceinline__ bool match_v2_body(const StoreView& st, int pair, int
           }
         }
       };
-      int t_first = wave;
-      if constexpr (PRE) {
-        if (wave < n_nt) {       // the first group: its "to" operands were loaded beside the staging DMA (full width; a tile
-          int f[NTL];            //  past the frame's rows is empty)
-          uint32_t a1[NTL], a2[NTL];
-          mf_scan<W, NTL, MF_PIPE>(fromD, Kf, B0, lane, a1, a2, f);
-#pragma unroll
-          for (int j = 0; j < NTL; ++j) {
-            const int t = tl0[j] * 32 + lane;
-            if (lane < 32 && t < Kt) {
-              const bool acc = (Kf >= 2) && !((float)a1[j] > nndr * (float)a2[j]);
-              if (acc) {
-                atomicAdd(&cnt[f[j]], 1);
-                owner[f[j]] = t;
-              } else {
-                ++rejected;
-              }
-            }
-          }
-        }
-        t_first = wave + NW * NTL;
-      }
-      for (int t0 = t_first; t0 < n_nt; t0 += NW * NTL) {
+      for (int t0 = wave; t0 < n_nt; t0 += NW * NTL) {
         const int avail = (n_nt - t0 + NW - 1) / NW;
         if (NTL >= 4 && avail >= 3) group(std::integral_constant<int, 4>{}, t0);
         else if (NTL >= 2 && avail >= 2) group(std::integral_constant<int, 2>{}, t0);

@@ -228,192 +228,11 @@ k_match_split(StoreView st, const int32_t* __restrict__ pair_from, const int32_t
   }
 }
 
-// ---- the persistent form of the matching launch (round 5, SF_MATCH_PERSIST) ---------------------------------------------
-// k_match_split spends a quarter of a pair's workgroup slot outside the scan: staging the "from" rows (3.3 of ~22 us under
-// load: a global -> register -> LDS copy with a barrier behind it), waiting for the slowest wavefront, compaction and
-// header.  Here a workgroup stays resident and walks pairs blockIdx.x, + gridDim.x, ...: while it scans pair p the "from"
-// rows of its NEXT pair arrive in a second LDS buffer by LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store
-// instructions, nothing to wait for until the next pair starts), queued by every wavefront right after its resident "to"
-// operands are built -- behind the last ordinary global load of the pair, so that the compiler's vmcnt(0) in front of a
-// use of such a load never waits for the DMA.  36.5 KB of LDS at K = 500 (two row buffers + counters): three workgroups
-// per CU as before (159 registers).  Same matching body otherwise, same bytes.
-typedef __attribute__((address_space(3))) void* lds_void_p;
-typedef __attribute__((address_space(1))) const void* glob_cvoid_p;
-template <int W>
-__global__ void __launch_bounds__(SF_BLOCK, 3)
-k_match_persist(StoreView st, const int32_t* __restrict__ pair_from, const int32_t* __restrict__ pair_to,
-                uint32_t* __restrict__ corr1, CorrHeader* __restrict__ hdr1, PassState* __restrict__ pass1,
-                CorrHeader* __restrict__ hdr2, PassState* __restrict__ pass2, uint8_t* __restrict__ guided_flag,
-                int32_t* __restrict__ list, int32_t* __restrict__ counter, sf_result* __restrict__ out, DeviceParams P,
-                int est, int n_pairs) {
-  extern __shared__ __attribute__((aligned(16))) int smem_i[];
-  constexpr int NT = SF_BLOCK, NW = NT / 64, NTL = W == 8 ? 4 : 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kcap = st.kcap;
-  uint32_t* const buf0 = reinterpret_cast<uint32_t*>(smem_i);
-  uint32_t* const buf1 = buf0 + (size_t)kcap * W;
-  int* const cnt = smem_i + 2 * kcap * W;        // [kcap]
-  int* const owner = cnt + kcap;                 // [kcap]
-  int* const misc = owner + kcap;                // [16]
-  // queue the LDS-DMA of a pair's "from" rows into dst (every wavefront a quarter of the 16-byte pieces)
-  auto stage = [&](int pr, uint32_t* dst) {
-    if (pr >= n_pairs) return;
-    const int sF = pair_from[pr];
-    if ((unsigned)sF >= (unsigned)st.n_slots) return;
-    const int n16 = st.meta[sF].x * (W / 4);
-    const uint4* src = reinterpret_cast<const uint4*>(st.desc + (size_t)sF * kcap * W);
-    for (int i0 = wave * 64; i0 < n16; i0 += NT) {
-      if (i0 + lane < n16)
-        __builtin_amdgcn_global_load_lds((glob_cvoid_p)(src + i0 + lane), (lds_void_p)(dst + 4 * i0), 16, 0, 0);
-    }
-  };
-  int pair = blockIdx.x;
-  stage(pair, buf0);
-  for (int cur = 0; pair < n_pairs; pair += (int)gridDim.x, cur ^= 1) {
-    uint32_t* const fromD = cur ? buf1 : buf0;
-    uint32_t* const nextD = cur ? buf0 : buf1;
-    const int next_pair = pair + (int)gridDim.x;
-    const int sF = pair_from[pair], sT = pair_to[pair];
-    uint32_t* const outl = corr1 + (size_t)pair * kcap;
-    if ((unsigned)sF >= (unsigned)st.n_slots || (unsigned)sT >= (unsigned)st.n_slots) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                              // (this buffer's DMA, if any, has landed before the next one is queued)
-      stage(next_pair, nextD);
-      if (tid == 0) {
-        const CorrHeader h = {0, 0, 0, 0};
-        hdr1[pair] = h;
-        PassState ps;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-        ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0; ps.matches = 0; ps.pad = 0;
-        pass1[pair] = ps;
-        if (P.dbg_corr) { hdr2[pair] = h; pass2[pair] = ps; guided_flag[pair] = 0; }
-        finalize_one(ps, ps, 0, out[pair]);
-        if (P.accept_on && P.accept.flags) P.accept.flags[pair] = 0;
-      }
-      continue;
-    }
-    const int4 mF = st.meta[sF], mT = st.meta[sT];
-    const int Kf = mF.x, Kt = mT.x;
-    const uint32_t* dT = st.desc + (size_t)sT * kcap * W;
-    for (int i = tid; i < Kf; i += NT) cnt[i] = 0;
-    if (tid < 16) misc[tid] = 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's pieces of the pair's rows have landed ...
-    __syncthreads();                                     // ... and everyone's; counters cleared
-    bool queued = false;
-    auto hook = [&]() {
-      if (!queued) {
-        __builtin_amdgcn_sched_barrier(0);               // behind the uses of the "to" rows' loads
-        stage(next_pair, nextD);
-        queued = true;
-      }
-    };
-    int rejected = 0;
-    if (Kf > 0) {
-      const int n_nt = (Kt + 31) >> 5;
-      auto group = [&](auto g, int t0) {
-        constexpr int G = decltype(g)::value;
-        int tl[G], f[G];
-        uint32_t a1[G], a2[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) tl[j] = t0 + j * NW;
-        knn2_mfma<W, G>(fromD, Kf, dT, Kt, tl, lane, a1, a2, f, hook);
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int t = tl[j] * 32 + lane;
-          if (lane < 32 && t < Kt) {
-            const bool acc = (Kf >= 2) && !((float)a1[j] > P.nndr * (float)a2[j]);
-            if (acc) {
-              atomicAdd(&cnt[f[j]], 1);
-              owner[f[j]] = t;
-            } else {
-              ++rejected;
-            }
-          }
-        }
-      };
-      for (int t0 = wave; t0 < n_nt; t0 += NW * NTL) {
-        const int avail = (n_nt - t0 + NW - 1) / NW;
-        if (NTL >= 4 && avail >= 3) group(std::integral_constant<int, 4>{}, t0);
-        else if (NTL >= 2 && avail >= 2) group(std::integral_constant<int, 2>{}, t0);
-        else group(std::integral_constant<int, 1>{}, t0);
-      }
-    }
-    hook();                                              // (a wavefront without a column tile, or an empty "from" frame)
-    for (int off = 32; off >= 1; off >>= 1) rejected += __shfl_xor(rejected, off);
-    if (lane == 0 && rejected) atomicAdd(&misc[0], rejected);
-    __syncthreads();
-    int running = 0;
-    for (int base = 0; base < Kf; base += NT) {
-      const int f = base + tid;
-      const bool flag = (f < Kf) && (cnt[f] == 1);
-      const unsigned long long bal = __ballot(flag);
-      const int before = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) misc[4 + wave] = __popcll(bal);
-      __syncthreads();
-      int woff = 0, total = 0;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const int c = misc[4 + w];
-        if (w < wave) woff += c;
-        total += c;
-      }
-      if (flag) outl[running + woff + before] = (uint32_t)f | ((uint32_t)owner[f] << 16);
-      running += total;
-      __syncthreads();
-    }
-    const int n_corr = running;
-    const int unique_to = (Kf > 0 && Kt > 0) ? misc[0] + n_corr : 0;
-    const int words_from = (Kf > 0 && mF.y > 0) ? Kf : 0;
-    const int words_to = (mT.y > 0) ? unique_to : 0;
-    const int min_inliers = P.min_inliers;
-    const bool motion = est == 0 ? (unique_to > 0 && words_from >= min_inliers && words_to >= min_inliers)
-                      : est == 1 ? (unique_to > 0 && words_from >= min_inliers && unique_to >= min_inliers)
-                                 : (est == 3 && unique_to > 0 && ((words_from >= min_inliers && unique_to >= min_inliers) ||
-                                                                  (words_to >= min_inliers && Kf >= min_inliers)));
-    const bool survivor = est == 3 ? (motion && n_corr > 0) : (motion && n_corr >= min_inliers && n_corr >= (est == 0 ? 3 : 4));
-    if (motion && !survivor) {
-      const float* xF = st.xyz + (size_t)sF * kcap * 3;
-      const float* xT = st.xyz + (size_t)sT * kcap * 3;
-      for (int i = tid; i < n_corr; i += NT) {
-        const uint32_t c = outl[i];
-        const float* a = xF + 3 * (c & 0xFFFFu);
-        const float* b = xT + 3 * (c >> 16);
-        bool ok = isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]);
-        if (est == 0)
-          ok = ok && isfinite(b[0]) && isfinite(b[1]) && isfinite(b[2]) && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f) &&
-               (b[0] != 0.f || b[1] != 0.f || b[2] != 0.f);
-        if (ok) atomicAdd(&misc[2], 1);
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      CorrHeader h;
-      h.n_corr = n_corr; h.words_from = words_from; h.words_to = words_to; h.words_to_2d = unique_to;
-      hdr1[pair] = h;
-      PassState ps;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) ps.T[i] = 0.f;
-      ps.var = 1.0; ps.var_ang = 1.0; ps.is_null = 1; ps.inliers = 0;
-      ps.matches = (motion && !survivor) ? misc[2] : 0;
-      ps.pad = 0;
-      pass1[pair] = ps;
-      if (survivor) {
-        const int pos = atomicAdd(counter, 1);
-        list[pos] = pair;
-      } else {
-        // no motion estimate: guided matching is not eligible (its pass state is pass 1's), the result is final
-        if (P.dbg_corr) {
-          const CorrHeader h0 = {0, 0, 0, 0};
-          hdr2[pair] = h0; pass2[pair] = ps; guided_flag[pair] = 0;
-        }
-        finalize_one(ps, ps, 0, out[pair]);
-        if (P.accept_on && P.accept.flags) P.accept.flags[pair] = 0;
-      }
-    }
-    __syncthreads();       // (misc / cnt are rewritten by the next pair's prologue)
-  }
-}
+// (Round 5 also built a PERSISTENT form of this launch -- resident workgroups walking the pairs, the next pair's "from" rows
+//  arriving in a second LDS buffer by LDS-DMA during the scan -- and short-lived workgroups of 2 / 4 pairs on it.  Correct,
+//  slower in every shape measured (21.4 / 20.9 against 22.7 M pairs/s: profiles/r05m_*, r05y_*; docs/notebook_r05.md
+//  sections 5 and 7): the second row buffer and 100-150 B of scratch cost more than the staging they hide.  Removed; the
+//  last commit that holds it is "Matcher experiments: k pairs per workgroup ...".)
 
 // NW: wavefronts per chain.  4 = the round-2 form (one 256-thread workgroup per survivor, 128 registers: a chain holds
 // a quarter of a CU's wave slots and registers while three of its four wavefronts wait at barriers most of the time).
@@ -789,22 +608,6 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
                      (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p, \
                      (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams, \
                      sf_est_mode(c))
-  static const bool persist = getenv("SF_MATCH_PERSIST") != nullptr && atoi(getenv("SF_MATCH_PERSIST")) != 0;
-  const size_t lds_p = lds_m + (size_t)st.kcap * st.w * 4;        // (a second row buffer)
-  if (persist && st.w == 8 && lds_p <= 64 * 1024 && !c->dparams.dbg_trace) {
-    if (c->cu_count <= 0) {
-      int cus = 0;
-      SF_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-      c->cu_count = cus > 0 ? cus : 256;
-    }
-    // (round 5, profiles/r05y_pairs_per_workgroup.txt: short-lived workgroups of 2 or 4 pairs each on this kernel, with
-    //  the pipelined scan: 20.9 against 22.7 M pairs/s on the 3D-3D step, 14.4 against 15.1 on the PnP step -- not kept)
-    const int grid = std::min(n, 3 * c->cu_count);
-    hipLaunchKernelGGL((k_match_persist<8>), dim3(grid), dim3(SF_BLOCK), lds_p, c->stream, st, d_from, d_to,
-                       (uint32_t*)c->corr1.p, (CorrHeader*)c->hdr1.p, (PassState*)c->pass1.p, (CorrHeader*)c->hdr2.p,
-                       (PassState*)c->pass2.p, (uint8_t*)c->flags.p, (int32_t*)c->list1.p, counters + 0, d_out, c->dparams,
-                       sf_est_mode(c), n);
-  } else
   // (shapes measured on the pipelined scan, profiles/r05t_match_split_shapes.txt: 4 tiles / 3 workgroups per CU 22.5 M
   //  pairs/s on the 3D-3D split step, 2 tiles / 4: 22.2, 2 tiles / 3: 21.3, 4 tiles / 2: 21.2; PnP 15.0 / 15.0 / 14.8 / 13.7)
   if (st.w == 8) SF_SPLIT_MATCH(8); else SF_SPLIT_MATCH(16);
