@@ -76,6 +76,58 @@ __device__ __forceinline__ void knn2_scan_l2(const uint32_t* __restrict__ dF, in
   }
 }
 
+// The same scan for rows of more than 64 dimensions (SIFT: 128) without keeping the whole "to" row in registers: the
+// 128 registers of the resident row left two wavefronts per SIMD to cover the scalar loads (9.8 ms per 2 048 pairs of
+// K = 500 against an issue bound of 6.2, profiles/r05zb_float_descriptors.txt).  Here a lane walks the "from" rows in blocks
+// of FB: the first 64 dimensions of the block's rows against the first half of its "to" row, then the second half -- one
+// 64-register half resident at a time, re-read from L2 per block (256 B per lane against 3 x 64 x FB vector instructions),
+// FB partial sums carried between the halves.  Per (from, to) pair the sum still runs over the dimensions in order: the
+// same operations on the same values, the same bits.
+template <int W>
+__device__ __forceinline__ void knn2_scan_l2_halves(const uint32_t* __restrict__ dF, int Kf,
+                                                    const uint32_t* __restrict__ qrow, float& d1, float& d2, int& i1) {
+  static_assert(W == 128, "two halves of 64 dimensions");
+  constexpr int H = 64, FB = 16;
+#pragma unroll 1
+  for (int f0 = 0; f0 < Kf; f0 += FB) {
+    float s[FB];
+#pragma unroll
+    for (int j = 0; j < FB; ++j) s[j] = 0.f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      uint32_t q[H];
+      {
+        const uint4* p = reinterpret_cast<const uint4*>(qrow + half * H);
+#pragma unroll
+        for (int c = 0; c < H / 4; ++c) {
+          const uint4 v = p[c];
+          q[4 * c] = v.x; q[4 * c + 1] = v.y; q[4 * c + 2] = v.z; q[4 * c + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        if (f0 + j < Kf) {                                       // wave-uniform
+          const uint32_t* r = dF + (size_t)(f0 + j) * W + half * H;   // wave-uniform: scalar loads
+          float a = s[j];
+#pragma unroll
+          for (int c = 0; c < H; ++c) {
+            const float d = __uint_as_float(q[c]) - __uint_as_float(r[c]);
+            a = a + d * d;
+          }
+          s[j] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      if (f0 + j < Kf) {
+        if (s[j] < d1) { d2 = d1; d1 = s[j]; i1 = f0 + j; }
+        else if (s[j] < d2) { d2 = s[j]; }
+      }
+    }
+  }
+}
+
 template <int W>
 __device__ __forceinline__ void load_desc(const uint32_t* __restrict__ base, int row, bool valid, uint32_t (&q)[W]) {
   const uint4* p = reinterpret_cast<const uint4*>(base + (size_t)(valid ? row : 0) * W);
@@ -134,12 +186,17 @@ k_match_global(StoreView st, const int32_t* __restrict__ pair_from, const int32_
     if (Kf > 0) {
       for (int base = 0; base < Kt; base += NT) {
         const int t = base + tid;
-        uint32_t q[W];
-        load_desc<W>(dT, t, t < Kt, q);
         float d1 = __int_as_float(0x7F800000), d2 = __int_as_float(0x7F800000);
         int i1 = -1;
-        if (Kt - base - (tid & ~63) > 0)          // (wave-uniform: this wavefront holds at least one valid row)
-          knn2_scan_l2<W>(dF, Kf, q, d1, d2, i1);
+        if constexpr (W > 64) {
+          if (Kt - base - (tid & ~63) > 0)        // (wave-uniform: this wavefront holds at least one valid row)
+            knn2_scan_l2_halves<W>(dF, Kf, dT + (size_t)(t < Kt ? t : 0) * W, d1, d2, i1);
+        } else {
+          uint32_t q[W];
+          load_desc<W>(dT, t, t < Kt, q);
+          if (Kt - base - (tid & ~63) > 0)
+            knn2_scan_l2<W>(dF, Kf, q, d1, d2, i1);
+        }
         if (t < Kt) {
           const bool acc = (Kf >= 2) && i1 >= 0 && !(d1 > nndr * d2);
           if (acc) {
