@@ -47,11 +47,12 @@ def test_float_descriptors_equal_the_oracle(oracle, dims, jitter, est):
     assert accepted >= np.sum(is_true) - 2 and accepted < len(A)        # the true pairs are found, the false ones are not
 
 
-def test_float_descriptor_edge_cases(oracle):
+@pytest.mark.parametrize("dims", [64, 128])
+def test_float_descriptor_edge_cases(oracle, dims):
     """Empty / single-row / two-row frames, identical rows on both sides (every distance 0: ties, NNDR 0 < 0.6 * 0 is
-    false), rows with NaN (never the nearest), frames of different sizes; the store refuses a row width other than 64
-    or 128 dimensions and a binary keyframe in a float handle's width class."""
-    dims = 64
+    false), rows with NaN (never the nearest), frames of different sizes (at 128 dimensions the scan walks the "from" rows
+    in blocks of 16: 15 / 16 / 17 / 33 rows); the store refuses a row width other than 64 or 128 dimensions and a binary
+    keyframe in a float handle's width class."""
     p = _params(dims)
     rng = np.random.default_rng(5)
     A, B, _, _ = _pairs(77, 6, 120, dims, 0.02, true_frac=1.0)
@@ -61,6 +62,8 @@ def test_float_descriptor_edge_cases(oracle):
                                            fa.xyz[:n], fa.kpts[:n])
     cases.append((cut(a, 0), b)); cases.append((a, cut(b, 0))); cases.append((cut(a, 1), b)); cases.append((cut(a, 2), cut(b, 2)))
     cases.append((cut(a, 120), cut(b, 50)))
+    for n in (15, 16, 17, 33):
+        cases.append((cut(a, n), b))
     same = _abi.FeatureArrays(np.tile(a.desc[:1].view(np.float32), (120, 1)), a.xyz, a.kpts)
     cases.append((same, same))
     d = a.desc.view(np.float32).reshape(120, -1).copy(); d[::7] = np.nan
