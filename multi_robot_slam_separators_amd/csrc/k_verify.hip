@@ -593,6 +593,11 @@ int sf_launch_verify_split(sf_context* c, StoreView st, const int32_t* d_from, c
   if (!(pnp ? sf_split_pnp_applicable(c, st) : sf_split_applicable(c, st)))
     return sf_fail(c, SF_EINVAL, "split verification pipeline not applicable");
   SF_HIP(c, hipMemsetAsync(c->counters.p, 0, 64, c->stream));
+  // (Round 5, profiles/r05zc_matcher_workgroups_per_cu.txt: with its workgroups per CU capped by an inflated LDS request the
+  //  launch alone takes 284 us at three per CU, 296 at two and 295 at ONE -- the pipelined scan keeps the matrix pipe busy
+  //  from one wavefront per SIMD.  Capping it inside the overlapped step changes nothing (23.2-23.3 M pairs/s either way):
+  //  the step as a whole is bound by vector instruction issue -- 425 M busy cycles of this kernel + 196 M of the chains +
+  //  35 M of the NN kernels per step over 1 024 SIMDs = 0.32-0.36 ms of the 0.43 ms step, profiles/r05w_sq_*.)
   const size_t lds_m = sf_match_lds_bytes(st.kcap, st.w);
   int32_t* counters = (int32_t*)c->counters.p;
   sf_prof_begin(c, SF_K_MATCH);
