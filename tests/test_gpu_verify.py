@@ -455,6 +455,42 @@ def test_split_pipeline_equals_fused_kernel(monkeypatch):
             assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1])
 
 
+def test_pipelined_scan_at_its_tile_boundaries(monkeypatch, oracle):
+    """k_match_split's scan is software-pipelined inside a wavefront (k_match.hip, mf_pipe_*: two accumulator tuples, the
+    top-2 update of a column tile issued in the gaps of the next tile's MFMAs, the ragged last "from" tile and groups of
+    fewer than two column tiles on the non-pipelined statements).  Every combination of "from" rows around the 32-row tile
+    edges (no full tile, exactly one, one + a ragged one, ...) and of "to" rows around the group sizes (one column tile
+    per wavefront or none, two, four, more than one group) against the oracle, correspondence lists included."""
+    from multi_robot_slam_separators_amd import lib
+    from test_gpu_fuzz import random_frame
+    rng = np.random.default_rng(2029)
+    base_a, base_b, _, _ = synth.make_pairs(91, 1, k=520, cols=32, true_frac=1.0)
+    a, b = base_a[0], base_b[0]
+    cut = lambda fa, n: _abi.FeatureArrays(fa.desc[:n], fa.xyz[:n], fa.kpts[:n])
+    kfs = (1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 129, 500, 511, 512, 520)
+    kts = (1, 31, 32, 33, 64, 127, 128, 129, 255, 256, 257, 300, 500, 512, 520)
+    A, B = [], []
+    for i, kf in enumerate(kfs):            # a diagonal + two off-diagonals of the grid, and random frames of the same sizes
+        for kt in (kts[i], kts[(i + 5) % len(kts)], kts[(i + 10) % len(kts)]):
+            A.append(cut(a, kf)); B.append(cut(b, kt))
+            A.append(random_frame(rng, kf, 32)); B.append(random_frame(rng, kt, 32))
+    p = synth.camera_params()
+    p.iterations = 200
+    p.min_inliers = 5
+    monkeypatch.setenv("SF_FUSED", "2")
+    monkeypatch.setenv("SF_DEBUG_CORR", "1")
+    with lib.SeparatorFinder(p) as f:
+        f.prof_enable(True)
+        got = f.estimate_transform_batch(A, B)
+        assert f.prof_get()["k_match_global"][0] >= 1          # (the split form's matching launch)
+        for i in range(len(A)):
+            o, c1, c2 = oracle.estimate_transform(p, A[i], B[i], debug=True)
+            g1 = f.debug_correspondences(i, 1)
+            assert np.array_equal(g1[0], c1[0]) and np.array_equal(g1[1], c1[1]), (i, len(A[i].desc), len(B[i].desc))
+            assert got[i].tobytes() == o.tobytes(), (i, len(A[i].desc), len(B[i].desc))
+    assert sum(int(g["success"]) for g in got) >= 5
+
+
 @pytest.mark.parametrize("est", [0, 1])
 @pytest.mark.parametrize("ba", [0, 1])
 def test_chain_widths_give_the_same_bytes(monkeypatch, ba, est):
