@@ -596,13 +596,14 @@ __device__ __forceinline__ void mf_load_b(const uint32_t* __restrict__ dT, int K
 
 // ---- round 5: the scan software-pipelined inside a wavefront (256-bit descriptors) -------------------------------------
 // knn2_mfma_tile above runs, per column tile, 4 dependent MFMAs, waits for the result (s_nop 11), then 20 dependent
-// vector instructions that consume it, on ONE accumulator tuple: nothing of a wavefront's own stream overlaps, and measured
-// over whole launches a SIMD spends 200-230 cycles per 32 x 32 tile pair = the SUM of its matrix-pipe time (4 x 32) and
-// its vector issue time (4 x 8 + 26 x 4; MI355X_MICROARCH.md, cycle constants) although three or four wavefronts share it
-// (cfg3-shaped k_match_split: 10.8 ms per 100 000 pairs = 108 ns per tile pair and SIMD, profiles/r05q_*).
+// vector instructions that consume it, on ONE accumulator tuple: nothing of a wavefront's own stream overlaps -- matrix-pipe
+// time (4 x 32 cycles per 32 x 32 tile pair) and vector issue time (4 x 8 + 26 x 4; MI355X_MICROARCH.md, cycle constants)
+// only overlap between the wavefronts that share a SIMD.
 // Here the top-2 update of tile j - 1 is issued in the gaps of tile j's MFMAs, from a SECOND accumulator tuple: five to six
 // vector instructions per 32-cycle gap (their issue cost 8 + 6 x 4 fits it), so a tile pair costs the matrix pipe's 128
-// cycles plus what stays outside (the spread of the "from" tile, the loop).  The MFMAs have to sit in the asm statements
+// cycles plus what stays outside (the spread of the "from" tile, the loop).  Measured (profiles/r05s_*, r05zc_*): the
+// cfg3-shaped launch 10.8 -> 10.0 ms per 100 000 pairs with the matrix pipe 75 % busy at the 1.69 GHz the chip sustains
+// under it, and ONE workgroup per CU now reaches 96 % of the rate of three.  The MFMAs have to sit in the asm statements
 // with the vector instructions (the compiler does not interleave an asm block with builtins), so the wait states are
 // written out by hand (cdna_hip_programming.md section 5.7 item 2):
 //   * a VALU-written A operand -> MFMA: s_nop 1 opens the first half (the spread is compiler code right in front); the
